@@ -1,0 +1,151 @@
+/*
+ * l2s.h - C-ABI of the MI355X-native Lip2Speech hot path (libl2s_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no native code:
+ * its hot path is the Python call chain
+ *
+ *     Lip2Speech.inference            /root/reference/model/model.py:43-59
+ *       VideoExtractor.forward        /root/reference/model/modules/video.py:76-87
+ *       Decoder.inference             /root/reference/model/modules/decoder.py:382-444
+ *     Lip2Speech.forward (eval)       /root/reference/model/model.py:23-40
+ *       Decoder.forward               /root/reference/model/modules/decoder.py:320-379
+ *
+ * and a binding for this library replaces the bodies of exactly those methods
+ * (INTEGRATION.md shows the ctypes stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no framework types.  `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).  Every entry point only enqueues
+ *     work on `stream`; nothing synchronises the device.
+ *   - all tensors are fp32, contiguous; "dev" = device memory, "host" = host memory.
+ *   - the caller owns every buffer, including the workspace; the library allocates
+ *     nothing persistent except the packed weight blob owned by an l2s_model, freed by
+ *     l2s_model_destroy.
+ *   - every function returns 0 on success, non-zero on error; l2s_last_error() gives
+ *     the message for the calling thread.
+ *   - lengths are ignored exactly as in the reference (no key masking, zero-padded
+ *     frames are encoded and attended like real ones; decoder.py:320-379).
+ */
+#ifndef L2S_H
+#define L2S_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct l2s_model l2s_model;
+
+/* fixed geometry of the path (reference/hparams.py, decoder.py:285-318, video.py:55-72) */
+#define L2S_N_MELS      80
+#define L2S_D_MODEL     512
+#define L2S_D_FEAT      768
+#define L2S_D_EMB       256
+#define L2S_D_VIS       1024
+#define L2S_VOCAB       501
+#define L2S_MAX_STEPS   300
+
+int         l2s_abi_version(void);
+const char* l2s_last_error(void);
+
+/* ---- weights: replaces nn.Module.load_state_dict for encoder.* / decoder.* keys -------------------
+ * A model may hold the encoder.* keys, the decoder.* keys, or both (net.encoder / net.decoder are usable on
+ * their own in the reference); a stage whose half is absent returns an error.
+ * (the on-disk format is the reference's state_dict; demo.py:30-38, evaluate.py:73-77).
+ * set_tensor copies `numel` floats from host memory under the checkpoint key (e.g.
+ * "decoder.K.0.conv.3.0.weight"); finalize validates that every key of the path is present with the
+ * right element count, derives BatchNorm scale/shift, re-lays the weights out for the kernels
+ * and uploads one device blob. */
+int l2s_model_create(l2s_model** out);
+int l2s_model_set_tensor(l2s_model* m, const char* key, const float* host_data, int64_t numel);
+int l2s_model_finalize(l2s_model* m, void* stream);
+int l2s_model_destroy(l2s_model* m);
+
+/* ---- sizes ---------------------------------------------------------------------------------------- */
+/* number of content slots min_T of Content.encode (decoder.py:239-246): min over the strided branches */
+int     l2s_min_T(int T);
+/* bytes of caller-provided device workspace for one call at these sizes (S = decode steps) */
+int64_t l2s_workspace_bytes(int B, int T, int H, int W, int S);
+/* floats in the decoder state buffer produced by l2s_decoder_prologue */
+int64_t l2s_state_floats(int B, int T);
+/* float offset of a field inside the state buffer; layouts:
+ *   L2S_ST_K      (B,T,512)   keys,   k[b][t][c]  (the reference holds (B,512,T))
+ *   L2S_ST_V      (B,T,512)   values
+ *   L2S_ST_CKEY   (B,m,256)   content keys   (reference: self.key (B,256,m))
+ *   L2S_ST_CVAL   (B,m,256)   content values (reference: self.value)
+ *   L2S_ST_ECELL  (B,512)     encoder_cell
+ *   L2S_ST_H / L2S_ST_C   decoder LSTM state, 2 layers, fragment layout
+ *   L2S_ST_ENC    (B,T,512)   encoder_outputs after encoder_proj + site + residual */
+enum { L2S_ST_K = 0, L2S_ST_V = 1, L2S_ST_CKEY = 2, L2S_ST_CVAL = 3, L2S_ST_ECELL = 4,
+       L2S_ST_H = 5, L2S_ST_C = 6, L2S_ST_ENC = 7, L2S_ST_STOPC = 8 };
+int64_t l2s_state_offset(int B, int T, int field);
+
+/* ---- stages ---------------------------------------------------------------------------------------- */
+/* VideoExtractor.forward (video.py:76-87): video dev (B,3,T,H,W) -> feat dev (B,T,768), L2-normalised.
+ * H = W in {88, 96}. */
+int l2s_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W,
+                    float* feat, void* ws, int64_t ws_bytes, void* stream);
+
+/* model.py:52-55: vis[b][t] = cat(feat[b][t] (768), emb[b] (256)) -> dev (B,T,1024) */
+int l2s_build_visual(const float* feat, const float* emb, int B, int T, float* vis, void* stream);
+
+/* Decoder prologue (decoder.py:383-410 / 321-351): vis dev (B,T,1024) = the `encoder_outputs` argument
+ * of Decoder.forward/inference, emb dev (B,256) = its `face_features[:, 0]`, gumbel dev (B*min_T,501) =
+ * the noise F.gumbel_softmax would draw (decoder.py:257).  Writes the state buffer and content_dis dev
+ * (B*min_T,501) (softmax of the content logits, the 6th output of Decoder.forward; may be NULL). */
+int l2s_decoder_prologue(l2s_model* m, const float* vis, const float* emb, const float* gumbel,
+                         int B, int T, float* state, float* content_dis,
+                         void* ws, int64_t ws_bytes, void* stream);
+
+/* The autoregressive loop (decoder.py:412-429 / 353-375), S steps from the state buffer.
+ *   teacher      dev (B,S,80) or NULL: frame fed at step i when teacher_mask[i] != 0
+ *                (= cat(BOS, mels)[:, i], decoder.py:349,357)
+ *   teacher_mask host (S) bytes or NULL: the scheduled-sampling decisions, made by the caller
+ *   mel          dev (B,S,80)  pre-postnet frames, channel-last
+ *   stop         dev (B,S)     stop-token logits
+ *   attn         dev (B,S,T) or NULL; post-softmax weights, or tau*q.k logits if attn_logits != 0
+ *                (inference() returns the former, forward() the latter) */
+int l2s_decode_steps(l2s_model* m, float* state, int B, int T, int S,
+                     const float* teacher, const uint8_t* teacher_mask,
+                     float* mel, float* stop, float* attn, int attn_logits,
+                     void* ws, int64_t ws_bytes, void* stream);
+
+/* Postnet + residual (decoder.py:143-156, 438-439): mel dev (B,S,80) -> mel_post dev (B,80,S) in the
+ * reference's layout; mel_cf dev (B,80,S) or NULL additionally receives the transposed pre-postnet mel. */
+int l2s_postnet(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf,
+                void* ws, int64_t ws_bytes, void* stream);
+
+/* decoder.py:429-435: lengths[b] = first i+1 with stop logit > 0, else S.  lengths dev (B) int64. */
+int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* stream);
+
+/* Lip2Speech.inference with a supplied speaker embedding (model.py:43-59), all stages on `stream`:
+ * mel_post dev (B,80,S), lengths dev (B) int64, attn dev (B,S,T) or NULL. */
+int l2s_inference(l2s_model* m, const float* video, const float* emb, const float* gumbel,
+                  int B, int T, int H, int W, int S,
+                  float* mel_post, int64_t* lengths, float* attn,
+                  void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
+/* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
+int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,
+                float* C, int M, int N, int K, int act, void* stream);
+/* Conv1d over channel-last sequences as an implicit GEMM: X (B,Tin,Cin), Wp (Cout, taps*Cin) with
+ * k = tap*Cin + ci, out (B,Tout,Cout), Tout = (Tin + 2*pad - taps)/stride + 1 */
+int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw,
+                  float* out, int B, int Tin, int Cin, int Cout, int taps, int stride, int pad, int act,
+                  void* stream);
+/* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
+ * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
+int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);
+/* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
+ * l2s_profile_get (which synchronises the events it reads).  Off by default. */
+int l2s_profile_enable(int on);
+int l2s_profile_reset(void);
+int l2s_profile_count(void);
+int l2s_profile_get(int idx, const char** name, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2S_H */

@@ -1,0 +1,216 @@
+// Tiled fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain).
+//
+// Serves every "dense over channel-last rows" op of the hot path: the ShuffleNet pointwise convs, the
+// decoder's Linear layers, and all Conv1d stacks (MultiHopConv K/V, Content.agg, Postnet) as implicit
+// GEMMs over (B,T,C) sequences - reference/model/modules/decoder.py:107-271, shufflenetv2.py:42-104.
+//
+// Block = 256 threads = 4 waves (2x2), block tile 64(M) x 64(N) x 32(K); each wave owns a 32x32 tile
+// (one f32x16 accumulator).  A and W tiles are staged through LDS row-major with K contiguous and a
+// +4 float row pad (144-B rows: ds_read_b128 conflict-free).  Operand fetch uses a K permutation so one
+// ds_read_b128 per operand feeds four MFMAs: within an 8-deep chunk, lane group g = lane>>5 holds
+// k = 8c + 4g + e (e = 0..3) and MFMA e consumes element e of both operands.
+// Global loads of tile t+1 are issued before the MFMAs of tile t (register prefetch).
+#include "l2s_common.h"
+
+namespace l2s {
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4;
+
+__device__ __forceinline__ float apply_act(float v, int act, const float* actw, int col) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_PSINE) return sinf(v) * actw[col];
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ float4 load_a(const GemmP& p, const float* rowbase, bool rowvalid, int tbase, int k) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!rowvalid) return r;
+    if (VEC == 4) {
+        if (k >= p.K) return r;
+        int tap = 0, ci = k;
+        if (p.taps > 1) { tap = k / p.Cin; ci = k - tap * p.Cin; }
+        int tin = tbase + tap;
+        if (tin < 0 || tin >= p.Tin) return r;
+        int col = ci + (ci >= p.a_split ? p.a_gap : 0);
+        return *reinterpret_cast<const float4*>(rowbase + (int64_t)tin * p.lda + col);
+    } else {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int kk = k + e;
+            v[e] = 0.f;
+            if (kk < p.K) {
+                int tap = 0, ci = kk;
+                if (p.taps > 1) { tap = kk / p.Cin; ci = kk - tap * p.Cin; }
+                int tin = tbase + tap;
+                if (tin >= 0 && tin < p.Tin) {
+                    int col = ci + (ci >= p.a_split ? p.a_gap : 0);
+                    v[e] = rowbase[(int64_t)tin * p.lda + col];
+                }
+            }
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ float4 load_w(const GemmP& p, const float* wrow, bool valid, int k) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!valid) return r;
+    if (VEC == 4) {
+        if (k >= p.K) return r;
+        return *reinterpret_cast<const float4*>(wrow + k);
+    } else {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? wrow[k + e] : 0.f;
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
+    const GemmP& p = batch.p[blockIdx.z];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= p.M || n0 >= p.N) return;
+
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lr = tid >> 3, kq = (tid & 7) * 4;
+
+    // per-thread row descriptors for the two A rows and two W rows this thread stages
+    const float* arow[2];
+    bool avalid[2];
+    int atbase[2];
+    const float* wrow[2];
+    bool wvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int m = m0 + lr + 32 * j;
+        avalid[j] = m < p.M;
+        int mm = avalid[j] ? m : 0;
+        int b = mm / p.Tout, t = mm - b * p.Tout;
+        atbase[j] = t * p.stride - p.pad;
+        arow[j] = p.A + (int64_t)b * p.Tin * p.lda;
+        int n = n0 + lr + 32 * j;
+        wvalid[j] = n < p.N;
+        wrow[j] = p.W + (int64_t)(wvalid[j] ? n : 0) * p.K;
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lg = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ra[j] = load_a<VEC>(p, arow[j], avalid[j], atbase[j], kq);
+        rb[j] = load_w<VEC>(p, wrow[j], wvalid[j], kq);
+    }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&As[(lr + 32 * j) * LDS_LD + kq]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[(lr + 32 * j) * LDS_LD + kq]) = rb[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            const int k = (kt + 1) * BK + kq;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ra[j] = load_a<VEC>(p, arow[j], avalid[j], atbase[j], k);
+                rb[j] = load_w<VEC>(p, wrow[j], wvalid[j], k);
+            }
+        }
+        const float* ap = &As[(wm * 32 + li) * LDS_LD + 4 * lg];
+        const float* bp = &Bs[(wn * 32 + li) * LDS_LD + 4 * lg];
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + li;
+    if (col >= p.N) return;
+    const float sc = p.scale ? p.scale[col] : 1.0f;
+    const float sh = p.shift ? p.shift[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row >= p.M) continue;
+        float v = acc[r] * sc + sh;
+        v = apply_act(v, p.act, p.actw, col);
+        if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];
+        if (p.R2) v += p.R2[(int64_t)(p.r2_div ? row / p.r2_div : (p.r2_mod ? row % p.r2_mod : row)) * p.ldr2 + col];
+        if (p.c_tr_T > 0) {
+            const int b = row / p.c_tr_T, t = row - b * p.c_tr_T;
+            p.C[((int64_t)b * p.N + col) * p.c_tr_T + t] = v;
+        } else {
+            p.C[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
+        }
+    }
+}
+
+GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K) {
+    GemmP p{};
+    p.A = A; p.W = W; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.Tout = M > 0 ? M : 1; p.Tin = p.Tout; p.taps = 1; p.stride = 1; p.pad = 0; p.Cin = K;
+    p.a_split = 1 << 30; p.a_gap = 0;
+    p.act = ACT_NONE;
+    p.ldc = ldc; p.c_cstride = 1; p.c_tr_T = 0;
+    p.vec = 4;
+    return p;
+}
+
+static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
+    L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP, "gemm group size");
+    int maxM = 0, maxN = 0;
+    bool vec4 = true;
+    for (int i = 0; i < b.count; ++i) {
+        const GemmP& p = b.p[i];
+        L2S_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm dims");
+        L2S_REQUIRE(p.taps * p.Cin == p.K, "gemm K = taps*Cin");
+        maxM = p.M > maxM ? p.M : maxM;
+        maxN = p.N > maxN ? p.N : maxN;
+        bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A) &&
+                   aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0);
+        vec4 = vec4 && ok4;
+    }
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
+    ProfScope ps(name, s);
+    if (vec4)
+        hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, b);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, b);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm1(const GemmP& p, hipStream_t s, const char* name) {
+    GemmBatch b{};
+    b.p[0] = p;
+    b.count = 1;
+    return launch_gemm(b, s, name);
+}
+
+}  // namespace l2s

@@ -1,0 +1,1025 @@
+// C-ABI of libl2s_hip.so (include/l2s.h): weight packing, workspace planning and the launch sequences of
+// the visual encoder, decoder prologue, decode loop and post-net.  Host code only orchestrates; all
+// arithmetic is in the kernels of gemm_nt.hip / encoder_kernels.hip / skinny.hip / decoder_kernels.hip.
+#include "../../include/l2s.h"
+#include "l2s_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace l2s {
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ------------------------------------------------------------------------------------------------ profiling
+struct ProfEntry { std::string name; int64_t launches = 0; double total_ms = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+static std::map<std::string, int> g_prof_idx;
+static int g_prof_cur = -1;
+static hipEvent_t g_prof_start;
+
+void prof_begin(const char* name, hipStream_t s) {
+    if (!g_prof_on) return;
+    auto it = g_prof_idx.find(name);
+    int idx;
+    if (it == g_prof_idx.end()) {
+        idx = (int)g_prof.size();
+        g_prof.push_back(ProfEntry{name});
+        g_prof_idx[name] = idx;
+    } else {
+        idx = it->second;
+    }
+    g_prof_cur = idx;
+    (void)hipEventCreate(&g_prof_start);
+    (void)hipEventRecord(g_prof_start, s);
+}
+void prof_end(hipStream_t s) {
+    if (!g_prof_on || g_prof_cur < 0) return;
+    hipEvent_t stop;
+    (void)hipEventCreate(&stop);
+    (void)hipEventRecord(stop, s);
+    g_prof[g_prof_cur].pending.emplace_back(g_prof_start, stop);
+    g_prof[g_prof_cur].launches++;
+    g_prof_cur = -1;
+}
+static void prof_drain() {
+    for (auto& e : g_prof) {
+        for (auto& pr : e.pending) {
+            (void)hipEventSynchronize(pr.second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) e.total_ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        e.pending.clear();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+constexpr int STAGE_CH[4] = {24, 116, 232, 464};
+constexpr int STAGE_REP[3] = {4, 8, 4};
+constexpr int N_UNITS = 16;
+constexpr int LAST_CH = 768;
+constexpr int MH_KS[4] = {1, 3, 7, 11};
+constexpr int CT_KS[4] = {1, 3, 5, 7};
+constexpr int D = 512;          // decoder width
+constexpr int NM = L2S_N_MELS;
+constexpr int VOC = L2S_VOCAB;
+constexpr int VOCP = 504;       // vocabulary padded to a multiple of 4 for float4 operand loads
+constexpr float BN_EPS = 1e-5f;
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int pad16(int b) { return (b + 15) & ~15; }
+
+// ------------------------------------------------------------------------------------------------ model
+struct ConvW { const float* W = nullptr; const float* scale = nullptr; const float* shift = nullptr; const float* actw = nullptr; };
+struct DwW { const float* w9 = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
+struct UnitW {
+    bool stride2 = false;
+    int cin = 0, half = 0;
+    DwW b1_dw; ConvW b1_pw;            // stride-2 units only
+    ConvW pw1; DwW dw; ConvW pw2;      // banch2
+};
+struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; };
+
+struct Weights {
+    FrontendW fe;
+    UnitW unit[N_UNITS];
+    ConvW conv_last;
+    // decoder prologue
+    ConvW resid, enc_site, attn_site, e_c, enc_proj;
+    const float* wih_cat = nullptr; const float* bih_cat = nullptr;     // [4096][1024], [4096]
+    SkW whh[2];                                                         // BiLSTM recurrent weights, permuted rows
+    ConvW mh_branch[2][4], mh_bott[2];                                  // K, V
+    const float* pos = nullptr;                                         // [300][512]
+    ConvW ct_branch[4], ct_bott, ct_k0, ct_k2, ct_fc0, ct_fc2, ct_fc4, ct_emb;
+    // decode step
+    SkW pre1, pre2, q, cq, aproj, lstm0, lstm1, fc;
+    const float* stop_tail = nullptr; const float* stop_bias = nullptr;
+    const float* bos = nullptr; const float* tau = nullptr; const float* tau_c = nullptr;
+    // postnet
+    ConvW post[5];
+};
+
+}  // namespace l2s
+
+struct l2s_model {
+    std::unordered_map<std::string, std::vector<float>> host;
+    float* blob = nullptr;
+    int64_t blob_floats = 0;
+    bool finalized = false;
+    bool has_enc = false, has_dec = false;
+    l2s::Weights w;
+};
+
+namespace l2s {
+
+// host-side blob builder: every sub-array 64-float (256 B) aligned
+struct Blob {
+    std::vector<float> data;
+    int64_t alloc(int64_t n) {
+        int64_t off = align_up((int64_t)data.size(), 64);
+        data.resize(off + n, 0.f);
+        return off;
+    }
+};
+
+struct Packer {
+    l2s_model* m;
+    Blob blob;
+    std::vector<std::pair<const float**, int64_t>> fixups;   // pointer slots to patch once the device address is known
+    std::string missing;
+
+    const std::vector<float>* get(const std::string& key, int64_t numel) {
+        auto it = m->host.find(key);
+        if (it == m->host.end()) { if (missing.empty()) missing = "missing tensor " + key; return nullptr; }
+        if ((int64_t)it->second.size() != numel) {
+            if (missing.empty()) missing = "tensor " + key + " has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(numel);
+            return nullptr;
+        }
+        return &it->second;
+    }
+    void bind(const float** slot, int64_t off) { fixups.emplace_back(slot, off); }
+
+    // BatchNorm (eval) as scale/shift, optionally absorbing a conv bias: v = (acc + b - mu) * s + beta
+    void bn(const std::string& p, int c, const std::vector<float>* bias, const float** scale, const float** shift) {
+        auto g = get(p + ".weight", c), b = get(p + ".bias", c), mu = get(p + ".running_mean", c), var = get(p + ".running_var", c);
+        if (!g || !b || !mu || !var) return;
+        int64_t so = blob.alloc(c), ho = blob.alloc(c);
+        for (int i = 0; i < c; ++i) {
+            float s = (*g)[i] / std::sqrt((*var)[i] + BN_EPS);
+            float cb = bias ? (*bias)[i] : 0.f;
+            blob.data[so + i] = s;
+            blob.data[ho + i] = (cb - (*mu)[i]) * s + (*b)[i];
+        }
+        bind(scale, so);
+        bind(shift, ho);
+    }
+    void copy(const std::string& key, int64_t n, const float** slot) {
+        auto v = get(key, n);
+        if (!v) return;
+        int64_t o = blob.alloc(n);
+        std::memcpy(&blob.data[o], v->data(), n * sizeof(float));
+        bind(slot, o);
+    }
+    // Conv1d weight (co, ci, k) -> [co][k*ci] (tap-major K)
+    void conv1d_w(const std::string& key, int co, int ci, int k, const float** slot) {
+        auto v = get(key, (int64_t)co * ci * k);
+        if (!v) return;
+        int64_t o = blob.alloc((int64_t)co * ci * k);
+        for (int n = 0; n < co; ++n)
+            for (int c = 0; c < ci; ++c)
+                for (int t = 0; t < k; ++t) blob.data[o + ((int64_t)n * k + t) * ci + c] = (*v)[((int64_t)n * ci + c) * k + t];
+        bind(slot, o);
+    }
+    // depthwise (c,1,3,3) -> [9][c]
+    void dw_w(const std::string& key, int c, const float** slot) {
+        auto v = get(key, (int64_t)c * 9);
+        if (!v) return;
+        int64_t o = blob.alloc((int64_t)c * 9);
+        for (int ch = 0; ch < c; ++ch)
+            for (int t = 0; t < 9; ++t) blob.data[o + (int64_t)t * c + ch] = (*v)[(int64_t)ch * 9 + t];
+        bind(slot, o);
+    }
+    // frag16 packing of rows[n] (each K long) of a virtual [Npad][K] matrix; row_of(n) returns nullptr for zero rows
+    template <typename RowFn>
+    void frag16(int Npad, int K, RowFn row_of, const float** slot) {
+        int64_t o = blob.alloc((int64_t)Npad * K);
+        const int NC = K / 16;
+        std::vector<float> row(K);
+        for (int n = 0; n < Npad; ++n) {
+            bool nz = row_of(n, row.data());
+            if (!nz) continue;
+            for (int k = 0; k < K; ++k) {
+                int tile = n >> 4, i = n & 15, c = k >> 4, g = (k >> 2) & 3, e = k & 3;
+                blob.data[o + ((int64_t)(tile * NC + c) * 64 + g * 16 + i) * 4 + e] = row[k];
+            }
+        }
+        bind(slot, o);
+    }
+};
+
+static int lstm_perm_row(int np, int H) {      // packed row (unit-major: 4*unit + gate) -> PyTorch row gate*H + unit
+    int unit = np >> 2, gate = np & 3;
+    return gate * H + unit;
+}
+
+static int pack_model(l2s_model* m, hipStream_t stream) {
+    Packer P{m};
+    m->w = Weights{};
+    Weights& w = m->w;
+    const std::string E = "encoder.", Dk = "decoder.";
+    // The two halves of the path are packed independently so that a VideoExtractor or a Decoder used on its
+    // own (as the reference allows: net.encoder / net.decoder) needs only its own keys.
+    auto has_prefix = [&](const std::string& pre) {
+        for (auto& kv : m->host) if (kv.first.compare(0, pre.size(), pre) == 0) return true;
+        return false;
+    };
+    const bool want_enc = has_prefix(E), want_dec = has_prefix(Dk);
+    if (!want_enc && !want_dec) { set_error("l2s_model_finalize: no encoder.* or decoder.* tensors were set"); return 1; }
+    if (want_enc) {
+
+    // ---- frontend: Conv3d (24,3,5,7,7) -> [slab = ci*5+kt][50][32]
+    {
+        auto v = P.get(E + "frontend3D.0.weight", 24 * 3 * 5 * 49);
+        if (v) {
+            int64_t o = P.blob.alloc(15 * 50 * 32);
+            for (int co = 0; co < 24; ++co)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int kt = 0; kt < 5; ++kt)
+                        for (int tap = 0; tap < 49; ++tap)
+                            P.blob.data[o + ((int64_t)(ci * 5 + kt) * 50 + tap) * 32 + co] = (*v)[(((int64_t)co * 3 + ci) * 5 + kt) * 49 + tap];
+            P.bind(&w.fe.w, o);
+        }
+        P.bn(E + "frontend3D.1", 24, nullptr, &w.fe.scale, &w.fe.shift);
+        P.copy(E + "frontend3D.2.weight", 24, &w.fe.slope);
+    }
+    // ---- ShuffleNet units
+    {
+        int u = 0, cin = STAGE_CH[0];
+        for (int st = 0; st < 3; ++st) {
+            int cout = STAGE_CH[st + 1], half = cout / 2;
+            for (int r = 0; r < STAGE_REP[st]; ++r, ++u) {
+                UnitW& U = w.unit[u];
+                std::string p = E + "trunk.0." + std::to_string(u) + ".";
+                U.stride2 = (r == 0);
+                U.cin = cin;
+                U.half = half;
+                int pw1_in = U.stride2 ? cin : half;
+                if (U.stride2) {
+                    P.dw_w(p + "banch1.0.weight", cin, &U.b1_dw.w9);
+                    P.bn(p + "banch1.1", cin, nullptr, &U.b1_dw.scale, &U.b1_dw.shift);
+                    P.copy(p + "banch1.2.weight", (int64_t)half * cin, &U.b1_pw.W);
+                    P.bn(p + "banch1.3", half, nullptr, &U.b1_pw.scale, &U.b1_pw.shift);
+                }
+                P.copy(p + "banch2.0.weight", (int64_t)half * pw1_in, &U.pw1.W);
+                P.bn(p + "banch2.1", half, nullptr, &U.pw1.scale, &U.pw1.shift);
+                P.dw_w(p + "banch2.3.weight", half, &U.dw.w9);
+                P.bn(p + "banch2.4", half, nullptr, &U.dw.scale, &U.dw.shift);
+                P.copy(p + "banch2.5.weight", (int64_t)half * half, &U.pw2.W);
+                P.bn(p + "banch2.6", half, nullptr, &U.pw2.scale, &U.pw2.shift);
+                cin = cout;
+            }
+        }
+        P.copy(E + "trunk.1.0.weight", (int64_t)LAST_CH * STAGE_CH[3], &w.conv_last.W);
+        P.bn(E + "trunk.1.1", LAST_CH, nullptr, &w.conv_last.scale, &w.conv_last.shift);
+    }
+    }   // want_enc
+    if (want_dec) {
+    // ---- decoder prologue
+    auto linear = [&](const std::string& p, int co, int ci, ConvW& c) {
+        P.copy(p + ".weight", (int64_t)co * ci, &c.W);
+        P.copy(p + ".bias", co, &c.shift);
+    };
+    P.conv1d_w(Dk + "residual_bottleneck.weight", D, 1024, 1, &w.resid.W);
+    P.copy(Dk + "residual_bottleneck.bias", D, &w.resid.shift);
+    linear(Dk + "encoder_site.0.linear_layer", D, 256, w.enc_site);
+    P.copy(Dk + "encoder_site.1.w", D, &w.enc_site.actw);
+    linear(Dk + "attention_site.0.linear_layer", D, 256, w.attn_site);
+    P.copy(Dk + "attention_site.1.w", D, &w.attn_site.actw);
+    linear(Dk + "E_C.linear_layer", D, 1024, w.e_c);
+    linear(Dk + "encoder_proj.linear_layer", D, 1024, w.enc_proj);
+    {   // BiLSTM: input weights of both directions stacked [4096][1024]; b_ih + b_hh folded into the GEMM shift
+        const char* suf[2] = {"l0", "l0_reverse"};
+        int64_t wo = P.blob.alloc((int64_t)4096 * 1024), bo = P.blob.alloc(4096);
+        for (int d = 0; d < 2; ++d) {
+            auto wi = P.get(Dk + "encoder_rnn.weight_ih_" + suf[d], (int64_t)2048 * 1024);
+            auto bi = P.get(Dk + "encoder_rnn.bias_ih_" + suf[d], 2048), bh = P.get(Dk + "encoder_rnn.bias_hh_" + suf[d], 2048);
+            auto wh = P.get(Dk + "encoder_rnn.weight_hh_" + suf[d], (int64_t)2048 * 512);
+            if (!wi || !bi || !bh || !wh) continue;
+            std::memcpy(&P.blob.data[wo + (int64_t)d * 2048 * 1024], wi->data(), sizeof(float) * 2048 * 1024);
+            for (int i = 0; i < 2048; ++i) P.blob.data[bo + d * 2048 + i] = (*bi)[i] + (*bh)[i];
+            P.frag16(2048, 512, [&](int np, float* row) {
+                std::memcpy(row, wh->data() + (int64_t)lstm_perm_row(np, 512) * 512, sizeof(float) * 512);
+                return true;
+            }, &w.whh[d].W);
+            w.whh[d].N = 2048; w.whh[d].K = 512; w.whh[d].tiles = 128;
+        }
+        P.bind(&w.wih_cat, wo);
+        P.bind(&w.bih_cat, bo);
+    }
+    for (int kv = 0; kv < 2; ++kv) {
+        std::string p = Dk + (kv == 0 ? "K" : "V");
+        for (int j = 0; j < 4; ++j) {
+            std::string c = p + ".0.conv." + std::to_string(j);
+            P.conv1d_w(c + ".0.weight", D, D, MH_KS[j], &w.mh_branch[kv][j].W);
+            P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.mh_branch[kv][j].scale, &w.mh_branch[kv][j].shift);
+        }
+        P.conv1d_w(p + ".0.bottleneck.weight", D, 5 * D, 1, &w.mh_bott[kv].W);
+        P.copy(p + ".0.bottleneck.bias", D, &w.mh_bott[kv].shift);
+        P.copy(p + ".1.w", D, &w.mh_bott[kv].actw);
+    }
+    P.copy(Dk + "positional_encodings.pos_table", (int64_t)L2S_MAX_STEPS * D, &w.pos);
+    for (int j = 0; j < 4; ++j) {
+        std::string c = Dk + "content.agg." + std::to_string(j);
+        P.conv1d_w(c + ".0.weight", D, D, CT_KS[j], &w.ct_branch[j].W);
+        P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.ct_branch[j].scale, &w.ct_branch[j].shift);
+    }
+    P.conv1d_w(Dk + "content.bottleneck.weight", 256, 5 * D, 1, &w.ct_bott.W);
+    P.copy(Dk + "content.bottleneck.bias", 256, &w.ct_bott.shift);
+    linear(Dk + "content.K.0", 256, 256, w.ct_k0);
+    linear(Dk + "content.K.2", 256, 256, w.ct_k2);
+    linear(Dk + "content.location_fc.0", 256, 256, w.ct_fc0);
+    linear(Dk + "content.location_fc.2", 256, 256, w.ct_fc2);
+    linear(Dk + "content.location_fc.4", VOC, 256, w.ct_fc4);
+    {   // word_embeddings (501,256) -> transposed, K padded: [256][504]
+        auto v = P.get(Dk + "content.word_embeddings", (int64_t)VOC * 256);
+        if (v) {
+            int64_t o = P.blob.alloc((int64_t)256 * VOCP);
+            for (int n = 0; n < 256; ++n)
+                for (int k = 0; k < VOC; ++k) P.blob.data[o + (int64_t)n * VOCP + k] = (*v)[(int64_t)k * 256 + n];
+            P.bind(&w.ct_emb.W, o);
+        }
+    }
+    // ---- decode-step weights in frag16 layout
+    auto sk_linear = [&](const std::string& wkey, const std::string& bkey, int N, int K, SkW& s) {
+        auto wv = P.get(wkey, (int64_t)N * K);
+        int Np = pad16(N);
+        if (wv)
+            P.frag16(Np, K, [&](int n, float* row) {
+                if (n >= N) return false;
+                std::memcpy(row, wv->data() + (int64_t)n * K, sizeof(float) * K);
+                return true;
+            }, &s.W);
+        auto bv = P.get(bkey, N);
+        if (bv) {
+            int64_t o = P.blob.alloc(Np);
+            std::memcpy(&P.blob.data[o], bv->data(), sizeof(float) * N);
+            P.bind(&s.bias, o);
+        }
+        s.N = N; s.K = K; s.tiles = Np / 16;
+    };
+    sk_linear(Dk + "prenet.0.linear_layer.weight", Dk + "prenet.0.linear_layer.bias", 256, NM, w.pre1);
+    P.copy(Dk + "prenet.1.w", 256, &w.pre1.actw);
+    sk_linear(Dk + "prenet.3.linear_layer.weight", Dk + "prenet.3.linear_layer.bias", 256, 256, w.pre2);
+    P.copy(Dk + "prenet.4.w", 256, &w.pre2.actw);
+    sk_linear(Dk + "Q.0.linear_layer.weight", Dk + "Q.0.linear_layer.bias", D, 1024, w.q);
+    P.copy(Dk + "Q.1.w", D, &w.q.actw);
+    sk_linear(Dk + "content.Q.0.weight", Dk + "content.Q.0.bias", 256, 1024, w.cq);
+    sk_linear(Dk + "attention_proj.linear_layer.weight", Dk + "attention_proj.linear_layer.bias", 256, D, w.aproj);
+    for (int l = 0; l < 2; ++l) {
+        SkW& s = l == 0 ? w.lstm0 : w.lstm1;
+        std::string sl = "l" + std::to_string(l);
+        auto wi = P.get(Dk + "decoder_rnn.weight_ih_" + sl, (int64_t)2048 * 512), wh = P.get(Dk + "decoder_rnn.weight_hh_" + sl, (int64_t)2048 * 512);
+        auto bi = P.get(Dk + "decoder_rnn.bias_ih_" + sl, 2048), bh = P.get(Dk + "decoder_rnn.bias_hh_" + sl, 2048);
+        if (!wi || !wh || !bi || !bh) continue;
+        P.frag16(2048, 1024, [&](int np, float* row) {
+            int r = lstm_perm_row(np, 512);
+            std::memcpy(row, wi->data() + (int64_t)r * 512, sizeof(float) * 512);
+            std::memcpy(row + 512, wh->data() + (int64_t)r * 512, sizeof(float) * 512);
+            return true;
+        }, &s.W);
+        int64_t o = P.blob.alloc(2048);
+        for (int np = 0; np < 2048; ++np) { int r = lstm_perm_row(np, 512); P.blob.data[o + np] = (*bi)[r] + (*bh)[r]; }
+        P.bind(&s.bias, o);
+        s.N = 2048; s.K = 1024; s.tiles = 128;
+    }
+    {   // fc_out (80 rows) + stop-token row over h1 (row 80) in one weight: [96][512]
+        auto wf = P.get(Dk + "fc_out.linear_layer.weight", (int64_t)NM * D), bf = P.get(Dk + "fc_out.linear_layer.bias", NM);
+        auto ws = P.get(Dk + "stop_token_layer.linear_layer.weight", 1024);
+        if (wf && bf && ws) {
+            P.frag16(96, D, [&](int n, float* row) {
+                if (n < NM) std::memcpy(row, wf->data() + (int64_t)n * D, sizeof(float) * D);
+                else if (n == NM) std::memcpy(row, ws->data(), sizeof(float) * D);
+                else return false;
+                return true;
+            }, &w.fc.W);
+            int64_t o = P.blob.alloc(96);
+            std::memcpy(&P.blob.data[o], bf->data(), sizeof(float) * NM);
+            P.bind(&w.fc.bias, o);
+            int64_t t = P.blob.alloc(D);
+            std::memcpy(&P.blob.data[t], ws->data() + D, sizeof(float) * D);
+            P.bind(&w.stop_tail, t);
+        }
+        w.fc.N = NM + 1; w.fc.K = D; w.fc.tiles = 6;
+        P.copy(Dk + "stop_token_layer.linear_layer.bias", 1, &w.stop_bias);
+    }
+    P.copy(Dk + "BOS", NM, &w.bos);
+    P.copy(Dk + "temperature", 1, &w.tau);
+    P.copy(Dk + "content.temperature", 1, &w.tau_c);
+    // ---- postnet
+    for (int i = 0; i < 5; ++i) {
+        int ci = i == 0 ? NM : D, co = i == 4 ? NM : D;
+        std::string c = Dk + "postnet.convolutions." + std::to_string(i);
+        P.conv1d_w(c + ".0.conv.weight", co, ci, 5, &w.post[i].W);
+        P.bn(c + ".1", co, P.get(c + ".0.conv.bias", co), &w.post[i].scale, &w.post[i].shift);
+        if (i < 4) P.copy(Dk + "postnet.sin_activation." + std::to_string(i) + ".w", D, &w.post[i].actw);
+    }
+    }   // want_dec
+    if (!P.missing.empty()) { set_error("l2s_model_finalize: " + P.missing); return 1; }
+
+    // upload and patch pointers
+    if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
+    m->blob_floats = (int64_t)P.blob.data.size();
+    L2S_CHECK_HIP(hipMalloc(&m->blob, m->blob_floats * sizeof(float)));
+    L2S_CHECK_HIP(hipMemcpyAsync(m->blob, P.blob.data.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+    L2S_CHECK_HIP(hipStreamSynchronize(stream));     // the host staging vector dies with this scope
+    for (auto& f : P.fixups) *f.first = m->blob + f.second;
+    m->finalized = true;
+    m->has_enc = want_enc;
+    m->has_dec = want_dec;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct Bump {
+    char* base; int64_t cap; int64_t off = 0; bool overflow = false;
+    Bump(void* p, int64_t c) : base((char*)p), cap(c) {}
+    float* f(int64_t n) {
+        int64_t bytes = align_up(n * (int64_t)sizeof(float), 256);
+        if (off + bytes > cap) { overflow = true; off += bytes; return nullptr; }
+        float* r = (float*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+struct EncPlan {
+    int NF, Hp;
+    int64_t act_a, act_b, t1, t2, last;
+};
+static EncPlan enc_plan(int B, int T, int H) {
+    EncPlan p{};
+    p.NF = B * T;
+    p.Hp = H / 4;
+    int64_t hw = (int64_t)p.Hp * p.Hp;
+    int64_t amax = (int64_t)p.NF * hw * STAGE_CH[0], t1 = 0, t2 = 0;
+    int cin = STAGE_CH[0];
+    int h = p.Hp;
+    for (int st = 0; st < 3; ++st) {
+        int cout = STAGE_CH[st + 1], half = cout / 2;
+        int ho = (h + 1) / 2;
+        int64_t in_px = (int64_t)p.NF * h * h, out_px = (int64_t)p.NF * ho * ho;
+        t1 = std::max(t1, std::max(in_px * half, out_px * half));     // pw1 output (stride-2: input resolution)
+        t2 = std::max(t2, std::max(out_px * cin, out_px * half));     // dw outputs
+        amax = std::max(amax, out_px * cout);
+        cin = cout;
+        h = ho;
+    }
+    p.act_a = amax; p.act_b = amax; p.t1 = t1; p.t2 = t2;
+    p.last = (int64_t)p.NF * h * h * LAST_CH;
+    return p;
+}
+static int64_t enc_ws_floats(int B, int T, int H) {
+    EncPlan p = enc_plan(B, T, H);
+    return p.act_a + p.act_b + p.t1 + p.t2 + p.last + 64 * 8;
+}
+
+static int content_lens(int T, int L[4]) {
+    int m = T;
+    for (int j = 0; j < 4; ++j) {
+        L[j] = (T - CT_KS[j]) / CT_KS[j] + 1;
+        m = std::min(m, L[j]);
+    }
+    return m;
+}
+
+static int64_t prologue_ws_floats(int B, int T) {
+    int L[4];
+    int m = content_lens(T, L);
+    int64_t BT = (int64_t)B * T, n = 0;
+    n += BT * 4096;            // BiLSTM input gates
+    n += BT * 1024;            // rnn_out
+    n += BT * 512;             // residual
+    n += (int64_t)B * 512 * 2; // s_e, s_a
+    n += (int64_t)pad16(B) * 512 * 6;   // h,c frags for both directions (ping-pong h)
+    n += (int64_t)B * 1024;    // cell cat
+    n += BT * 4608;            // cat buffer [x | K branches | V branches]
+    for (int j = 0; j < 4; ++j) n += (int64_t)B * L[j] * 512;
+    n += (int64_t)B * m * 2560;
+    n += (int64_t)B * m * 256 * 4;
+    n += (int64_t)B * m * (VOC + VOCP);
+    return n + 64 * 40;
+}
+static int64_t decode_ws_floats(int B) {
+    int64_t Bp = pad16(B);
+    return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
+}
+static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 2 + 64 * 4; }
+
+struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, total; int m; };
+static StateLayout state_layout(int B, int T) {
+    StateLayout s{};
+    int L[4];
+    s.m = content_lens(T, L);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
+    s.k = take((int64_t)B * T * 512);
+    s.v = take((int64_t)B * T * 512);
+    s.ckey = take((int64_t)B * s.m * 256);
+    s.cval = take((int64_t)B * s.m * 256);
+    s.ecell = take((int64_t)B * 512);
+    s.h = take((int64_t)pad16(B) * 512 * 2);
+    s.c = take((int64_t)pad16(B) * 512 * 2);
+    s.enc = take((int64_t)B * T * 512);
+    s.stopc = take(B);
+    s.total = o;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
+                     int64_t M, int N, int K, int act) {
+    GemmP p = gemm_plain(A + a_off, lda, c.W, C + c_off, ldc, (int)M, N, K);
+    p.scale = c.scale; p.shift = c.shift; p.actw = c.actw; p.act = act; p.c_cstride = cstride;
+    return p;
+}
+
+static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, int W, const float* emb, float* vis,
+                       float* feat, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    EncPlan pl = enc_plan(B, T, H);
+    Bump bp(ws, ws_bytes);
+    float* a = bp.f(pl.act_a); float* b = bp.f(pl.act_b); float* t1 = bp.f(pl.t1); float* t2 = bp.f(pl.t2); float* last = bp.f(pl.last);
+    L2S_REQUIRE(!bp.overflow, "encoder workspace too small");
+    if (launch_frontend(w.fe, video, B, T, H, W, a, s)) return 1;
+    float* x = a; float* y = b;
+    int h = pl.Hp;
+    const int NF = pl.NF;
+    for (int u = 0; u < N_UNITS; ++u) {
+        const UnitW& U = w.unit[u];
+        const int half = U.half, cout = 2 * half;
+        if (U.stride2) {
+            const int cin = U.cin, ho = (h + 1) / 2;
+            const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
+            // banch1: dw s2 (+BN) -> pw (+BN+ReLU) -> even output channels
+            if (launch_dwconv(x, NF, h, h, cin, 0, cin, 2, U.b1_dw.w9, U.b1_dw.scale, U.b1_dw.shift, t2, cin, 0, s)) return 1;
+            if (launch_gemm1(pw_gemm(t2, cin, 0, U.b1_pw, y, cout, 0, 2, out_px, half, cin, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
+            // banch2: pw -> dw s2 -> pw -> odd output channels
+            if (launch_gemm1(pw_gemm(x, cin, 0, U.pw1, t1, half, 0, 1, in_px, half, cin, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
+            if (launch_dwconv(t1, NF, h, h, half, 0, half, 2, U.dw.w9, U.dw.scale, U.dw.shift, t2, half, 0, s)) return 1;
+            if (launch_gemm1(pw_gemm(t2, half, 0, U.pw2, y, cout, 1, 2, out_px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
+            h = ho;
+        } else {
+            const int64_t px = (int64_t)NF * h * h;
+            if (launch_copy_cols(x, cout, 0, y, cout, 0, 2, px, half, s)) return 1;
+            if (launch_gemm1(pw_gemm(x, cout, half, U.pw1, t1, half, 0, 1, px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
+            if (launch_dwconv(t1, NF, h, h, half, 0, half, 1, U.dw.w9, U.dw.scale, U.dw.shift, t2, half, 0, s)) return 1;
+            if (launch_gemm1(pw_gemm(t2, half, 0, U.pw2, y, cout, 1, 2, px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
+        }
+        std::swap(x, y);
+    }
+    const int64_t px = (int64_t)NF * h * h;
+    if (launch_gemm1(pw_gemm(x, STAGE_CH[3], 0, w.conv_last, last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3], ACT_RELU), s, "conv_last_gemm")) return 1;
+    if (launch_pool_norm_cat(last, NF, h * h, LAST_CH, emb, L2S_D_EMB, T, vis, L2S_D_VIS, feat, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder prologue
+static GemmP conv_gemm(const float* X, int lda, int B, int Tin, int Cin, const ConvW& c, int Cout, int taps, int stride, int pad,
+                       float* out, int ldc, int act) {
+    const int Tout = (Tin + 2 * pad - taps) / stride + 1;
+    GemmP p = gemm_plain(X, lda, c.W, out, ldc, B * Tout, Cout, taps * Cin);
+    p.Tout = Tout; p.Tin = Tin; p.taps = taps; p.stride = stride; p.pad = pad; p.Cin = Cin;
+    p.scale = c.scale; p.shift = c.shift; p.actw = c.actw; p.act = act;
+    return p;
+}
+
+static SkinnyP sk_base(const SkW& sw, int B) {
+    SkinnyP p{};
+    p.W = sw.W; p.bias = sw.bias; p.actw = sw.actw;
+    p.B = B; p.N = sw.N; p.K = sw.K;
+    p.act = ACT_NONE; p.epi = SK_PLAIN;
+    return p;
+}
+
+static int prologue_run(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T,
+                        float* state, float* content_dis, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    int L[4];
+    const int mT = content_lens(T, L);
+    L2S_REQUIRE(T >= 7 && T <= L2S_MAX_STEPS, "T must be in [7, 300] (Content.agg stride-7 branch; positional table)");
+    const int BT = B * T, Bp = pad16(B);
+    Bump bp(ws, ws_bytes);
+    float* gin = bp.f((int64_t)BT * 4096);
+    float* rnn = bp.f((int64_t)BT * 1024);
+    float* resid = bp.f((int64_t)BT * 512);
+    float* s_e = bp.f((int64_t)B * 512);
+    float* s_a = bp.f((int64_t)B * 512);
+    float* hf[2][2]; float* cf[2];
+    for (int d = 0; d < 2; ++d) { hf[d][0] = bp.f((int64_t)Bp * 512); hf[d][1] = bp.f((int64_t)Bp * 512); cf[d] = bp.f((int64_t)Bp * 512); }
+    float* cellcat = bp.f((int64_t)B * 1024);
+    float* cat = bp.f((int64_t)BT * 4608);
+    float* cmap[4];
+    for (int j = 0; j < 4; ++j) cmap[j] = bp.f((int64_t)B * L[j] * 512);
+    float* pooled = bp.f((int64_t)B * mT * 2560);
+    float* wv = bp.f((int64_t)B * mT * 256);
+    float* tA = bp.f((int64_t)B * mT * 256);
+    float* tB = bp.f((int64_t)B * mT * 256);
+    float* tC = bp.f((int64_t)B * mT * 256);
+    float* logits = bp.f((int64_t)B * mT * VOC);
+    float* z = bp.f((int64_t)B * mT * VOCP);
+    L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
+
+    // residual_bottleneck, site embeddings
+    {
+        GemmP p = gemm_plain(vis, 1024, w.resid.W, resid, 512, BT, 512, 1024);
+        p.shift = w.resid.shift;
+        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        GemmBatch gb{};
+        gb.p[0] = gemm_plain(emb, 256, w.enc_site.W, s_e, 512, B, 512, 256);
+        gb.p[0].shift = w.enc_site.shift; gb.p[0].act = ACT_PSINE; gb.p[0].actw = w.enc_site.actw;
+        gb.p[1] = gemm_plain(emb, 256, w.attn_site.W, s_a, 512, B, 512, 256);
+        gb.p[1].shift = w.attn_site.shift; gb.p[1].act = ACT_PSINE; gb.p[1].actw = w.attn_site.actw;
+        gb.count = 2;
+        if (launch_gemm(gb, s, "prologue_gemm")) return 1;
+    }
+    // BiLSTM input gates for both directions: (B*T,1024) x (1024,4096)
+    {
+        GemmP p = gemm_plain(vis, 1024, w.wih_cat, gin, 4096, BT, 4096, 1024);
+        p.shift = w.bih_cat;
+        if (launch_gemm1(p, s, "bilstm_input_gemm")) return 1;
+    }
+    // recurrence: h0 = c0 = s_e for both directions (decoder.py:386-389)
+    for (int d = 0; d < 2; ++d) {
+        if (launch_to_frag(s_e, 512, B, 512, hf[d][0], 512, 0, 0, s)) return 1;
+        if (launch_to_frag(s_e, 512, B, 512, cf[d], 512, 0, 0, s)) return 1;
+        if (launch_fill(hf[d][1], (int64_t)Bp * 512, 0.f, s)) return 1;
+    }
+    for (int step = 0; step < T; ++step) {
+        SkinnyBatch sb{};
+        const int cur = step & 1, nxt = cur ^ 1;
+        for (int d = 0; d < 2; ++d) {
+            const int t = d == 0 ? step : T - 1 - step;
+            SkinnyP p = sk_base(w.whh[d], B);
+            p.seg[0] = {hf[d][cur], 32}; p.nseg = 1;
+            p.epi = SK_LSTM; p.H = 512;
+            p.pre = gin + (int64_t)t * 4096 + d * 2048; p.ld_pre = (int64_t)T * 4096;
+            p.c_in = cf[d]; p.c_out = cf[d];
+            p.h_out = hf[d][nxt]; p.h_out_K = 512; p.h_out_off = 0;
+            p.h_seq = rnn + (int64_t)t * 1024 + d * 512; p.ld_hseq = (int64_t)T * 1024;
+            sb.p[d] = p; sb.ntiles[d] = w.whh[d].tiles;
+        }
+        sb.count = 2;
+        if (launch_skinny(sb, s, "bilstm_step")) return 1;
+    }
+    const int fin = T & 1;     // buffer holding the final hidden states
+    // decoder initial hidden = BiLSTM finals (fwd -> layer 0, bwd -> layer 1); kept in the state buffer as frag16
+    L2S_CHECK_HIP(hipMemcpyAsync(state + sl.h, hf[0][fin], sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(state + sl.h + (int64_t)Bp * 512, hf[1][fin], sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    // encoder_cell = E_C(cat(c_fwd, c_bwd))
+    if (launch_from_frag(cf[0], 512, B, 512, cellcat, 1024, 0, s)) return 1;
+    if (launch_from_frag(cf[1], 512, B, 512, cellcat, 1024, 512, s)) return 1;
+    {
+        GemmP p = gemm_plain(cellcat, 1024, w.e_c.W, state + sl.ecell, 512, B, 512, 1024);
+        p.shift = w.e_c.shift;
+        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        if (launch_stop_const(state + sl.ecell, w.stop_tail, w.stop_bias, B, state + sl.stopc, s)) return 1;
+    }
+    // enc = encoder_proj(rnn_out) + s_a (broadcast over T) + residual  -> cat[:, 0:512] and the state
+    {
+        GemmP p = gemm_plain(rnn, 1024, w.enc_proj.W, cat, 4608, BT, 512, 1024);
+        p.shift = w.enc_proj.shift;
+        p.R1 = resid; p.ldr1 = 512; p.r1_mod = 0;
+        p.R2 = s_a; p.ldr2 = 512; p.r2_div = T;     // attention_site embedding, broadcast over the T frames of a clip
+        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        if (launch_copy_cols(cat, 4608, 0, state + sl.enc, 512, 0, 1, BT, 512, s)) return 1;
+    }
+    // MultiHopConv branches of K and V (8 convs, one grouped launch), then the two bottlenecks (+PSine +pos)
+    {
+        GemmBatch gb{};
+        for (int kv = 0; kv < 2; ++kv)
+            for (int j = 0; j < 4; ++j) {
+                GemmP p = conv_gemm(cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2,
+                                    cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU);
+                gb.p[kv * 4 + j] = p;
+            }
+        gb.count = 8;
+        if (launch_gemm(gb, s, "multihop_conv_gemm")) return 1;
+        GemmBatch bb{};
+        for (int kv = 0; kv < 2; ++kv) {
+            GemmP p = gemm_plain(cat, 4608, w.mh_bott[kv].W, state + (kv == 0 ? sl.k : sl.v), 512, BT, 512, 2560);
+            if (kv == 1) { p.a_split = 512; p.a_gap = 2048; }     // V reads [x | V branches]
+            p.shift = w.mh_bott[kv].shift; p.act = ACT_PSINE; p.actw = w.mh_bott[kv].actw;
+            p.R1 = w.pos; p.ldr1 = 512; p.r1_mod = T;             // + pos_table[t]
+            bb.p[kv] = p;
+        }
+        bb.count = 2;
+        if (launch_gemm(bb, s, "multihop_bottleneck_gemm")) return 1;
+    }
+    // Content.encode (decoder.py:239-260)
+    {
+        GemmBatch gb{};
+        for (int j = 0; j < 4; ++j)
+            gb.p[j] = conv_gemm(cat, 4608, B, T, 512, w.ct_branch[j], 512, CT_KS[j], CT_KS[j], 0, cmap[j], 512, ACT_SILU);
+        gb.count = 4;
+        if (launch_gemm(gb, s, "content_agg_gemm")) return 1;
+        PoolCatP pc{};
+        pc.x[0] = cat; pc.L[0] = T; pc.ld[0] = 4608;
+        for (int j = 0; j < 4; ++j) { pc.x[j + 1] = cmap[j]; pc.L[j + 1] = L[j]; pc.ld[j + 1] = 512; }
+        pc.nmaps = 5; pc.B = B; pc.m = mT; pc.C = 512; pc.out = pooled;
+        if (launch_pool_cat(pc, s)) return 1;
+        const int R = B * mT;
+        GemmP p = gemm_plain(pooled, 2560, w.ct_bott.W, wv, 256, R, 256, 2560);
+        p.shift = w.ct_bott.shift;
+        if (launch_gemm1(p, s, "content_gemm")) return 1;
+        GemmBatch g1{};
+        g1.p[0] = gemm_plain(wv, 256, w.ct_k0.W, tA, 256, R, 256, 256); g1.p[0].shift = w.ct_k0.shift; g1.p[0].act = ACT_SILU;
+        g1.p[1] = gemm_plain(wv, 256, w.ct_fc0.W, tB, 256, R, 256, 256); g1.p[1].shift = w.ct_fc0.shift; g1.p[1].act = ACT_SILU;
+        g1.count = 2;
+        if (launch_gemm(g1, s, "content_gemm")) return 1;
+        GemmBatch g2{};
+        g2.p[0] = gemm_plain(tA, 256, w.ct_k2.W, state + sl.ckey, 256, R, 256, 256); g2.p[0].shift = w.ct_k2.shift; g2.p[0].act = ACT_SILU;
+        g2.p[1] = gemm_plain(tB, 256, w.ct_fc2.W, tC, 256, R, 256, 256); g2.p[1].shift = w.ct_fc2.shift; g2.p[1].act = ACT_SILU;
+        g2.count = 2;
+        if (launch_gemm(g2, s, "content_gemm")) return 1;
+        GemmP p3 = gemm_plain(tC, 256, w.ct_fc4.W, logits, VOC, R, VOC, 256);
+        p3.shift = w.ct_fc4.shift; p3.act = ACT_SILU;
+        if (launch_gemm1(p3, s, "content_gemm")) return 1;
+        if (launch_gumbel_softmax(logits, gumbel, R, VOC, 0.1f, z, VOCP, content_dis, s)) return 1;
+        GemmP p4 = gemm_plain(z, VOCP, w.ct_emb.W, state + sl.cval, 256, R, 256, VOCP);
+        if (launch_gemm1(p4, s, "content_gemm")) return 1;
+    }
+    // decoder cell state starts at zero (decoder.py:406)
+    if (launch_fill(state + sl.c, (int64_t)Bp * 512 * 2, 0.f, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ decode loop
+static int decode_run(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
+                      float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
+    const int Bp = pad16(B);
+    Bump bp(ws, ws_bytes);
+    float* h0[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* h1[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* c0 = bp.f((int64_t)Bp * 512);
+    float* c1 = bp.f((int64_t)Bp * 512);
+    float* av = bp.f((int64_t)Bp * 512);
+    float* p1 = bp.f((int64_t)Bp * 256);
+    float* cc = bp.f((int64_t)Bp * 256);
+    float* uu = bp.f((int64_t)Bp * 256);
+    float* yf = bp.f((int64_t)Bp * 96);
+    float* q = bp.f((int64_t)B * 512);
+    float* qc = bp.f((int64_t)B * 256);
+    float* p2 = bp.f((int64_t)B * 256);
+    L2S_REQUIRE(!bp.overflow, "decode workspace too small");
+
+    // initial state: h from the prologue, c = 0, y = BOS; padded rows of every frag buffer zero
+    L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    if (launch_fill(h0[1], (int64_t)Bp * 512, 0.f, s)) return 1;
+    if (launch_fill(h1[1], (int64_t)Bp * 512, 0.f, s)) return 1;
+    if (launch_fill(c0, (int64_t)Bp * 512, 0.f, s)) return 1;
+    if (launch_fill(c1, (int64_t)Bp * 512, 0.f, s)) return 1;
+    if (launch_fill(av, (int64_t)Bp * 512, 0.f, s)) return 1;
+    if (launch_fill(p1, (int64_t)Bp * 256, 0.f, s)) return 1;
+    if (launch_fill(cc, (int64_t)Bp * 256, 0.f, s)) return 1;
+    if (launch_fill(uu, (int64_t)Bp * 256, 0.f, s)) return 1;
+    if (launch_to_frag(w.bos, 0, B, 80, yf, 80, 0, 1, s)) return 1;
+
+    for (int i = 0; i < S; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        if (teacher && teacher_mask && teacher_mask[i])
+            if (launch_to_frag(teacher + (int64_t)i * NM, S * NM, B, 80, yf, 80, 0, 0, s)) return 1;
+        {   // phase A: prenet layer 1, Q (+PSine +pos[i]), content Q (+SiLU)
+            SkinnyBatch sb{};
+            SkinnyP a = sk_base(w.pre1, B);
+            a.seg[0] = {yf, 5}; a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
+            SkinnyP b = sk_base(w.q, B);
+            b.seg[0] = {h0[cur], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2; b.act = ACT_PSINE; b.epi = SK_PLAIN; b.out = q; b.ldo = 512;
+            b.addrow = w.pos + (int64_t)i * 512;
+            SkinnyP c = sk_base(w.cq, B);
+            c.seg[0] = {c0, 32}; c.seg[1] = {c1, 32}; c.nseg = 2; c.act = ACT_SILU; c.epi = SK_PLAIN; c.out = qc; c.ldo = 256;
+            sb.p[0] = a; sb.ntiles[0] = w.pre1.tiles;
+            sb.p[1] = b; sb.ntiles[1] = w.q.tiles;
+            sb.p[2] = c; sb.ntiles[2] = w.cq.tiles;
+            sb.count = 3;
+            if (launch_skinny(sb, s, "step_prenet1_q_cq")) return 1;
+        }
+        {   // phase B: attention + content attention per batch row; prenet layer 2
+            AttnP at{};
+            at.q = q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = av;
+            at.attn_out = attn ? attn + (int64_t)i * T : nullptr; at.ld_attn_b = (int64_t)S * T; at.attn_logits = attn_logits;
+            at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
+            at.B = B; at.T = T; at.m = sl.m;
+            SkinnyP pr = sk_base(w.pre2, B);
+            pr.seg[0] = {p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE; pr.epi = SK_PLAIN; pr.out = p2; pr.ldo = 256;
+            if (launch_step_attn(at, pr, w.pre2.tiles, s)) return 1;
+        }
+        {   // phase C: u = prenet + attention_proj(a @ v)
+            SkinnyBatch sb{};
+            SkinnyP a = sk_base(w.aproj, B);
+            a.seg[0] = {av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = uu; a.ldo = 256; a.add = p2; a.ld_add = 256;
+            sb.p[0] = a; sb.ntiles[0] = w.aproj.tiles; sb.count = 1;
+            if (launch_skinny(sb, s, "step_attention_proj")) return 1;
+        }
+        {   // phase D: LSTM layer 0 on cat(content, u), h0
+            SkinnyBatch sb{};
+            SkinnyP a = sk_base(w.lstm0, B);
+            a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3;
+            a.epi = SK_LSTM; a.H = 512; a.c_in = c0; a.c_out = c0; a.h_out = h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+            sb.p[0] = a; sb.ntiles[0] = w.lstm0.tiles; sb.count = 1;
+            if (launch_skinny(sb, s, "step_lstm0")) return 1;
+        }
+        {   // phase E: LSTM layer 1 on the new h0
+            SkinnyBatch sb{};
+            SkinnyP a = sk_base(w.lstm1, B);
+            a.seg[0] = {h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2;
+            a.epi = SK_LSTM; a.H = 512; a.c_in = c1; a.c_out = c1; a.h_out = h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+            sb.p[0] = a; sb.ntiles[0] = w.lstm1.tiles; sb.count = 1;
+            if (launch_skinny(sb, s, "step_lstm1")) return 1;
+        }
+        {   // phase F: mel frame + stop logit
+            SkinnyBatch sb{};
+            SkinnyP a = sk_base(w.fc, B);
+            a.seg[0] = {h1[nxt], 32}; a.nseg = 1; a.epi = SK_MEL;
+            a.mel = mel + (int64_t)i * NM; a.ld_mel_b = (int64_t)S * NM;
+            a.stop = stop + i; a.ld_stop_b = S; a.stop_const = state + sl.stopc; a.yfrag = yf;
+            sb.p[0] = a; sb.ntiles[0] = w.fc.tiles; sb.count = 1;
+            if (launch_skinny(sb, s, "step_fc_out_stop")) return 1;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ postnet
+static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    Bump bp(ws, ws_bytes);
+    float* xa = bp.f((int64_t)B * S * 512);
+    float* xb = bp.f((int64_t)B * S * 512);
+    L2S_REQUIRE(!bp.overflow, "postnet workspace too small");
+    GemmP p0 = conv_gemm(mel, NM, B, S, NM, w.post[0], 512, 5, 1, 2, xa, 512, ACT_PSINE);
+    if (launch_gemm1(p0, s, "postnet_conv_gemm")) return 1;
+    float* x = xa; float* y = xb;
+    for (int i = 1; i < 4; ++i) {
+        GemmP p = conv_gemm(x, 512, B, S, 512, w.post[i], 512, 5, 1, 2, y, 512, ACT_PSINE);
+        p.R1 = x; p.ldr1 = 512; p.r1_mod = 0;
+        if (launch_gemm1(p, s, "postnet_conv_gemm")) return 1;
+        std::swap(x, y);
+    }
+    GemmP p4 = conv_gemm(x, 512, B, S, 512, w.post[4], NM, 5, 1, 2, mel_post, NM, ACT_NONE);
+    p4.R1 = mel; p4.ldr1 = NM; p4.r1_mod = 0;
+    p4.c_tr_T = S;
+    if (launch_gemm1(p4, s, "postnet_conv_gemm")) return 1;
+    if (mel_cf && launch_transpose_bsc(mel, B, S, NM, mel_cf, s)) return 1;
+    return 0;
+}
+
+}  // namespace l2s
+
+// ================================================================================================ C ABI
+using namespace l2s;
+
+extern "C" {
+
+int l2s_abi_version(void) { return 1; }
+const char* l2s_last_error(void) { return g_err.c_str(); }
+
+int l2s_model_create(l2s_model** out) {
+    L2S_REQUIRE(out != nullptr, "null out pointer");
+    *out = new l2s_model();
+    return 0;
+}
+int l2s_model_set_tensor(l2s_model* m, const char* key, const float* host_data, int64_t numel) {
+    L2S_REQUIRE(m && key && host_data && numel >= 0, "bad arguments");
+    m->host[key].assign(host_data, host_data + numel);
+    m->finalized = false;
+    return 0;
+}
+int l2s_model_finalize(l2s_model* m, void* stream) {
+    L2S_REQUIRE(m != nullptr, "null model");
+    int rc = pack_model(m, (hipStream_t)stream);
+    if (rc == 0) m->host.clear();
+    return rc;
+}
+int l2s_model_destroy(l2s_model* m) {
+    if (!m) return 0;
+    if (m->blob) (void)hipFree(m->blob);
+    delete m;
+    return 0;
+}
+
+int l2s_min_T(int T) { int L[4]; return content_lens(T, L); }
+
+int64_t l2s_workspace_bytes(int B, int T, int H, int W, int S) {
+    (void)W;
+    int64_t enc = enc_ws_floats(B, T, H), pro = prologue_ws_floats(B, T), dec = decode_ws_floats(B), post = postnet_ws_floats(B, S);
+    int64_t io = (int64_t)B * T * 1024 + l2s_state_floats(B, T) + (int64_t)B * S * (NM + 1) + 64 * 8;   // l2s_inference intermediates
+    int64_t mx = std::max(std::max(enc, pro), std::max(dec, post));
+    return (mx + io) * (int64_t)sizeof(float) + (1 << 16);
+}
+int64_t l2s_state_floats(int B, int T) { return state_layout(B, T).total; }
+int64_t l2s_state_offset(int B, int T, int field) {
+    StateLayout s = state_layout(B, T);
+    switch (field) {
+        case L2S_ST_K: return s.k;
+        case L2S_ST_V: return s.v;
+        case L2S_ST_CKEY: return s.ckey;
+        case L2S_ST_CVAL: return s.cval;
+        case L2S_ST_ECELL: return s.ecell;
+        case L2S_ST_H: return s.h;
+        case L2S_ST_C: return s.c;
+        case L2S_ST_ENC: return s.enc;
+        case L2S_ST_STOPC: return s.stopc;
+    }
+    return -1;
+}
+
+#define L2S_MODEL_READY(m) L2S_REQUIRE((m) && (m)->finalized, "model not finalized (call l2s_model_finalize)")
+#define L2S_ENC_READY(m) L2S_MODEL_READY(m); L2S_REQUIRE((m)->has_enc, "model holds no encoder.* weights")
+#define L2S_DEC_READY(m) L2S_MODEL_READY(m); L2S_REQUIRE((m)->has_dec, "model holds no decoder.* weights")
+
+int l2s_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W, float* feat, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_REQUIRE(video && feat && ws && B > 0 && T > 0, "bad arguments");
+    return encoder_run(m, video, B, T, H, W, nullptr, nullptr, feat, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_build_visual(const float* feat, const float* emb, int B, int T, float* vis, void* stream) {
+    L2S_REQUIRE(feat && emb && vis && B > 0 && T > 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_copy_cols(feat, L2S_D_FEAT, 0, vis, L2S_D_VIS, 0, 1, (int64_t)B * T, L2S_D_FEAT, s)) return 1;
+    return launch_tile_rows(emb, L2S_D_EMB, vis + L2S_D_FEAT, L2S_D_VIS, B, T, L2S_D_EMB, s);
+}
+
+int l2s_decoder_prologue(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T, float* state,
+                         float* content_dis, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(vis && emb && gumbel && state && ws && B > 0, "bad arguments");
+    return prologue_run(m, vis, emb, gumbel, B, T, state, content_dis, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_decode_steps(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask, float* mel,
+                     float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(state && mel && stop && ws && B > 0, "bad arguments");
+    return decode_run(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_postnet(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(mel && mel_post && ws && B > 0 && S > 0, "bad arguments");
+    return postnet_run(m, mel, B, S, mel_post, mel_cf, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* stream) {
+    L2S_REQUIRE(stop && lengths && B > 0 && S > 0, "bad arguments");
+    return launch_output_lengths(stop, B, S, lengths, (hipStream_t)stream);
+}
+
+int l2s_inference(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                  float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(video && emb && gumbel && mel_post && lengths && ws, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    Bump bp(ws, ws_bytes);
+    float* vis = bp.f((int64_t)B * T * 1024);
+    float* state = bp.f(l2s_state_floats(B, T));
+    float* mel = bp.f((int64_t)B * S * NM);
+    float* stop = bp.f((int64_t)B * S);
+    L2S_REQUIRE(!bp.overflow, "workspace too small (l2s_workspace_bytes)");
+    void* rest = (char*)ws + bp.off;
+    const int64_t rest_bytes = ws_bytes - bp.off;
+    if (encoder_run(m, video, B, T, H, W, emb, vis, nullptr, rest, rest_bytes, s)) return 1;
+    if (prologue_run(m, vis, emb, gumbel, B, T, state, nullptr, rest, rest_bytes, s)) return 1;
+    if (decode_run(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s)) return 1;
+    if (postnet_run(m, mel, B, S, mel_post, nullptr, rest, rest_bytes, s)) return 1;
+    return launch_output_lengths(stop, B, S, lengths, s);
+}
+
+// ---- operator-level entry points
+int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
+                int K, int act, void* stream) {
+    GemmP p = gemm_plain(A, K, Wt, C, N, M, N, K);
+    p.scale = scale; p.shift = shift; p.actw = actw; p.act = act;
+    return launch_gemm1(p, (hipStream_t)stream, "op_gemm");
+}
+int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
+                  int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, void* stream) {
+    ConvW c; c.W = Wp; c.scale = scale; c.shift = shift; c.actw = actw;
+    GemmP p = conv_gemm(X, Cin, B, Tin, Cin, c, Cout, taps, stride, pad, out, Cout, act);
+    return launch_gemm1(p, (hipStream_t)stream, "op_conv1d");
+}
+int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
+    L2S_ENC_READY(m);
+    return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);
+}
+
+int l2s_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+int l2s_profile_reset(void) { prof_drain(); g_prof.clear(); g_prof_idx.clear(); return 0; }
+int l2s_profile_count(void) { prof_drain(); return (int)g_prof.size(); }
+int l2s_profile_get(int idx, const char** name, int64_t* launches, double* total_ms) {
+    prof_drain();
+    L2S_REQUIRE(idx >= 0 && idx < (int)g_prof.size(), "profile index");
+    if (name) *name = g_prof[idx].name.c_str();
+    if (launches) *launches = g_prof[idx].launches;
+    if (total_ms) *total_ms = g_prof[idx].total_ms;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Internal declarations shared by the HIP translation units of libl2s_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define L2S_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace l2s {
+
+// ---------------------------------------------------------------- error handling
+void set_error(const std::string& msg);
+#define L2S_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            l2s::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+#define L2S_REQUIRE(cond, msg)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            l2s::set_error(std::string("l2s: ") + (msg) + " [" #cond "]");                    \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------- optional per-kernel event timing
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s;
+    ProfScope(const char* name, hipStream_t st) : s(st) { prof_begin(name, st); }
+    ~ProfScope() { prof_end(s); }
+};
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_PSINE = 3 };
+
+// ---------------------------------------------------------------- tiled fp32 MFMA GEMM (gemm_nt.hip)
+// C[m, n] = epilogue( sum_k A(m,k) * W[n*K + k] ), A addressed as an implicit Conv1d over channel-last
+// sequences: row m = (b, t), k = (tap, ci), element X[(b*Tin + t*stride + tap - pad) * lda + col(ci)].
+struct GemmP {
+    const float* A;
+    const float* W;       // [N][K], K contiguous, k = tap*Cin + ci
+    const float* scale;   // [N] or null (1)
+    const float* shift;   // [N] or null (0)     v = acc*scale + shift
+    const float* actw;    // [N] for ACT_PSINE
+    const float* R1;      // optional addend after the activation: R1[(r1_mod ? m % r1_mod : m)*ldr1 + n]
+    const float* R2;
+    float* C;
+    int M, N, K;
+    int lda, Tout, Tin, taps, stride, pad, Cin;
+    int a_split, a_gap;   // channel ci >= a_split reads column ci + a_gap (two-segment A rows)
+    int act;
+    int ldr1, r1_mod, ldr2, r2_mod;
+    int r2_div;           // > 0: R2 row index = m / r2_div (a per-sequence row broadcast over its time steps)
+    int ldc, c_cstride;   // C[m*ldc + n*c_cstride]
+    int c_tr_T;           // > 0: C[((m / T)*N + n)*T + m % T]  (channel-first store per sequence)
+    int vec;              // 4: float4 operand loads (K, Cin, lda, offsets multiples of 4); 1: scalar loads
+};
+constexpr int GEMM_MAX_GROUP = 8;
+struct GemmBatch {
+    GemmP p[GEMM_MAX_GROUP];
+    int count;
+};
+GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K);
+int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name);
+int launch_gemm1(const GemmP& p, hipStream_t s, const char* name);
+
+// ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
+struct FrontendW {          // device pointers into the weight blob
+    const float* w;         // [15 slabs (ci*5+kt)][50 (kh*7+kw, padded)][32 (co, padded)]
+    const float* scale;     // [24] BN scale
+    const float* shift;     // [24]
+    const float* slope;     // [24] PReLU
+};
+int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s);
+
+// depthwise 3x3, pad 1, channel-last: in (N,Hi,Wi,ldi) channels [ci_off, ci_off+C) -> out (N,Ho,Wo,ldo) at co_off
+int launch_dwconv(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,
+                  const float* w9 /*[9][C]*/, const float* scale, const float* shift,
+                  float* out, int ldo, int co_off, hipStream_t s);
+// out[r*ldo + off_o + c*cs_o] = in[r*ldi + off_i + c]
+int launch_copy_cols(const float* in, int ldi, int off_i, float* out, int ldo, int off_o, int cs_o,
+                     int64_t rows, int cols, hipStream_t s);
+// x (NF, P, C) -> mean over P -> L2 normalise over C -> vis[f*ldv + c]; emb (B,E) tiled into vis[f*ldv + C + e]
+int launch_pool_norm_cat(const float* x, int NF, int P, int C, const float* emb, int E, int T,
+                         float* vis, int ldv, float* feat /*optional (NF,C)*/, hipStream_t s);
+
+// ---------------------------------------------------------------- skinny (batch-row) MFMA kernels (skinny.hip)
+// "frag16" layout of a row-major X[R][K] (R padded to 16, K multiple of 16):
+//   F[(rt*(K/16) + c)*256 + l*4 + e] = X[16*rt + (l&15)][16*c + 4*(l>>4) + e]      (l = lane 0..63)
+// One float4 per lane per 16-deep K chunk = exactly the A (or B) operands of four v_mfma_f32_16x16x4_f32.
+__host__ __device__ inline int64_t frag16_index(int row, int k, int K) {
+    int rt = row >> 4, i = row & 15, c = k >> 4, g = (k >> 2) & 3, e = k & 3;
+    return ((int64_t)(rt * (K >> 4) + c) * 64 + (g * 16 + i)) * 4 + e;
+}
+
+enum SkinnyEpi {
+    SK_PLAIN = 0,      // out[row*ldo + n] = act(v)                       (+ optional pos/add rows)
+    SK_FRAG = 1,       // out frag16 (K = N) = act(v) (+add)
+    SK_LSTM = 2,       // LSTM cell: rows of W permuted to (unit, gate); updates h (frag), c (frag)
+    SK_MEL = 3,        // fc_out(+stop row): writes mel[b][step][n], y frag16, stop[b][step]
+};
+struct SkinnySeg { const float* a; int nchunks; };   // one K segment of A in frag16 layout (K = 16*nchunks)
+struct SkinnyP {
+    SkinnySeg seg[3];
+    int nseg;
+    const float* W;        // packed frag16 of the [Npad][K] weight, K = sum of segments
+    const float* bias;     // [Npad] (permuted order for SK_LSTM)
+    const float* actw;     // [N] psine weights
+    const float* add;      // optional plain [B][ld_add] added after activation (SK_PLAIN/SK_FRAG)
+    int ld_add;
+    const float* addrow;   // optional [N] row added after activation (positional encoding of this step)
+    float* out;            // SK_PLAIN: [B][ldo]; SK_FRAG: frag16 with K = N
+    int ldo;
+    int B, N, K;           // N = valid output columns
+    int act;
+    int epi;
+    // SK_LSTM
+    const float* pre;      // optional precomputed input gates: pre[b*ld_pre + gate*H + unit]
+    int64_t ld_pre;
+    const float* c_in;     // frag16 (K = H) previous cell
+    float* c_out;          // frag16
+    float* h_out;          // frag16 (K = h_out_K) at column offset h_out_off
+    int h_out_K, h_out_off;
+    float* h_seq;          // optional plain: h_seq[b*ld_hseq + unit]
+    int64_t ld_hseq;
+    float* h_plain;        // optional second plain copy
+    int ld_hplain;
+    int H;
+    // SK_MEL
+    float* mel; int64_t ld_mel_b;      // mel[b*ld_mel_b + n] (already offset to this step)
+    float* stop; int64_t ld_stop_b;    // stop[b*ld_stop_b]   (already offset to this step)
+    const float* stop_const;           // [B]
+    float* yfrag;                      // frag16, K = 80
+};
+constexpr int SKINNY_MAX_GROUP = 4;
+struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
+int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name);
+
+// ---------------------------------------------------------------- decoder helper kernels (decoder_kernels.hip)
+struct AttnP {
+    const float* q; int ldq;          // [B][512]
+    const float* k;                   // [B][T][512]
+    const float* v;                   // [B][T][512]
+    const float* tau;                 // device scalar
+    float* av_frag;                   // frag16, K = 512
+    float* attn_out; int64_t ld_attn_b; int attn_logits;   // optional [b*ld + t]
+    const float* qc; int ldqc;        // [B][256]
+    const float* ckey;                // [B][m][256]
+    const float* cval;                // [B][m][256]
+    const float* tau_c;
+    float* cc_frag;                   // frag16, K = 256
+    int B, T, m;
+};
+// attention role + second prenet layer in one grid (skinny.hip)
+int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s);
+// adaptive average pooling of up to 5 channel-last maps into a concatenated (B, m, nmaps*C) buffer
+struct PoolCatP { const float* x[5]; int L[5]; int ld[5]; int nmaps; int B, m, C; float* out; };
+int launch_pool_cat(const PoolCatP& p, hipStream_t s);
+// rows softmax: z = softmax((l+g)/tau) into zpad [rows][ldz] (zero padded), dis = softmax(l) (optional)
+int launch_gumbel_softmax(const float* logits, const float* gumbel, int rows, int n, float tau,
+                          float* z, int ldz, float* dis, hipStream_t s);
+// plain [B][K] -> frag16 (rows padded with zeros); K multiple of 16; optional broadcast of a single row
+int launch_to_frag(const float* x, int ldx, int B, int K, float* frag, int Kfrag, int koff, int broadcast_row, hipStream_t s);
+int launch_fill(float* p, int64_t n, float v, hipStream_t s);
+// frag16 -> plain: out[b*ldo + ooff + k] = frag[b][k]
+int launch_from_frag(const float* frag, int Kfrag, int B, int K, float* out, int ldo, int ooff, hipStream_t s);
+// dst[(b*T + t)*ldd + c] = src[b*lds + c]
+int launch_tile_rows(const float* src, int lds, float* dst, int ldd, int B, int T, int C, hipStream_t s);
+// (B,S,C) -> (B,C,S)
+int launch_transpose_bsc(const float* in, int B, int S, int C, float* out, hipStream_t s);
+int launch_output_lengths(const float* stop, int B, int S, int64_t* lengths, hipStream_t s);
+// stop_const[b] = dot(ecell[b], w[512:1024]) + bias
+int launch_stop_const(const float* ecell, const float* w_tail, const float* bias, int B, float* out, hipStream_t s);
+
+}  // namespace l2s

@@ -1,0 +1,71 @@
+"""Parameter containers for the boundary modules.
+
+The reference's modules matter to callers in two ways only: their ``state_dict`` key names (the
+on-disk format) and being ``nn.Module``s (``.parameters()``, ``.to()``,
+``.eval()``).  ``ParamTree`` builds exactly that from the key table in ``statespec`` - a tree of
+sub-modules whose leaves are the tensors - without any forward arithmetic: the arithmetic is in
+the HIP library.  ``NativeBacked`` adds the (re)packing of those tensors into the library's
+device blob whenever they change.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+from torch import nn
+
+from ... import native, statespec, synth
+
+
+class ParamTree(nn.Module):
+    def __init__(self, spec: Optional[Iterable] = None, seed: int = 1234, key_prefix: str = ""):
+        super().__init__()
+        if spec is None:
+            return
+        for key, shape, kind in spec:
+            value = synth._draw(key_prefix + key, tuple(shape), kind, seed)
+            node = self
+            parts = key.split(".")
+            for name in parts[:-1]:
+                if name not in node._modules:
+                    node.add_module(name, ParamTree())
+                node = node._modules[name]
+            if kind in statespec.BUFFER_KINDS:
+                node.register_buffer(parts[-1], value)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(value))
+
+    def forward(self, *a, **k):  # pragma: no cover - containers are never called
+        raise RuntimeError("ParamTree is a parameter container; the arithmetic runs in libl2s_hip")
+
+
+class NativeBacked(nn.Module):
+    """Mixin: keeps a NativeModel in sync with this module's tensors (lazy, re-packed on change)."""
+
+    _key_prefix = ""          # checkpoint prefix of this module's keys inside the library ("encoder." ...)
+
+    def _init_native(self):
+        self.__dict__["_native"] = None
+        self.__dict__["_native_sig"] = None
+        self.__dict__["_native_parent"] = None
+
+    def _tensors(self):
+        return {self._key_prefix + k: v for k, v in self.state_dict(keep_vars=True).items()}
+
+    def _signature(self, tensors):
+        return tuple((t.data_ptr(), t._version) for t in tensors.values())
+
+    def native_model(self) -> native.NativeModel:
+        parent = self.__dict__.get("_native_parent")
+        if parent is not None:
+            return parent.native_model()
+        tensors = self._tensors()
+        sig = self._signature(tensors)
+        if self.__dict__["_native"] is None or sig != self.__dict__["_native_sig"]:
+            if not next(iter(tensors.values())).is_cuda:
+                raise RuntimeError("the Lip2Speech hot path runs on the GPU: call .to('cuda') first (no CPU fallback)")
+            nm = native.NativeModel()
+            nm.load(tensors, list(tensors.keys()))
+            self.__dict__["_native"] = nm
+            self.__dict__["_native_sig"] = sig
+        return self.__dict__["_native"]

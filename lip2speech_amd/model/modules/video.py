@@ -1,0 +1,34 @@
+"""``VideoExtractor`` of the boundary (reference: /root/reference/model/modules/video.py:26-87).
+
+Same constructor defaults, same ``state_dict`` keys (``frontend3D.*``, ``trunk.0.<unit>.banch*``,
+``trunk.1.*``), same call contract ``(B,3,T,H,W) -> (B,T,768)`` L2-normalised; the arithmetic is
+``l2s_encoder_fwd`` (fused Conv3d front-end + ShuffleNetV2 trunk in HIP).  Inference only:
+gradients are a later row of SURVEY.md §8(f).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import statespec
+from ._tree import NativeBacked, ParamTree
+
+
+class VideoExtractor(ParamTree, NativeBacked):
+    _key_prefix = "encoder."
+
+    def __init__(self, modality="video", hidden_dim=256, backbone_type="shufflenet", num_classes=500,
+                 relu_type="prelu", tcn_options=None, width_mult=1.0, extract_feats=False):
+        if backbone_type != "shufflenet" or width_mult != 1.0 or relu_type != "prelu":
+            raise NotImplementedError("the HIP encoder implements the configuration the reference instantiates: "
+                                      "ShuffleNetV2 1.0x trunk with a PReLU front-end (video.py:55-72)")
+        ParamTree.__init__(self, statespec.encoder_spec(""), key_prefix="encoder.")
+        self._init_native()
+        self.frontend_nout = statespec.FRONT_CH
+        self.backend_out = statespec.LAST_CH
+        self.modality, self.backbone_type, self.extract_feats = modality, backbone_type, extract_feats
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("training (backward) through the HIP encoder is not implemented yet; "
+                                      "use .eval() / torch.no_grad() (SURVEY.md §8(f) row 2)")
+        return self.native_model().encoder_fwd(x)

@@ -1,0 +1,269 @@
+"""ctypes binding of libl2s_hip.so (the C-ABI declared in include/l2s.h).
+
+PyTorch is used here for what it is good at on the host side of this path - device
+memory (caching allocator), streams, ``torch.distributed`` - and nothing else: every
+function below hands raw device pointers and the current HIP stream to the native
+library.  There is no fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libl2s_hip.so")
+
+# every symbol include/l2s.h declares; tests check the built library exports all of them
+ABI_SYMBOLS = (
+    "l2s_abi_version", "l2s_last_error",
+    "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
+    "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
+    "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
+    "l2s_output_lengths", "l2s_inference",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend",
+    "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
+)
+
+ST_K, ST_V, ST_CKEY, ST_CVAL, ST_ECELL, ST_H, ST_C, ST_ENC, ST_STOPC = range(9)
+
+_lib = None
+_vp, _i, _i64, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+
+
+def lib() -> ctypes.CDLL:
+    """Load the native library (once).  Fails loudly - the HIP path is the only path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"native library not built: {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C lip2speech_amd/csrc` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the Lip2Speech hot path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.l2s_last_error.restype = ctypes.c_char_p
+    L.l2s_abi_version.restype = _i
+    L.l2s_model_create.argtypes = [ctypes.POINTER(_vp)]
+    L.l2s_model_set_tensor.argtypes = [_vp, ctypes.c_char_p, _vp, _i64]
+    L.l2s_model_finalize.argtypes = [_vp, _vp]
+    L.l2s_model_destroy.argtypes = [_vp]
+    L.l2s_min_T.argtypes = [_i]
+    L.l2s_workspace_bytes.argtypes = [_i] * 5
+    L.l2s_workspace_bytes.restype = _i64
+    L.l2s_state_floats.argtypes = [_i, _i]
+    L.l2s_state_floats.restype = _i64
+    L.l2s_state_offset.argtypes = [_i, _i, _i]
+    L.l2s_state_offset.restype = _i64
+    L.l2s_encoder_fwd.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp, _i64, _vp]
+    L.l2s_build_visual.argtypes = [_fp, _fp, _i, _i, _fp, _vp]
+    L.l2s_decoder_prologue.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_decode_steps.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _fp, _fp, _fp, _i, _vp, _i64, _vp]
+    L.l2s_postnet.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_output_lengths.argtypes = [_fp, _i, _i, _vp, _vp]
+    L.l2s_inference.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
+    L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
+    L.l2s_profile_enable.argtypes = [_i]
+    L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("libl2s_hip: " + lib().l2s_last_error().decode("utf-8", "replace"))
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("the Lip2Speech hot path runs on the GPU: move inputs to cuda (no CPU fallback)")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def min_T(T: int) -> int:
+    return int(lib().l2s_min_T(T))
+
+
+class NativeModel:
+    """Owns an ``l2s_model`` (the packed device weight blob)."""
+
+    def __init__(self):
+        self._h = _vp()
+        check(lib().l2s_model_create(ctypes.byref(self._h)))
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().l2s_model_destroy(self._h)
+        except Exception:
+            pass
+
+    def load(self, tensors: Dict[str, torch.Tensor], keys: Iterable[str]) -> None:
+        """Hand the checkpoint tensors named ``keys`` (reference key names) to the library and pack them."""
+        L = lib()
+        for key in keys:
+            t = tensors[key]
+            if not t.is_floating_point():
+                continue                                   # num_batches_tracked: not used in eval arithmetic
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            check(L.l2s_model_set_tensor(self._h, key.encode(), a.ctypes.data_as(_vp), a.size))
+        check(L.l2s_model_finalize(self._h, _stream()))
+
+    # ------------------------------------------------------------------ workspace (caller-owned, cached)
+    def workspace(self, B: int, T: int, H: int, W: int, S: int, device) -> torch.Tensor:
+        need = int(lib().l2s_workspace_bytes(B, T, H, W, S))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ stages
+    def encoder_fwd(self, video: torch.Tensor) -> torch.Tensor:
+        video = _f32(video)
+        B, C, T, H, W = video.shape
+        assert C == 3, "frames are (B,3,T,H,W) RGB"
+        feat = torch.empty(B, T, 768, dtype=torch.float32, device=video.device)
+        ws = self.workspace(B, T, H, W, 1, video.device)
+        check(lib().l2s_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(feat), _ptr(ws), ws.numel(), _stream()))
+        return feat
+
+    def decoder_prologue(self, vis: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, want_dis: bool = True):
+        vis, emb, gumbel = _f32(vis), _f32(emb), _f32(gumbel)
+        B, T, C = vis.shape
+        assert C == 1024 and emb.shape == (B, 256)
+        m = min_T(T)
+        assert gumbel.shape == (B * m, 501), f"gumbel noise must be {(B * m, 501)}"
+        state = torch.zeros(int(lib().l2s_state_floats(B, T)), dtype=torch.float32, device=vis.device)
+        dis = torch.empty(B * m, 501, dtype=torch.float32, device=vis.device) if want_dis else None
+        ws = self.workspace(B, T, 96, 96, 1, vis.device)
+        check(lib().l2s_decoder_prologue(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis),
+                                         _ptr(ws), ws.numel(), _stream()))
+        return state, dis
+
+    def decode_steps(self, state: torch.Tensor, B: int, T: int, S: int, teacher: Optional[torch.Tensor] = None,
+                     teacher_mask=None, want_attn: bool = True, attn_logits: bool = False):
+        dev = state.device
+        mel = torch.empty(B, S, 80, dtype=torch.float32, device=dev)
+        stop = torch.empty(B, S, dtype=torch.float32, device=dev)
+        attn = torch.empty(B, S, T, dtype=torch.float32, device=dev) if want_attn else None
+        mask_buf = None
+        if teacher is not None and teacher_mask is not None:
+            teacher = _f32(teacher)
+            assert teacher.shape == (B, S, 80)
+            mask_np = np.ascontiguousarray(np.asarray(teacher_mask, dtype=np.uint8))
+            assert mask_np.shape == (S,)
+            mask_buf = mask_np.ctypes.data_as(_vp)
+        else:
+            teacher = None
+        ws = self.workspace(B, T, 96, 96, S, dev)
+        check(lib().l2s_decode_steps(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_buf, _ptr(mel), _ptr(stop),
+                                     _ptr(attn), 1 if attn_logits else 0, _ptr(ws), ws.numel(), _stream()))
+        return mel, stop, attn
+
+    def postnet(self, mel: torch.Tensor, want_cf: bool = False):
+        mel = _f32(mel)
+        B, S, C = mel.shape
+        assert C == 80
+        out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
+        cf = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device) if want_cf else None
+        ws = self.workspace(B, 29, 96, 96, S, mel.device)
+        check(lib().l2s_postnet(self._h, _ptr(mel), B, S, _ptr(out), _ptr(cf), _ptr(ws), ws.numel(), _stream()))
+        return out, cf
+
+    def inference(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int = 300, want_attn: bool = False):
+        video, emb, gumbel = _f32(video), _f32(emb), _f32(gumbel)
+        B, _, T, H, W = video.shape
+        mel_post = torch.empty(B, 80, S, dtype=torch.float32, device=video.device)
+        lengths = torch.empty(B, dtype=torch.int64, device=video.device)
+        attn = torch.empty(B, S, T, dtype=torch.float32, device=video.device) if want_attn else None
+        ws = self.workspace(B, T, H, W, S, video.device)
+        check(lib().l2s_inference(self._h, _ptr(video), _ptr(emb), _ptr(gumbel), B, T, H, W, S, _ptr(mel_post),
+                                  _ptr(lengths), _ptr(attn), _ptr(ws), ws.numel(), _stream()))
+        return mel_post, lengths, attn
+
+    def op_frontend(self, video: torch.Tensor) -> torch.Tensor:
+        video = _f32(video)
+        B, _, T, H, W = video.shape
+        out = torch.empty(B * T, H // 4, W // 4, 24, dtype=torch.float32, device=video.device)
+        check(lib().l2s_op_frontend(self._h, _ptr(video), B, T, H, W, _ptr(out), _stream()))
+        return out
+
+
+def build_visual(feat: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    feat, emb = _f32(feat), _f32(emb)
+    B, T, _ = feat.shape
+    vis = torch.empty(B, T, 1024, dtype=torch.float32, device=feat.device)
+    check(lib().l2s_build_visual(_ptr(feat), _ptr(emb), B, T, _ptr(vis), _stream()))
+    return vis
+
+
+def output_lengths(stop: torch.Tensor) -> torch.Tensor:
+    stop = _f32(stop)
+    B, S = stop.shape
+    out = torch.empty(B, dtype=torch.int64, device=stop.device)
+    check(lib().l2s_output_lengths(_ptr(stop), B, S, _ptr(out), _stream()))
+    return out
+
+
+def state_field(state: torch.Tensor, B: int, T: int, field: int, shape) -> torch.Tensor:
+    off = int(lib().l2s_state_offset(B, T, field))
+    n = int(np.prod(shape))
+    return state[off:off + n].view(*shape)
+
+
+def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0) -> torch.Tensor:
+    A, Wt = _f32(A), _f32(Wt)
+    M, K = A.shape
+    N = Wt.shape[0]
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(lib().l2s_op_gemm(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, _stream()))
+    return C
+
+
+def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0, act: int = 0) -> torch.Tensor:
+    """X (B,Tin,Cin) channel-last, Wp (Cout, taps*Cin) tap-major."""
+    X, Wp = _f32(X), _f32(Wp)
+    B, Tin, Cin = X.shape
+    Cout = Wp.shape[0]
+    Tout = (Tin + 2 * pad - taps) // stride + 1
+    out = torch.empty(B, Tout, Cout, dtype=torch.float32, device=X.device)
+    check(lib().l2s_op_conv1d(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
+                              taps, stride, pad, act, _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- profiling
+def profile_enable(on: bool) -> None:
+    check(lib().l2s_profile_enable(1 if on else 0))
+
+
+def profile_reset() -> None:
+    check(lib().l2s_profile_reset())
+
+
+def profile_read():
+    """[(kernel name, launches, total ms)] measured with HIP events on the launch stream."""
+    L = lib()
+    out = []
+    for i in range(L.l2s_profile_count()):
+        name, n, ms = ctypes.c_char_p(), _i64(), ctypes.c_double()
+        check(L.l2s_profile_get(i, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms)))
+        out.append((name.value.decode(), int(n.value), float(ms.value)))
+    return out

@@ -1,0 +1,50 @@
+"""Shared helpers of the GPU parity tests: run the HIP path stage by stage next to the oracle."""
+import os
+
+import numpy as np
+import torch
+
+from lip2speech_amd import native, synth
+from oracle import l2s_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def top2(a):
+    srt, idx = torch.sort(a, dim=-1, descending=True)
+    return idx[..., 0].to(torch.int32), srt[..., 0] - srt[..., 1]
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+_models = {}
+
+
+def native_model(sd=None):
+    """One packed NativeModel for the synthetic checkpoint (cached per process)."""
+    if "m" not in _models:
+        sd = synth.synth_state_dict() if sd is None else sd
+        nm = native.NativeModel()
+        nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+        _models["m"] = nm
+    return _models["m"]
+
+
+def lrw2_inputs():
+    g = golden("inference_lrw_b2.npz")
+    video = synth.synth_video(2, 29, tag="video-lrw2")
+    emb = synth.synth_speaker_embedding(2, tag="spk-lrw2")
+    return g, video, emb
+
+
+def unfrag(frag, B, K):
+    """frag16 buffer (flat) -> (B,K) on the host."""
+    Bp = (B + 15) // 16 * 16
+    f = frag.detach().cpu().view(Bp // 16, K // 16, 4, 16, 4)       # [rt][c][g][i][e]
+    return f.permute(0, 3, 1, 2, 4).reshape(Bp, K)[:B]
