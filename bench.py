@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark of the hot path: mel-frames/s of Lip2Speech.inference on LRW-shaped clips.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole path (visual encoder -> decoder prologue -> 300 autoregressive steps ->
+post-net -> stop bookkeeping; `l2s_inference`) over one synthetic batch of B=32 clips of 29 frames
+(BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  With N ranks every rank runs its
+own B=32 batch (clips are independent: weak scaling, no data-path collective); the reported value is the whole-job
+aggregate N*K*B*S / max-over-ranks(time).
+
+The JSON line also carries
+  roofline     for the kernel with the largest share of GPU time, timed live with HIP events on the launch stream
+               in a separate profiled pass (l2s_profile_*), against its algorithmic FLOPs / bytes;
+  cpu_baseline the CPU oracle (oracle/l2s_oracle.py, "port" of the reference math, verified against the imported
+               reference) timed on this host's cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lip2speech_amd import native, synth  # noqa: E402
+
+B, T, HW, S = 32, 29, 96, 300
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector rate
+HBM_PEAK_GBS = 8000.0
+
+
+def kernel_model(name):
+    """Algorithmic (FLOPs, bytes) of ONE launch of a kernel of the path at B=32, T=29."""
+    m = native.min_T(T)
+    w4 = 4
+    table = {
+        "step_lstm0": (2 * B * 2048 * 1024, (2048 * 1024 + 2048) * w4 + B * (1024 + 3 * 512) * w4),
+        "step_lstm1": (2 * B * 2048 * 1024, (2048 * 1024 + 2048) * w4 + B * (1024 + 3 * 512) * w4),
+        "step_prenet1_q_cq": (2 * B * (256 * 80 + 512 * 1024 + 256 * 1024),
+                              (256 * 80 + 512 * 1024 + 256 * 1024 + 1024) * w4 + B * (80 + 2048 + 256 + 512 + 256) * w4),
+        "step_attention_prenet2": (2 * B * (2 * T * 512 + 2 * m * 256 + 256 * 256),
+                                   B * (2 * T * 512 + 2 * m * 256 + 512 + 256 + 512 + 256 + T) * w4 + (256 * 256) * w4),
+        "step_attention_proj": (2 * B * 256 * 512, 256 * 512 * w4 + B * (512 + 512) * w4),
+        "step_fc_out_stop": (2 * B * 81 * 512, 96 * 512 * w4 + B * (512 + 160) * w4),
+        "frontend3d_conv_bn_prelu_pool": (2 * 1178.6e6 * B, (B * 3 * T * HW * HW + B * T * 24 * 24 * 24 + 17640) * w4),
+        "postnet_conv_gemm": (2 * 4.34e6 * S * B / 5, (B * S * (80 + 512 * 4 * 2 + 80) + 4.35e6) * w4 / 5),
+        "decode_persistent": (2 * B * 5.27e6 * S, 21.0e6 + B * (2 * T * 512 + S * (80 + 1 + T)) * w4),
+    }
+    return table.get(name)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU oracle on this host's cores, same B=32 / T=29 / S=300 workload, same synthetic checkpoint."""
+    from oracle import l2s_oracle as orc
+    sd = synth.synth_state_dict()
+    video = synth.synth_video(B, T, tag="bench")
+    emb = synth.synth_speaker_embedding(B, tag="bench")
+    gum = synth.synth_gumbel(B * native.min_T(T), tag="bench")
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        orc.inference(sd, video, emb, gum, S=S)             # warm-up pass (also page-in)
+        warm = time.time() - t0
+        times = []
+        while sum(times) < seconds_budget and len(times) < 5:
+            t0 = time.time()
+            orc.inference(sd, video, emb, gum, S=S)
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * S / med, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full passes of the B={B},T={T},S={S} batch after 1 warm-up ({warm:.1f}s); median {med:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # replicated weights, per-rank shard of clips (no exchange step on the inference path)
+    sd = synth.synth_state_dict()
+    nm = native.NativeModel()
+    nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+    video = synth.synth_video(B, T, tag=f"bench{rank}" if rank else "bench").cuda()
+    emb = synth.synth_speaker_embedding(B, tag=f"bench{rank}" if rank else "bench").cuda()
+    gum = synth.synth_gumbel(B * native.min_T(T), tag="bench").cuda()
+
+    def step():
+        return nm.inference(video, emb, gum, S=S)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out[0]).all(), "non-finite mel output"
+
+    if rank == 0:
+        # per-kernel HIP-event timing in its own pass (events around every launch perturb the pipeline)
+        native.profile_enable(True)
+        native.profile_reset()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof = sorted(native.profile_read(), key=lambda r: -r[2])
+        native.profile_enable(False)
+        gpu_ms = sum(r[2] for r in prof)
+        name, launches, total_ms = prof[0]
+        avg_s = total_ms / launches * 1e-3
+        roof = {"kernel": name, "launches_per_step": launches // 2, "avg_us": avg_s * 1e6,
+                "share_of_gpu_time": total_ms / gpu_ms}
+        model = kernel_model(name)
+        if model:
+            flops, nbytes = model
+            ai = flops / nbytes
+            if ai < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                ach = nbytes / avg_s / 1e9
+                roof.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+            else:
+                ach = flops / avg_s / 1e12
+                roof.update(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TFLOPS)
+            roof["algorithmic_flops"] = flops
+            roof["algorithmic_bytes"] = nbytes
+        roof["traffic"] = None      # HBM bytes from PMC counters: collected offline, see profiles/ and DESIGN.md
+        # whole-path figure against the fp32 matrix peak (36.18 MFLOP per mel frame)
+        per_gpu = B * S * args.steps / elapsed
+        roof["path_tflops"] = per_gpu * 36.18e6 / 1e12
+        roof["path_frac_fp32_peak"] = roof["path_tflops"] / FP32_MFMA_PEAK_TFLOPS
+
+        value = world * B * S * args.steps / elapsed
+        line = {
+            "metric": "mel-frames/sec at LRW batch=32, 29-frame clips (Lip2Speech.inference, S=300)",
+            "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LRW single-word, batch=32 per GPU, 29x96x96 RGB mouth crops, S=300 decode steps, "
+                                   "speaker embedding supplied (encoding=voice), random-init weights",
+                       "batch_per_gpu": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.skip_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -477,7 +477,7 @@ static int64_t enc_ws_floats(int B, int T, int H) {
 static int content_lens(int T, int L[4]) {
     int m = T;
     for (int j = 0; j < 4; ++j) {
-        L[j] = (T - CT_KS[j]) / CT_KS[j] + 1;
+        L[j] = T >= CT_KS[j] ? (T - CT_KS[j]) / CT_KS[j] + 1 : 0;
         m = std::min(m, L[j]);
     }
     return m;

@@ -149,7 +149,7 @@ class NativeModel:
         B, T, C = vis.shape
         assert C == 1024 and emb.shape == (B, 256)
         m = min_T(T)
-        assert gumbel.shape == (B * m, 501), f"gumbel noise must be {(B * m, 501)}"
+        assert m == 0 or gumbel.shape == (B * m, 501), f"gumbel noise must be {(B * m, 501)}"
         state = torch.zeros(int(lib().l2s_state_floats(B, T)), dtype=torch.float32, device=vis.device)
         dis = torch.empty(B * m, 501, dtype=torch.float32, device=vis.device) if want_dis else None
         ws = self.workspace(B, T, 96, 96, 1, vis.device)

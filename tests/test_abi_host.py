@@ -1,0 +1,84 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol include/l2s.h declares, the host
+mirror has the reference's interface, and the sizing helpers are consistent.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from lip2speech_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lip2speech_amd", "csrc"), "-j", "8"], check=True)
+    return ctypes.CDLL(native.LIB_PATH)
+
+
+def test_header_symbols_exported(built_lib):
+    from lip2speech_amd import native
+    header = open(os.path.join(ROOT, "include", "l2s.h")).read()
+    declared = set(re.findall(r"\b(l2s_[a-z_0-9A-Z]+)\s*\(", header))
+    assert declared == set(native.ABI_SYMBOLS), declared ^ set(native.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(built_lib, sym), f"{sym} not exported"
+    assert built_lib.l2s_abi_version() == 1
+
+
+def test_sizes_and_errors(built_lib):
+    from lip2speech_amd import native
+    L = native.lib()
+    assert [native.min_T(t) for t in (29, 75, 50, 25, 7)] == [4, 10, 7, 3, 1]
+    assert L.l2s_workspace_bytes(32, 29, 96, 96, 300) > L.l2s_workspace_bytes(2, 29, 96, 96, 300) > 0
+    offs = [L.l2s_state_offset(2, 29, f) for f in range(9)]
+    assert offs == sorted(offs) and offs[0] == 0 and L.l2s_state_floats(2, 29) > offs[-1]
+    # error path: finalize without tensors -> non-zero + message
+    h = ctypes.c_void_p()
+    assert L.l2s_model_create(ctypes.byref(h)) == 0
+    assert L.l2s_model_finalize(h, None) != 0
+    assert b"no encoder" in L.l2s_last_error()
+    L.l2s_model_destroy(h)
+
+
+def test_boundary_interface_matches_reference():
+    """Names/signatures of the reference's model.model / hparams API."""
+    import inspect
+
+    import hparams
+    from model.model import Lip2Speech, get_network
+    from model.modules import Decoder, FaceRecognizer, SpeakerEncoder, VideoExtractor  # noqa: F401
+    net = get_network("test")
+    assert not net.training and get_network("train").training
+    assert list(inspect.signature(Lip2Speech.forward).parameters)[:9] == [
+        "self", "video_frames", "face_frames", "audio_frames", "melspecs", "video_lengths", "audio_lengths",
+        "melspec_lengths", "tf_ratio"]
+    assert list(inspect.signature(Lip2Speech.inference).parameters)[:4] == ["self", "video_frames", "face_frames", "speaker_embedding"]
+    for attr in ("encoder", "decoder", "vgg_face"):
+        assert isinstance(getattr(net, attr), torch.nn.Module)
+    hp = hparams.create_hparams()
+    assert (hp.max_decoder_steps, hp.n_mel_channels, hp.batch_size, hp.seed, hp.learning_rate) == (300, 80, 64, 1234, 1e-4)
+    # optimizer groups as train.py:102-104 builds them
+    n = sum(p.numel() for p in net.decoder.parameters()) + sum(p.numel() for p in net.encoder.parameters())
+    assert n == 38_436_836
+    # strict checkpoint round trip with the reference's key names
+    from lip2speech_amd import synth
+    sd = synth.synth_state_dict(seed=7)
+    net.load_state_dict(sd, strict=True)
+    assert torch.equal(net.state_dict()["encoder.trunk.0.4.banch2.3.weight"], sd["encoder.trunk.0.4.banch2.3.weight"])
+
+
+def test_product_path_has_no_cpu_fallback():
+    """CPU tensors must raise, not silently compute elsewhere; and the product never imports the oracle."""
+    from model.model import get_network
+    net = get_network("test")
+    with pytest.raises(RuntimeError):
+        net.inference(torch.zeros(1, 3, 8, 96, 96), None, speaker_embedding=torch.zeros(1, 256))
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lip2speech_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"

@@ -1,0 +1,205 @@
+"""Parity of the HIP path (through the C-ABI) against the reference goldens and the CPU oracle.  `-m gpu`.
+
+Tolerances: the north star asks |d| < 1e-3 fp32 on mel frames and identical attention argmax; intermediate
+tensors are held to much tighter bounds so a regression is caught where it starts."""
+import numpy as np
+import pytest
+import torch
+
+from lip2speech_amd import native, synth
+from oracle import l2s_oracle as orc
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def nm(synth_sd):
+    return pc.native_model(synth_sd)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(64, 64, 32, 0), (100, 70, 36, 1), (928, 512, 1024, 2), (37, 501, 256, 3),
+                                       (130, 58, 58, 1), (9, 80, 2560, 0), (1, 1, 4, 0)])
+def test_gemm_operator(M, N, K, act):
+    torch.manual_seed(M * 7 + N)
+    A = torch.randn(M, K).cuda()
+    W = (torch.randn(N, K) / K ** 0.5).cuda()
+    sc, sh, aw = (torch.rand(N) + 0.5).cuda(), torch.randn(N).cuda(), (torch.rand(N) + 0.5).cuda()
+    C = native.op_gemm(A, W, sc, sh, aw, act)
+    ref = (A.double() @ W.double().t()) * sc.double() + sh.double()
+    ref = [ref, ref.relu(), ref * torch.sigmoid(ref), torch.sin(ref) * aw.double()][act]
+    assert pc.maxdiff(C, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,T,Ci,Co,k,st,pad", [(2, 29, 512, 512, 11, 1, 5), (2, 29, 512, 512, 7, 7, 0), (3, 40, 80, 512, 5, 1, 2),
+                                                 (2, 75, 512, 80, 5, 1, 2), (2, 29, 512, 512, 3, 3, 0), (1, 7, 512, 512, 7, 7, 0)])
+def test_conv1d_operator(B, T, Ci, Co, k, st, pad):
+    torch.manual_seed(T + k)
+    X = torch.randn(B, T, Ci)
+    Wt = torch.randn(Co, Ci, k) / (Ci * k) ** 0.5
+    Wp = Wt.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()
+    out = native.op_conv1d(X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad)
+    ref = torch.nn.functional.conv1d(X.double().permute(0, 2, 1), Wt.double(), stride=st, padding=pad).permute(0, 2, 1)
+    assert pc.maxdiff(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("hw,T", [(96, 4), (88, 3), (96, 1)])
+def test_frontend_kernel(nm, synth_sd, hw, T):
+    v = synth.synth_video(1, T, hw, hw, tag=f"fe{hw}")
+    out = nm.op_frontend(v.cuda())
+    ref = orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)
+    assert pc.maxdiff(out, ref) < 2e-5
+
+
+def test_encoder_matches_reference_golden(nm):
+    g, video, _ = pc.lrw2_inputs()
+    feat = nm.encoder_fwd(video.cuda())
+    assert pc.maxdiff(feat, g["feat"]) < 1e-5
+    norms = feat.norm(dim=2)
+    assert (norms - 1).abs().max() < 1e-5                       # F.normalize over the 768 channels
+
+
+def test_prologue_matches_oracle(nm):
+    g, _, emb = pc.lrw2_inputs()
+    B, T = 2, 29
+    vis = native.build_visual(g["feat"].cuda(), emb.cuda())
+    assert pc.maxdiff(vis, orc.build_visual(g["feat"], emb)) == 0.0
+    state, dis = nm.decoder_prologue(vis, emb.cuda(), g["gumbel"].cuda())
+    sf = lambda f, shape: native.state_field(state, B, T, f, shape)      # noqa: E731
+    assert pc.maxdiff(sf(native.ST_ENC, (B, T, 512)), g["oracle_enc"]) < 2e-5
+    assert pc.maxdiff(sf(native.ST_K, (B, T, 512)), g["oracle_k"].permute(0, 2, 1)) < 5e-5
+    assert pc.maxdiff(sf(native.ST_V, (B, T, 512)), g["oracle_v"]) < 5e-5
+    assert pc.maxdiff(sf(native.ST_CKEY, (B, 4, 256)), g["oracle_key"].permute(0, 2, 1)) < 2e-5
+    assert pc.maxdiff(sf(native.ST_CVAL, (B, 4, 256)), g["oracle_value"]) < 1e-4
+    assert pc.maxdiff(sf(native.ST_ECELL, (B, 512)), g["oracle_encoder_cell"]) < 2e-5
+    hfrag = sf(native.ST_H, (2, 16 * 512))
+    for layer in range(2):
+        assert pc.maxdiff(pc.unfrag(hfrag[layer], B, 512), g["oracle_hidden"][layer]) < 2e-5
+    assert pc.maxdiff(dis, pc.golden("forward_lrw_b2_s77.npz")["content_dis"]) < 1e-6
+
+
+def test_inference_matches_reference_golden(nm):
+    """The headline parity gate: Lip2Speech.inference, S=300, identical Gumbel noise."""
+    g, video, emb = pc.lrw2_inputs()
+    mel_post, lengths, attn = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=300, want_attn=True)
+    assert pc.maxdiff(mel_post, g["mel_post"]) < MEL_TOL
+    assert torch.equal(lengths.cpu(), g["output_lengths"])
+    amax, _ = pc.top2(attn.cpu())
+    sure = g["attn_margin"] > 1e-4
+    assert torch.equal(amax[sure], g["attn_argmax"][sure]), "attention argmax differs from the reference"
+    assert pc.maxdiff(attn[:, ::50], g["attn_rows"]) < MEL_TOL
+
+
+def test_model_api_inference(synth_sd):
+    """Through the boundary the reference's callers use: get_network('test').inference(...) (demo.py:82-86)."""
+    from model.model import get_network
+    g, video, emb = pc.lrw2_inputs()
+    net = get_network("test")
+    net.load_state_dict(synth_sd, strict=True)
+    net = net.cuda()
+    mel, lengths, attn = net.inference(video.cuda(), None, speaker_embedding=emb.cuda(), return_attention_map=True,
+                                       gumbel_noise=g["gumbel"].cuda())
+    assert mel.shape == (2, 80, 300) and lengths.dtype == torch.int64 and attn.shape == (2, 300, 29)
+    assert pc.maxdiff(mel, g["mel_post"]) < MEL_TOL
+    # the staged route (net.encoder / net.decoder used separately, as train.py / demo.py may) agrees with the fused call
+    feat = net.encoder(video.cuda())
+    vis = native.build_visual(feat, emb.cuda())
+    mel2, len2 = net.decoder.inference(vis, emb.cuda().unsqueeze(1).expand(-1, 29, -1), gumbel_noise=g["gumbel"].cuda())
+    assert pc.maxdiff(mel2, mel) == 0.0 and torch.equal(len2, lengths)
+    # without supplied noise the call draws its own (eval-mode stochasticity of the reference, decoder.py:257)
+    mel3, _ = net.inference(video.cuda(), None, speaker_embedding=emb.cuda())
+    assert torch.isfinite(mel3).all() and pc.maxdiff(mel3, mel) > 0
+
+
+@pytest.mark.parametrize("name,B,T,S,tag", [
+    ("forward_lrw_b2_s77.npz", 2, 29, 77, "lrw2"),
+    ("forward_grid_b2_t75_s188.npz", 2, 75, 188, "grid2"),      # variable-T: min_T = 10
+    ("forward_pad_b2_t50_s128.npz", 2, 50, 128, "pad2"),        # zero-padded clip: lengths are ignored
+])
+def test_forward_eval_matches_reference_golden(synth_sd, name, B, T, S, tag):
+    """evaluate.py:38 semantics: net(...,tf_ratio=1) in eval mode -> list of 7."""
+    from model.model import get_network
+    g = pc.golden(name)
+    video = synth.synth_video(B, T, tag=f"video-{tag}")
+    if tag == "pad2":
+        video[0, :, 25:] = 0
+    emb = synth.synth_speaker_embedding(B, tag=f"spk-{tag}")
+    mels = synth.synth_mels(B, S, tag=f"mel-{tag}")
+    gum = g["gumbel"] if "gumbel" in g else pc.golden("inference_lrw_b2.npz")["gumbel"]
+    net = get_network("test")
+    net.load_state_dict(synth_sd, strict=True)
+    net = net.cuda()
+    lens = torch.full((B,), T)
+    out = net(video.cuda(), None, None, mels.cuda(), lens, None, torch.full((B,), S), 1,
+              speaker_embedding=emb.cuda(), gumbel_noise=gum.cuda())
+    assert len(out) == 7 and out[6] is lens
+    assert pc.maxdiff(out[0], g["mel"]) < 1e-4
+    assert pc.maxdiff(out[1], g["mel_post"]) < MEL_TOL
+    assert out[2].shape == (B, S, 1) and pc.maxdiff(out[2], g["stop"]) < 1e-4
+    assert pc.maxdiff(out[3], emb) == 0.0
+    scale = g["attn_logits"].abs().max().item()
+    assert pc.maxdiff(out[4], g["attn_logits"]) / scale < 1e-5      # pre-softmax logits, |values| in the thousands
+    assert pc.maxdiff(out[5], g["content_dis"]) < 1e-6
+
+
+def test_teacher_forced_steps(nm):
+    """Scheduled sampling made explicit: the reference's own torch.rand draws, replayed as a step mask."""
+    g = pc.golden("forward_lrw_b2_s77_tf05.npz")
+    base, video, emb = pc.lrw2_inputs()
+    B, T, S = 2, 29, 77
+    mels = synth.synth_mels(B, S, tag="mel-lrw2")
+    vis = native.build_visual(base["feat"].cuda(), emb.cuda())
+    state, _ = nm.decoder_prologue(vis, emb.cuda(), base["gumbel"].cuda())
+    sd = synth.synth_state_dict()
+    teacher = torch.cat([sd["decoder.BOS"].expand(B, 1, -1), mels.permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
+    mel, stop, _ = nm.decode_steps(state, B, T, S, teacher=teacher.cuda(), teacher_mask=g["teacher_mask"].numpy())
+    post, cf = nm.postnet(mel, want_cf=True)
+    assert pc.maxdiff(cf, g["mel"]) < 1e-4
+    assert pc.maxdiff(post, g["mel_post"]) < MEL_TOL
+
+
+def test_full_batch_rows_are_independent(nm):
+    """BASELINE size (B=32, T=29, S=300): clips are independent, so rows 0-1 of a full batch whose first two clips
+    are the golden clips must reproduce the reference golden, whatever the other 30 clips are."""
+    g, video2, emb2 = pc.lrw2_inputs()
+    B = 32
+    video = synth.synth_video(B, 29, tag="full").clone()
+    emb = synth.synth_speaker_embedding(B, tag="full").clone()
+    gum = synth.synth_gumbel(B * 4, tag="full").clone()
+    video[:2], emb[:2], gum[:8] = video2, emb2, g["gumbel"]
+    mel_post, lengths, attn = nm.inference(video.cuda(), emb.cuda(), gum.cuda(), S=300, want_attn=True)
+    assert torch.isfinite(mel_post).all()
+    assert pc.maxdiff(mel_post[:2], g["mel_post"]) < MEL_TOL
+    assert torch.equal(lengths[:2].cpu(), g["output_lengths"])
+    # permutation equivariance over the batch (a checksum-of-rows property at full size)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    gperm = gum.view(B, 4, -1)[perm].reshape(B * 4, -1)
+    mel_p, len_p, _ = nm.inference(video[perm].cuda(), emb[perm].cuda(), gperm.cuda(), S=300)
+    assert pc.maxdiff(mel_p, mel_post[perm.cuda()]) < 1e-4
+    assert torch.equal(len_p, lengths[perm.cuda()])
+
+
+def test_edge_shapes(nm, synth_sd):
+    """B=1, the shortest clip the reference accepts (T=7: the stride-7 content branch), S=1, and B not a multiple of 16."""
+    for B, T, S in [(1, 7, 1), (3, 12, 5), (17, 9, 3)]:
+        video = synth.synth_video(B, T, tag=f"edge{B}")
+        emb = synth.synth_speaker_embedding(B, tag=f"edge{B}")
+        gum = synth.synth_gumbel(B * native.min_T(T), tag=f"edge{B}")
+        mels = synth.synth_mels(B, S, tag=f"edge{B}")
+        feat = nm.encoder_fwd(video.cuda())
+        state, _ = nm.decoder_prologue(native.build_visual(feat, emb.cuda()), emb.cuda(), gum.cuda())
+        mel, stop, attn = nm.decode_steps(state, B, T, S, attn_logits=True)
+        post, cf = nm.postnet(mel, want_cf=True)
+        with torch.no_grad():
+            ref = orc.forward_eval(synth_sd, video, emb, mels, gum)
+        assert pc.maxdiff(cf, ref[0]) < 1e-4 and pc.maxdiff(post, ref[1]) < MEL_TOL
+        assert pc.maxdiff(stop, ref[2][:, :, 0]) < 1e-4
+    with pytest.raises(RuntimeError):                      # T < 7 is rejected like the reference (conv kernel > input)
+        nm.decoder_prologue(torch.zeros(1, 6, 1024).cuda(), torch.zeros(1, 256).cuda(), torch.zeros(1, 501).cuda())
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
