@@ -104,6 +104,7 @@ struct Weights {
     ConvW ct_branch[4], ct_bott, ct_k0, ct_k2, ct_fc0, ct_fc2, ct_fc4, ct_emb;
     // decode step
     SkW pre1, pre2, q, cq, aproj, lstm0, lstm1, fc;
+    SkW pre1f, lstm0f;                 // phase-merged forms: prenet1 o fc_out over h1; LSTM0 with attention_proj folded in
     const float* stop_tail = nullptr; const float* stop_bias = nullptr;
     const float* bos = nullptr; const float* tau = nullptr; const float* tau_c = nullptr;
     // postnet
@@ -119,6 +120,11 @@ struct l2s_model {
     bool finalized = false;
     bool has_enc = false, has_dec = false;
     l2s::Weights w;
+    // captured decode loops (hipGraph), replayed on a private non-blocking stream fenced against the caller's stream
+    struct GraphEntry { int B, T, S, attn_logits, fold; const void *state, *mel, *stop, *attn, *ws; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 namespace l2s {
@@ -403,6 +409,65 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         w.fc.N = NM + 1; w.fc.K = D; w.fc.tiles = 6;
         P.copy(Dk + "stop_token_layer.linear_layer.bias", 1, &w.stop_bias);
     }
+    {   // Phase merging: two linear maps that are applied back to back with nothing in between are
+        // pre-multiplied once, in fp64, and rounded to fp32:
+        //   prenet1(fc_out(h1)) = PSine(W_p1 (W_out h1 + b_out) + b_p1) = PSine((W_p1 W_out) h1 + (W_p1 b_out + b_p1))
+        //   LSTM0 gates on u = p2 + W_ap av + b_ap:  W_ih[:,256:] u = W_ih[:,256:] p2 + (W_ih[:,256:] W_ap) av + W_ih[:,256:] b_ap
+        auto wp1 = P.get(Dk + "prenet.0.linear_layer.weight", (int64_t)256 * NM), bp1 = P.get(Dk + "prenet.0.linear_layer.bias", 256);
+        auto wo = P.get(Dk + "fc_out.linear_layer.weight", (int64_t)NM * D), bo = P.get(Dk + "fc_out.linear_layer.bias", NM);
+        if (wp1 && bp1 && wo && bo) {
+            std::vector<float> wf((size_t)256 * D);
+            int64_t bo_off = P.blob.alloc(256);
+            std::vector<double> row(D);
+            for (int n = 0; n < 256; ++n) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bacc = (*bp1)[n];
+                for (int k = 0; k < NM; ++k) {
+                    const double a = (*wp1)[(int64_t)n * NM + k];
+                    const float* wr = wo->data() + (int64_t)k * D;
+                    for (int j = 0; j < D; ++j) row[j] += a * wr[j];
+                    bacc += a * (*bo)[k];
+                }
+                for (int j = 0; j < D; ++j) wf[(size_t)n * D + j] = (float)row[j];
+                P.blob.data[bo_off + n] = (float)bacc;
+            }
+            P.frag16(256, D, [&](int n, float* r) { std::memcpy(r, wf.data() + (size_t)n * D, sizeof(float) * D); return true; }, &w.pre1f.W);
+            P.bind(&w.pre1f.bias, bo_off);
+            P.copy(Dk + "prenet.1.w", 256, &w.pre1f.actw);
+            w.pre1f.N = 256; w.pre1f.K = D; w.pre1f.tiles = 16;
+        }
+        auto wi = P.get(Dk + "decoder_rnn.weight_ih_l0", (int64_t)2048 * 512), wh = P.get(Dk + "decoder_rnn.weight_hh_l0", (int64_t)2048 * 512);
+        auto bi = P.get(Dk + "decoder_rnn.bias_ih_l0", 2048), bh = P.get(Dk + "decoder_rnn.bias_hh_l0", 2048);
+        auto wap = P.get(Dk + "attention_proj.linear_layer.weight", (int64_t)256 * D), bap = P.get(Dk + "attention_proj.linear_layer.bias", 256);
+        if (wi && wh && bi && bh && wap && bap) {
+            std::vector<float> prod((size_t)2048 * D);      // (W_ih[:,256:512] @ W_ap) in PyTorch row order
+            std::vector<float> badd(2048);
+            std::vector<double> row(D);
+            for (int r = 0; r < 2048; ++r) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bacc = 0.0;
+                for (int k = 0; k < 256; ++k) {
+                    const double a = (*wi)[(int64_t)r * 512 + 256 + k];
+                    const float* wr = wap->data() + (int64_t)k * D;
+                    for (int j = 0; j < D; ++j) row[j] += a * wr[j];
+                    bacc += a * (*bap)[k];
+                }
+                for (int j = 0; j < D; ++j) prod[(size_t)r * D + j] = (float)row[j];
+                badd[r] = (float)((double)(*bi)[r] + (double)(*bh)[r] + bacc);
+            }
+            P.frag16(2048, 1536, [&](int np, float* rowp) {
+                int r = lstm_perm_row(np, 512);
+                std::memcpy(rowp, wi->data() + (int64_t)r * 512, sizeof(float) * 512);          // [cc | p2] columns of W_ih
+                std::memcpy(rowp + 512, prod.data() + (size_t)r * D, sizeof(float) * D);         // av columns
+                std::memcpy(rowp + 1024, wh->data() + (int64_t)r * 512, sizeof(float) * 512);   // h0 columns
+                return true;
+            }, &w.lstm0f.W);
+            int64_t o = P.blob.alloc(2048);
+            for (int np = 0; np < 2048; ++np) P.blob.data[o + np] = badd[lstm_perm_row(np, 512)];
+            P.bind(&w.lstm0f.bias, o);
+            w.lstm0f.N = 2048; w.lstm0f.K = 1536; w.lstm0f.tiles = 128;
+        }
+    }
     P.copy(Dk + "BOS", NM, &w.bos);
     P.copy(Dk + "temperature", 1, &w.tau);
     P.copy(Dk + "content.temperature", 1, &w.tau_c);
@@ -418,6 +483,8 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     if (!P.missing.empty()) { set_error("l2s_model_finalize: " + P.missing); return 1; }
 
     // upload and patch pointers
+    for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    m->graphs.clear();
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     m->blob_floats = (int64_t)P.blob.data.size();
     L2S_CHECK_HIP(hipMalloc(&m->blob, m->blob_floats * sizeof(float)));
@@ -502,7 +569,7 @@ static int64_t prologue_ws_floats(int B, int T) {
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
-    return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
+    return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
 }
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 2 + 64 * 4; }
 
@@ -746,102 +813,152 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
 }
 
 // ------------------------------------------------------------------------------------------------ decode loop
-static int decode_run(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
-                      float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
+static int g_opt_fold = 1;       // phase-merged step (4 launches) vs the literal 6-phase step
+static int g_opt_graph = 0;      // replay the loop from a captured hipGraph (measured slower than stream launches on MI355X: 15.0 vs 13.7 ms)
+
+struct DecodeBufs {
+    float *h0[2], *h1[2], *c0, *c1, *av, *p1, *cc, *uu, *yf, *p2f, *q, *qc, *p2;
+};
+
+static int decode_launches(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
+                           float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s, bool fold) {
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
-    L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
     const int Bp = pad16(B);
     Bump bp(ws, ws_bytes);
-    float* h0[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
-    float* h1[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
-    float* c0 = bp.f((int64_t)Bp * 512);
-    float* c1 = bp.f((int64_t)Bp * 512);
-    float* av = bp.f((int64_t)Bp * 512);
-    float* p1 = bp.f((int64_t)Bp * 256);
-    float* cc = bp.f((int64_t)Bp * 256);
-    float* uu = bp.f((int64_t)Bp * 256);
-    float* yf = bp.f((int64_t)Bp * 96);
-    float* q = bp.f((int64_t)B * 512);
-    float* qc = bp.f((int64_t)B * 256);
-    float* p2 = bp.f((int64_t)B * 256);
+    DecodeBufs d;
+    for (int i = 0; i < 2; ++i) d.h0[i] = bp.f((int64_t)Bp * 512);
+    for (int i = 0; i < 2; ++i) d.h1[i] = bp.f((int64_t)Bp * 512);
+    d.c0 = bp.f((int64_t)Bp * 512); d.c1 = bp.f((int64_t)Bp * 512); d.av = bp.f((int64_t)Bp * 512);
+    d.p1 = bp.f((int64_t)Bp * 256); d.cc = bp.f((int64_t)Bp * 256); d.uu = bp.f((int64_t)Bp * 256); d.p2f = bp.f((int64_t)Bp * 256);
+    d.yf = bp.f((int64_t)Bp * 96);
+    d.q = bp.f((int64_t)B * 512); d.qc = bp.f((int64_t)B * 256); d.p2 = bp.f((int64_t)B * 256);
     L2S_REQUIRE(!bp.overflow, "decode workspace too small");
 
     // initial state: h from the prologue, c = 0, y = BOS; padded rows of every frag buffer zero
-    L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
-    L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
-    if (launch_fill(h0[1], (int64_t)Bp * 512, 0.f, s)) return 1;
-    if (launch_fill(h1[1], (int64_t)Bp * 512, 0.f, s)) return 1;
-    if (launch_fill(c0, (int64_t)Bp * 512, 0.f, s)) return 1;
-    if (launch_fill(c1, (int64_t)Bp * 512, 0.f, s)) return 1;
-    if (launch_fill(av, (int64_t)Bp * 512, 0.f, s)) return 1;
-    if (launch_fill(p1, (int64_t)Bp * 256, 0.f, s)) return 1;
-    if (launch_fill(cc, (int64_t)Bp * 256, 0.f, s)) return 1;
-    if (launch_fill(uu, (int64_t)Bp * 256, 0.f, s)) return 1;
-    if (launch_to_frag(w.bos, 0, B, 80, yf, 80, 0, 1, s)) return 1;
+    L2S_CHECK_HIP(hipMemcpyAsync(d.h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(d.h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    // one fill over the contiguous run h0[1] .. p2f is not possible (h0[0]/h1[0] sit in between); fill individually
+    float* zero512[] = {d.h0[1], d.h1[1], d.c0, d.c1, d.av};
+    for (float* z : zero512) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
+    float* zero256[] = {d.p1, d.cc, d.uu, d.p2f};
+    for (float* z : zero256) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
+    if (launch_to_frag(w.bos, 0, B, 80, d.yf, 80, 0, 1, s)) return 1;
+
+    auto fc_group = [&](int step, const float* h1buf, bool write_y) {
+        SkinnyP a = sk_base(w.fc, B);
+        a.seg[0] = {h1buf, 32}; a.nseg = 1; a.epi = SK_MEL;
+        a.mel = mel + (int64_t)step * NM; a.ld_mel_b = (int64_t)S * NM;
+        a.stop = stop + step; a.ld_stop_b = S; a.stop_const = state + sl.stopc; a.yfrag = write_y ? d.yf : nullptr;
+        return a;
+    };
 
     for (int i = 0; i < S; ++i) {
         const int cur = i & 1, nxt = cur ^ 1;
-        if (teacher && teacher_mask && teacher_mask[i])
-            if (launch_to_frag(teacher + (int64_t)i * NM, S * NM, B, 80, yf, 80, 0, 0, s)) return 1;
-        {   // phase A: prenet layer 1, Q (+PSine +pos[i]), content Q (+SiLU)
+        const bool forced = teacher && teacher_mask && teacher_mask[i];
+        if (forced)
+            if (launch_to_frag(teacher + (int64_t)i * NM, S * NM, B, 80, d.yf, 80, 0, 0, s)) return 1;
+        {   // phase A: prenet layer 1, Q (+PSine +pos[i]), content Q (+SiLU) [, mel frame + stop logit of step i-1]
             SkinnyBatch sb{};
-            SkinnyP a = sk_base(w.pre1, B);
-            a.seg[0] = {yf, 5}; a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
+            const bool from_frame = !fold || i == 0 || forced;      // prenet input is an explicit frame (BOS / teacher / unfolded y)
+            SkinnyP a = sk_base(from_frame ? w.pre1 : w.pre1f, B);
+            if (from_frame) a.seg[0] = {d.yf, 5}; else a.seg[0] = {d.h1[cur], 32};
+            a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = d.p1; a.ldo = 256;
             SkinnyP b = sk_base(w.q, B);
-            b.seg[0] = {h0[cur], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2; b.act = ACT_PSINE; b.epi = SK_PLAIN; b.out = q; b.ldo = 512;
+            b.seg[0] = {d.h0[cur], 32}; b.seg[1] = {d.h1[cur], 32}; b.nseg = 2; b.act = ACT_PSINE; b.epi = SK_PLAIN; b.out = d.q; b.ldo = 512;
             b.addrow = w.pos + (int64_t)i * 512;
             SkinnyP c = sk_base(w.cq, B);
-            c.seg[0] = {c0, 32}; c.seg[1] = {c1, 32}; c.nseg = 2; c.act = ACT_SILU; c.epi = SK_PLAIN; c.out = qc; c.ldo = 256;
-            sb.p[0] = a; sb.ntiles[0] = w.pre1.tiles;
+            c.seg[0] = {d.c0, 32}; c.seg[1] = {d.c1, 32}; c.nseg = 2; c.act = ACT_SILU; c.epi = SK_PLAIN; c.out = d.qc; c.ldo = 256;
+            sb.p[0] = a; sb.ntiles[0] = 16;
             sb.p[1] = b; sb.ntiles[1] = w.q.tiles;
             sb.p[2] = c; sb.ntiles[2] = w.cq.tiles;
             sb.count = 3;
-            if (launch_skinny(sb, s, "step_prenet1_q_cq")) return 1;
+            if (fold && i > 0) { sb.p[3] = fc_group(i - 1, d.h1[cur], false); sb.ntiles[3] = w.fc.tiles; sb.count = 4; }
+            if (launch_skinny(sb, s, fold ? "step_prenet1_q_cq_fc" : "step_prenet1_q_cq")) return 1;
         }
         {   // phase B: attention + content attention per batch row; prenet layer 2
             AttnP at{};
-            at.q = q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = av;
+            at.q = d.q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = d.av;
             at.attn_out = attn ? attn + (int64_t)i * T : nullptr; at.ld_attn_b = (int64_t)S * T; at.attn_logits = attn_logits;
-            at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
+            at.qc = d.qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = d.cc;
             at.B = B; at.T = T; at.m = sl.m;
             SkinnyP pr = sk_base(w.pre2, B);
-            pr.seg[0] = {p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE; pr.epi = SK_PLAIN; pr.out = p2; pr.ldo = 256;
+            pr.seg[0] = {d.p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE;
+            if (fold) { pr.epi = SK_FRAG; pr.out = d.p2f; pr.ldo = 256; }
+            else { pr.epi = SK_PLAIN; pr.out = d.p2; pr.ldo = 256; }
             if (launch_step_attn(at, pr, w.pre2.tiles, s)) return 1;
         }
-        {   // phase C: u = prenet + attention_proj(a @ v)
+        if (!fold) {   // phase C: u = prenet + attention_proj(a @ v)
             SkinnyBatch sb{};
             SkinnyP a = sk_base(w.aproj, B);
-            a.seg[0] = {av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = uu; a.ldo = 256; a.add = p2; a.ld_add = 256;
+            a.seg[0] = {d.av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = d.uu; a.ldo = 256; a.add = d.p2; a.ld_add = 256;
             sb.p[0] = a; sb.ntiles[0] = w.aproj.tiles; sb.count = 1;
             if (launch_skinny(sb, s, "step_attention_proj")) return 1;
         }
-        {   // phase D: LSTM layer 0 on cat(content, u), h0
+        {   // phase D: LSTM layer 0 on cat(content, u), h0  (folded: cat(content, prenet, a@v) against [W_ih | W_ih_u W_ap | W_hh])
             SkinnyBatch sb{};
-            SkinnyP a = sk_base(w.lstm0, B);
-            a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3;
-            a.epi = SK_LSTM; a.H = 512; a.c_in = c0; a.c_out = c0; a.h_out = h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
-            sb.p[0] = a; sb.ntiles[0] = w.lstm0.tiles; sb.count = 1;
+            SkinnyP a = sk_base(fold ? w.lstm0f : w.lstm0, B);
+            if (fold) { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.p2f, 16}; a.seg[2] = {d.av, 32}; a.seg[3] = {d.h0[cur], 32}; a.nseg = 4; }
+            else { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.uu, 16}; a.seg[2] = {d.h0[cur], 32}; a.nseg = 3; }
+            a.epi = SK_LSTM; a.H = 512; a.c_in = d.c0; a.c_out = d.c0; a.h_out = d.h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+            sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
             if (launch_skinny(sb, s, "step_lstm0")) return 1;
         }
         {   // phase E: LSTM layer 1 on the new h0
             SkinnyBatch sb{};
             SkinnyP a = sk_base(w.lstm1, B);
-            a.seg[0] = {h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2;
-            a.epi = SK_LSTM; a.H = 512; a.c_in = c1; a.c_out = c1; a.h_out = h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+            a.seg[0] = {d.h0[nxt], 32}; a.seg[1] = {d.h1[cur], 32}; a.nseg = 2;
+            a.epi = SK_LSTM; a.H = 512; a.c_in = d.c1; a.c_out = d.c1; a.h_out = d.h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = w.lstm1.tiles; sb.count = 1;
             if (launch_skinny(sb, s, "step_lstm1")) return 1;
         }
-        {   // phase F: mel frame + stop logit
+        if (!fold || i == S - 1) {   // phase F: mel frame + stop logit (folded mode: only the last step needs its own launch)
             SkinnyBatch sb{};
-            SkinnyP a = sk_base(w.fc, B);
-            a.seg[0] = {h1[nxt], 32}; a.nseg = 1; a.epi = SK_MEL;
-            a.mel = mel + (int64_t)i * NM; a.ld_mel_b = (int64_t)S * NM;
-            a.stop = stop + i; a.ld_stop_b = S; a.stop_const = state + sl.stopc; a.yfrag = yf;
-            sb.p[0] = a; sb.ntiles[0] = w.fc.tiles; sb.count = 1;
+            sb.p[0] = fc_group(i, d.h1[nxt], !fold); sb.ntiles[0] = w.fc.tiles; sb.count = 1;
             if (launch_skinny(sb, s, "step_fc_out_stop")) return 1;
         }
     }
+    return 0;
+}
+
+static int decode_run(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
+                      float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
+    L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
+    const bool fold = g_opt_fold != 0;
+    const bool use_graph = g_opt_graph && !teacher && !g_prof_on;
+    if (!use_graph) return decode_launches(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, s, fold);
+
+    if (!m->side) {
+        L2S_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+        L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming));
+    }
+    l2s_model::GraphEntry* hit = nullptr;
+    for (auto& g : m->graphs)
+        if (g.B == B && g.T == T && g.S == S && g.attn_logits == attn_logits && g.fold == (int)fold && g.state == state && g.mel == mel &&
+            g.stop == stop && g.attn == attn && g.ws == ws) { hit = &g; break; }
+    if (!hit) {
+        hipGraph_t graph = nullptr;
+        L2S_CHECK_HIP(hipStreamBeginCapture(m->side, hipStreamCaptureModeThreadLocal));
+        int rc = decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, attn_logits, ws, ws_bytes, m->side, fold);
+        hipError_t ce = hipStreamEndCapture(m->side, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+        L2S_CHECK_HIP(ce);
+        hipGraphExec_t exec = nullptr;
+        L2S_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (m->graphs.size() >= 8) {           // small FIFO: shapes/buffers rarely change in a serving loop
+            (void)hipGraphExecDestroy(m->graphs.front().exec);
+            (void)hipGraphDestroy(m->graphs.front().graph);
+            m->graphs.erase(m->graphs.begin());
+        }
+        m->graphs.push_back({B, T, S, attn_logits, (int)fold, state, mel, stop, attn, ws, graph, exec});
+        hit = &m->graphs.back();
+    }
+    L2S_CHECK_HIP(hipEventRecord(m->ev_in, s));
+    L2S_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_in, 0));
+    L2S_CHECK_HIP(hipGraphLaunch(hit->exec, m->side));
+    L2S_CHECK_HIP(hipEventRecord(m->ev_out, m->side));
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, m->ev_out, 0));
     return 0;
 }
 
@@ -898,6 +1015,8 @@ int l2s_model_finalize(l2s_model* m, void* stream) {
 }
 int l2s_model_destroy(l2s_model* m) {
     if (!m) return 0;
+    for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_in); (void)hipEventDestroy(m->ev_out); }
     if (m->blob) (void)hipFree(m->blob);
     delete m;
     return 0;
@@ -1008,6 +1127,14 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
     L2S_ENC_READY(m);
     return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);
+}
+
+int l2s_set_option(const char* name, int value) {
+    L2S_REQUIRE(name != nullptr, "null option name");
+    if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
+    else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
+    else { set_error(std::string("unknown option ") + name); return 1; }
+    return 0;
 }
 
 int l2s_profile_enable(int on) { g_prof_on = on != 0; return 0; }

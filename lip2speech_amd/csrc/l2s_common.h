@@ -108,7 +108,7 @@ enum SkinnyEpi {
 };
 struct SkinnySeg { const float* a; int nchunks; };   // one K segment of A in frag16 layout (K = 16*nchunks)
 struct SkinnyP {
-    SkinnySeg seg[3];
+    SkinnySeg seg[4];
     int nseg;
     const float* W;        // packed frag16 of the [Npad][K] weight, K = sum of segments
     const float* bias;     // [Npad] (permuted order for SK_LSTM)

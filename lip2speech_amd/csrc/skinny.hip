@@ -21,50 +21,94 @@ __device__ __forceinline__ float act_apply(float v, int act, const float* actw, 
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One block: output tile `tile` (16 columns) x batch tile `mt` (16 rows).
-__device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[4][16][17] + [16][17]*/) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int NC = p.K >> 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float4* wbase = reinterpret_cast<const float4*>(p.W) + (int64_t)tile * NC * 64 + lane;
+// One block (8 waves): output tile `tile` (16 columns) x batch tile `mt` (16 rows).  Wave w owns the K chunks
+// c = w, w+8, w+16, ...; ALL of its operand loads (<= 12 A + 12 W float4 per lane) are issued before the first MFMA so
+// the whole K slice is one round trip to L2/HBM instead of a load->MFMA->load chain.
+constexpr int SK_WAVES = 8;
+constexpr int SK_MAXC = 12;                 // chunks per wave: K <= 16 * 8 * 12 = 1536
 
-    int c_lo = 0;
-    for (int sidx = 0; sidx < p.nseg; ++sidx) {
-        const int n = p.seg[sidx].nchunks;
-        const float4* abase = reinterpret_cast<const float4*>(p.seg[sidx].a) + (int64_t)mt * n * 64 + lane;
-        // this wave takes the chunks c of the segment with (c_lo + c) % 4 == wave
-        int first = (wave - (c_lo & 3) + 4) & 3;
-#pragma unroll 4
-        for (int c = first; c < n; c += 4) {
-            const float4 a4 = abase[(int64_t)c * 64];
-            const float4 w4 = wbase[(int64_t)(c_lo + c) * 64];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4.w, acc, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NC = p.K >> 4;
+    const float4* wbase = reinterpret_cast<const float4*>(p.W) + (int64_t)tile * NC * 64 + lane;
+    const int e0 = p.seg[0].nchunks, e1 = e0 + p.seg[1].nchunks, e2 = e1 + p.seg[2].nchunks;
+
+    // epilogue operands have launch-time addresses too: fetch them now, under the same round trip as the K slice
+    const int e_row = tid >> 4, e_col = tid & 15;
+    const int e_b = mt * 16 + e_row, e_np = tile * 16 + e_col;
+    float pf_bias = 0.f, pf_extra = 0.f, pf_c = 0.f;
+    if (tid < 256) {
+        if (p.bias) pf_bias = p.bias[e_np];
+        if (p.epi == SK_LSTM) {
+            if (p.pre && e_b < p.B) pf_extra = p.pre[(int64_t)e_b * p.ld_pre + (e_col & 3) * p.H + tile * 4 + (e_col >> 2)];
+        } else if (p.epi != SK_MEL && e_b < p.B && e_np < p.N) {
+            if (p.add) pf_extra = p.add[(int64_t)e_b * p.ld_add + e_np];
+            if (p.addrow) pf_extra += p.addrow[e_np];
         }
-        c_lo += n;
+    }
+    if (p.epi == SK_LSTM && tid < 64) {
+        const int b2 = mt * 16 + (tid >> 2);
+        if (b2 < p.B) pf_c = p.c_in[frag16_index(b2, tile * 4 + (tid & 3), p.H)];
+    }
+
+    float4 a[SK_MAXC], w[SK_MAXC];
+#pragma unroll
+    for (int j = 0; j < SK_MAXC; ++j) {
+        const int c = wave + SK_WAVES * j;          // wave-uniform
+        if (c < NC) {
+            int sidx = 0, lc = c;
+            if (c >= e2) { sidx = 3; lc = c - e2; }
+            else if (c >= e1) { sidx = 2; lc = c - e1; }
+            else if (c >= e0) { sidx = 1; lc = c - e0; }
+            const float4* ab = reinterpret_cast<const float4*>(p.seg[sidx].a);
+            a[j] = ab[((int64_t)mt * p.seg[sidx].nchunks + lc) * 64 + lane];
+            w[j] = wbase[(int64_t)c * 64];
+        }
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SK_MAXC; ++j) {
+        const int c = wave + SK_WAVES * j;
+        if (c < NC) {
+            if (j & 1) acc1 = mfma4(a[j], w[j], acc1);
+            else acc0 = mfma4(a[j], w[j], acc0);
+        }
     }
     // D layout: col = lane&15, row = 4*(lane>>4) + r
     {
         const int col = lane & 15, rb = 4 * (lane >> 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 16 + rb + r) * 17 + col] = acc[r];
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + rb + r) * 17 + col] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    const int row = tid >> 4, col = tid & 15;
+    float* gt = red + SK_WAVES * 16 * 17;               // reduced tile [16][17]
+    const int row = tid >> 4, col = tid & 15;          // valid for tid < 256
     const int b = mt * 16 + row;
-    const int np = tile * 16 + col;                       // (permuted) weight row
-    float v = red[(0 * 16 + row) * 17 + col] + red[(1 * 16 + row) * 17 + col] + red[(2 * 16 + row) * 17 + col] +
-              red[(3 * 16 + row) * 17 + col];
-    if (p.bias) v += p.bias[np];
+    const int np = tile * 16 + col;                     // (permuted) weight row
+    float v = 0.f;
+    if (tid < 256) {
+#pragma unroll
+        for (int wv = 0; wv < SK_WAVES; ++wv) v += red[(wv * 16 + row) * 17 + col];
+        v += pf_bias;
+    }
 
     if (p.epi == SK_LSTM) {
-        float* gt = red + 4 * 16 * 17;                    // reduced gate tile [16][17]
-        const int u = col >> 2, gate = col & 3;
-        const int unit = tile * 4 + u;
-        if (p.pre && b < p.B) v += p.pre[(int64_t)b * p.ld_pre + gate * p.H + unit];
-        gt[row * 17 + col] = v;
+        if (tid < 256) {
+            const int u = col >> 2, gate = col & 3;
+            const int unit = tile * 4 + u;
+            (void)unit; (void)gate;
+            v += pf_extra;
+            gt[row * 17 + col] = v;
+        }
         __syncthreads();
         if (tid < 64) {
             const int r2 = tid >> 2, u2 = tid & 3;
@@ -73,7 +117,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
                 const float gi = gt[r2 * 17 + 4 * u2 + 0], gf = gt[r2 * 17 + 4 * u2 + 1];
                 const float gg = gt[r2 * 17 + 4 * u2 + 2], go = gt[r2 * 17 + 4 * u2 + 3];
                 const int64_t ci = frag16_index(b2, unit2, p.H);
-                const float cprev = p.c_in[ci];
+                const float cprev = pf_c;
                 const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
                 const float hn = sigmoidf_(go) * tanhf(cn);
                 p.c_out[ci] = cn;
@@ -84,11 +128,11 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         }
         return;
     }
-    if (b >= p.B) return;
+    if (tid >= 256 || b >= p.B) return;
     if (p.epi == SK_MEL) {
         if (np < 80) {
             p.mel[(int64_t)b * p.ld_mel_b + np] = v;
-            p.yfrag[frag16_index(b, np, 80)] = v;
+            if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
         } else if (np == 80) {
             p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
         }
@@ -96,16 +140,17 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
     }
     if (np >= p.N) return;
     v = act_apply(v, p.act, p.actw, np);
-    if (p.add) v += p.add[(int64_t)b * p.ld_add + np];
-    if (p.addrow) v += p.addrow[np];
+    v += pf_extra;
     if (p.epi == SK_FRAG)
         p.out[frag16_index(b, np, p.ldo)] = v;
     else
         p.out[(int64_t)b * p.ldo + np] = v;
 }
 
-__global__ __launch_bounds__(256) void skinny_kernel(const SkinnyBatch batch) {
-    __shared__ float red[5 * 16 * 17];
+constexpr int SK_RED_FLOATS = (SK_WAVES + 1) * 16 * 17;
+
+__global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
+    __shared__ float red[SK_RED_FLOATS];
     const int g = blockIdx.z;
     if ((int)blockIdx.x >= batch.ntiles[g]) return;
     skinny_block(batch.p[g], blockIdx.x, blockIdx.y, red);
@@ -117,8 +162,8 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
     for (int i = 0; i < b.count; ++i) {
         const SkinnyP& p = b.p[i];
         int k = 0;
-        for (int j = 0; j < p.nseg; ++j) k += 16 * p.seg[j].nchunks;
-        L2S_REQUIRE(k == p.K && p.K % 16 == 0, "skinny K segments");
+        for (int j = 0; j < 4; ++j) k += 16 * p.seg[j].nchunks;
+        L2S_REQUIRE(k == p.K && p.K % 16 == 0 && p.K <= 16 * SK_WAVES * SK_MAXC, "skinny K segments");
         L2S_REQUIRE(p.B >= 1, "skinny B");
         maxt = b.ntiles[i] > maxt ? b.ntiles[i] : maxt;
         int m = (p.B + 15) / 16;
@@ -126,7 +171,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
         mts = m;
     }
     ProfScope ps(name, s);
-    hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, b);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -161,105 +206,163 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 }
 
 constexpr int ATT_MAXT = 320;
+constexpr int ATT_SM_FLOATS = 512 + ATT_MAXT + 16 + 16;
 
-__device__ __forceinline__ float block_max(float x, float* scratch) {
+__device__ __forceinline__ float block_max8(float x, float* scratch) {
     x = wave_max_f(x);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
     __syncthreads();
-    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float m = scratch[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, scratch[i]);
+    return m;
 }
-__device__ __forceinline__ float block_sum(float x, float* scratch) {
+__device__ __forceinline__ float block_sum8(float x, float* scratch) {
     x = wave_sum_f(x);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    return ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) + ((scratch[4] + scratch[5]) + (scratch[6] + scratch[7]));
 }
 
+// 512 threads (8 waves) per batch row.  Every global operand of the block (q, this wave's k rows, this thread's v
+// column) has an address known at launch, so all loads are issued before the first dependent instruction: one memory
+// round trip instead of five serialized ones.
 __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm) {
-    float* qs = sm;                 // 512
-    float* sc = sm + 512;           // ATT_MAXT
-    float* scratch = sc + ATT_MAXT; // 8
-    float* csc = scratch + 8;       // 16
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* qs = sm;                  // 512
+    float* sc = sm + 512;            // ATT_MAXT
+    float* scratch = sc + ATT_MAXT;  // 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T;
+    const float* kb = p.k + (int64_t)b * T * 512 + lane * 8;
+    const float* vb = p.v + (int64_t)b * T * 512 + tid;
+    // ---- loads
+    const float qv = p.q[(int64_t)b * p.ldq + tid];
     const float tau = p.tau[0];
-    for (int j = tid; j < 512; j += 256) qs[j] = p.q[(int64_t)b * p.ldq + j] * tau;
+    float4 k0[4], k1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = wave + 8 * r;
+        if (t < T) {
+            k0[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
+            k1[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+        }
+    }
+    float vv[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) vv[e] = e < T ? vb[(int64_t)e * 512] : 0.f;
+    // ---- logits
+    qs[tid] = qv * tau;
     __syncthreads();
-    const float* kb = p.k + (int64_t)b * p.T * 512;
-    for (int t = wave; t < p.T; t += 4) {
-        const float4 k0 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + lane * 8);
-        const float4 k1 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + lane * 8 + 4);
-        const float* qq = qs + lane * 8;
-        double d = (double)qq[0] * k0.x + (double)qq[1] * k0.y + (double)qq[2] * k0.z + (double)qq[3] * k0.w +
-                   (double)qq[4] * k1.x + (double)qq[5] * k1.y + (double)qq[6] * k1.z + (double)qq[7] * k1.w;
+    float qq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qq[e] = qs[lane * 8 + e];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = wave + 8 * r;
+        if (t < T) {
+            double d = (double)qq[0] * k0[r].x + (double)qq[1] * k0[r].y + (double)qq[2] * k0[r].z + (double)qq[3] * k0[r].w +
+                       (double)qq[4] * k1[r].x + (double)qq[5] * k1[r].y + (double)qq[6] * k1[r].z + (double)qq[7] * k1[r].w;
+            d = wave_sum_d(d);
+            if (lane == 0) sc[t] = (float)d;
+        }
+    }
+    for (int t = wave + 32; t < T; t += 8) {             // clips longer than 32 frames: remaining rows, one at a time
+        const float4 a0 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
+        const float4 a1 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+        double d = (double)qq[0] * a0.x + (double)qq[1] * a0.y + (double)qq[2] * a0.z + (double)qq[3] * a0.w +
+                   (double)qq[4] * a1.x + (double)qq[5] * a1.y + (double)qq[6] * a1.z + (double)qq[7] * a1.w;
         d = wave_sum_d(d);
         if (lane == 0) sc[t] = (float)d;
     }
     __syncthreads();
-    // softmax over T
-    float mx = -INFINITY;
-    for (int t = tid; t < p.T; t += 256) mx = fmaxf(mx, sc[t]);
-    mx = block_max(mx, scratch);
-    float part = 0.f;
-    float ex[2] = {0.f, 0.f};
-    int cnt = 0;
-    for (int t = tid; t < p.T; t += 256, ++cnt) {
-        if (p.attn_out && p.attn_logits) p.attn_out[(int64_t)b * p.ld_attn_b + t] = sc[t];
-        ex[cnt] = expf(sc[t] - mx);
-        part += ex[cnt];
-    }
-    const float tot = block_sum(part, scratch);
-    cnt = 0;
-    for (int t = tid; t < p.T; t += 256, ++cnt) {
-        const float a = ex[cnt] / tot;
-        sc[t] = a;
-        if (p.attn_out && !p.attn_logits) p.attn_out[(int64_t)b * p.ld_attn_b + t] = a;
+    // ---- softmax over T (T <= 320 < 512: one element per thread)
+    const bool on = tid < T;
+    const float x = on ? sc[tid] : -INFINITY;
+    const float mx = block_max8(x, scratch);
+    const float ex = on ? expf(x - mx) : 0.f;
+    const float tot = block_sum8(ex, scratch);
+    if (on) {
+        const float aw = ex / tot;
+        if (p.attn_out) p.attn_out[(int64_t)b * p.ld_attn_b + tid] = p.attn_logits ? x : aw;
+        sc[tid] = aw;
     }
     __syncthreads();
-    // av = a @ v : thread owns columns tid and tid+256
-    {
-        const float* vb = p.v + (int64_t)b * p.T * 512;
-        float a0 = 0.f, a1 = 0.f;
-        for (int t = 0; t < p.T; ++t) {
-            const float a = sc[t];
-            a0 = fmaf(a, vb[(int64_t)t * 512 + tid], a0);
-            a1 = fmaf(a, vb[(int64_t)t * 512 + 256 + tid], a1);
-        }
-        p.av_frag[frag16_index(b, tid, 512)] = a0;
-        p.av_frag[frag16_index(b, tid + 256, 512)] = a1;
+    // ---- av = a @ v : one column per thread, t ascending
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e)
+        if (e < T) acc = fmaf(sc[e], vv[e], acc);
+    for (int t0 = 32; t0 < T; t0 += 16) {
+        float v2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v2[e] = (t0 + e < T) ? vb[(int64_t)(t0 + e) * 512] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (t0 + e < T) acc = fmaf(sc[t0 + e], v2[e], acc);
     }
-    // content attention (m <= 16 slots)
-    __syncthreads();
-    const float tau_c = p.tau_c[0];
-    qs[tid] = p.qc[(int64_t)b * p.ldqc + tid] * tau_c;
-    __syncthreads();
-    const float* keyb = p.ckey + (int64_t)b * p.m * 256;
-    for (int i = wave; i < p.m; i += 4) {
-        const float4 k0 = *reinterpret_cast<const float4*>(keyb + (int64_t)i * 256 + lane * 4);
-        const float* qq = qs + lane * 4;
-        double d = (double)qq[0] * k0.x + (double)qq[1] * k0.y + (double)qq[2] * k0.z + (double)qq[3] * k0.w;
-        d = wave_sum_d(d);
-        if (lane == 0) csc[i] = d;
-    }
-    __syncthreads();
-    float cmx = -INFINITY;
-    for (int i = 0; i < p.m; ++i) cmx = fmaxf(cmx, csc[i]);
-    float csum = 0.f;
-    for (int i = 0; i < p.m; ++i) csum += expf(csc[i] - cmx);
-    const float* valb = p.cval + (int64_t)b * p.m * 256;
-    float o = 0.f;
-    for (int i = 0; i < p.m; ++i) o = fmaf(expf(csc[i] - cmx) / csum, valb[(int64_t)i * 256 + tid], o);
-    p.cc_frag[frag16_index(b, tid, 256)] = o;
+    p.av_frag[frag16_index(b, tid, 512)] = acc;
 }
 
-__global__ __launch_bounds__(256) void step_attn_kernel(const StepB sb) {
-    __shared__ __attribute__((aligned(16))) float sm[512 + ATT_MAXT + 8 + 16 + 5 * 16 * 17];
+// Content.forward (decoder.py:262-271) for one batch row: alpha = softmax_m(SiLU(..)*tau_c . key), cc = alpha @ value
+__device__ __forceinline__ void content_block(const AttnP& p, int b, float* sm) {
+    float* qs = sm;                  // 256
+    float* csc = sm + 512;           // 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = p.m;
+    const int col = tid & 255;
+    const float qv = p.qc[(int64_t)b * p.ldqc + col];
+    const float tau_c = p.tau_c[0];
+    const float* keyb = p.ckey + (int64_t)b * m * 256 + lane * 4;
+    const float* valb = p.cval + (int64_t)b * m * 256 + col;
+    float4 kk[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = wave + 8 * r;
+        if (i < m) kk[r] = *reinterpret_cast<const float4*>(keyb + (int64_t)i * 256);
+    }
+    float vals[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vals[i] = i < m ? valb[(int64_t)i * 256] : 0.f;
+    if (tid < 256) qs[tid] = qv * tau_c;
+    __syncthreads();
+    const float* q4 = qs + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = wave + 8 * r;
+        if (i < m) {
+            double d = (double)q4[0] * kk[r].x + (double)q4[1] * kk[r].y + (double)q4[2] * kk[r].z + (double)q4[3] * kk[r].w;
+            d = wave_sum_d(d);
+            if (lane == 0) csc[i] = (float)d;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float cmx = -INFINITY;
+        for (int i = 0; i < m; ++i) cmx = fmaxf(cmx, csc[i]);
+        float csum = 0.f;
+        for (int i = 0; i < m; ++i) csum += expf(csc[i] - cmx);
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < m) o = fmaf(expf(csc[i] - cmx) / csum, vals[i], o);
+        p.cc_frag[frag16_index(b, tid, 256)] = o;
+    }
+}
+
+__global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
+    __shared__ __attribute__((aligned(16))) float sm[ATT_SM_FLOATS > SK_RED_FLOATS ? ATT_SM_FLOATS : SK_RED_FLOATS];
     const int nb = sb.at.B;
-    if ((int)blockIdx.x < nb) {
-        attention_block(sb.at, blockIdx.x, sm);
+    const int bid = blockIdx.x;
+    if (bid < nb) {
+        attention_block(sb.at, bid, sm);
+    } else if (bid < 2 * nb) {
+        content_block(sb.at, bid - nb, sm);
     } else {
-        const int j = blockIdx.x - nb;
+        const int j = bid - 2 * nb;
         const int tile = j % sb.pre2_tiles, mt = j / sb.pre2_tiles;
         skinny_block(sb.pre2, tile, mt, sm);
     }
@@ -273,7 +376,7 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     sb.pre2_tiles = pre2_tiles;
     sb.mts = (at.B + 15) / 16;
     ProfScope ps("step_attention_prenet2", s);
-    hipLaunchKernelGGL(step_attn_kernel, dim3(at.B + pre2_tiles * sb.mts), dim3(256), 0, s, sb);
+    hipLaunchKernelGGL(step_attn_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
 
@@ -69,6 +69,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
+    L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -247,6 +248,10 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
     check(lib().l2s_op_conv1d(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
                               taps, stride, pad, act, _stream()))
     return out
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib().l2s_set_option(name.encode(), int(value)))
 
 
 # ---------------------------------------------------------------------------------------------- profiling

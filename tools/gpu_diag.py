@@ -92,10 +92,17 @@ def decoder_stages():
     line("prologue hidden[1]", pc.maxdiff(pc.unfrag(hfrag[1], B, 512), g["oracle_hidden"][1]), 2e-5)
     fg = pc.golden("forward_lrw_b2_s77.npz")
     line("prologue content_dis", pc.maxdiff(dis, fg["content_dis"]), 1e-6)
-    for Sx in (3, 77, 300):
-        mel, stop, attn = nm.decode_steps(state, B, T, Sx, want_attn=True)
-        line(f"decode S={Sx} mel_pre", pc.maxdiff(mel.permute(0, 2, 1), g["oracle_mel_pre"][:, :, :Sx]), 1e-3)
-        line(f"decode S={Sx} stop", pc.maxdiff(stop, g["oracle_stop"][:, :Sx]), 1e-3)
+    for fold, graph in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph)
+        for Sx in (3, 77, 300):
+            mel, stop, attn = nm.decode_steps(state, B, T, Sx, want_attn=True)
+            line(f"fold{fold} graph{graph} decode S={Sx} mel_pre", pc.maxdiff(mel.permute(0, 2, 1), g["oracle_mel_pre"][:, :, :Sx]), 1e-3)
+            line(f"fold{fold} graph{graph} decode S={Sx} stop", pc.maxdiff(stop, g["oracle_stop"][:, :Sx]), 1e-3)
+        post, _ = nm.postnet(mel)
+        line(f"fold{fold} graph{graph} mel_post vs reference", pc.maxdiff(post, g["mel_post"]), 1e-3)
+        am, _ = pc.top2(attn.cpu())
+        sure0 = g["attn_margin"] > 1e-4
+        print("   attention argmax mismatches:", int((am[sure0] != g["attn_argmax"][sure0]).sum()))
     am, _ = pc.top2(attn.cpu())
     sure = g["attn_margin"] > 1e-4
     print("   attention argmax mismatches (margin>1e-4):", int((am[sure] != g["attn_argmax"][sure]).sum()), "of", int(sure.sum()))
@@ -119,11 +126,13 @@ def timing():
     video = synth.synth_video(B, T, tag="bench").cuda()
     emb = synth.synth_speaker_embedding(B, tag="bench").cuda()
     gum = synth.synth_gumbel(B * 4, tag="bench").cuda()
-    for it in range(3):
-        torch.cuda.synchronize(); t0 = time.time()
-        nm.inference(video, emb, gum, S=S)
-        torch.cuda.synchronize(); dt = time.time() - t0
-        print(f"   B=32 inference iter {it}: {dt * 1e3:.1f} ms -> {B * S / dt:.0f} mel-frames/s", flush=True)
+    for fold, graph in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph)
+        for it in range(4):
+            torch.cuda.synchronize(); t0 = time.time()
+            nm.inference(video, emb, gum, S=S)
+            torch.cuda.synchronize(); dt = time.time() - t0
+            print(f"   fold{fold} graph{graph} B=32 inference iter {it}: {dt * 1e3:.1f} ms -> {B * S / dt:.0f} mel-frames/s", flush=True)
     native.profile_enable(True); native.profile_reset()
     nm.inference(video, emb, gum, S=S)
     torch.cuda.synchronize()
