@@ -41,8 +41,10 @@ def kernel_model(name):
     m = native.min_T(T)
     w4 = 4
     table = {
-        "step_lstm0": (2 * B * 2048 * 1536, (2048 * 1536 + 2048) * w4 + B * (1536 + 3 * 512) * w4),
-        "step_lstm1": (2 * B * 2048 * 1024, (2048 * 1024 + 2048) * w4 + B * (1024 + 3 * 512) * w4),
+        # both decoder LSTM layers run the same kernel (600 launches per pass): layer 0 has K=1536 (attention_proj folded in),
+        # layer 1 K=1024; figures are the per-launch mean of the two
+        "step_lstm_cell": (2 * B * 2048 * (1536 + 1024) / 2,
+                           ((2048 * (1536 + 1024) / 2 + 2048) * w4 + B * ((1536 + 1024) / 2 + 3 * 512) * w4)),
         "step_prenet1_q_cq_fc": (2 * B * (256 * 512 + 512 * 1024 + 256 * 1024 + 81 * 512),
                                  (256 * 512 + 512 * 1024 + 256 * 1024 + 96 * 512 + 1024) * w4 + B * (2048 + 256 + 512 + 256 + 81) * w4),
         "step_attention_prenet2": (2 * B * (2 * T * 512 + 2 * m * 256 + 256 * 256),
@@ -168,7 +170,16 @@ def main():
                 roof.update(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TFLOPS)
             roof["algorithmic_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
-        roof["traffic"] = None      # HBM bytes from PMC counters: collected offline, see profiles/ and DESIGN.md
+        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+        # offline with tools/prof_decode.py and committed as profiles/r01_pmc_decode.json
+        roof["traffic"] = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_decode.json")))["kernels"]
+            if name in pmc:
+                roof["traffic"] = pmc[name]["traffic_bytes_per_launch"]
+                roof["l2_hit_rate"] = pmc[name]["l2_hit_rate"]
+        except OSError:
+            pass
         # whole-path figure against the fp32 matrix peak (36.18 MFLOP per mel frame)
         per_gpu = B * S * args.steps / elapsed
         roof["path_tflops"] = per_gpu * 36.18e6 / 1e12

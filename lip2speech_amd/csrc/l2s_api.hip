@@ -88,6 +88,7 @@ struct UnitW {
     int cin = 0, half = 0;
     DwW b1_dw; ConvW b1_pw;            // stride-2 units only
     ConvW pw1; DwW dw; ConvW pw2;      // banch2
+    const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // stride-1 units: frag16 [pad16(half)][kpad]
 };
 struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; };
 
@@ -273,6 +274,20 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
                 P.bn(p + "banch2.4", half, nullptr, &U.dw.scale, &U.dw.shift);
                 P.copy(p + "banch2.5.weight", (int64_t)half * half, &U.pw2.W);
                 P.bn(p + "banch2.6", half, nullptr, &U.pw2.scale, &U.pw2.shift);
+                if (!U.stride2) {      // fused-unit operands: both pointwise weights in frag16 layout, K zero-padded to 16
+                    U.kpad = (half + 15) & ~15;
+                    const int kpad = U.kpad;
+                    for (int which = 0; which < 2; ++which) {
+                        auto wv = P.get(p + (which == 0 ? "banch2.0.weight" : "banch2.5.weight"), (int64_t)half * half);
+                        if (!wv) continue;
+                        P.frag16(pad16(half), kpad, [&](int n, float* row) {
+                            if (n >= half) return false;
+                            std::memset(row, 0, sizeof(float) * kpad);
+                            std::memcpy(row, wv->data() + (int64_t)n * half, sizeof(float) * half);
+                            return true;
+                        }, which == 0 ? &U.pw1_frag : &U.pw2_frag);
+                    }
+                }
                 cin = cout;
             }
         }
@@ -594,6 +609,8 @@ static StateLayout state_layout(int B, int T) {
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
+static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each
+
 static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
                      int64_t M, int N, int K, int act) {
     GemmP p = gemm_plain(A + a_off, lda, c.W, C + c_off, ldc, (int)M, N, K);
@@ -626,6 +643,15 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             if (launch_dwconv(t1, NF, h, h, half, 0, half, 2, U.dw.w9, U.dw.scale, U.dw.shift, t2, half, 0, s)) return 1;
             if (launch_gemm1(pw_gemm(t2, half, 0, U.pw2, y, cout, 1, 2, out_px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
             h = ho;
+        } else if (g_opt_fuse_trunk) {
+            ShuffleS1P sp{};
+            sp.x = x; sp.out = y;
+            sp.w1f = U.pw1_frag; sp.s1 = U.pw1.scale; sp.b1 = U.pw1.shift;
+            sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
+            sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
+            sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
+            sp.F = std::max(1, 8352 / (h * h * half));        // ~33 KB of activations per LDS buffer
+            if (launch_shuffle_s1(sp, s)) return 1;
         } else {
             const int64_t px = (int64_t)NF * h * h;
             if (launch_copy_cols(x, cout, 0, y, cout, 0, 2, px, half, s)) return 1;
@@ -902,7 +928,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             else { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.uu, 16}; a.seg[2] = {d.h0[cur], 32}; a.nseg = 3; }
             a.epi = SK_LSTM; a.H = 512; a.c_in = d.c0; a.c_out = d.c0; a.h_out = d.h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
-            if (launch_skinny(sb, s, "step_lstm0")) return 1;
+            if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
         }
         {   // phase E: LSTM layer 1 on the new h0
             SkinnyBatch sb{};
@@ -910,7 +936,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             a.seg[0] = {d.h0[nxt], 32}; a.seg[1] = {d.h1[cur], 32}; a.nseg = 2;
             a.epi = SK_LSTM; a.H = 512; a.c_in = d.c1; a.c_out = d.c1; a.h_out = d.h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = w.lstm1.tiles; sb.count = 1;
-            if (launch_skinny(sb, s, "step_lstm1")) return 1;
+            if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
         }
         if (!fold || i == S - 1) {   // phase F: mel frame + stop logit (folded mode: only the last step needs its own launch)
             SkinnyBatch sb{};
@@ -1133,6 +1159,7 @@ int l2s_set_option(const char* name, int value) {
     L2S_REQUIRE(name != nullptr, "null option name");
     if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
+    else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
     else { set_error(std::string("unknown option ") + name); return 1; }
     return 0;
 }

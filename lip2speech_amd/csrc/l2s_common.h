@@ -84,6 +84,15 @@ int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H,
 int launch_dwconv(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,
                   const float* w9 /*[9][C]*/, const float* scale, const float* shift,
                   float* out, int ldo, int co_off, hipStream_t s);
+// fused stride-1 ShuffleNet unit (encoder_kernels.hip)
+struct ShuffleS1P {
+    const float* x; float* out;                              // (NF, h, h, 2*half) channel-last
+    const float* w1f; const float* s1; const float* b1;      // pw1: frag16 [pad16(half)][Kpad], BN scale/shift
+    const float* wd; const float* sd; const float* bd;       // dw: [9][half], BN scale/shift
+    const float* w2f; const float* s2; const float* b2;      // pw2
+    int NF, h, half, Kpad, F;
+};
+int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s);
 // out[r*ldo + off_o + c*cs_o] = in[r*ldi + off_i + c]
 int launch_copy_cols(const float* in, int ldi, int off_i, float* out, int ldo, int off_o, int cs_o,
                      int64_t rows, int cols, hipStream_t s);

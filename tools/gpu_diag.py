@@ -67,8 +67,14 @@ def encoder_stages():
     full = nm.op_frontend(video.cuda())
     frames = g["frames"].tolist()
     line("frontend3d vs golden taps", pc.maxdiff(full[frames], g["oracle_frontend"].permute(0, 2, 3, 1)), 2e-5)
-    feat = nm.encoder_fwd(video.cuda())
-    line("encoder feat vs reference golden", pc.maxdiff(feat, g["feat"]), 1e-5)
+    for fuse in (0, 1):
+        native.set_option("fuse_trunk", fuse)
+        feat = nm.encoder_fwd(video.cuda())
+        line(f"fuse_trunk={fuse} encoder feat vs reference golden", pc.maxdiff(feat, g["feat"]), 1e-5)
+        v32 = synth.synth_video(32, 29, tag="bench").cuda()
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.time(); nm.encoder_fwd(v32); torch.cuda.synchronize()
+            print(f"   fuse_trunk={fuse} encoder B=32: {(time.time() - t0) * 1e3:.2f} ms")
     feat88 = nm.encoder_fwd(v88.cuda())
     line("encoder feat 88x88 vs oracle", pc.maxdiff(feat88, orc.encoder_forward(sd, v88)), 1e-5)
 
