@@ -138,8 +138,11 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 /* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
  * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);
-/* run-time options: "fold_step_weights" (default 1: 4-launch step with pre-multiplied prenet1*fc_out and
- * W_ih*attention_proj; 0: literal 6-phase step), "use_graph" (default 0; 1: replay the decode loop from a captured hipGraph) */
+/* run-time options (A/B switches kept for measurement; defaults are the fastest measured):
+ *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
+ *   "use_graph"         (0)  replay the decode loop from a captured hipGraph
+ *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
+ *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop */
 int l2s_set_option(const char* name, int value);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         int m = m0 + lr + 32 * j;
         avalid[j] = m < p.M;
         int mm = avalid[j] ? m : 0;
-        int b = mm / p.Tout, t = mm - b * p.Tout;
+        int b = mm / p.Tout, t = mm - b * p.Tout + p.win_off;
         atbase[j] = t * p.stride - p.pad;
         arow[j] = p.A + (int64_t)b * p.Tin * p.lda;
         int n = n0 + lr + 32 * j;
@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const float sh = p.shift ? p.shift[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
         if (row >= p.M) continue;
+        if (p.win_T > 0) { const int wb = row / p.Tout; row = wb * p.win_T + p.win_off + (row - wb * p.Tout); }
         float v = acc[r] * sc + sh;
         v = apply_act(v, p.act, p.actw, col);
         if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];

@@ -5,6 +5,7 @@
 #include "l2s_common.h"
 
 #include <cmath>
+#include <functional>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -126,6 +127,7 @@ struct l2s_model {
     std::vector<GraphEntry> graphs;
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace l2s {
@@ -586,7 +588,7 @@ static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
     return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
 }
-static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 2 + 64 * 4; }
+static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
 
 struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, total; int m; };
 static StateLayout state_layout(int B, int T) {
@@ -840,14 +842,17 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
 
 // ------------------------------------------------------------------------------------------------ decode loop
 static int g_opt_fold = 1;       // phase-merged step (4 launches) vs the literal 6-phase step
+static int g_opt_overlap_postnet = 0;   // l2s_inference: post-net in time windows on a second stream under the decode loop (bit-identical; measured SLOWER on MI355X, 13.1 vs 12.0 ms: the GEMM blocks delay the latency-critical step launches)
 static int g_opt_graph = 0;      // replay the loop from a captured hipGraph (measured slower than stream launches on MI355X: 15.0 vs 13.7 ms)
 
 struct DecodeBufs {
     float *h0[2], *h1[2], *c0, *c1, *av, *p1, *cc, *uu, *yf, *p2f, *q, *qc, *p2;
 };
 
+// on_frames(n): called (if set) right after the launch that completes mel frames [0, n) has been enqueued on `s`
 static int decode_launches(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
-                           float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s, bool fold) {
+                           float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s, bool fold,
+                           const std::function<int(int)>* on_frames = nullptr) {
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     const int Bp = pad16(B);
@@ -901,6 +906,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             sb.count = 3;
             if (fold && i > 0) { sb.p[3] = fc_group(i - 1, d.h1[cur], false); sb.ntiles[3] = w.fc.tiles; sb.count = 4; }
             if (launch_skinny(sb, s, fold ? "step_prenet1_q_cq_fc" : "step_prenet1_q_cq")) return 1;
+            if (fold && i > 0 && on_frames && (*on_frames)(i)) return 1;
         }
         {   // phase B: attention + content attention per batch row; prenet layer 2
             AttnP at{};
@@ -942,6 +948,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             SkinnyBatch sb{};
             sb.p[0] = fc_group(i, d.h1[nxt], !fold); sb.ntiles[0] = w.fc.tiles; sb.count = 1;
             if (launch_skinny(sb, s, "step_fc_out_stop")) return 1;
+            if (on_frames && (*on_frames)(i + 1)) return 1;
         }
     }
     return 0;
@@ -989,25 +996,35 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ postnet
+struct PostBufs { float* x[4]; };
+
+static int postnet_alloc(Bump& bp, int B, int S, PostBufs& pb) {
+    for (int i = 0; i < 4; ++i) pb.x[i] = bp.f((int64_t)B * S * 512);
+    return bp.overflow ? 1 : 0;
+}
+
+// One post-net layer (decoder.py:143-156) over the frames [t0, t1) of every sequence; layer 0..4.
+// Layer i reads buffer i (mel for i = 0) and writes buffer i+1 (mel_post, channel-first, for i = 4).
+static int postnet_layer(const Weights& w, int layer, const float* mel, const PostBufs& pb, float* mel_post, int B, int S, int t0, int t1, hipStream_t s) {
+    if (t1 <= t0) return 0;
+    float* const* bufs = pb.x;
+    const float* in = layer == 0 ? mel : bufs[layer - 1];
+    const int cin = layer == 0 ? NM : 512;
+    GemmP p = conv_gemm(in, cin, B, S, cin, w.post[layer], layer == 4 ? NM : 512, 5, 1, 2, layer == 4 ? mel_post : bufs[layer], layer == 4 ? NM : 512,
+                        layer == 4 ? ACT_NONE : ACT_PSINE);
+    p.M = B * (t1 - t0); p.Tout = t1 - t0; p.win_T = S; p.win_off = t0;
+    if (layer >= 1 && layer <= 3) { p.R1 = in; p.ldr1 = 512; p.r1_mod = 0; }
+    if (layer == 4) { p.R1 = mel; p.ldr1 = NM; p.r1_mod = 0; p.c_tr_T = S; }
+    return launch_gemm1(p, s, "postnet_conv_gemm");
+}
+
 static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf, void* ws, int64_t ws_bytes, hipStream_t s) {
     const Weights& w = m->w;
     Bump bp(ws, ws_bytes);
-    float* xa = bp.f((int64_t)B * S * 512);
-    float* xb = bp.f((int64_t)B * S * 512);
-    L2S_REQUIRE(!bp.overflow, "postnet workspace too small");
-    GemmP p0 = conv_gemm(mel, NM, B, S, NM, w.post[0], 512, 5, 1, 2, xa, 512, ACT_PSINE);
-    if (launch_gemm1(p0, s, "postnet_conv_gemm")) return 1;
-    float* x = xa; float* y = xb;
-    for (int i = 1; i < 4; ++i) {
-        GemmP p = conv_gemm(x, 512, B, S, 512, w.post[i], 512, 5, 1, 2, y, 512, ACT_PSINE);
-        p.R1 = x; p.ldr1 = 512; p.r1_mod = 0;
-        if (launch_gemm1(p, s, "postnet_conv_gemm")) return 1;
-        std::swap(x, y);
-    }
-    GemmP p4 = conv_gemm(x, 512, B, S, 512, w.post[4], NM, 5, 1, 2, mel_post, NM, ACT_NONE);
-    p4.R1 = mel; p4.ldr1 = NM; p4.r1_mod = 0;
-    p4.c_tr_T = S;
-    if (launch_gemm1(p4, s, "postnet_conv_gemm")) return 1;
+    PostBufs pb;
+    L2S_REQUIRE(postnet_alloc(bp, B, S, pb) == 0, "postnet workspace too small");
+    for (int layer = 0; layer < 5; ++layer)
+        if (postnet_layer(w, layer, mel, pb, mel_post, B, S, 0, S, s)) return 1;
     if (mel_cf && launch_transpose_bsc(mel, B, S, NM, mel_cf, s)) return 1;
     return 0;
 }
@@ -1043,6 +1060,7 @@ int l2s_model_destroy(l2s_model* m) {
     if (!m) return 0;
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_in); (void)hipEventDestroy(m->ev_out); }
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->blob) (void)hipFree(m->blob);
     delete m;
     return 0;
@@ -1054,7 +1072,7 @@ int64_t l2s_workspace_bytes(int B, int T, int H, int W, int S) {
     (void)W;
     int64_t enc = enc_ws_floats(B, T, H), pro = prologue_ws_floats(B, T), dec = decode_ws_floats(B), post = postnet_ws_floats(B, S);
     int64_t io = (int64_t)B * T * 1024 + l2s_state_floats(B, T) + (int64_t)B * S * (NM + 1) + 64 * 8;   // l2s_inference intermediates
-    int64_t mx = std::max(std::max(enc, pro), std::max(dec, post));
+    int64_t mx = std::max(std::max(enc, pro), dec + post + 64);      // decode and post-net buffers are live together (overlap)
     return (mx + io) * (int64_t)sizeof(float) + (1 << 16);
 }
 int64_t l2s_state_floats(int B, int T) { return state_layout(B, T).total; }
@@ -1132,8 +1150,48 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
     const int64_t rest_bytes = ws_bytes - bp.off;
     if (encoder_run(m, video, B, T, H, W, emb, vis, nullptr, rest, rest_bytes, s)) return 1;
     if (prologue_run(m, vis, emb, gumbel, B, T, state, nullptr, rest, rest_bytes, s)) return 1;
-    if (decode_run(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s)) return 1;
-    if (postnet_run(m, mel, B, S, mel_post, nullptr, rest, rest_bytes, s)) return 1;
+    if (!g_opt_overlap_postnet || g_prof_on || g_opt_graph) {
+        if (decode_run(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s)) return 1;
+        if (postnet_run(m, mel, B, S, mel_post, nullptr, rest, rest_bytes, s)) return 1;
+    } else {
+        // The decode loop is a chain of small latency-bound launches that leaves most CUs idle, and the post-net of frame t
+        // only needs mel frames t-10..t+10: run the post-net in time windows on a second stream while later steps decode.
+        if (!m->side) {
+            L2S_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+            L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+            L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming));
+        }
+        Bump pbump((char*)rest + align_up(decode_ws_floats(B) * (int64_t)sizeof(float), 256), rest_bytes - align_up(decode_ws_floats(B) * (int64_t)sizeof(float), 256));
+        PostBufs pb;
+        L2S_REQUIRE(postnet_alloc(pbump, B, S, pb) == 0, "workspace too small (l2s_workspace_bytes)");
+        int done[5] = {0, 0, 0, 0, 0};      // frames finished per post-net layer
+        size_t ev_used = 0;
+        const int chunk = 64, tail = 12;
+        std::function<int(int)> on_frames = [&](int n) -> int {
+            const bool boundary = (n == S) || (n % chunk == 0 && n < S - tail) || (n == S - tail && S > tail);
+            if (!boundary) return 0;
+            if (ev_used >= m->ev_pool.size()) {
+                hipEvent_t e;
+                L2S_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                m->ev_pool.push_back(e);
+            }
+            hipEvent_t ev = m->ev_pool[ev_used++];
+            L2S_CHECK_HIP(hipEventRecord(ev, s));
+            L2S_CHECK_HIP(hipStreamWaitEvent(m->side, ev, 0));
+            for (int layer = 0; layer < 5; ++layer) {
+                const int end = n == S ? S : std::max(done[layer], n - 2 * (layer + 1));
+                if (postnet_layer(m->w, layer, mel, pb, mel_post, B, S, done[layer], end, m->side)) return 1;
+                done[layer] = end;
+            }
+            return 0;
+        };
+        // the side stream must not start before earlier work on `s` (previous users of these buffers) is done
+        L2S_CHECK_HIP(hipEventRecord(m->ev_in, s));
+        L2S_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_in, 0));
+        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, g_opt_fold != 0, &on_frames)) return 1;
+        L2S_CHECK_HIP(hipEventRecord(m->ev_out, m->side));
+        L2S_CHECK_HIP(hipStreamWaitEvent(s, m->ev_out, 0));
+    }
     return launch_output_lengths(stop, B, S, lengths, s);
 }
 
@@ -1160,6 +1218,7 @@ int l2s_set_option(const char* name, int value) {
     if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
+    else if (!std::strcmp(name, "overlap_postnet")) g_opt_overlap_postnet = value;
     else { set_error(std::string("unknown option ") + name); return 1; }
     return 0;
 }

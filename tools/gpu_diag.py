@@ -119,11 +119,20 @@ def decoder_stages():
     line("postnet alone (oracle mel in)", pc.maxdiff(post_only, g["mel_post"]), 1e-4)
     lens = native.output_lengths(stop)
     print("   output_lengths", lens.tolist(), "golden", g["output_lengths"].tolist())
-    t0 = time.time()
-    mp, ln, at = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=300, want_attn=True)
-    torch.cuda.synchronize()
-    line("l2s_inference mel_post", pc.maxdiff(mp, g["mel_post"]), 1e-3)
-    print(f"   l2s_inference B=2 wall {time.time() - t0:.3f}s")
+    native.set_option("fold_step_weights", 1); native.set_option("use_graph", 0)
+    for ov in (0, 1, 1):
+        native.set_option("overlap_postnet", ov)
+        t0 = time.time()
+        mp, ln, at = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=300, want_attn=True)
+        torch.cuda.synchronize()
+        line(f"overlap_postnet={ov} l2s_inference mel_post", pc.maxdiff(mp, g["mel_post"]), 1e-3)
+        print(f"   l2s_inference B=2 wall {time.time() - t0:.3f}s lengths {ln.tolist()}")
+    for Sx in (5, 13, 70, 130):
+        native.set_option("overlap_postnet", 0)
+        a, _, _ = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=Sx)
+        native.set_option("overlap_postnet", 1)
+        b, _, _ = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=Sx)
+        line(f"overlap vs sequential post-net, S={Sx}", pc.maxdiff(a, b), 1e-12)
 
 
 def timing():
@@ -132,13 +141,13 @@ def timing():
     video = synth.synth_video(B, T, tag="bench").cuda()
     emb = synth.synth_speaker_embedding(B, tag="bench").cuda()
     gum = synth.synth_gumbel(B * 4, tag="bench").cuda()
-    for fold, graph in ((0, 0), (1, 0), (0, 1), (1, 1)):
-        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph)
+    for fold, graph, ov in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 1)):
+        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph); native.set_option("overlap_postnet", ov)
         for it in range(4):
             torch.cuda.synchronize(); t0 = time.time()
             nm.inference(video, emb, gum, S=S)
             torch.cuda.synchronize(); dt = time.time() - t0
-            print(f"   fold{fold} graph{graph} B=32 inference iter {it}: {dt * 1e3:.1f} ms -> {B * S / dt:.0f} mel-frames/s", flush=True)
+            print(f"   fold{fold} graph{graph} overlap{ov} B=32 inference iter {it}: {dt * 1e3:.1f} ms -> {B * S / dt:.0f} mel-frames/s", flush=True)
     native.profile_enable(True); native.profile_reset()
     nm.inference(video, emb, gum, S=S)
     torch.cuda.synchronize()
