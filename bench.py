@@ -111,7 +111,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl")
 
     # replicated weights, per-rank shard of clips (no exchange step on the inference path)
     sd = synth.synth_state_dict()

@@ -1,0 +1,54 @@
+"""Data boundary of the path (reference: /root/reference/datasets/__init__.py:7-89, datasets/spectograms.py:41-59).
+
+Host-side only: these functions define the tensor layouts that cross into the model -
+``(B,3,T,96,96)`` frames zero-padded to the batch maximum, mel targets padded with ln(1e-5), gate = 1 from the
+last real frame on.  The model ignores the returned lengths, so the padding IS part of the
+semantics and is reproduced exactly.
+"""
+from __future__ import annotations
+
+import torch
+
+from .spectrograms import MelSpectrogram  # noqa: F401
+from .lrw import LRW  # noqa: F401
+
+MEL_PAD = -11.5129      # ln(1e-5), the floor of the log-mel transform
+
+
+def _collate(batch, with_paths: bool):
+    if with_paths:
+        mouths, speeches, melspecs, faces, paths = zip(*batch)
+    else:
+        mouths, speeches, melspecs, faces = zip(*batch)
+        paths = None
+    n = len(mouths)
+    t_max = max(m.shape[0] for m in mouths)
+    a_max = max(s.shape[1] for s in speeches)
+    m_max = max(m.shape[1] for m in melspecs)
+    video = torch.zeros(n, t_max, *mouths[0].shape[1:])
+    audio = torch.zeros(n, a_max)
+    mels = torch.full((n, melspecs[0].shape[0], m_max), MEL_PAD)
+    gate = torch.zeros(n, m_max)
+    v_len, a_len, m_len = [], [], []
+    for i, (mouth, speech, mel) in enumerate(zip(mouths, speeches, melspecs)):
+        video[i, :mouth.shape[0]] = mouth
+        audio[i, :speech.shape[-1]] = speech.reshape(-1)
+        mels[i, :, :mel.shape[-1]] = mel
+        gate[i, mel.shape[-1] - 1:] = 1.0
+        v_len.append(mouth.shape[0]); a_len.append(speech.shape[-1]); m_len.append(mel.shape[-1])
+    out = ((video.permute(0, 2, 1, 3, 4), torch.tensor(v_len)), (audio, torch.tensor(a_len)),
+           (mels, torch.tensor(m_len), gate), torch.stack(list(faces), dim=0))
+    return out + (paths,) if with_paths else out
+
+
+def train_collate_fn_pad(batch):
+    """[(mouth (T,3,H,W), speech (1,N), melspec (80,M), face_crop (2,3,160,160))] -> the reference's 4-tuple."""
+    return _collate(batch, with_paths=False)
+
+
+def test_collate_fn_pad(batch):
+    """Same with the per-item file paths appended (demo.py:60)."""
+    return _collate(batch, with_paths=True)
+
+
+test_collate_fn_pad.__test__ = False      # not a pytest test despite the reference's name

@@ -1,0 +1,74 @@
+"""Data boundary (collates, mel transform, LRW sample loader) - CPU."""
+import os
+
+import numpy as np
+import torch
+
+from lip2speech_amd.datasets import LRW, MelSpectrogram, test_collate_fn_pad, train_collate_fn_pad
+from lip2speech_amd.datasets.lrw import load_frames, normalise_mouth
+
+SAMPLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_lrw")
+
+
+def _item(T, N, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(T, 3, 96, 96, generator=g), torch.randn(1, N, generator=g), torch.randn(80, M, generator=g), torch.randn(2, 3, 160, 160, generator=g))
+
+
+def test_collate_layouts_and_padding():
+    batch = [_item(25, 16000, 63, 0), _item(29, 19456, 77, 1)]
+    (video, vlen), (audio, alen), (mels, mlen, gate), faces = train_collate_fn_pad(batch)
+    assert video.shape == (2, 3, 29, 96, 96) and vlen.tolist() == [25, 29]
+    assert torch.equal(video[0, :, 25:], torch.zeros(3, 4, 96, 96))                 # zero frames after the clip end
+    assert torch.equal(video[0, :, :25], batch[0][0].permute(1, 0, 2, 3))
+    assert audio.shape == (2, 19456) and alen.tolist() == [16000, 19456] and audio[0, 16000:].abs().sum() == 0
+    assert mels.shape == (2, 80, 77) and torch.all(mels[0, :, 63:] == -11.5129)
+    assert gate[0].tolist() == [0.0] * 62 + [1.0] * 15 and gate[1].tolist() == [0.0] * 76 + [1.0]
+    assert faces.shape == (2, 2, 3, 160, 160)
+    out = test_collate_fn_pad([b + (("f", "a"),) for b in batch])
+    assert len(out) == 5 and out[4] == (("f", "a"), ("f", "a"))
+
+
+def test_mel_transform_against_direct_dft():
+    """80-mel / n_fft 1024 / hop 256 log-mel: check torch.stft route against an explicit DFT of one frame."""
+    mel = MelSpectrogram()
+    t = torch.arange(19456) / 16000.0
+    wav = (0.3 * torch.sin(2 * np.pi * 440 * t) + 0.1 * torch.sin(2 * np.pi * 3000 * t)).unsqueeze(0)
+    out = mel(wav)
+    assert out.shape == (1, 80, 19456 // 256 + 1) and out.min() >= np.log(1e-5) - 1e-6
+    # frame 10 by hand: reflect-padded signal, hann window, |DFT|^2, triangular HTK filters
+    padded = torch.nn.functional.pad(wav.unsqueeze(0), (512, 512), mode="reflect")[0, 0]
+    frame = padded[10 * 256: 10 * 256 + 1024].double() * torch.hann_window(1024, periodic=True).double()
+    k = torch.arange(513).double().unsqueeze(1) * torch.arange(1024).double().unsqueeze(0) * (2 * np.pi / 1024)
+    power = (torch.cos(k) @ frame) ** 2 + (torch.sin(k) @ frame) ** 2
+    want = torch.log(torch.clamp(power.float() @ mel.fb, min=1e-5))
+    assert (out[0, :, 10] - want).abs().max() < 1e-3
+    assert out[0, :, 10].argmax() == want.argmax()
+    # speaker-encoder front-end shape: 40 mels, n_fft 400, hop 160, no log (audio.py:121)
+    m40 = MelSpectrogram(n_fft=400, hop_length=160, win_length=400, n_mels=40, f_min=0.0, f_max=8000.0, log=False)
+    assert m40(wav).shape == (1, 40, 19456 // 160 + 1)
+
+
+def test_lrw_sample_clips_load():
+    frames = load_frames(os.path.join(SAMPLE, "ABOUT_00001_mouth.npz"))
+    assert frames.shape == (29, 96, 96, 3) and frames.dtype == np.uint8
+    x = normalise_mouth(frames)
+    assert x.shape == (29, 3, 96, 96) and abs(float(x.mean())) < 3
+    audio = np.load(os.path.join(SAMPLE, "ABOUT_00001.npz"))["data"]
+    assert audio.shape == (19456,) and audio.dtype == np.float32
+    assert MelSpectrogram()(torch.from_numpy(audio[None])).shape == (1, 80, 77)     # LRW: S = 77
+
+
+def test_lrw_dataset_index_rebuild(tmp_path):
+    # lay the two fixture clips out like the reference's tree; the CSV index is absent there too
+    import shutil
+    d = tmp_path / "LRW_Faces" / "ABOUT" / "test"
+    a = tmp_path / "lipread_audio" / "ABOUT" / "test"
+    d.mkdir(parents=True); a.mkdir(parents=True)
+    for i in (1, 2):
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}_mouth.npz"), d / f"ABOUT_0000{i}_mouth.npz")
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}.npz"), a / f"ABOUT_0000{i}.npz")
+    ds = LRW(str(tmp_path), mode="test")
+    assert len(ds) == 2
+    (video, vlen), (audio, alen), (mels, mlen, gate), faces = train_collate_fn_pad([ds[0], ds[1]])
+    assert video.shape == (2, 3, 29, 96, 96) and mels.shape == (2, 80, 77) and vlen.tolist() == [29, 29]

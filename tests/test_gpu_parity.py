@@ -203,3 +203,28 @@ def test_edge_shapes(nm, synth_sd):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_sample_lrw_clips_plumbing(nm, synth_sd):
+    """BASELINE config[0] shape: two real SAMPLE_LRW mouth clips (JPEG -> PIL -> ImageNet normalisation -> collate) through
+    the HIP path vs the oracle on the same frames (plumbing with real data; synthetic weights, supplied embedding)."""
+    import os
+    from lip2speech_amd.datasets import train_collate_fn_pad
+    from lip2speech_amd.datasets.lrw import load_frames, normalise_mouth
+    from lip2speech_amd.datasets.spectrograms import MelSpectrogram
+    root = os.path.join(pc.GOLDEN, "sample_lrw")
+    mel_t = MelSpectrogram()
+    items = []
+    for i in (1, 2):
+        mouth = normalise_mouth(load_frames(os.path.join(root, f"ABOUT_0000{i}_mouth.npz")))
+        speech = torch.from_numpy(np.load(os.path.join(root, f"ABOUT_0000{i}.npz"))["data"][None])
+        items.append((mouth, speech, mel_t(speech).squeeze(0), torch.zeros(2, 3, 160, 160)))
+    (video, vlen), _, (mels, mlen, gate), _ = train_collate_fn_pad(items)
+    assert video.shape == (2, 3, 29, 96, 96) and mels.shape == (2, 80, 77)
+    emb = synth.synth_speaker_embedding(2, tag="sample")
+    gum = synth.synth_gumbel(2 * 4, tag="sample")
+    mel_post, lengths, _ = nm.inference(video.cuda(), emb.cuda(), gum.cuda(), S=300)
+    with torch.no_grad():
+        ref_post, ref_len, _ = orc.inference(synth_sd, video, emb, gum, S=300)
+    assert pc.maxdiff(mel_post, ref_post) < MEL_TOL
+    assert torch.equal(lengths.cpu(), ref_len)
