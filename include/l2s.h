@@ -116,6 +116,13 @@ int l2s_decode_steps(l2s_model* m, float* state, int B, int T, int S,
 int l2s_postnet(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf,
                 void* ws, int64_t ws_bytes, void* stream);
 
+/* SpeakerEncoder.inference (model/modules/audio.py:131-150; called at demo.py:84): audio dev (B, n_samples) 16 kHz ->
+ * 40-band mel power spectrogram (n_fft 400, hop 160, hann, centre/reflect, HTK, no log) -> 3 x LSTM(256) ->
+ * Linear(last hidden) -> ReLU -> L2 normalise -> emb dev (B,256).  Needs the speaker_encoder.* keys in the model. */
+int64_t l2s_speaker_workspace_bytes(int B, int n_samples);
+int l2s_speaker_encoder_fwd(l2s_model* m, const float* audio, int B, int n_samples, float* emb,
+                            void* ws, int64_t ws_bytes, void* stream);
+
 /* decoder.py:429-435: lengths[b] = first i+1 with stop logit > 0, else S.  lengths dev (B) int64. */
 int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* stream);
 

@@ -227,4 +227,55 @@ int launch_stop_const(const float* ecell, const float* w_tail, const float* bias
     return 0;
 }
 
+// SpeakerEncoder front-end (audio.py:121,131: torchaudio MelSpectrogram n_fft 400 / hop 160, centre + reflect padding):
+// frames[(b*L + l)*400 + j] = reflect_pad(audio[b])[l*160 + j] * hann[j]
+__global__ __launch_bounds__(256) void frame_window_kernel(const float* __restrict__ audio, int B, int N, int L, int n_fft, int hop,
+                                                           const float* __restrict__ window, float* __restrict__ frames) {
+    const int64_t total = (int64_t)B * L * n_fft;
+    const int half = n_fft / 2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = idx % n_fft;
+        const int64_t r = idx / n_fft;
+        const int l = r % L;
+        const int b = r / L;
+        int i = l * hop + j - half;
+        if (i < 0) i = -i;
+        if (i >= N) i = 2 * (N - 1) - i;
+        frames[idx] = audio[(int64_t)b * N + i] * window[j];
+    }
+}
+int launch_frame_window(const float* audio, int B, int N, int L, int n_fft, int hop, const float* window, float* frames, hipStream_t s) {
+    const int64_t total = (int64_t)B * L * n_fft;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    ProfScope ps("spk_frame_window", s);
+    hipLaunchKernelGGL(frame_window_kernel, dim3(blocks), dim3(256), 0, s, audio, B, N, L, n_fft, hop, window, frames);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// power[r][k] = re[r][k]^2 + im[r][k]^2 from the DFT GEMM output spec[r] = [re(0..nf-1) | im(0..nf-1)] (ld = lds); columns nf..ldp-1 zero
+__global__ __launch_bounds__(256) void power_kernel(const float* __restrict__ spec, int lds, int64_t rows, int nf, float* __restrict__ power, int ldp) {
+    const int64_t total = rows * ldp;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int k = idx % ldp;
+        const int64_t r = idx / ldp;
+        float v = 0.f;
+        if (k < nf) {
+            const float re = spec[r * lds + k], im = spec[r * lds + nf + k];
+            v = re * re + im * im;
+        }
+        power[idx] = v;
+    }
+}
+int launch_power(const float* spec, int lds, int64_t rows, int nf, float* power, int ldp, hipStream_t s) {
+    const int64_t total = rows * ldp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    ProfScope ps("spk_power_spectrum", s);
+    hipLaunchKernelGGL(power_kernel, dim3(blocks), dim3(256), 0, s, spec, lds, rows, nf, power, ldp);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace l2s

@@ -111,6 +111,11 @@ struct Weights {
     const float* bos = nullptr; const float* tau = nullptr; const float* tau_c = nullptr;
     // postnet
     ConvW post[5];
+    // speaker encoder (audio.py:110-150): mel40 front-end tables + 3-layer LSTM(256) + Linear
+    const float* spk_window = nullptr; const float* spk_dft = nullptr; const float* spk_fbT = nullptr;   // [400], [402][400], [40][204]
+    ConvW spk_ih[3];                 // input weights [1024][in] with shift = b_ih + b_hh
+    SkW spk_hh[3];                   // recurrent weights, frag16, rows permuted to (unit, gate)
+    ConvW spk_linear;
 };
 
 }  // namespace l2s
@@ -120,7 +125,7 @@ struct l2s_model {
     float* blob = nullptr;
     int64_t blob_floats = 0;
     bool finalized = false;
-    bool has_enc = false, has_dec = false;
+    bool has_enc = false, has_dec = false, has_spk = false;
     l2s::Weights w;
     // captured decode loops (hipGraph), replayed on a private non-blocking stream fenced against the caller's stream
     struct GraphEntry { int B, T, S, attn_logits, fold; const void *state, *mel, *stop, *attn, *ws; hipGraph_t graph; hipGraphExec_t exec; };
@@ -233,8 +238,9 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         for (auto& kv : m->host) if (kv.first.compare(0, pre.size(), pre) == 0) return true;
         return false;
     };
-    const bool want_enc = has_prefix(E), want_dec = has_prefix(Dk);
-    if (!want_enc && !want_dec) { set_error("l2s_model_finalize: no encoder.* or decoder.* tensors were set"); return 1; }
+    const std::string Sk = "speaker_encoder.";
+    const bool want_enc = has_prefix(E), want_dec = has_prefix(Dk), want_spk = has_prefix(Sk);
+    if (!want_enc && !want_dec && !want_spk) { set_error("l2s_model_finalize: no encoder.* / decoder.* / speaker_encoder.* tensors were set"); return 1; }
     if (want_enc) {
 
     // ---- frontend: Conv3d (24,3,5,7,7) -> [slab = ci*5+kt][50][32]
@@ -497,6 +503,54 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         if (i < 4) P.copy(Dk + "postnet.sin_activation." + std::to_string(i) + ".w", D, &w.post[i].actw);
     }
     }   // want_dec
+    if (want_spk) {
+        constexpr int NFFT = 400, NF = 201, NMEL = 40, NFP = 204;
+        {   // hann window (periodic), real-DFT matrix [cos | sin] and HTK mel filterbank, all computed in fp64
+            const double PI = 3.14159265358979323846;
+            int64_t wo = P.blob.alloc(NFFT), dof = P.blob.alloc((int64_t)2 * NF * NFFT), fo = P.blob.alloc((int64_t)NMEL * NFP);
+            for (int j = 0; j < NFFT; ++j) P.blob.data[wo + j] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * j / NFFT));
+            for (int k = 0; k < NF; ++k)
+                for (int j = 0; j < NFFT; ++j) {
+                    const double ang = 2.0 * PI * (double)((int64_t)k * j % NFFT) / NFFT;
+                    P.blob.data[dof + (int64_t)k * NFFT + j] = (float)std::cos(ang);
+                    P.blob.data[dof + (int64_t)(NF + k) * NFFT + j] = (float)std::sin(ang);
+                }
+            // torchaudio.functional.create_fb_matrix(n_freqs=201, f_min=0, f_max=8000, n_mels=40, sample_rate=16000, norm=None), HTK scale
+            std::vector<double> fpts(NMEL + 2);
+            const double m_min = 0.0, m_max = 2595.0 * std::log10(1.0 + 8000.0 / 700.0);
+            for (int i = 0; i < NMEL + 2; ++i) {
+                const double mpt = m_min + (m_max - m_min) * i / (NMEL + 1);
+                fpts[i] = 700.0 * (std::pow(10.0, mpt / 2595.0) - 1.0);
+            }
+            for (int k = 0; k < NF; ++k) {
+                const double f = 8000.0 * k / (NF - 1);
+                for (int mm = 0; mm < NMEL; ++mm) {
+                    const double down = (f - fpts[mm]) / (fpts[mm + 1] - fpts[mm]);
+                    const double up = (fpts[mm + 2] - f) / (fpts[mm + 2] - fpts[mm + 1]);
+                    P.blob.data[fo + (int64_t)mm * NFP + k] = (float)std::max(0.0, std::min(down, up));
+                }
+            }
+            P.bind(&w.spk_window, wo); P.bind(&w.spk_dft, dof); P.bind(&w.spk_fbT, fo);
+        }
+        for (int l = 0; l < 3; ++l) {
+            const int in = l == 0 ? 40 : 256;
+            const std::string sl = "l" + std::to_string(l);
+            auto wi = P.get(Sk + "lstm.weight_ih_" + sl, (int64_t)1024 * in), wh = P.get(Sk + "lstm.weight_hh_" + sl, (int64_t)1024 * 256);
+            auto bi = P.get(Sk + "lstm.bias_ih_" + sl, 1024), bh = P.get(Sk + "lstm.bias_hh_" + sl, 1024);
+            if (!wi || !wh || !bi || !bh) continue;
+            P.copy(Sk + "lstm.weight_ih_" + sl, (int64_t)1024 * in, &w.spk_ih[l].W);
+            int64_t bo = P.blob.alloc(1024);
+            for (int i = 0; i < 1024; ++i) P.blob.data[bo + i] = (*bi)[i] + (*bh)[i];
+            P.bind(&w.spk_ih[l].shift, bo);
+            P.frag16(1024, 256, [&](int np, float* row) {
+                std::memcpy(row, wh->data() + (int64_t)lstm_perm_row(np, 256) * 256, sizeof(float) * 256);
+                return true;
+            }, &w.spk_hh[l].W);
+            w.spk_hh[l].N = 1024; w.spk_hh[l].K = 256; w.spk_hh[l].tiles = 64;
+        }
+        P.copy(Sk + "linear.weight", (int64_t)256 * 256, &w.spk_linear.W);
+        P.copy(Sk + "linear.bias", 256, &w.spk_linear.shift);
+    }   // want_spk
     if (!P.missing.empty()) { set_error("l2s_model_finalize: " + P.missing); return 1; }
 
     // upload and patch pointers
@@ -511,6 +565,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     m->finalized = true;
     m->has_enc = want_enc;
     m->has_dec = want_dec;
+    m->has_spk = want_spk;
     return 0;
 }
 
@@ -1029,6 +1084,60 @@ static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ speaker encoder
+static int64_t spk_ws_floats(int B, int N) {
+    const int64_t L = N / 160 + 1, R = (int64_t)B * L;
+    return R * (400 + 402 + 204 + 40 + 1024 + 256 * 2) + (int64_t)pad16(B) * 256 * 3 + (int64_t)B * 256 + 64 * 16;
+}
+
+// SpeakerEncoder.inference (audio.py:131-150): mel40 -> 3 x LSTM(256), zero initial state -> Linear(h_last) -> ReLU -> L2 norm
+static int speaker_run(l2s_model* m, const float* audio, int B, int N, float* emb, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    L2S_REQUIRE(N > 200, "audio shorter than the reflect padding (200 samples)");
+    const int L = N / 160 + 1, Bp = pad16(B);
+    const int64_t R = (int64_t)B * L;
+    Bump bp(ws, ws_bytes);
+    float* frames = bp.f(R * 400); float* spec = bp.f(R * 402); float* power = bp.f(R * 204); float* mel = bp.f(R * 40);
+    float* pre = bp.f(R * 1024); float* hseq[2] = {bp.f(R * 256), bp.f(R * 256)};
+    float* hf[2] = {bp.f((int64_t)Bp * 256), bp.f((int64_t)Bp * 256)}; float* cf = bp.f((int64_t)Bp * 256);
+    float* lin = bp.f((int64_t)B * 256);
+    L2S_REQUIRE(!bp.overflow, "speaker-encoder workspace too small");
+    if (launch_frame_window(audio, B, N, L, 400, 160, w.spk_window, frames, s)) return 1;
+    if (launch_gemm1(gemm_plain(frames, 400, w.spk_dft, spec, 402, (int)R, 402, 400), s, "spk_dft_gemm")) return 1;
+    if (launch_power(spec, 402, R, 201, power, 204, s)) return 1;
+    if (launch_gemm1(gemm_plain(power, 204, w.spk_fbT, mel, 40, (int)R, 40, 204), s, "spk_mel_gemm")) return 1;
+    const float* x = mel;
+    int xin = 40;
+    for (int l = 0; l < 3; ++l) {
+        GemmP g = gemm_plain(x, xin, w.spk_ih[l].W, pre, 1024, (int)R, 1024, xin);
+        g.shift = w.spk_ih[l].shift;
+        if (launch_gemm1(g, s, "spk_lstm_input_gemm")) return 1;
+        if (launch_fill(hf[0], (int64_t)Bp * 256, 0.f, s)) return 1;
+        if (launch_fill(hf[1], (int64_t)Bp * 256, 0.f, s)) return 1;
+        if (launch_fill(cf, (int64_t)Bp * 256, 0.f, s)) return 1;
+        float* out = hseq[l & 1];
+        for (int t = 0; t < L; ++t) {
+            SkinnyBatch sb{};
+            SkinnyP p = sk_base(w.spk_hh[l], B);
+            p.seg[0] = {hf[t & 1], 16}; p.nseg = 1;
+            p.epi = SK_LSTM; p.H = 256;
+            p.pre = pre + (int64_t)t * 1024; p.ld_pre = (int64_t)L * 1024;
+            p.c_in = cf; p.c_out = cf;
+            p.h_out = hf[(t & 1) ^ 1]; p.h_out_K = 256; p.h_out_off = 0;
+            p.h_seq = out + (int64_t)t * 256; p.ld_hseq = (int64_t)L * 256;
+            sb.p[0] = p; sb.ntiles[0] = 64; sb.count = 1;
+            if (launch_skinny(sb, s, "spk_lstm_step")) return 1;
+        }
+        x = out;
+        xin = 256;
+    }
+    // embeds = normalize(relu(linear(h_last))), h_last = top layer's output at the last frame
+    GemmP g = gemm_plain(x + (int64_t)(L - 1) * 256, L * 256, w.spk_linear.W, lin, 256, B, 256, 256);
+    g.shift = w.spk_linear.shift; g.act = ACT_RELU;
+    if (launch_gemm1(g, s, "spk_linear_gemm")) return 1;
+    return launch_pool_norm_cat(lin, B, 1, 256, nullptr, 0, 1, nullptr, 0, emb, s);
+}
+
 }  // namespace l2s
 
 // ================================================================================================ C ABI
@@ -1127,6 +1236,15 @@ int l2s_postnet(l2s_model* m, const float* mel, int B, int S, float* mel_post, f
     L2S_DEC_READY(m);
     L2S_REQUIRE(mel && mel_post && ws && B > 0 && S > 0, "bad arguments");
     return postnet_run(m, mel, B, S, mel_post, mel_cf, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int64_t l2s_speaker_workspace_bytes(int B, int n_samples) { return spk_ws_floats(B, n_samples) * (int64_t)sizeof(float) + (1 << 12); }
+
+int l2s_speaker_encoder_fwd(l2s_model* m, const float* audio, int B, int n_samples, float* emb, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_MODEL_READY(m);
+    L2S_REQUIRE(m->has_spk, "model holds no speaker_encoder.* weights");
+    L2S_REQUIRE(audio && emb && ws && B > 0, "bad arguments");
+    return speaker_run(m, audio, B, n_samples, emb, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* stream) {

@@ -187,6 +187,8 @@ int launch_tile_rows(const float* src, int lds, float* dst, int ldd, int B, int 
 // (B,S,C) -> (B,C,S)
 int launch_transpose_bsc(const float* in, int B, int S, int C, float* out, hipStream_t s);
 int launch_output_lengths(const float* stop, int B, int S, int64_t* lengths, hipStream_t s);
+int launch_frame_window(const float* audio, int B, int N, int L, int n_fft, int hop, const float* window, float* frames, hipStream_t s);
+int launch_power(const float* spec, int lds, int64_t rows, int nf, float* power, int ldp, hipStream_t s);
 // stop_const[b] = dot(ecell[b], w[512:1024]) + bias
 int launch_stop_const(const float* ecell, const float* w_tail, const float* bias, int B, float* out, hipStream_t s);
 

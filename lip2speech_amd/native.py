@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
-    "l2s_output_lengths", "l2s_inference",
+    "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
@@ -65,6 +65,9 @@ def lib() -> ctypes.CDLL:
     L.l2s_decode_steps.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _fp, _fp, _fp, _i, _vp, _i64, _vp]
     L.l2s_postnet.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
     L.l2s_output_lengths.argtypes = [_fp, _i, _i, _vp, _vp]
+    L.l2s_speaker_workspace_bytes.argtypes = [_i, _i]
+    L.l2s_speaker_workspace_bytes.restype = _i64
+    L.l2s_speaker_encoder_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _vp, _i64, _vp]
     L.l2s_inference.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
@@ -198,6 +201,14 @@ class NativeModel:
         check(lib().l2s_inference(self._h, _ptr(video), _ptr(emb), _ptr(gumbel), B, T, H, W, S, _ptr(mel_post),
                                   _ptr(lengths), _ptr(attn), _ptr(ws), ws.numel(), _stream()))
         return mel_post, lengths, attn
+
+    def speaker_encoder_fwd(self, audio: torch.Tensor) -> torch.Tensor:
+        audio = _f32(audio)
+        B, N = audio.shape
+        emb = torch.empty(B, 256, dtype=torch.float32, device=audio.device)
+        ws = torch.empty(int(lib().l2s_speaker_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
+        check(lib().l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
+        return emb
 
     def op_frontend(self, video: torch.Tensor) -> torch.Tensor:
         video = _f32(video)

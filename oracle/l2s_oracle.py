@@ -322,5 +322,49 @@ def forward_eval(sd: SD, video: torch.Tensor, emb: torch.Tensor, mels: torch.Ten
     return [mel_cf, postnet(sd, mel_cf) + mel_cf, stop.unsqueeze(2), emb, attn, st["content_dis"]]
 
 
+# ----------------------------------------------------------------------------------
+# speaker encoder  (audio.py:110-150).  The mel front-end is torchaudio's (absent here): its published algorithm is
+# restated below - PARITY UNPINNED for that piece; the LSTM/Linear tail is plain nn.LSTM math.
+# ----------------------------------------------------------------------------------
+def htk_mel_filterbank(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int, dtype=torch.float64) -> torch.Tensor:
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=dtype)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    f_pts = 700.0 * (10.0 ** (torch.linspace(m_min, m_max, n_mels + 2, dtype=dtype) / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+
+
+def mel40(audio: torch.Tensor) -> torch.Tensor:
+    """(B,N) -> (B,L,40): power spectrogram n_fft 400 / hop 160 / hann / centre-reflect, HTK mel 0-8 kHz, no log."""
+    win = torch.hann_window(400, periodic=True, dtype=audio.dtype)
+    spec = torch.stft(audio, 400, hop_length=160, win_length=400, window=win, center=True, pad_mode="reflect", return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2
+    fb = htk_mel_filterbank(201, 0.0, 8000.0, 40, 16000).to(audio.dtype)
+    return power.transpose(1, 2) @ fb
+
+
+def speaker_lstm_tail(sd: SD, mel: torch.Tensor, p: str = "speaker_encoder.") -> torch.Tensor:
+    """3 x LSTM(256) from a zero state over (B,L,40) -> Linear(h_last) -> ReLU -> L2 normalise."""
+    x = mel
+    B, L, _ = x.shape
+    for layer in range(3):
+        h = torch.zeros(B, 256, dtype=x.dtype)
+        c = torch.zeros(B, 256, dtype=x.dtype)
+        outs = []
+        for t in range(L):
+            h, c = lstm_cell(x[:, t], h, c, sd[f"{p}lstm.weight_ih_l{layer}"], sd[f"{p}lstm.weight_hh_l{layer}"],
+                             sd[f"{p}lstm.bias_ih_l{layer}"], sd[f"{p}lstm.bias_hh_l{layer}"])
+            outs.append(h)
+        x = torch.stack(outs, dim=1)
+    e = torch.relu(x[:, -1] @ sd[p + "linear.weight"].t() + sd[p + "linear.bias"])
+    return e / torch.clamp(torch.sqrt((e * e).sum(dim=1, keepdim=True)), min=1e-12)
+
+
+def speaker_encoder_inference(sd: SD, audio: torch.Tensor) -> torch.Tensor:
+    return speaker_lstm_tail(sd, mel40(audio))
+
+
 def to_dtype(sd: SD, dtype) -> SD:
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
