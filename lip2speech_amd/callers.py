@@ -1,0 +1,43 @@
+"""The model-facing halves of the reference's caller loops, without their I/O:
+
+  * ``demo_clip``      - demo.py:60-90: per clip, speaker embedding from the VOICE tower (``--encoding voice``) or a
+                         supplied one, ``net.inference(..., return_attention_map=True)``, truncate to ``output_lengths[0]``.
+  * ``evaluate_mels``  - evaluate.py:22-51: ``net(..., tf_ratio=1)[1]`` in eval mode over collated batches.
+
+The reference then vocodes the mels (InverseMelScale + Griffin-Lim, torchaudio) and scores ESTOI (pystoi); both are
+third-party, stochastic and out of scope here - these functions return the mels.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+
+def demo_clip(net, batch, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda"):
+    """``batch`` = one item of ``DataLoader(ds, batch_size=1, collate_fn=test_collate_fn_pad)``."""
+    (videos, _), (audios, _), _, face_crops, _ = batch
+    with torch.no_grad():
+        if speaker_embedding is None:
+            if speaker_encoder is None:
+                raise ValueError("pass a SpeakerEncoder (voice route) or a speaker_embedding")
+            speaker_embedding = speaker_encoder.inference(audios.to(device))
+        mel, lengths, attn = net.inference(videos.to(device), face_crops.to(device), speaker_embedding.to(device),
+                                           return_attention_map=True)
+    n = int(lengths[0])
+    return mel[:1, :, :n], lengths, attn[:, :n]
+
+
+def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda") -> List[torch.Tensor]:
+    """Post-net mels of ``net(..., tf_ratio=1)[1]`` for every collated batch (``train_collate_fn_pad`` layout)."""
+    was_training = net.training
+    net.eval()
+    outs = []
+    with torch.no_grad():
+        for (videos, vlen), (audios, alen), (melspecs, mlen, _gate), face_crops in batches:
+            emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
+            out = net(videos.to(device), face_crops.to(device), audios.to(device), melspecs.to(device), vlen, alen, mlen, 1,
+                      speaker_embedding=emb)
+            outs.append(out[1])
+    net.train(was_training)
+    return outs

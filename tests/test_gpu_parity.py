@@ -228,3 +228,38 @@ def test_sample_lrw_clips_plumbing(nm, synth_sd):
         ref_post, ref_len, _ = orc.inference(synth_sd, video, emb, gum, S=300)
     assert pc.maxdiff(mel_post, ref_post) < MEL_TOL
     assert torch.equal(lengths.cpu(), ref_len)
+
+
+def test_caller_loops_voice_route(synth_sd):
+    """demo.py / evaluate.py model-facing loops on real SAMPLE_LRW clips with the voice tower supplying the embedding."""
+    import os
+    from torch.utils.data import DataLoader
+    from lip2speech_amd import callers, statespec
+    from lip2speech_amd.datasets import test_collate_fn_pad, train_collate_fn_pad
+    from lip2speech_amd.datasets.lrw import load_frames, normalise_mouth
+    from lip2speech_amd.datasets.spectrograms import MelSpectrogram
+    from model.model import get_network
+    from model.modules import SpeakerEncoder
+    root = os.path.join(pc.GOLDEN, "sample_lrw")
+    mel_t = MelSpectrogram()
+    items = []
+    for i in (1, 2):
+        mouth = normalise_mouth(load_frames(os.path.join(root, f"ABOUT_0000{i}_mouth.npz")))
+        speech = torch.from_numpy(np.load(os.path.join(root, f"ABOUT_0000{i}.npz"))["data"][None])
+        items.append((mouth, speech, mel_t(speech).squeeze(0), torch.zeros(2, 3, 160, 160)))
+    net = get_network("test")
+    net.load_state_dict(synth_sd, strict=True)
+    net = net.cuda()
+    spk_sd = synth.synth_state_dict(statespec.speaker_encoder_spec("speaker_encoder."), seed=99)
+    spk = SpeakerEncoder(state_dict={k[len("speaker_encoder."):]: v for k, v in spk_sd.items()}).cuda()
+    # demo: batch_size 1, file paths appended by the test collate
+    one = test_collate_fn_pad([items[0] + (("face.npz", "audio.npz"),)])
+    mel, lengths, attn = callers.demo_clip(net, one, speaker_encoder=spk)
+    assert mel.shape[0] == 1 and mel.shape[1] == 80 and mel.shape[2] == int(lengths[0]) and attn.shape[2] == 29
+    # evaluate: B=2 batch, tf_ratio=1 -> S = 77 target frames
+    outs = callers.evaluate_mels(net, [train_collate_fn_pad(items)], speaker_encoder=spk)
+    assert outs[0].shape == (2, 80, 77) and torch.isfinite(outs[0]).all()
+    # same embedding computed by the oracle -> same first mel frames through the oracle path
+    with torch.no_grad():
+        emb_ref = orc.speaker_encoder_inference(spk_sd, torch.cat([it[1] for it in items], dim=0))
+    assert pc.maxdiff(spk.inference(torch.cat([it[1] for it in items], dim=0).cuda()), emb_ref) < 2e-4
