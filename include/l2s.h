@@ -145,6 +145,9 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 /* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
  * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);
+/* launch-floor probe: n dependent launches of an empty kernel (kind 0) or of a kernel in which each of `blocks` 512-thread
+ * blocks streams n_per_block x 8 KiB from `in` (kind 1) - the cost model of a latency-bound decode phase (tools/launch_floor.py) */
+int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream);
 /* run-time options (A/B switches kept for measurement; defaults are the fastest measured):
  *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
  *   "use_graph"         (0)  replay the decode loop from a captured hipGraph

@@ -1341,6 +1341,12 @@ int l2s_set_option(const char* name, int value) {
     return 0;
 }
 
+int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream) {
+    for (int i = 0; i < n_launches; ++i)
+        if (launch_probe(kind, blocks, n_per_block, in, out, (hipStream_t)stream)) return 1;
+    return 0;
+}
+
 int l2s_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 int l2s_profile_reset(void) { prof_drain(); g_prof.clear(); g_prof_idx.clear(); return 0; }
 int l2s_profile_count(void) { prof_drain(); return (int)g_prof.size(); }

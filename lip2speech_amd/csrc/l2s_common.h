@@ -154,6 +154,8 @@ constexpr int SKINNY_MAX_GROUP = 4;
 struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name);
 
+int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);
+
 // ---------------------------------------------------------------- decoder helper kernels (decoder_kernels.hip)
 struct AttnP {
     const float* q; int ldq;          // [B][512]

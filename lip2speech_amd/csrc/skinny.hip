@@ -35,44 +35,59 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 a
     return acc;
 }
 
-__device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/) {
+// Pin a set of wave-uniform kernel parameters in SGPRs at this point.  Without it hipcc fetches each parameter from the kernarg
+// segment lazily, right before its first use, behind its own `s_waitcnt lgkmcnt(0)`: the block start becomes a chain of ~15
+// dependent scalar-cache round trips (the kernarg was just written by the host, so they miss) in front of the first operand load.
+#define L2S_PIN_S(...) asm volatile("" ::__VA_ARGS__)
+
+__device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/, int ntiles = 1 << 30) {
+    // ---- every parameter the block needs, fetched in one batch of scalar loads
+    const float* const W = p.W;
+    const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
+    const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
+    const int K = p.K, epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
+    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
+    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
+    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(K), "s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act));
+    L2S_PIN_S("s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow), "s"(ntiles));
+    if (tile >= ntiles) return;                      // block-uniform: grid x is sized for the widest group of the launch
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NC = p.K >> 4;
-    const float4* wbase = reinterpret_cast<const float4*>(p.W) + (int64_t)tile * NC * 64 + lane;
-    const int e0 = p.seg[0].nchunks, e1 = e0 + p.seg[1].nchunks, e2 = e1 + p.seg[2].nchunks;
+    const int NC = K >> 4;
+    const float4* wbase = reinterpret_cast<const float4*>(W) + (int64_t)tile * NC * 64 + lane;
+    const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2;
 
-    // epilogue operands have launch-time addresses too: fetch them now, under the same round trip as the K slice
-    const int e_row = tid >> 4, e_col = tid & 15;
-    const int e_b = mt * 16 + e_row, e_np = tile * 16 + e_col;
-    float pf_bias = 0.f, pf_extra = 0.f, pf_c = 0.f;
-    if (tid < 256) {
-        if (p.bias) pf_bias = p.bias[e_np];
-        if (p.epi == SK_LSTM) {
-            if (p.pre && e_b < p.B) pf_extra = p.pre[(int64_t)e_b * p.ld_pre + (e_col & 3) * p.H + tile * 4 + (e_col >> 2)];
-        } else if (p.epi != SK_MEL && e_b < p.B && e_np < p.N) {
-            if (p.add) pf_extra = p.add[(int64_t)e_b * p.ld_add + e_np];
-            if (p.addrow) pf_extra += p.addrow[e_np];
-        }
-    }
-    if (p.epi == SK_LSTM && tid < 64) {
-        const int b2 = mt * 16 + (tid >> 2);
-        if (b2 < p.B) pf_c = p.c_in[frag16_index(b2, tile * 4 + (tid & 3), p.H)];
-    }
-
+    // ---- main operand loads first: the whole K slice of this wave in one round trip
     float4 a[SK_MAXC], w[SK_MAXC];
 #pragma unroll
     for (int j = 0; j < SK_MAXC; ++j) {
         const int c = wave + SK_WAVES * j;          // wave-uniform
         if (c < NC) {
-            int sidx = 0, lc = c;
-            if (c >= e2) { sidx = 3; lc = c - e2; }
-            else if (c >= e1) { sidx = 2; lc = c - e1; }
-            else if (c >= e0) { sidx = 1; lc = c - e0; }
-            const float4* ab = reinterpret_cast<const float4*>(p.seg[sidx].a);
-            a[j] = ab[((int64_t)mt * p.seg[sidx].nchunks + lc) * 64 + lane];
+            const float* ab = sa0; int lc = c, nn = n0;
+            if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
+            else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
+            else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
+            a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
             w[j] = wbase[(int64_t)c * 64];
         }
+    }
+    // ---- epilogue operands have launch-time addresses too: fetch them under the same round trip
+    const int e_row = tid >> 4, e_col = tid & 15;
+    const int e_b = mt * 16 + e_row, e_np = tile * 16 + e_col;
+    float pf_bias = 0.f, pf_extra = 0.f, pf_c = 0.f;
+    if (tid < 256) {
+        if (bias) pf_bias = bias[e_np];
+        if (epi == SK_LSTM) {
+            if (pre && e_b < nB) pf_extra = pre[(int64_t)e_b * ld_pre + (e_col & 3) * H + tile * 4 + (e_col >> 2)];
+        } else if (epi != SK_MEL && e_b < nB && e_np < N) {
+            if (add) pf_extra = add[(int64_t)e_b * ld_add + e_np];
+            if (addrow) pf_extra += addrow[e_np];
+        }
+    }
+    if (epi == SK_LSTM && tid < 64) {
+        const int b2 = mt * 16 + (tid >> 2);
+        if (b2 < nB) pf_c = c_in[frag16_index(b2, tile * 4 + (tid & 3), H)];
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -101,7 +116,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         v += pf_bias;
     }
 
-    if (p.epi == SK_LSTM) {
+    if (epi == SK_LSTM) {
         if (tid < 256) {
             const int u = col >> 2, gate = col & 3;
             const int unit = tile * 4 + u;
@@ -113,10 +128,10 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         if (tid < 64) {
             const int r2 = tid >> 2, u2 = tid & 3;
             const int b2 = mt * 16 + r2, unit2 = tile * 4 + u2;
-            if (b2 < p.B) {
+            if (b2 < nB) {
                 const float gi = gt[r2 * 17 + 4 * u2 + 0], gf = gt[r2 * 17 + 4 * u2 + 1];
                 const float gg = gt[r2 * 17 + 4 * u2 + 2], go = gt[r2 * 17 + 4 * u2 + 3];
-                const int64_t ci = frag16_index(b2, unit2, p.H);
+                const int64_t ci = frag16_index(b2, unit2, H);
                 const float cprev = pf_c;
                 const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
                 const float hn = sigmoidf_(go) * tanhf(cn);
@@ -128,8 +143,8 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         }
         return;
     }
-    if (tid >= 256 || b >= p.B) return;
-    if (p.epi == SK_MEL) {
+    if (tid >= 256 || b >= nB) return;
+    if (epi == SK_MEL) {
         if (np < 80) {
             p.mel[(int64_t)b * p.ld_mel_b + np] = v;
             if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
@@ -138,10 +153,10 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         }
         return;
     }
-    if (np >= p.N) return;
-    v = act_apply(v, p.act, p.actw, np);
+    if (np >= N) return;
+    v = act_apply(v, act, p.actw, np);
     v += pf_extra;
-    if (p.epi == SK_FRAG)
+    if (epi == SK_FRAG)
         p.out[frag16_index(b, np, p.ldo)] = v;
     else
         p.out[(int64_t)b * p.ldo + np] = v;
@@ -152,8 +167,7 @@ constexpr int SK_RED_FLOATS = (SK_WAVES + 1) * 16 * 17;
 __global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
     __shared__ float red[SK_RED_FLOATS];
     const int g = blockIdx.z;
-    if ((int)blockIdx.x >= batch.ntiles[g]) return;
-    skinny_block(batch.p[g], blockIdx.x, blockIdx.y, red);
+    skinny_block(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
@@ -236,11 +250,15 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T;
-    const float* kb = p.k + (int64_t)b * T * 512 + lane * 8;
-    const float* vb = p.v + (int64_t)b * T * 512 + tid;
+    const float* const pq = p.q; const float* const pk = p.k; const float* const pv = p.v; const float* const ptau = p.tau;
+    float* const pav = p.av_frag; float* const pattn = p.attn_out;
+    const int ldq = p.ldq, logits = p.attn_logits; const int64_t ld_attn = p.ld_attn_b;
+    L2S_PIN_S("s"(T), "s"(pq), "s"(pk), "s"(pv), "s"(ptau), "s"(pav), "s"(pattn), "s"(ldq), "s"(logits), "s"(ld_attn));
+    const float* kb = pk + (int64_t)b * T * 512 + lane * 8;
+    const float* vb = pv + (int64_t)b * T * 512 + tid;
     // ---- loads
-    const float qv = p.q[(int64_t)b * p.ldq + tid];
-    const float tau = p.tau[0];
+    const float qv = pq[(int64_t)b * ldq + tid];
+    const float tau = ptau[0];
     float4 k0[4], k1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -286,7 +304,7 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     const float tot = block_sum8(ex, scratch);
     if (on) {
         const float aw = ex / tot;
-        if (p.attn_out) p.attn_out[(int64_t)b * p.ld_attn_b + tid] = p.attn_logits ? x : aw;
+        if (pattn) pattn[(int64_t)b * ld_attn + tid] = logits ? x : aw;
         sc[tid] = aw;
     }
     __syncthreads();
@@ -303,7 +321,7 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
         for (int e = 0; e < 16; ++e)
             if (t0 + e < T) acc = fmaf(sc[t0 + e], v2[e], acc);
     }
-    p.av_frag[frag16_index(b, tid, 512)] = acc;
+    pav[frag16_index(b, tid, 512)] = acc;
 }
 
 // Content.forward (decoder.py:262-271) for one batch row: alpha = softmax_m(SiLU(..)*tau_c . key), cc = alpha @ value
@@ -314,10 +332,13 @@ __device__ __forceinline__ void content_block(const AttnP& p, int b, float* sm) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = p.m;
     const int col = tid & 255;
-    const float qv = p.qc[(int64_t)b * p.ldqc + col];
-    const float tau_c = p.tau_c[0];
-    const float* keyb = p.ckey + (int64_t)b * m * 256 + lane * 4;
-    const float* valb = p.cval + (int64_t)b * m * 256 + col;
+    const float* const pqc = p.qc; const float* const pkey = p.ckey; const float* const pval = p.cval; const float* const ptc = p.tau_c;
+    float* const pcc = p.cc_frag; const int ldqc = p.ldqc;
+    L2S_PIN_S("s"(m), "s"(pqc), "s"(pkey), "s"(pval), "s"(ptc), "s"(pcc), "s"(ldqc));
+    const float qv = pqc[(int64_t)b * ldqc + col];
+    const float tau_c = ptc[0];
+    const float* keyb = pkey + (int64_t)b * m * 256 + lane * 4;
+    const float* valb = pval + (int64_t)b * m * 256 + col;
     float4 kk[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -349,13 +370,14 @@ __device__ __forceinline__ void content_block(const AttnP& p, int b, float* sm) 
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (i < m) o = fmaf(expf(csc[i] - cmx) / csum, vals[i], o);
-        p.cc_frag[frag16_index(b, tid, 256)] = o;
+        pcc[frag16_index(b, tid, 256)] = o;
     }
 }
 
 __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
     __shared__ __attribute__((aligned(16))) float sm[ATT_SM_FLOATS > SK_RED_FLOATS ? ATT_SM_FLOATS : SK_RED_FLOATS];
-    const int nb = sb.at.B;
+    const int nb = sb.at.B, ptiles = sb.pre2_tiles;
+    L2S_PIN_S("s"(nb), "s"(ptiles));
     const int bid = blockIdx.x;
     if (bid < nb) {
         attention_block(sb.at, bid, sm);
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
         content_block(sb.at, bid - nb, sm);
     } else {
         const int j = bid - 2 * nb;
-        const int tile = j % sb.pre2_tiles, mt = j / sb.pre2_tiles;
+        const int tile = j % ptiles, mt = j / ptiles;
         skinny_block(sb.pre2, tile, mt, sm);
     }
 }
@@ -377,6 +399,28 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     sb.mts = (at.B + 15) / 16;
     ProfScope ps("step_attention_prenet2", s);
     hipLaunchKernelGGL(step_attn_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- launch-floor probes (tools/launch_floor.py): chains of dependent launches shaped like a decode phase
+__global__ __launch_bounds__(512) void probe_empty_kernel(float* out) {
+    if (threadIdx.x == 1023) out[0] = 0.f;
+}
+__global__ __launch_bounds__(512) void probe_touch_kernel(const float* __restrict__ in, float* __restrict__ out, int n_per_block) {
+    // every block reads n_per_block KiB-sized wave loads (like a K slice) and writes one value per block
+    const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)blockIdx.x * n_per_block * 64 * 8;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < n_per_block; ++j) {
+        const float4 v = src[(int64_t)(j * 8 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+    if (threadIdx.x == 0) out[blockIdx.x] = acc.x;
+}
+int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s) {
+    if (kind == 0) hipLaunchKernelGGL(probe_empty_kernel, dim3(blocks), dim3(512), 0, s, out);
+    else hipLaunchKernelGGL(probe_touch_kernel, dim3(blocks), dim3(512), 0, s, in, out, n_per_block);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

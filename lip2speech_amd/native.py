@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libl2s_hip.so")
+LIB_PATH = os.environ.get("L2S_LIB") or os.path.join(_HERE, "csrc", "libl2s_hip.so")   # L2S_LIB: A/B another build of the same ABI
 
 # every symbol include/l2s.h declares; tests check the built library exports all of them
 ABI_SYMBOLS = (
@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
 
@@ -73,6 +73,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
+    L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
     _lib = L
