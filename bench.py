@@ -156,8 +156,13 @@ def main():
         gpu_ms = sum(r[2] for r in prof)
         name, launches, total_ms = prof[0]
         avg_s = total_ms / launches * 1e-3
-        roof = {"kernel": name, "launches_per_step": launches // 2, "avg_us": avg_s * 1e6,
-                "share_of_gpu_time": total_ms / gpu_ms}
+        roof = {"kernel": name, "launches_per_step": launches // 2, "share_of_gpu_time": total_ms / gpu_ms,
+                "avg_us_event_per_launch": avg_s * 1e6}
+        if name == "step_lstm_cell":
+            # per-launch event brackets inflate a 6 us kernel by ~1.8 us; time the same launches as one chain between ONE event pair
+            avg_s = nm.lstm_cell_chain_us(B, 300) * 1e-6
+            roof["timing"] = "one HIP-event pair around a chain of 600 launches (300 x {layer 0, layer 1}) on the launch stream"
+        roof["avg_us"] = avg_s * 1e6
         model = kernel_model(name)
         if model:
             flops, nbytes = model

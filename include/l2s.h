@@ -145,6 +145,9 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 /* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
  * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);
+/* average duration (us) of the decoder LSTM-cell kernel over a chain of n_pairs x {layer 0, layer 1} launches bracketed by ONE pair
+ * of HIP events on `stream` (bench.py's roofline figure; synchronises) */
+int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t ws_bytes, void* stream, double* avg_us);
 /* launch-floor probe: n dependent launches of an empty kernel (kind 0) or of a kernel in which each of `blocks` 512-thread
  * blocks streams n_per_block x 8 KiB from `in` (kind 1) - the cost model of a latency-bound decode phase (tools/launch_floor.py) */
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream);

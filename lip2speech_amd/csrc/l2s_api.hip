@@ -1341,6 +1341,53 @@ int l2s_set_option(const char* name, int value) {
     return 0;
 }
 
+// Average duration of the decoder LSTM-cell kernel (the kernel with the largest share of GPU time) measured with ONE pair of HIP
+// events around a chain of n_pairs x {layer 0 (K=1536), layer 1 (K=1024)} launches on `stream` - the same launches the decode loop
+// issues, on zeroed state.  Per-launch event brackets (l2s_profile_*) add ~1.8 us to a 6 us kernel; this does not.  Synchronises.
+int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t ws_bytes, void* stream, double* avg_us) {
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(ws && avg_us && B > 0 && n_pairs > 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const Weights& w = m->w;
+    const int Bp = pad16(B);
+    Bump bp(ws, ws_bytes);
+    float* h0[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* h1[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* c0 = bp.f((int64_t)Bp * 512); float* c1 = bp.f((int64_t)Bp * 512); float* av = bp.f((int64_t)Bp * 512);
+    float* cc = bp.f((int64_t)Bp * 256); float* p2f = bp.f((int64_t)Bp * 256);
+    L2S_REQUIRE(!bp.overflow, "workspace too small");
+    for (float* z : {h0[0], h0[1], h1[0], h1[1], c0, c1, av}) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
+    for (float* z : {cc, p2f}) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
+    hipEvent_t e0, e1;
+    L2S_CHECK_HIP(hipEventCreate(&e0));
+    L2S_CHECK_HIP(hipEventCreate(&e1));
+    auto pair = [&](int cur) -> int {
+        const int nxt = cur ^ 1;
+        SkinnyBatch sb{};
+        SkinnyP a = sk_base(w.lstm0f, B);
+        a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.seg[2] = {av, 32}; a.seg[3] = {h0[cur], 32}; a.nseg = 4;
+        a.epi = SK_LSTM; a.H = 512; a.c_in = c0; a.c_out = c0; a.h_out = h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+        sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
+        if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
+        SkinnyBatch sc{};
+        SkinnyP b = sk_base(w.lstm1, B);
+        b.seg[0] = {h0[nxt], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2;
+        b.epi = SK_LSTM; b.H = 512; b.c_in = c1; b.c_out = c1; b.h_out = h1[nxt]; b.h_out_K = 512; b.h_out_off = 0;
+        sc.p[0] = b; sc.ntiles[0] = 128; sc.count = 1;
+        return launch_skinny(sc, s, "step_lstm_cell");
+    };
+    for (int i = 0; i < 8; ++i) if (pair(i & 1)) return 1;                   // warm-up
+    L2S_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < n_pairs; ++i) if (pair(i & 1)) return 1;
+    L2S_CHECK_HIP(hipEventRecord(e1, s));
+    L2S_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    L2S_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / (2.0 * n_pairs);
+    return 0;
+}
+
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream) {
     for (int i = 0; i < n_launches; ++i)
         if (launch_probe(kind, blocks, n_per_block, in, out, (hipStream_t)stream)) return 1;

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
 
@@ -74,6 +74,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
     L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
+    L.l2s_op_lstm_cell_chain.argtypes = [_vp, _i, _i, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_double)]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -210,6 +211,13 @@ class NativeModel:
         ws = torch.empty(int(lib().l2s_speaker_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
         check(lib().l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
         return emb
+
+    def lstm_cell_chain_us(self, B: int, n_pairs: int = 300) -> float:
+        """Average duration of the decoder LSTM-cell kernel, one HIP-event pair around 2*n_pairs chained launches."""
+        ws = self.workspace(B, 29, 96, 96, 300, torch.device("cuda", torch.cuda.current_device()))
+        out = ctypes.c_double()
+        check(lib().l2s_op_lstm_cell_chain(self._h, B, n_pairs, _ptr(ws), ws.numel(), _stream(), ctypes.byref(out)))
+        return float(out.value)
 
     def op_frontend(self, video: torch.Tensor) -> torch.Tensor:
         video = _f32(video)
