@@ -133,6 +133,24 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
                   float* mel_post, int64_t* lengths, float* attn,
                   void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- training-side primitives of the data-parallel step (train.py:102-104,172-193; train_utils/losses.py:69-77) ----------
+ * scratch: l2s_train_scratch_bytes() of device memory.  Reductions are two-stage fp64 (deterministic). */
+int64_t l2s_train_scratch_bytes(void);
+/* losses5 dev = {mel MSE, 10 * post-net mel MSE, gate BCE-with-logits, KLD(content_dis || uniform), sum}; mel/mel_post/mel_target are
+ * (B,80,S) channel-first as Decoder.forward returns them, stop/gate (B,S), content_dis (R,501).  d* (may be NULL) receive the
+ * gradients of the summed loss. */
+int l2s_loss(const float* mel, const float* mel_post, const float* mel_target, const float* stop, const float* gate_target,
+             const float* content_dis, int B, int S, int R, float* losses5, float* dmel, float* dmel_post, float* dstop, float* ddis,
+             void* scratch, void* stream);
+/* norm_out dev [1] = ||grads||_2 over a flat gradient range (torch.nn.utils.clip_grad_norm_'s total norm) */
+int l2s_grad_norm(const float* grads, int64_t n, void* scratch, float* norm_out, void* stream);
+/* torch.optim.AdamW(amsgrad=True) on a flat range, fused with gradient averaging and clipping:
+ * g_eff = grads * grad_mul * min(1, max_norm / (grad_norm[0] * grad_mul + 1e-6)); grad_norm dev [1] or NULL (no clipping).
+ * grad_mul = 1/world_size after a sum all-reduce.  step counts from 1. */
+int l2s_adamw_amsgrad_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm,
+                           float grad_mul, float max_norm, void* stream);
+
 /* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
 /* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,

@@ -1,0 +1,185 @@
+// Training-side primitives of the data-parallel step (reference: /root/reference/train.py:102-104,172-193 and
+// train_utils/losses.py:35-79): the 4-term loss with its gradients, the global gradient norm for clipping, and a fused
+// AdamW(amsgrad) update that applies the clip coefficient and the 1/world averaging of the all-reduced gradient in the
+// same pass.  All reductions are two-stage (per-block partials in fp64, then one block) so results are run-to-run
+// deterministic - no floating-point atomics.
+#include "l2s_common.h"
+
+namespace l2s {
+
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ double block_sum_d(double x, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partials) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = x[i];
+        acc += v * v;
+    }
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partials, int np, float* __restrict__ norm_out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partials[i];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) norm_out[0] = (float)sqrt(acc);
+}
+
+int launch_l2_norm(const float* x, int64_t n, double* partials /*[RED_BLOCKS]*/, float* norm_out, hipStream_t s) {
+    ProfScope ps("grad_l2_norm", s);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, x, n, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partials, RED_BLOCKS, norm_out);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// torch.optim.AdamW(amsgrad=True) on a flat parameter range; g_eff = g * grad_mul * min(1, max_norm / (norm + 1e-6))
+// (torch.nn.utils.clip_grad_norm_ semantics; `norm` is the norm of g * grad_mul, i.e. *norm_dev * grad_mul).
+__global__ __launch_bounds__(256) void adamw_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, float* __restrict__ vmax, int64_t n, float lr, float b1,
+                                                            float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                            const float* __restrict__ norm_dev, float grad_mul, float max_norm) {
+    float scale = grad_mul;
+    if (norm_dev && max_norm > 0.f) {
+        const float total = norm_dev[0] * grad_mul;
+        const float coef = max_norm / (total + 1e-6f);
+        if (coef < 1.f) scale *= coef;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * scale;
+        float pi = p[i];
+        pi *= 1.f - lr * wd;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float vm = fmaxf(vmax[i], vi);
+        const float denom = sqrtf(vm) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi; vmax[i] = vm;
+    }
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                 int step, const float* norm_dev, float grad_mul, float max_norm, hipStream_t s) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    ProfScope ps("adamw_amsgrad_clip", s);
+    hipLaunchKernelGGL(adamw_amsgrad_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, vmax, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, norm_dev,
+                       grad_mul, max_norm);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- loss (train_utils/losses.py:69-77): mel MSE + 10 * post-net mel MSE + BCE-with-logits on the gate + KLD(content_dis || uniform)
+// term: 0 = sum (a-b)^2 over mel, 1 = same for mel_post, 2 = BCE sum, 3 = KLD sum.  Gradients are written in the same pass.
+struct LossP {
+    const float* mel; const float* mel_post; const float* mel_tgt;    // (B,80,S) channel-first, like the reference's outputs
+    const float* stop; const float* gate;                            // (B,S)
+    const float* dis;                                                // (R,V)
+    float* dmel; float* dmel_post; float* dstop; float* ddis;        // gradients of the summed loss (may be null)
+    int64_t n_mel, n_stop, n_dis; int R, V;
+};
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const LossP p, double* __restrict__ partials /*[4][RED_BLOCKS]*/) {
+    __shared__ double sh[4];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256, start = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float inv_mel = 1.f / (float)p.n_mel, inv_stop = 1.f / (float)p.n_stop, inv_R = 1.f / (float)p.R;
+    for (int64_t i = start; i < p.n_mel; i += stride) {
+        const float t = p.mel_tgt[i];
+        const float d0 = p.mel[i] - t, d1 = p.mel_post[i] - t;
+        a0 += (double)d0 * d0;
+        a1 += (double)d1 * d1;
+        if (p.dmel) p.dmel[i] = 2.f * d0 * inv_mel;
+        if (p.dmel_post) p.dmel_post[i] = 20.f * d1 * inv_mel;
+    }
+    for (int64_t i = start; i < p.n_stop; i += stride) {
+        const float x = p.stop[i], y = p.gate[i];
+        // BCEWithLogits: max(x,0) - x*y + log(1 + exp(-|x|))
+        a2 += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+        if (p.dstop) p.dstop[i] = (1.f / (1.f + expf(-x)) - y) * inv_stop;
+    }
+    for (int64_t i = start; i < p.n_dis; i += stride) {
+        const float q = p.dis[i];
+        const float arg = q * (float)p.V + 1e-20f;
+        const float lr = logf(arg);
+        a3 += (double)(q * lr);
+        if (p.ddis) p.ddis[i] = (lr + q * (float)p.V / arg) * inv_R;
+    }
+    a0 = block_sum_d(a0, sh); a1 = block_sum_d(a1, sh); a2 = block_sum_d(a2, sh); a3 = block_sum_d(a3, sh);
+    if (threadIdx.x == 0) {
+        partials[0 * RED_BLOCKS + blockIdx.x] = a0; partials[1 * RED_BLOCKS + blockIdx.x] = a1;
+        partials[2 * RED_BLOCKS + blockIdx.x] = a2; partials[3 * RED_BLOCKS + blockIdx.x] = a3;
+    }
+}
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partials, const LossP p, float* __restrict__ out /*[5]*/) {
+    __shared__ double sh[4];
+    double tot[4];
+    for (int t = 0; t < 4; ++t) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) acc += partials[t * RED_BLOCKS + i];
+        tot[t] = block_sum_d(acc, sh);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(tot[0] / (double)p.n_mel);                 // mel_loss
+        out[1] = (float)(10.0 * tot[1] / (double)p.n_mel);          // postnet_mel_loss
+        out[2] = (float)(tot[2] / (double)p.n_stop);                // gate_loss
+        out[3] = (float)(tot[3] / (double)p.R);                     // KLD
+        out[4] = out[0] + out[1] + out[2] + out[3];
+    }
+}
+
+int launch_loss(const LossP& p, double* partials /*[4*RED_BLOCKS]*/, float* out5, hipStream_t s) {
+    ProfScope ps("loss_fwd_bwd", s);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, p, partials);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, partials, p, out5);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s
+
+// ================================================================================================ C ABI
+#include "../../include/l2s.h"
+using namespace l2s;
+
+extern "C" {
+
+int64_t l2s_train_scratch_bytes(void) { return (int64_t)4 * RED_BLOCKS * sizeof(double); }
+
+int l2s_grad_norm(const float* grads, int64_t n, void* scratch, float* norm_out, void* stream) {
+    L2S_REQUIRE(grads && scratch && norm_out && n > 0, "bad arguments");
+    return launch_l2_norm(grads, n, (double*)scratch, norm_out, (hipStream_t)stream);
+}
+
+int l2s_adamw_amsgrad_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm,
+                           float grad_mul, float max_norm, void* stream) {
+    L2S_REQUIRE(params && grads && exp_avg && exp_avg_sq && max_exp_avg_sq && n > 0 && step >= 1, "bad arguments");
+    return launch_adamw(params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_norm,
+                        grad_mul, max_norm, (hipStream_t)stream);
+}
+
+int l2s_loss(const float* mel, const float* mel_post, const float* mel_target, const float* stop, const float* gate_target,
+             const float* content_dis, int B, int S, int R, float* losses5, float* dmel, float* dmel_post, float* dstop, float* ddis,
+             void* scratch, void* stream) {
+    L2S_REQUIRE(mel && mel_post && mel_target && stop && gate_target && content_dis && losses5 && scratch, "bad arguments");
+    LossP p{};
+    p.mel = mel; p.mel_post = mel_post; p.mel_tgt = mel_target; p.stop = stop; p.gate = gate_target; p.dis = content_dis;
+    p.dmel = dmel; p.dmel_post = dmel_post; p.dstop = dstop; p.ddis = ddis;
+    p.n_mel = (int64_t)B * L2S_N_MELS * S; p.n_stop = (int64_t)B * S; p.R = R; p.V = L2S_VOCAB; p.n_dis = (int64_t)R * L2S_VOCAB;
+    return launch_loss(p, (double*)scratch, losses5, (hipStream_t)stream);
+}
+
+}  // extern "C"

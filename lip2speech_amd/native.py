@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
+    "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
 
@@ -75,6 +76,11 @@ def lib() -> ctypes.CDLL:
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
     L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
     L.l2s_op_lstm_cell_chain.argtypes = [_vp, _i, _i, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_double)]
+    L.l2s_train_scratch_bytes.restype = _i64
+    L.l2s_loss.argtypes = [_fp] * 6 + [_i, _i, _i] + [_fp] * 5 + [_vp, _vp]
+    L.l2s_grad_norm.argtypes = [_fp, _i64, _vp, _fp, _vp]
+    _f = ctypes.c_float
+    L.l2s_adamw_amsgrad_step.argtypes = [_fp] * 5 + [_i64, _f, _f, _f, _f, _f, _i, _fp, _f, _f, _vp]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
     _lib = L
