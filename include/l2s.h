@@ -160,6 +160,10 @@ int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float
 int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw,
                   float* out, int B, int Tin, int Cin, int Cout, int taps, int stride, int pad, int act,
                   void* stream);
+/* backward of l2s_op_conv1d (no scale/shift/activation): dZ (B,Tout,Cout), X (B,Tin,Cin), Wp (Cout, taps*Cin) ->
+ * dX (B,Tin,Cin) (stride 1 only; may be NULL) and dWp (Cout, taps*Cin) (may be NULL) */
+int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
+                      int stride, int pad, void* stream);
 /* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
  * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);

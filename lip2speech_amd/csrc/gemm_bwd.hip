@@ -1,0 +1,160 @@
+// Backward GEMMs of the dense / Conv1d layers (fp32 MFMA, same 64x64x32 tile and K-permuted operand fetch as gemm_nt.hip):
+//
+//   BWD_DX : dX[m][j]  = sum_r dZcol(m, r) * Wp[n(r)][tap(r)*Cin + j]        - input gradient.  For a Conv1d (stride 1) the rows of
+//            dZ are gathered with the flipped-tap implicit addressing, r = (tap', n); the weight operand is read in its forward
+//            layout [Nout][taps*Cin] and transposed on its way into LDS.
+//   BWD_DW : dWp[n][j] = sum_m dZ[m][n] * Xcol(m, j),  j = (tap, ci)          - weight gradient; Xcol is the forward implicit
+//            im2col of the input; both operands are transposed on their way into LDS (the reduction runs over rows).
+//
+// Reference semantics: autograd of nn.Linear / nn.Conv1d in /root/reference/model/modules/decoder.py (train.py:184 loss.backward()).
+#include "l2s_common.h"
+
+namespace l2s {
+
+constexpr int TB = 64, TK = 32, TLD = TK + 4;
+
+// stage a [32 reduction rows][64 cols] global tile transposed into S[col][row]; this thread owns rows r0, r0+16 and cols c4..c4+3
+__device__ __forceinline__ void stage_transposed(float* S, int r0, int c4, const float4& v0, const float4& v1) {
+    S[(c4 + 0) * TLD + r0] = v0.x; S[(c4 + 1) * TLD + r0] = v0.y; S[(c4 + 2) * TLD + r0] = v0.z; S[(c4 + 3) * TLD + r0] = v0.w;
+    S[(c4 + 0) * TLD + r0 + 16] = v1.x; S[(c4 + 1) * TLD + r0 + 16] = v1.y; S[(c4 + 2) * TLD + r0 + 16] = v1.z; S[(c4 + 3) * TLD + r0 + 16] = v1.w;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
+    const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+    __shared__ __attribute__((aligned(16))) float As[TB * TLD];
+    __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, li = lane & 31, lg = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nkt = (p.K + TK - 1) / TK;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- per-mode loaders ------------------------------------------------------------------------------------------------
+    // DX: A = dZ gathered (row-major staging: thread -> row lr (+32), k-quad kq), B = Wp transposed staging
+    // DW: A = dZ transposed staging (reduction = rows m), B = Xcol transposed staging
+    const int lr = tid >> 3, kq = (tid & 7) * 4;      // row-major staging coordinates
+    const int r0 = tid >> 4, c4 = (tid & 15) * 4;     // transposed staging coordinates
+
+    auto load_dx_a = [&](int j, int k) -> float4 {     // dZcol(m, r..r+3), r = tap'*Nout + n, 4 consecutive n
+        const int m = m0 + lr + 32 * j;
+        if (m >= p.M || k >= p.K) return zero4;
+        const int b = m / p.Tx, t = m - b * p.Tx;
+        int tap = 0, n = k;
+        if (p.taps > 1) { tap = k / p.Nout; n = k - tap * p.Nout; }
+        const int tz = t + tap - p.padp;
+        if (tz < 0 || tz >= p.Tz) return zero4;
+        return *reinterpret_cast<const float4*>(p.A + ((int64_t)b * p.Tz + tz) * p.lda + n);
+    };
+    auto load_dx_b = [&](int j, int k0) -> float4 {    // Wp[n(r)][(taps-1-tap')*Cin + col..col+3] for reduction row r = k0 + r0 + 16j
+        const int r = k0 + r0 + 16 * j, col = n0 + c4;
+        if (r >= p.K || col >= p.N) return zero4;
+        int tap = 0, n = r;
+        if (p.taps > 1) { tap = r / p.Nout; n = r - tap * p.Nout; }
+        return *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + (p.taps - 1 - tap) * p.Cin + col);
+    };
+    auto load_dw_a = [&](int j, int k0) -> float4 {    // dZ[m][n0 + c4 ..], m = k0 + r0 + 16j
+        const int m = k0 + r0 + 16 * j, col = m0 + c4;
+        if (m >= p.K || col >= p.M) return zero4;
+        return *reinterpret_cast<const float4*>(p.A + (int64_t)m * p.lda + col);
+    };
+    auto load_dw_b = [&](int j, int k0) -> float4 {    // Xcol(m, jcol..jcol+3), jcol = (tap, ci)
+        const int m = k0 + r0 + 16 * j, col = n0 + c4;
+        if (m >= p.K || col >= p.N) return zero4;
+        const int b = m / p.Tz, t = m - b * p.Tz;
+        int tap = 0, ci = col;
+        if (p.taps > 1) { tap = col / p.Cin; ci = col - tap * p.Cin; }
+        const int tx = t * p.stride + tap - p.pad;
+        if (tx < 0 || tx >= p.Tx) return zero4;
+        return *reinterpret_cast<const float4*>(p.B + ((int64_t)b * p.Tx + tx) * p.ldb + ci);
+    };
+
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (MODE == BWD_DX) { ra[j] = load_dx_a(j, kq); rb[j] = load_dx_b(j, 0); }
+        else { ra[j] = load_dw_a(j, 0); rb[j] = load_dw_b(j, 0); }
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (MODE == BWD_DX) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(lr + 32 * j) * TLD + kq]) = ra[j];
+        } else {
+            stage_transposed(As, r0, c4, ra[0], ra[1]);
+        }
+        stage_transposed(Bs, r0, c4, rb[0], rb[1]);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            const int k0 = (kt + 1) * TK;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (MODE == BWD_DX) { ra[j] = load_dx_a(j, k0 + kq); rb[j] = load_dx_b(j, k0); }
+                else { ra[j] = load_dw_a(j, k0); rb[j] = load_dw_b(j, k0); }
+            }
+        }
+        const float* ap = &As[(wm * 32 + li) * TLD + 4 * lg];
+        const float* bp = &Bs[(wn * 32 + li) * TLD + 4 * lg];
+#pragma unroll
+        for (int c = 0; c < TK / 8; ++c) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + li;
+    if (col >= p.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row >= p.M) continue;
+        int64_t off;
+        if (p.c_T > 0) { const int b = row / p.c_T; off = (int64_t)b * p.c_seq_stride + (int64_t)(row - b * p.c_T) * p.ldc + col; }
+        else off = (int64_t)row * p.ldc + col;
+        const float v = acc[r] * p.alpha;
+        p.C[off] = p.accumulate ? p.C[off] + v : v;
+    }
+}
+
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
+    L2S_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "bwd gemm dims");
+    L2S_REQUIRE(al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0, "bwd gemm operands must be 16-byte aligned with ld % 4 == 0");
+    if (p.mode == BWD_DX) L2S_REQUIRE(p.Nout % 4 == 0 && p.N % 4 == 0 && p.Cin % 4 == 0, "dX gemm: channel counts must be multiples of 4");
+    else L2S_REQUIRE(p.M % 4 == 0 && p.Cin % 4 == 0, "dW gemm: channel counts must be multiples of 4");
+    dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB);
+    ProfScope ps(name, s);
+    if (p.mode == BWD_DX) hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DX>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DW>, grid, dim3(256), 0, s, p);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// dX of a Conv1d / Linear layer: dZ (B,Tz,Nout) -> dX (B,Tx,Cin); Wp [Nout][taps*Cin] (forward layout); stride 1
+BwdGemmP bwd_dx(const float* dZ, int ldz, const float* Wp, float* dX, int ldx, int B, int Tz, int Tx, int Nout, int Cin, int taps, int pad,
+                bool accumulate) {
+    BwdGemmP p{};
+    p.mode = BWD_DX; p.A = dZ; p.lda = ldz; p.B = Wp; p.ldb = taps * Cin; p.C = dX; p.ldc = ldx;
+    p.M = B * Tx; p.N = Cin; p.K = taps * Nout;
+    p.Tx = Tx; p.Tz = Tz; p.taps = taps; p.stride = 1; p.pad = pad; p.padp = taps - 1 - pad; p.Nout = Nout; p.Cin = Cin;
+    p.alpha = 1.f; p.accumulate = accumulate ? 1 : 0;
+    return p;
+}
+// dWp [Nout][taps*Cin] of a Conv1d / Linear layer from dZ (B,Tz,Nout) and X (B,Tx,Cin)
+BwdGemmP bwd_dw(const float* dZ, int ldz, const float* X, int ldx, float* dWp, int B, int Tz, int Tx, int Nout, int Cin, int taps, int stride,
+                int pad, bool accumulate) {
+    BwdGemmP p{};
+    p.mode = BWD_DW; p.A = dZ; p.lda = ldz; p.B = X; p.ldb = ldx; p.C = dWp; p.ldc = taps * Cin;
+    p.M = Nout; p.N = taps * Cin; p.K = B * Tz;
+    p.Tx = Tx; p.Tz = Tz; p.taps = taps; p.stride = stride; p.pad = pad; p.Nout = Nout; p.Cin = Cin;
+    p.alpha = 1.f; p.accumulate = accumulate ? 1 : 0;
+    return p;
+}
+
+}  // namespace l2s

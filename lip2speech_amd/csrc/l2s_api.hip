@@ -1326,6 +1326,17 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
     GemmP p = conv_gemm(X, Cin, B, Tin, Cin, c, Cout, taps, stride, pad, out, Cout, act);
     return launch_gemm1(p, (hipStream_t)stream, "op_conv1d");
 }
+int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
+                      int stride, int pad, void* stream) {
+    L2S_REQUIRE(dZ && X && Wp, "bad arguments");
+    const int Tout = (Tin + 2 * pad - taps) / stride + 1;
+    if (dX) {
+        L2S_REQUIRE(stride == 1, "dX of a strided Conv1d is computed on the (B*Tout, taps*Cin) view by the caller");
+        if (launch_gemm_bwd(bwd_dx(dZ, Cout, Wp, dX, Cin, B, Tout, Tin, Cout, Cin, taps, pad, false), (hipStream_t)stream, "op_conv1d_dx")) return 1;
+    }
+    if (dWp && launch_gemm_bwd(bwd_dw(dZ, Cout, X, Cin, dWp, B, Tout, Tin, Cout, Cin, taps, stride, pad, false), (hipStream_t)stream, "op_conv1d_dw")) return 1;
+    return 0;
+}
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
     L2S_ENC_READY(m);
     return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);

@@ -73,6 +73,22 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name);
 int launch_gemm1(const GemmP& p, hipStream_t s, const char* name);
 
+// ---------------------------------------------------------------- backward GEMMs (gemm_bwd.hip)
+enum BwdMode { BWD_DX = 0, BWD_DW = 1 };
+struct BwdGemmP {
+    int mode;
+    const float* A; int lda;     // dZ
+    const float* B; int ldb;     // DX: forward-layout weight [Nout][taps*Cin];  DW: forward input X (B,Tx,Cin)
+    float* C; int ldc;           // DX: dX;  DW: dWp [Nout][taps*Cin]
+    int M, N, K;                 // C is M x N, reduction length K
+    int Tx, Tz, taps, stride, pad, padp, Nout, Cin;
+    int c_T; int64_t c_seq_stride;   // c_T > 0: C row = (m / c_T) * c_seq_stride + (m % c_T) * ldc
+    float alpha; int accumulate;
+};
+BwdGemmP bwd_dx(const float* dZ, int ldz, const float* Wp, float* dX, int ldx, int B, int Tz, int Tx, int Nout, int Cin, int taps, int pad, bool accumulate);
+BwdGemmP bwd_dw(const float* dZ, int ldz, const float* X, int ldx, float* dWp, int B, int Tz, int Tx, int Nout, int Cin, int taps, int stride, int pad, bool accumulate);
+int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name);
+
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
 struct FrontendW {          // device pointers into the weight blob
     const float* w;         // [15 slabs (ci*5+kt)][50 (kh*7+kw, padded)][32 (co, padded)]

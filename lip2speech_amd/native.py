@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
@@ -72,6 +72,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_inference.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
     L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
@@ -278,6 +279,17 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
 
 def set_option(name: str, value: int) -> None:
     check(lib().l2s_set_option(name.encode(), int(value)))
+
+
+def op_conv1d_bwd(dZ, X, Wp, taps=1, stride=1, pad=0, want_dx=True):
+    """Gradients of op_conv1d wrt its input (stride 1) and its tap-major weight."""
+    dZ, X, Wp = _f32(dZ), _f32(X), _f32(Wp)
+    B, Tin, Cin = X.shape
+    Cout = Wp.shape[0]
+    dX = torch.empty_like(X) if want_dx else None
+    dW = torch.empty_like(Wp)
+    check(lib().l2s_op_conv1d_bwd(_ptr(dZ), _ptr(X), _ptr(Wp), _ptr(dX), _ptr(dW), B, Tin, Cin, Cout, taps, stride, pad, _stream()))
+    return dX, dW
 
 
 # ---------------------------------------------------------------------------------------------- profiling

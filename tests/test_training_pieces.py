@@ -89,3 +89,24 @@ def test_fused_adamw_amsgrad_clip_matches_torch():
     opt.step(max_norm=1.0, grad_mul=0.25)
     b = flat.data.clone()
     assert (a - b).abs().max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,Ci,Co,k,st,pad", [(2, 29, 512, 512, 11, 1, 5), (3, 40, 80, 512, 5, 1, 2), (2, 75, 512, 80, 5, 1, 2),
+                                                 (2, 29, 512, 512, 7, 7, 0), (4, 1, 1024, 512, 1, 1, 0), (2, 29, 2560, 256, 1, 1, 0)])
+def test_conv1d_backward_gemms(B, T, Ci, Co, k, st, pad):
+    """dX (flipped-tap implicit GEMM) and dW (reduction over rows) of the Conv1d/Linear layers vs autograd in fp64."""
+    from lip2speech_amd import native
+    torch.manual_seed(T + k + Co)
+    X = torch.randn(B, T, Ci)
+    Wt = torch.randn(Co, Ci, k) / (Ci * k) ** 0.5
+    Wp = Wt.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()
+    Xd, Wd = X.double().requires_grad_(True), Wt.double().requires_grad_(True)
+    out = torch.nn.functional.conv1d(Xd.permute(0, 2, 1), Wd, stride=st, padding=pad).permute(0, 2, 1)
+    dZ = torch.randn(out.shape)
+    out.backward(dZ.double())
+    dX, dW = native.op_conv1d_bwd(dZ.cuda(), X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad, want_dx=(st == 1))
+    dW_ref = Wd.grad.permute(0, 2, 1).reshape(Co, k * Ci)
+    assert (dW.cpu().double() - dW_ref).abs().max() < 2e-5 * max(1.0, dW_ref.abs().max().item())
+    if st == 1:
+        assert (dX.cpu().double() - Xd.grad).abs().max() < 2e-5 * max(1.0, Xd.grad.abs().max().item())
