@@ -151,6 +151,18 @@ int l2s_adamw_amsgrad_step(float* params, const float* grads, float* exp_avg, fl
                            float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm,
                            float grad_mul, float max_norm, void* stream);
 
+/* ---- training path of the model (in progress: stage 1 = post-net) -------------------------------------------------------------
+ * l2s_train_bind: device pointers of a parameter in its canonical (checkpoint) layout and of its gradient slot (may be NULL), by key.
+ * The backward entry points write parameter gradients into the bound slots (overwrite, not accumulate). */
+int l2s_train_bind(l2s_model* m, const char* key, float* param_dev, float* grad_dev);
+/* Post-net forward with a tape (decoder.py:143-156, eval-mode BatchNorm statistics, no dropout) and its backward:
+ * mel dev (B,S,80) -> mel_post dev (B,80,S);  dmel_post dev (B,80,S) -> dmel dev (B,S,80) is ACCUMULATED into. */
+int64_t l2s_train_postnet_tape_floats(int B, int S);
+int64_t l2s_train_postnet_ws_bytes(int B, int S);
+int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, void* stream);
+int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel,
+                          void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
 /* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,

@@ -3,6 +3,7 @@
 // arithmetic is in the kernels of gemm_nt.hip / encoder_kernels.hip / skinny.hip / decoder_kernels.hip.
 #include "../../include/l2s.h"
 #include "l2s_common.h"
+#include "l2s_model.h"
 
 #include <cmath>
 #include <functional>
@@ -22,7 +23,7 @@ void set_error(const std::string& msg) { g_err = msg; }
 
 // ------------------------------------------------------------------------------------------------ profiling
 struct ProfEntry { std::string name; int64_t launches = 0; double total_ms = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
-static bool g_prof_on = false;
+bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
 static std::map<std::string, int> g_prof_idx;
 static int g_prof_cur = -1;
@@ -65,75 +66,7 @@ static void prof_drain() {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ geometry
-constexpr int STAGE_CH[4] = {24, 116, 232, 464};
-constexpr int STAGE_REP[3] = {4, 8, 4};
-constexpr int N_UNITS = 16;
-constexpr int LAST_CH = 768;
-constexpr int MH_KS[4] = {1, 3, 7, 11};
-constexpr int CT_KS[4] = {1, 3, 5, 7};
-constexpr int D = 512;          // decoder width
-constexpr int NM = L2S_N_MELS;
-constexpr int VOC = L2S_VOCAB;
-constexpr int VOCP = 504;       // vocabulary padded to a multiple of 4 for float4 operand loads
-constexpr float BN_EPS = 1e-5f;
-
-static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
-static inline int pad16(int b) { return (b + 15) & ~15; }
-
-// ------------------------------------------------------------------------------------------------ model
-struct ConvW { const float* W = nullptr; const float* scale = nullptr; const float* shift = nullptr; const float* actw = nullptr; };
-struct DwW { const float* w9 = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
-struct UnitW {
-    bool stride2 = false;
-    int cin = 0, half = 0;
-    DwW b1_dw; ConvW b1_pw;            // stride-2 units only
-    ConvW pw1; DwW dw; ConvW pw2;      // banch2
-    const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // stride-1 units: frag16 [pad16(half)][kpad]
-};
-struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; };
-
-struct Weights {
-    FrontendW fe;
-    UnitW unit[N_UNITS];
-    ConvW conv_last;
-    // decoder prologue
-    ConvW resid, enc_site, attn_site, e_c, enc_proj;
-    const float* wih_cat = nullptr; const float* bih_cat = nullptr;     // [4096][1024], [4096]
-    SkW whh[2];                                                         // BiLSTM recurrent weights, permuted rows
-    ConvW mh_branch[2][4], mh_bott[2];                                  // K, V
-    const float* pos = nullptr;                                         // [300][512]
-    ConvW ct_branch[4], ct_bott, ct_k0, ct_k2, ct_fc0, ct_fc2, ct_fc4, ct_emb;
-    // decode step
-    SkW pre1, pre2, q, cq, aproj, lstm0, lstm1, fc;
-    SkW pre1f, lstm0f;                 // phase-merged forms: prenet1 o fc_out over h1; LSTM0 with attention_proj folded in
-    const float* stop_tail = nullptr; const float* stop_bias = nullptr;
-    const float* bos = nullptr; const float* tau = nullptr; const float* tau_c = nullptr;
-    // postnet
-    ConvW post[5];
-    // speaker encoder (audio.py:110-150): mel40 front-end tables + 3-layer LSTM(256) + Linear
-    const float* spk_window = nullptr; const float* spk_dft = nullptr; const float* spk_fbT = nullptr;   // [400], [402][400], [40][204]
-    ConvW spk_ih[3];                 // input weights [1024][in] with shift = b_ih + b_hh
-    SkW spk_hh[3];                   // recurrent weights, frag16, rows permuted to (unit, gate)
-    ConvW spk_linear;
-};
-
 }  // namespace l2s
-
-struct l2s_model {
-    std::unordered_map<std::string, std::vector<float>> host;
-    float* blob = nullptr;
-    int64_t blob_floats = 0;
-    bool finalized = false;
-    bool has_enc = false, has_dec = false, has_spk = false;
-    l2s::Weights w;
-    // captured decode loops (hipGraph), replayed on a private non-blocking stream fenced against the caller's stream
-    struct GraphEntry { int B, T, S, attn_logits, fold; const void *state, *mel, *stop, *attn, *ws; hipGraph_t graph; hipGraphExec_t exec; };
-    std::vector<GraphEntry> graphs;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    std::vector<hipEvent_t> ev_pool;
-};
 
 namespace l2s {
 
@@ -570,18 +503,6 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
-struct Bump {
-    char* base; int64_t cap; int64_t off = 0; bool overflow = false;
-    Bump(void* p, int64_t c) : base((char*)p), cap(c) {}
-    float* f(int64_t n) {
-        int64_t bytes = align_up(n * (int64_t)sizeof(float), 256);
-        if (off + bytes > cap) { overflow = true; off += bytes; return nullptr; }
-        float* r = (float*)(base + off);
-        off += bytes;
-        return r;
-    }
-};
-
 struct EncPlan {
     int NF, Hp;
     int64_t act_a, act_b, t1, t2, last;

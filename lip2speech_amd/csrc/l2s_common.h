@@ -60,6 +60,7 @@ struct GemmP {
     int r2_div;           // > 0: R2 row index = m / r2_div (a per-sequence row broadcast over its time steps)
     int ldc, c_cstride;   // C[m*ldc + n*c_cstride]
     int c_tr_T;           // > 0: C[((m / T)*N + n)*T + m % T]  (channel-first store per sequence)
+    float* Zout;          // training: pre-activation value (after scale/shift), same addressing as C (row-major form only)
     int win_T, win_off;   // win_T > 0: rows cover the time window [win_off, win_off + Tout) of sequences of length win_T:
                           //   input frame = (win_off + t)*stride + tap - pad, output/residual row = b*win_T + win_off + t
     int vec;              // 4: float4 operand loads (K, Cin, lda, offsets multiples of 4); 1: scalar loads

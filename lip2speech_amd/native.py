@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
+    "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
 
@@ -77,6 +78,13 @@ def lib() -> ctypes.CDLL:
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
     L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
     L.l2s_op_lstm_cell_chain.argtypes = [_vp, _i, _i, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_double)]
+    L.l2s_train_bind.argtypes = [_vp, ctypes.c_char_p, _fp, _fp]
+    L.l2s_train_postnet_tape_floats.argtypes = [_i, _i]
+    L.l2s_train_postnet_tape_floats.restype = _i64
+    L.l2s_train_postnet_ws_bytes.argtypes = [_i, _i]
+    L.l2s_train_postnet_ws_bytes.restype = _i64
+    L.l2s_train_postnet_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _vp]
+    L.l2s_train_postnet_bwd.argtypes = [_vp, _fp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_scratch_bytes.restype = _i64
     L.l2s_loss.argtypes = [_fp] * 6 + [_i, _i, _i] + [_fp] * 5 + [_vp, _vp]
     L.l2s_grad_norm.argtypes = [_fp, _i64, _vp, _fp, _vp]
@@ -218,6 +226,29 @@ class NativeModel:
         ws = torch.empty(int(lib().l2s_speaker_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
         check(lib().l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
         return emb
+
+    # ------------------------------------------------------------------ training (in progress)
+    def train_bind(self, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]) -> None:
+        """Bind canonical-layout device parameters and their gradient slots by checkpoint key."""
+        self._bound = (params, grads)                       # keep the tensors alive
+        for key, p in params.items():
+            if not p.is_floating_point():
+                continue
+            g = grads.get(key)
+            check(lib().l2s_train_bind(self._h, key.encode(), _ptr(p), _ptr(g) if g is not None else None))
+
+    def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor):
+        """Post-net forward + backward (stage 1 of the training path): returns mel_post (B,80,S) and dmel (B,S,80)."""
+        mel, dmel_post = _f32(mel), _f32(dmel_post)
+        B, S, _ = mel.shape
+        L = lib()
+        tape = torch.zeros(int(L.l2s_train_postnet_tape_floats(B, S)), dtype=torch.float32, device=mel.device)
+        out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
+        check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _stream()))
+        dmel = torch.zeros_like(mel)
+        ws = torch.empty(int(L.l2s_train_postnet_ws_bytes(B, S)), dtype=torch.uint8, device=mel.device)
+        check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(ws), ws.numel(), _stream()))
+        return out, dmel
 
     def lstm_cell_chain_us(self, B: int, n_pairs: int = 300) -> float:
         """Average duration of the decoder LSTM-cell kernel, one HIP-event pair around 2*n_pairs chained launches."""

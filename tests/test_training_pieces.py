@@ -110,3 +110,32 @@ def test_conv1d_backward_gemms(B, T, Ci, Co, k, st, pad):
     assert (dW.cpu().double() - dW_ref).abs().max() < 2e-5 * max(1.0, dW_ref.abs().max().item())
     if st == 1:
         assert (dX.cpu().double() - Xd.grad).abs().max() < 2e-5 * max(1.0, Xd.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_postnet_backward_matches_autograd(synth_sd):
+    """Stage 1 of the model's training path: post-net forward-with-tape and backward (input and every parameter gradient)
+    against autograd through the oracle's post-net in fp64."""
+    import parity_common as pc
+    from oracle import l2s_oracle as orc
+    B, S = 3, 41
+    torch.manual_seed(3)
+    mel = torch.randn(B, S, 80)
+    dpost = torch.randn(B, 80, S)
+    keys = [k for k in synth_sd if k.startswith("decoder.postnet.") and synth_sd[k].is_floating_point()]
+    sd64 = {k: synth_sd[k].double().requires_grad_(not k.endswith(("running_mean", "running_var"))) for k in keys}
+    mel_cf = mel.double().permute(0, 2, 1).contiguous().requires_grad_(True)
+    out = orc.postnet(sd64, mel_cf) + mel_cf
+    out.backward(dpost.double())
+    nm = pc.native_model(synth_sd)
+    params = {k: synth_sd[k].cuda() for k in keys}
+    grads = {k: torch.zeros_like(v) for k, v in params.items() if not k.endswith(("running_mean", "running_var"))}
+    nm.train_bind(params, grads)
+    got_out, dmel = nm.train_postnet(mel.cuda(), dpost.cuda())
+    assert pc.maxdiff(got_out, out) < 1e-4
+    ref_dmel = mel_cf.grad.permute(0, 2, 1)
+    assert pc.maxdiff(dmel, ref_dmel) < 2e-4 * max(1.0, ref_dmel.abs().max().item())
+    for k, g in grads.items():
+        ref = sd64[k].grad
+        assert ref is not None, k
+        assert pc.maxdiff(g, ref.reshape(g.shape)) < 3e-4 * max(1.0, ref.abs().max().item()), k
