@@ -163,6 +163,23 @@ int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* t
 int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel,
                           void* ws, int64_t ws_bytes, void* stream);
 
+/* Stage 2: the autoregressive loop with a tape and its back-propagation through time (decoder.py:353-375; the literal 6-phase
+ * step, eval-mode statistics, no dropout).  `state` is the buffer of l2s_decoder_prologue.  Forward: mel dev (B,S,80), stop dev (B,S),
+ * attn_logits dev (B,S,T) (also read by the backward).  Backward: dmel dev (B,S,80) = total gradient of the pre-postnet frames,
+ * dstop dev (B,S); wbuf = l2s_train_steps_weights_floats() floats filled by l2s_train_steps_pack_weights (transposed step weights packed on
+ * the device from the bound canonical parameters - repack after every optimizer step).  Outputs: parameter gradients into the bound
+ * slots, dk / dv dev (B,T,512), dckey / dcval dev (B,min_T,256), dh_init dev (2,B,512), de_c dev (B,512). */
+int64_t l2s_train_steps_tape_floats(int B, int S);
+int64_t l2s_train_steps_weights_floats(void);
+int64_t l2s_train_steps_ws_bytes(int B, int S);
+int l2s_train_steps_pack_weights(l2s_model* m, float* wbuf, void* stream);
+int l2s_train_steps_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
+                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes,
+                        void* stream);
+int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* teacher_mask, float* tape, const float* attn_logits,
+                        const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
+                        float* de_c, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
 /* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,

@@ -534,15 +534,6 @@ static int64_t enc_ws_floats(int B, int T, int H) {
     return p.act_a + p.act_b + p.t1 + p.t2 + p.last + 64 * 8;
 }
 
-static int content_lens(int T, int L[4]) {
-    int m = T;
-    for (int j = 0; j < 4; ++j) {
-        L[j] = T >= CT_KS[j] ? (T - CT_KS[j]) / CT_KS[j] + 1 : 0;
-        m = std::min(m, L[j]);
-    }
-    return m;
-}
-
 static int64_t prologue_ws_floats(int B, int T) {
     int L[4];
     int m = content_lens(T, L);
@@ -565,26 +556,6 @@ static int64_t decode_ws_floats(int B) {
     return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
 }
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
-
-struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, total; int m; };
-static StateLayout state_layout(int B, int T) {
-    StateLayout s{};
-    int L[4];
-    s.m = content_lens(T, L);
-    int64_t o = 0;
-    auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
-    s.k = take((int64_t)B * T * 512);
-    s.v = take((int64_t)B * T * 512);
-    s.ckey = take((int64_t)B * s.m * 256);
-    s.cval = take((int64_t)B * s.m * 256);
-    s.ecell = take((int64_t)B * 512);
-    s.h = take((int64_t)pad16(B) * 512 * 2);
-    s.c = take((int64_t)pad16(B) * 512 * 2);
-    s.enc = take((int64_t)B * T * 512);
-    s.stopc = take(B);
-    s.total = o;
-    return s;
-}
 
 // ------------------------------------------------------------------------------------------------ encoder
 static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each

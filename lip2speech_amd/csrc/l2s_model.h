@@ -3,6 +3,7 @@
 #include "../../include/l2s.h"
 #include "l2s_common.h"
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -99,4 +100,34 @@ struct Bump {
     }
 };
 extern bool g_prof_on;
+
+inline int content_lens(int T, int L[4]) {
+    int m = T;
+    for (int j = 0; j < 4; ++j) {
+        L[j] = T >= CT_KS[j] ? (T - CT_KS[j]) / CT_KS[j] + 1 : 0;
+        m = std::min(m, L[j]);
+    }
+    return m;
+}
+
+struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, total; int m; };
+inline StateLayout state_layout(int B, int T) {
+    StateLayout s{};
+    int L[4];
+    s.m = content_lens(T, L);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += align_up(n, 64); return r; };
+    s.k = take((int64_t)B * T * 512);
+    s.v = take((int64_t)B * T * 512);
+    s.ckey = take((int64_t)B * s.m * 256);
+    s.cval = take((int64_t)B * s.m * 256);
+    s.ecell = take((int64_t)B * 512);
+    s.h = take((int64_t)pad16(B) * 512 * 2);
+    s.c = take((int64_t)pad16(B) * 512 * 2);
+    s.enc = take((int64_t)B * T * 512);
+    s.stopc = take(B);
+    s.total = o;
+    return s;
+}
+
 }  // namespace l2s

@@ -1,0 +1,361 @@
+// Device code of the batch-row ("skinny") blocks, shared by the inference kernels (skinny.hip) and the training-forward
+// kernels (train_decoder.hip).  TRAIN=true adds the stores the backward pass needs (pre-activations, LSTM gates, plain
+// copies); with TRAIN=false those paths are compiled out and the code is the tuned inference code.
+#pragma once
+#include "l2s_common.h"
+
+namespace l2s {
+
+struct SkinnyTrain {               // training-side stores of one skinny group (any pointer may be null)
+    float* zsave; int ld_z;            // pre-activation value (after bias / pre-gates), plain [b*ld_z + n]
+    float* gates; int64_t ld_gates;    // SK_LSTM: post-nonlinearity i,f,g,o at [b*ld_gates + gate*H + unit]
+    float* c_new; int64_t ld_c;        // SK_LSTM: plain copy of the new cell state [b*ld_c + unit]
+    float* out_plain; int ld_out;      // SK_FRAG: plain copy of the output [b*ld_out + n]
+};
+struct AttnTrain {
+    float* alpha; int ld_alpha;        // content attention weights [b*ld_alpha + j]
+    float* av_plain;                   // [b*512 + c]
+    float* cc_plain;                   // [b*256 + c]
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, const float* actw, int n) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_PSINE) return sinf(v) * actw[n];
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One block (8 waves): output tile `tile` (16 columns) x batch tile `mt` (16 rows).  Wave w owns the K chunks
+// c = w, w+8, w+16, ...; ALL of its operand loads (<= 12 A + 12 W float4 per lane) are issued before the first MFMA so
+// the whole K slice is one round trip to L2/HBM instead of a load->MFMA->load chain.
+constexpr int SK_WAVES = 8;
+constexpr int SK_MAXC = 12;                 // chunks per wave: K <= 16 * 8 * 12 = 1536
+
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+    return acc;
+}
+
+// Pin a set of wave-uniform kernel parameters in SGPRs at this point.  Without it hipcc fetches each parameter from the kernarg
+// segment lazily, right before its first use, behind its own `s_waitcnt lgkmcnt(0)`: the block start becomes a chain of ~15
+// dependent scalar-cache round trips (the kernarg was just written by the host, so they miss) in front of the first operand load.
+#define L2S_PIN_S(...) asm volatile("" ::__VA_ARGS__)
+
+template <bool TRAIN = false, int MAXC = SK_MAXC>
+__device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/, int ntiles = 1 << 30,
+                                             const SkinnyTrain* tr = nullptr) {
+    // ---- every parameter the block needs, fetched in one batch of scalar loads
+    const float* const W = p.W;
+    const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
+    const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
+    const int K = p.K, epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
+    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
+    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
+    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(K), "s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act));
+    L2S_PIN_S("s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow), "s"(ntiles));
+    if (tile >= ntiles) return;                      // block-uniform: grid x is sized for the widest group of the launch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NC = K >> 4;
+    const float4* wbase = reinterpret_cast<const float4*>(W) + (int64_t)tile * NC * 64 + lane;
+    const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2;
+
+    // ---- main operand loads first: the whole K slice of this wave in one round trip
+    float4 a[MAXC], w[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = wave + SK_WAVES * j;          // wave-uniform
+        if (c < NC) {
+            const float* ab = sa0; int lc = c, nn = n0;
+            if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
+            else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
+            else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
+            a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
+            w[j] = wbase[(int64_t)c * 64];
+        }
+    }
+    // ---- epilogue operands have launch-time addresses too: fetch them under the same round trip
+    const int e_row = tid >> 4, e_col = tid & 15;
+    const int e_b = mt * 16 + e_row, e_np = tile * 16 + e_col;
+    float pf_bias = 0.f, pf_extra = 0.f, pf_c = 0.f;
+    if (tid < 256) {
+        if (bias) pf_bias = bias[e_np];
+        if (epi == SK_LSTM) {
+            if (pre && e_b < nB) pf_extra = pre[(int64_t)e_b * ld_pre + (e_col & 3) * H + tile * 4 + (e_col >> 2)];
+        } else if (epi != SK_MEL && e_b < nB && e_np < N) {
+            if (add) pf_extra = add[(int64_t)e_b * ld_add + e_np];
+            if (addrow) pf_extra += addrow[e_np];
+        }
+    }
+    if (epi == SK_LSTM && tid < 64) {
+        const int b2 = mt * 16 + (tid >> 2);
+        if (b2 < nB) pf_c = c_in[frag16_index(b2, tile * 4 + (tid & 3), H)];
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = wave + SK_WAVES * j;
+        if (c < NC) {
+            if (j & 1) acc1 = mfma4(a[j], w[j], acc1);
+            else acc0 = mfma4(a[j], w[j], acc0);
+        }
+    }
+    // D layout: col = lane&15, row = 4*(lane>>4) + r
+    {
+        const int col = lane & 15, rb = 4 * (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + rb + r) * 17 + col] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    float* gt = red + SK_WAVES * 16 * 17;               // reduced tile [16][17]
+    const int row = tid >> 4, col = tid & 15;          // valid for tid < 256
+    const int b = mt * 16 + row;
+    const int np = tile * 16 + col;                     // (permuted) weight row
+    float v = 0.f;
+    if (tid < 256) {
+#pragma unroll
+        for (int wv = 0; wv < SK_WAVES; ++wv) v += red[(wv * 16 + row) * 17 + col];
+        v += pf_bias;
+    }
+
+    if (epi == SK_LSTM) {
+        if (tid < 256) {
+            const int u = col >> 2, gate = col & 3;
+            const int unit = tile * 4 + u;
+            (void)unit; (void)gate;
+            v += pf_extra;
+            gt[row * 17 + col] = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int r2 = tid >> 2, u2 = tid & 3;
+            const int b2 = mt * 16 + r2, unit2 = tile * 4 + u2;
+            if (b2 < nB) {
+                const float gi = gt[r2 * 17 + 4 * u2 + 0], gf = gt[r2 * 17 + 4 * u2 + 1];
+                const float gg = gt[r2 * 17 + 4 * u2 + 2], go = gt[r2 * 17 + 4 * u2 + 3];
+                const int64_t ci = frag16_index(b2, unit2, H);
+                const float cprev = pf_c;
+                const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+                const float hn = sigmoidf_(go) * tanhf(cn);
+                p.c_out[ci] = cn;
+                p.h_out[frag16_index(b2, p.h_out_off + unit2, p.h_out_K)] = hn;
+                if constexpr (TRAIN) {
+                    if (tr->gates) {
+                        float* gs = tr->gates + (int64_t)b2 * tr->ld_gates + unit2;
+                        gs[0] = sigmoidf_(gi); gs[H] = sigmoidf_(gf); gs[2 * H] = tanhf(gg); gs[3 * H] = sigmoidf_(go);
+                    }
+                    if (tr->c_new) tr->c_new[(int64_t)b2 * tr->ld_c + unit2] = cn;
+                }
+                if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
+                if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
+            }
+        }
+        return;
+    }
+    if (tid >= 256 || b >= nB) return;
+    if (epi == SK_MEL) {
+        if (np < 80) {
+            p.mel[(int64_t)b * p.ld_mel_b + np] = v;
+            if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
+        } else if (np == 80) {
+            p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
+        }
+        return;
+    }
+    if (np >= N) return;
+    if constexpr (TRAIN) { if (tr->zsave) tr->zsave[(int64_t)b * tr->ld_z + np] = v; }
+    v = act_apply(v, act, p.actw, np);
+    v += pf_extra;
+    if constexpr (TRAIN) { if (tr->out_plain) tr->out_plain[(int64_t)b * tr->ld_out + np] = v; }
+    if (epi == SK_FRAG)
+        p.out[frag16_index(b, np, p.ldo)] = v;
+    else
+        p.out[(int64_t)b * p.ldo + np] = v;
+}
+
+constexpr int SK_RED_FLOATS = (SK_WAVES + 1) * 16 * 17;
+
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+constexpr int ATT_MAXT = 320;
+constexpr int ATT_SM_FLOATS = 512 + ATT_MAXT + 16 + 16;
+
+__device__ __forceinline__ float block_max8(float x, float* scratch) {
+    x = wave_max_f(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
+    __syncthreads();
+    float m = scratch[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, scratch[i]);
+    return m;
+}
+__device__ __forceinline__ float block_sum8(float x, float* scratch) {
+    x = wave_sum_f(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) + ((scratch[4] + scratch[5]) + (scratch[6] + scratch[7]));
+}
+
+// 512 threads (8 waves) per batch row.  Every global operand of the block (q, this wave's k rows, this thread's v
+// column) has an address known at launch, so all loads are issued before the first dependent instruction: one memory
+// round trip instead of five serialized ones.
+template <bool TRAIN = false>
+__device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm, const AttnTrain* tr = nullptr) {
+    float* qs = sm;                  // 512
+    float* sc = sm + 512;            // ATT_MAXT
+    float* scratch = sc + ATT_MAXT;  // 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T;
+    const float* const pq = p.q; const float* const pk = p.k; const float* const pv = p.v; const float* const ptau = p.tau;
+    float* const pav = p.av_frag; float* const pattn = p.attn_out;
+    const int ldq = p.ldq, logits = p.attn_logits; const int64_t ld_attn = p.ld_attn_b;
+    L2S_PIN_S("s"(T), "s"(pq), "s"(pk), "s"(pv), "s"(ptau), "s"(pav), "s"(pattn), "s"(ldq), "s"(logits), "s"(ld_attn));
+    const float* kb = pk + (int64_t)b * T * 512 + lane * 8;
+    const float* vb = pv + (int64_t)b * T * 512 + tid;
+    // ---- loads
+    const float qv = pq[(int64_t)b * ldq + tid];
+    const float tau = ptau[0];
+    float4 k0[4], k1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = wave + 8 * r;
+        if (t < T) {
+            k0[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
+            k1[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+        }
+    }
+    float vv[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) vv[e] = e < T ? vb[(int64_t)e * 512] : 0.f;
+    // ---- logits
+    qs[tid] = qv * tau;
+    __syncthreads();
+    float qq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qq[e] = qs[lane * 8 + e];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = wave + 8 * r;
+        if (t < T) {
+            double d = (double)qq[0] * k0[r].x + (double)qq[1] * k0[r].y + (double)qq[2] * k0[r].z + (double)qq[3] * k0[r].w +
+                       (double)qq[4] * k1[r].x + (double)qq[5] * k1[r].y + (double)qq[6] * k1[r].z + (double)qq[7] * k1[r].w;
+            d = wave_sum_d(d);
+            if (lane == 0) sc[t] = (float)d;
+        }
+    }
+    for (int t = wave + 32; t < T; t += 8) {             // clips longer than 32 frames: remaining rows, one at a time
+        const float4 a0 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
+        const float4 a1 = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+        double d = (double)qq[0] * a0.x + (double)qq[1] * a0.y + (double)qq[2] * a0.z + (double)qq[3] * a0.w +
+                   (double)qq[4] * a1.x + (double)qq[5] * a1.y + (double)qq[6] * a1.z + (double)qq[7] * a1.w;
+        d = wave_sum_d(d);
+        if (lane == 0) sc[t] = (float)d;
+    }
+    __syncthreads();
+    // ---- softmax over T (T <= 320 < 512: one element per thread)
+    const bool on = tid < T;
+    const float x = on ? sc[tid] : -INFINITY;
+    const float mx = block_max8(x, scratch);
+    const float ex = on ? expf(x - mx) : 0.f;
+    const float tot = block_sum8(ex, scratch);
+    if (on) {
+        const float aw = ex / tot;
+        if (pattn) pattn[(int64_t)b * ld_attn + tid] = logits ? x : aw;
+        sc[tid] = aw;
+    }
+    __syncthreads();
+    // ---- av = a @ v : one column per thread, t ascending
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e)
+        if (e < T) acc = fmaf(sc[e], vv[e], acc);
+    for (int t0 = 32; t0 < T; t0 += 16) {
+        float v2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v2[e] = (t0 + e < T) ? vb[(int64_t)(t0 + e) * 512] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (t0 + e < T) acc = fmaf(sc[t0 + e], v2[e], acc);
+    }
+    pav[frag16_index(b, tid, 512)] = acc;
+    if constexpr (TRAIN) { if (tr->av_plain) tr->av_plain[(int64_t)b * 512 + tid] = acc; }
+}
+
+// Content.forward (decoder.py:262-271) for one batch row: alpha = softmax_m(SiLU(..)*tau_c . key), cc = alpha @ value
+template <bool TRAIN = false>
+__device__ __forceinline__ void content_block(const AttnP& p, int b, float* sm, const AttnTrain* tr = nullptr) {
+    float* qs = sm;                  // 256
+    float* csc = sm + 512;           // 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = p.m;
+    const int col = tid & 255;
+    const float* const pqc = p.qc; const float* const pkey = p.ckey; const float* const pval = p.cval; const float* const ptc = p.tau_c;
+    float* const pcc = p.cc_frag; const int ldqc = p.ldqc;
+    L2S_PIN_S("s"(m), "s"(pqc), "s"(pkey), "s"(pval), "s"(ptc), "s"(pcc), "s"(ldqc));
+    const float qv = pqc[(int64_t)b * ldqc + col];
+    const float tau_c = ptc[0];
+    const float* keyb = pkey + (int64_t)b * m * 256 + lane * 4;
+    const float* valb = pval + (int64_t)b * m * 256 + col;
+    float4 kk[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = wave + 8 * r;
+        if (i < m) kk[r] = *reinterpret_cast<const float4*>(keyb + (int64_t)i * 256);
+    }
+    float vals[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vals[i] = i < m ? valb[(int64_t)i * 256] : 0.f;
+    if (tid < 256) qs[tid] = qv * tau_c;
+    __syncthreads();
+    const float* q4 = qs + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = wave + 8 * r;
+        if (i < m) {
+            double d = (double)q4[0] * kk[r].x + (double)q4[1] * kk[r].y + (double)q4[2] * kk[r].z + (double)q4[3] * kk[r].w;
+            d = wave_sum_d(d);
+            if (lane == 0) csc[i] = (float)d;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float cmx = -INFINITY;
+        for (int i = 0; i < m; ++i) cmx = fmaxf(cmx, csc[i]);
+        float csum = 0.f;
+        for (int i = 0; i < m; ++i) csum += expf(csc[i] - cmx);
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < m) o = fmaf(expf(csc[i] - cmx) / csum, vals[i], o);
+        pcc[frag16_index(b, tid, 256)] = o;
+        if constexpr (TRAIN) {
+            if (tr->cc_plain) tr->cc_plain[(int64_t)b * 256 + tid] = o;
+            if (tr->alpha && tid < m) tr->alpha[(int64_t)b * tr->ld_alpha + tid] = expf(csc[tid] - cmx) / csum;
+        }
+    }
+}
+
+}  // namespace l2s

@@ -207,6 +207,662 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
 
 }  // namespace l2s
 
+
+// =====================================================================================================================
+// Stage 2: the autoregressive loop (decoder.py:353-375) - forward with a tape, then back-propagation through time.
+// =====================================================================================================================
+#include "skinny_dev.h"
+namespace l2s {
+
+constexpr int TR_MAXC = 16;      // K <= 2048 for the backward products with the LSTM gate gradients
+
+struct TrainSkinnyBatch { SkinnyTrain t[SKINNY_MAX_GROUP]; };
+
+__global__ __launch_bounds__(512) void train_skinny_kernel(const SkinnyBatch batch, const TrainSkinnyBatch tb) {
+    __shared__ float red[SK_RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block<true, TR_MAXC>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], &tb.t[g]);
+}
+static int launch_train_skinny(const SkinnyBatch& b, const TrainSkinnyBatch& tb, hipStream_t s, const char* name) {
+    int maxt = 0, mts = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const SkinnyP& p = b.p[i];
+        int k = 0;
+        for (int j = 0; j < 4; ++j) k += 16 * p.seg[j].nchunks;
+        L2S_REQUIRE(k == p.K && p.K % 16 == 0 && p.K <= 16 * SK_WAVES * TR_MAXC, "train skinny K segments");
+        maxt = std::max(maxt, b.ntiles[i]);
+        mts = (p.B + 15) / 16;
+    }
+    ProfScope ps(name, s);
+    hipLaunchKernelGGL(train_skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, b, tb);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+struct TrainStepB { AttnP at; AttnTrain att; SkinnyP pre2; SkinnyTrain pre2t; int pre2_tiles; };
+__global__ __launch_bounds__(512) void train_step_attn_kernel(const TrainStepB sb) {
+    __shared__ __attribute__((aligned(16))) float sm[ATT_SM_FLOATS > SK_RED_FLOATS ? ATT_SM_FLOATS : SK_RED_FLOATS];
+    const int nb = sb.at.B, bid = blockIdx.x;
+    if (bid < nb) attention_block<true>(sb.at, bid, sm, &sb.att);
+    else if (bid < 2 * nb) content_block<true>(sb.at, bid - nb, sm, &sb.att);
+    else { const int j = bid - 2 * nb; skinny_block<true, TR_MAXC>(sb.pre2, j % sb.pre2_tiles, j / sb.pre2_tiles, sm, 1 << 30, &sb.pre2t); }
+}
+
+// ---- tape of the loop: time-major plain tensors
+struct StepTape {
+    float *h0, *h1, *c0, *c1;       // (S+1, B, 512): state before step s (s = S: final)
+    float *z1, *z2, *zc, *cc, *u;   // (S, B, 256)
+    float *zq, *av;                 // (S, B, 512)
+    float *alpha;                   // (S, B, 16)
+    float *g0, *g1;                 // (S, B, 2048) gates i,f,g,o after their nonlinearities
+    float *yprev;                   // (S, B, 96)  frame fed to the prenet at step s (cols 80.. zero)
+};
+static int64_t step_tape_floats(int B, int S) {
+    return (int64_t)(S + 1) * B * 512 * 4 + (int64_t)S * B * (256 * 5 + 512 * 2 + 16 + 2048 * 2 + 96) + 64 * 20;
+}
+static StepTape step_tape(float* base, int B, int S) {
+    StepTape t;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
+    const int64_t SB = (int64_t)S * B, S1B = (int64_t)(S + 1) * B;
+    t.h0 = take(S1B * 512); t.h1 = take(S1B * 512); t.c0 = take(S1B * 512); t.c1 = take(S1B * 512);
+    t.z1 = take(SB * 256); t.z2 = take(SB * 256); t.zc = take(SB * 256); t.cc = take(SB * 256); t.u = take(SB * 256);
+    t.zq = take(SB * 512); t.av = take(SB * 512); t.alpha = take(SB * 16); t.g0 = take(SB * 2048); t.g1 = take(SB * 2048);
+    t.yprev = take(SB * 96);
+    return t;
+}
+
+// yprev[s][b][n] = s == 0 ? BOS[n] : (forced[s] ? teacher[b][s][n] : mel[b][s-1][n]);  teacher[b][0] = BOS by construction
+__global__ __launch_bounds__(256) void build_yprev_kernel(const float* __restrict__ mel, const float* __restrict__ teacher, const unsigned char* __restrict__ mask,
+                                                          const float* __restrict__ bos, int B, int S, float* __restrict__ yprev) {
+    const int64_t total = (int64_t)S * B * 96;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int n = idx % 96;
+        const int64_t r = idx / 96;
+        const int b = r % B, sidx = r / B;
+        float v = 0.f;
+        if (n < 80) {
+            if (sidx == 0) v = bos[n];
+            else if (teacher && mask && mask[sidx]) v = teacher[((int64_t)b * S + sidx) * 80 + n];
+            else v = mel[((int64_t)b * S + sidx - 1) * 80 + n];
+        }
+        yprev[idx] = v;
+    }
+}
+
+// ---- backward elementwise kernels (B <= 96 rows; one thread per element)
+// LSTM cell backward: dh = dh_a (+ dh_b); dc = dc_carry + dh*o*(1-tanh(c_new)^2); pre-activation gate gradients in canonical order
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh_a, int ld_a, const float* __restrict__ dh_b, int ld_b,
+                                                       float* __restrict__ dc_carry, const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ c_new, int B, int H, float* __restrict__ dg_frag, float* __restrict__ dg_stack) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, u = idx - b * H;
+    float dh = dh_a[(int64_t)b * ld_a + u];
+    if (dh_b) dh += dh_b[(int64_t)b * ld_b + u];
+    const float* g = gates + (int64_t)b * 4 * H + u;
+    const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
+    const float tc = tanhf(c_new[idx]);
+    const float dc = dc_carry[idx] + dh * go * (1.f - tc * tc);
+    const float dzi = dc * gg * gi * (1.f - gi);
+    const float dzf = dc * c_prev[idx] * gf * (1.f - gf);
+    const float dzg = dc * gi * (1.f - gg * gg);
+    const float dzo = dh * tc * go * (1.f - go);
+    dc_carry[idx] = dc * gf;
+    const float vals[4] = {dzi, dzf, dzg, dzo};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dg_frag[frag16_index(b, k * H + u, 4 * H)] = vals[k];
+        dg_stack[(int64_t)b * 4 * H + k * H + u] = vals[k];
+    }
+}
+
+// total gradient of the frame y_s: dyt = dmel_total[:, s] (+ dy_carry) with the stop-logit gradient in column 80 -> frag16 (K=96) + stack
+__global__ __launch_bounds__(256) void build_dy_kernel(const float* __restrict__ dmel, const float* __restrict__ dstop, const float* __restrict__ dy_carry,
+                                                       int use_carry, int B, int S, int sidx, float* __restrict__ frag, float* __restrict__ stack) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int Bp = (B + 15) & ~15;
+    if (idx >= Bp * 96) return;
+    const int b = idx / 96, n = idx - b * 96;
+    float v = 0.f;
+    if (b < B) {
+        if (n < 80) { v = dmel[((int64_t)b * S + sidx) * 80 + n]; if (use_carry) v += dy_carry[b * 80 + n]; }
+        else if (n == 80) v = dstop[(int64_t)b * S + sidx];
+        stack[b * 96 + n] = v;
+    }
+    frag[frag16_index(b, n, 96)] = v;
+}
+
+// generic: dz = dy * f'(z) with f = PSine(w) / SiLU / identity; writes dz as frag16 (K = C) and dy to a stack (for the parameter sums)
+__global__ __launch_bounds__(256) void act_bwd_small_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int act,
+                                                            const float* __restrict__ actw, int B, int C, float* __restrict__ dz_frag,
+                                                            float* __restrict__ dy_stack) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int Bp = (B + 15) & ~15;
+    if (idx >= Bp * C) return;
+    const int b = idx / C, c = idx - b * C;
+    float dzv = 0.f;
+    if (b < B) {
+        const float d = dy[(int64_t)b * ld_dy + c];
+        if (dy_stack) dy_stack[idx] = d;
+        dzv = d;
+        if (act == ACT_PSINE) dzv = d * cosf(z[idx]) * actw[c];
+        else if (act == ACT_SILU) { const float zz = z[idx], sg = 1.f / (1.f + expf(-zz)); dzv = d * sg * (1.f + zz * (1.f - sg)); }
+    }
+    dz_frag[frag16_index(b, c, C)] = dzv;
+}
+
+// carries for the previous step: dh0 = d0x[:,512:] + dhq[:,:512]; dh1 = d01[:,512:] + dhq[:,512:]; dc0 += dcq[:,:512]; dc1 += dcq[:,512:]
+__global__ __launch_bounds__(256) void carry_update_kernel(const float* __restrict__ d0x, const float* __restrict__ d01, const float* __restrict__ dhq,
+                                                           const float* __restrict__ dcq, int B, float* __restrict__ dh0, float* __restrict__ dh1,
+                                                           float* __restrict__ dc0, float* __restrict__ dc1) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * 512) return;
+    const int b = idx / 512, u = idx - b * 512;
+    dh0[idx] = d0x[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + u];
+    dh1[idx] = d01[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + 512 + u];
+    dc0[idx] += dcq[(int64_t)b * 1024 + u];
+    dc1[idx] += dcq[(int64_t)b * 1024 + 512 + u];
+}
+
+// ---- attention + content attention backward, one 512-thread block per batch row (decoder.py:414-419, 262-271)
+struct AttnBwdP {
+    const float* dav;                 // [B][512]
+    const float* dcc; int ld_dcc;     // [B][ld]
+    const float* logits; int64_t ld_logit_b;   // logits of this step: [b*ld + t]
+    const float* k; const float* v;   // [B][T][512]
+    const float* zq; const float* wq; const float* pos; const float* tau;
+    const float* alpha;               // [B][16]
+    const float* ckey; const float* cval; const float* zc; const float* tau_c;
+    float* dk; float* dv; float* dckey; float* dcval;         // accumulated over steps
+    float* dzq_frag; float* dq_stack;                         // frag16 K=512; [B][512]
+    float* dzc_frag; float* dqc_stack;                        // frag16 K=256; [B][256]
+    float* dtau_part; float* dtauc_part;                      // [B] partial sums of this step
+    int B, T, m;
+};
+
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnBwdP p) {
+    __shared__ float s_dav[512], s_a[ATT_MAXT], s_dl[ATT_MAXT], s_red[16], s_dcc[256], s_qc[256], s_dlc[16], s_al[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T, m = p.m;
+    const float tau = p.tau[0], tau_c = p.tau_c[0];
+    const float* kb = p.k + (int64_t)b * T * 512;
+    const float* vb = p.v + (int64_t)b * T * 512;
+    s_dav[tid] = p.dav[(int64_t)b * 512 + tid];
+    // softmax of the stored logits
+    const bool on = tid < T;
+    const float l = on ? p.logits[(int64_t)b * p.ld_logit_b + tid] : -INFINITY;
+    float mx = wave_max_f(l);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, s_red[i]);
+    const float ex = on ? expf(l - mx) : 0.f;
+    float sm = wave_sum_f(ex);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = sm;
+    __syncthreads();
+    sm = 0.f;
+    for (int i = 0; i < 8; ++i) sm += s_red[i];
+    if (on) s_a[tid] = ex / sm;
+    __syncthreads();
+    // da[t] = dav . v[t]  (wave per row)
+    for (int t = wave; t < T; t += 8) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(s_dav[lane * 8 + e], vb[(int64_t)t * 512 + lane * 8 + e], acc);
+        acc = wave_sum_f(acc);
+        if (lane == 0) s_dl[t] = acc;                    // holds da for now
+    }
+    __syncthreads();
+    float part = on ? s_a[tid] * s_dl[tid] : 0.f;        // sum_t a*da
+    part = wave_sum_f(part);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    float sad = 0.f;
+    for (int i = 0; i < 8; ++i) sad += s_red[i];
+    __syncthreads();
+    float dlt = 0.f;
+    if (on) { dlt = s_a[tid] * (s_dl[tid] - sad); }
+    __syncthreads();
+    if (on) s_dl[tid] = dlt;
+    // d tau: sum_t dl_t * (l_t / tau)
+    float pt = on ? dlt * (l / tau) : 0.f;
+    pt = wave_sum_f(pt);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = pt;
+    __syncthreads();
+    if (tid == 0) { float tt = 0.f; for (int i = 0; i < 8; ++i) tt += s_red[i]; p.dtau_part[b] = tt; }
+    // per column c = tid: q, dq, dk, dv
+    {
+        const float zq = p.zq[(int64_t)b * 512 + tid], wq = p.wq[tid];
+        const float q = sinf(zq) * wq + p.pos[tid];
+        const float dav = s_dav[tid];
+        float dq = 0.f;
+        float* dkb = p.dk + (int64_t)b * T * 512 + tid;
+        float* dvb = p.dv + (int64_t)b * T * 512 + tid;
+        for (int t = 0; t < T; ++t) {
+            const float dl_t = s_dl[t];
+            dq = fmaf(dl_t, kb[(int64_t)t * 512 + tid], dq);
+            dkb[(int64_t)t * 512] += tau * dl_t * q;
+            dvb[(int64_t)t * 512] += s_a[t] * dav;
+        }
+        dq *= tau;
+        p.dq_stack[(int64_t)b * 512 + tid] = dq;
+        p.dzq_frag[frag16_index(b, tid, 512)] = dq * cosf(zq) * wq;
+    }
+    // ---- content attention
+    __syncthreads();
+    if (tid < 256) {
+        s_dcc[tid] = p.dcc[(int64_t)b * p.ld_dcc + tid];
+        const float zc = p.zc[(int64_t)b * 256 + tid];
+        s_qc[tid] = zc / (1.f + expf(-zc));
+    }
+    if (tid < 16) s_al[tid] = tid < m ? p.alpha[(int64_t)b * 16 + tid] : 0.f;
+    __syncthreads();
+    const float* keyb = p.ckey + (int64_t)b * m * 256;
+    const float* valb = p.cval + (int64_t)b * m * 256;
+    __shared__ float s_dal[16], s_dot[16];
+    for (int j = wave; j < m; j += 8) {                  // d alpha_j = dcc . value_j ; dot_j = qc . key_j
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0 = fmaf(s_dcc[lane * 4 + e], valb[(int64_t)j * 256 + lane * 4 + e], a0);
+            a1 = fmaf(s_qc[lane * 4 + e], keyb[(int64_t)j * 256 + lane * 4 + e], a1);
+        }
+        a0 = wave_sum_f(a0); a1 = wave_sum_f(a1);
+        if (lane == 0) { s_dal[j] = a0; s_dot[j] = a1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sa = 0.f;
+        for (int j = 0; j < m; ++j) sa += s_al[j] * s_dal[j];
+        float dtc = 0.f;
+        for (int j = 0; j < m; ++j) { const float d = s_al[j] * (s_dal[j] - sa); s_dlc[j] = d; dtc += d * s_dot[j]; }
+        p.dtauc_part[b] = dtc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float dqc = 0.f;
+        for (int j = 0; j < m; ++j) {
+            dqc = fmaf(s_dlc[j], keyb[(int64_t)j * 256 + tid], dqc);
+            p.dckey[((int64_t)b * m + j) * 256 + tid] += tau_c * s_dlc[j] * s_qc[tid];
+            p.dcval[((int64_t)b * m + j) * 256 + tid] += s_al[j] * s_dcc[tid];
+        }
+        dqc *= tau_c;
+        p.dqc_stack[(int64_t)b * 256 + tid] = dqc;
+        const float zc = p.zc[(int64_t)b * 256 + tid], sg = 1.f / (1.f + expf(-zc));
+        p.dzc_frag[frag16_index(b, tid, 256)] = dqc * sg * (1.f + zc * (1.f - sg));
+    }
+}
+
+// transposed frag16 pack of up to two canonical source blocks: F[n'][k'] = src[(k'-k_lo)*ld + (n'-n_lo)]
+struct PackSeg { const float* src; int ld, n_lo, n_hi, k_lo, k_hi; };
+__global__ __launch_bounds__(256) void pack_fragT_kernel(float* __restrict__ dst, int Npad, int K, PackSeg s0, PackSeg s1, PackSeg s2) {
+    const int64_t total = (int64_t)Npad * K;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int k = idx % K, n = idx / K;
+        float v = 0.f;
+        const PackSeg* segs[3] = {&s0, &s1, &s2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const PackSeg& sg = *segs[q];
+            if (sg.src && n >= sg.n_lo && n < sg.n_hi && k >= sg.k_lo && k < sg.k_hi) v = sg.src[(int64_t)(k - sg.k_lo) * sg.ld + (n - sg.n_lo)];
+        }
+        dst[frag16_index(n, k, K)] = v;
+    }
+}
+static int pack_fragT(float* dst, int Npad, int K, PackSeg s0, PackSeg s1, PackSeg s2, hipStream_t s) {
+    const int64_t total = (int64_t)Npad * K;
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    ProfScope ps("train_pack_transposed_weights", s);
+    hipLaunchKernelGGL(pack_fragT_kernel, dim3(blocks), dim3(256), 0, s, dst, Npad, K, s0, s1, s2);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// column sums of a (rows x C) stack, two-stage (reuses the act_bwd machinery with the identity activation)
+static int colsum(const float* x, int64_t rows, int C, float* partials, float* scratch_dconv, float* out, bool accumulate, hipStream_t s) {
+    ActBwdP a{};
+    a.dy = x; a.z = x; a.dconv = scratch_dconv; a.rows = rows; a.C = C; a.act = ACT_NONE; a.partials = partials;
+    return act_bwd(a, out, nullptr, nullptr, nullptr, accumulate, s);
+}
+
+}  // namespace l2s
+
+namespace l2s {
+
+static SkinnyP tsk(const SkW& sw, int B) {
+    SkinnyP p{};
+    p.W = sw.W; p.bias = sw.bias; p.actw = sw.actw; p.B = B; p.N = sw.N; p.K = sw.K; p.act = ACT_NONE; p.epi = SK_PLAIN;
+    return p;
+}
+
+// ---- forward of the loop with the tape (the literal 6-phase step; eval-mode statistics, no dropout)
+static int64_t step_fwd_ws_floats(int B) { return (int64_t)pad16(B) * (512 * 7 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 20; }
+
+static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* mask, const uint8_t* mask_dev,
+                            float* tape_base, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    StepTape tp = step_tape(tape_base, B, S);
+    const int Bp = pad16(B);
+    Bump bp(ws, ws_bytes);
+    float* h0[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* h1[2] = {bp.f((int64_t)Bp * 512), bp.f((int64_t)Bp * 512)};
+    float* c0 = bp.f((int64_t)Bp * 512); float* c1 = bp.f((int64_t)Bp * 512); float* av = bp.f((int64_t)Bp * 512);
+    float* p1 = bp.f((int64_t)Bp * 256); float* cc = bp.f((int64_t)Bp * 256); float* uu = bp.f((int64_t)Bp * 256);
+    float* yf = bp.f((int64_t)Bp * 96);
+    float* q = bp.f((int64_t)B * 512); float* qc = bp.f((int64_t)B * 256); float* p2 = bp.f((int64_t)B * 256);
+    L2S_REQUIRE(!bp.overflow, "training decode workspace too small");
+    L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    for (float* z : {h0[1], h1[1], c0, c1, av}) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
+    for (float* z : {p1, cc, uu}) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
+    if (launch_to_frag(w.bos, 0, B, 80, yf, 80, 0, 1, s)) return 1;
+    // tape row 0 of the state sequences
+    if (launch_from_frag(h0[0], 512, B, 512, tp.h0, 512, 0, s)) return 1;
+    if (launch_from_frag(h1[0], 512, B, 512, tp.h1, 512, 0, s)) return 1;
+    if (launch_fill(tp.c0, (int64_t)B * 512, 0.f, s)) return 1;
+    if (launch_fill(tp.c1, (int64_t)B * 512, 0.f, s)) return 1;
+
+    for (int i = 0; i < S; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const int64_t r256 = (int64_t)i * B * 256, r512 = (int64_t)i * B * 512;
+        if (teacher && mask && mask[i])
+            if (launch_to_frag(teacher + (int64_t)i * NM_, S * NM_, B, 80, yf, 80, 0, 0, s)) return 1;
+        {
+            SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+            SkinnyP a = tsk(w.pre1, B);
+            a.seg[0] = {yf, 5}; a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
+            tb.t[0].zsave = tp.z1 + r256; tb.t[0].ld_z = 256;
+            SkinnyP b = tsk(w.q, B);
+            b.seg[0] = {h0[cur], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2; b.act = ACT_PSINE; b.out = q; b.ldo = 512;
+            b.addrow = w.pos + (int64_t)i * 512;
+            tb.t[1].zsave = tp.zq + r512; tb.t[1].ld_z = 512;
+            SkinnyP c = tsk(w.cq, B);
+            c.seg[0] = {c0, 32}; c.seg[1] = {c1, 32}; c.nseg = 2; c.act = ACT_SILU; c.out = qc; c.ldo = 256;
+            tb.t[2].zsave = tp.zc + r256; tb.t[2].ld_z = 256;
+            sb.p[0] = a; sb.ntiles[0] = 16; sb.p[1] = b; sb.ntiles[1] = w.q.tiles; sb.p[2] = c; sb.ntiles[2] = w.cq.tiles; sb.count = 3;
+            if (launch_train_skinny(sb, tb, s, "train_step_prenet1_q_cq")) return 1;
+        }
+        {
+            TrainStepB sb{};
+            AttnP& at = sb.at;
+            at.q = q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = av;
+            at.attn_out = attn_logits + (int64_t)i * T; at.ld_attn_b = (int64_t)S * T; at.attn_logits = 1;
+            at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
+            at.B = B; at.T = T; at.m = sl.m;
+            sb.att.alpha = tp.alpha + (int64_t)i * B * 16; sb.att.ld_alpha = 16; sb.att.av_plain = tp.av + r512; sb.att.cc_plain = tp.cc + r256;
+            sb.pre2 = tsk(w.pre2, B);
+            sb.pre2.seg[0] = {p1, 16}; sb.pre2.nseg = 1; sb.pre2.act = ACT_PSINE; sb.pre2.out = p2; sb.pre2.ldo = 256;
+            sb.pre2t.zsave = tp.z2 + r256; sb.pre2t.ld_z = 256;
+            sb.pre2_tiles = w.pre2.tiles;
+            ProfScope ps("train_step_attention_prenet2", s);
+            hipLaunchKernelGGL(train_step_attn_kernel, dim3(2 * B + w.pre2.tiles * (Bp / 16)), dim3(512), 0, s, sb);
+            L2S_CHECK_HIP(hipGetLastError());
+        }
+        {
+            SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+            SkinnyP a = tsk(w.aproj, B);
+            a.seg[0] = {av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = uu; a.ldo = 256; a.add = p2; a.ld_add = 256;
+            tb.t[0].out_plain = tp.u + r256; tb.t[0].ld_out = 256;
+            sb.p[0] = a; sb.ntiles[0] = w.aproj.tiles; sb.count = 1;
+            if (launch_train_skinny(sb, tb, s, "train_step_attention_proj")) return 1;
+        }
+        for (int layer = 0; layer < 2; ++layer) {
+            SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+            SkinnyP a = tsk(layer == 0 ? w.lstm0 : w.lstm1, B);
+            if (layer == 0) { a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3; }
+            else { a.seg[0] = {h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2; }
+            a.epi = SK_LSTM; a.H = 512;
+            a.c_in = layer == 0 ? c0 : c1; a.c_out = a.c_in == c0 ? c0 : c1;
+            a.h_out = layer == 0 ? h0[nxt] : h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
+            a.h_seq = (layer == 0 ? tp.h0 : tp.h1) + (int64_t)(i + 1) * B * 512; a.ld_hseq = 512;
+            tb.t[0].gates = (layer == 0 ? tp.g0 : tp.g1) + (int64_t)i * B * 2048; tb.t[0].ld_gates = 2048;
+            tb.t[0].c_new = (layer == 0 ? tp.c0 : tp.c1) + (int64_t)(i + 1) * B * 512; tb.t[0].ld_c = 512;
+            sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
+            if (launch_train_skinny(sb, tb, s, "train_step_lstm_cell")) return 1;
+        }
+        {
+            SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+            SkinnyP a = tsk(w.fc, B);
+            a.seg[0] = {h1[nxt], 32}; a.nseg = 1; a.epi = SK_MEL;
+            a.mel = mel + (int64_t)i * NM_; a.ld_mel_b = (int64_t)S * NM_; a.stop = stop + i; a.ld_stop_b = S;
+            a.stop_const = state + sl.stopc; a.yfrag = yf;
+            sb.p[0] = a; sb.ntiles[0] = w.fc.tiles; sb.count = 1;
+            if (launch_train_skinny(sb, tb, s, "train_step_fc_out_stop")) return 1;
+        }
+    }
+    {
+        const int64_t total = (int64_t)S * B * 96;
+        ProfScope ps("train_build_yprev", s);
+        hipLaunchKernelGGL(build_yprev_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, mel, teacher, mask_dev, w.bos, B, S, tp.yprev);
+        L2S_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- transposed step weights for the backward products, packed on the device from the canonical parameters
+struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1; };
+static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 64 * 10; }
+static TrainW train_w(float* base) {
+    TrainW t; int64_t o = 0;
+    auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
+    t.fc = take((int64_t)512 * 96); t.l1 = take((int64_t)1024 * 2048); t.l0 = take((int64_t)1024 * 2048); t.ap = take((int64_t)512 * 256);
+    t.q = take((int64_t)1024 * 512); t.cq = take((int64_t)1024 * 256); t.p2 = take(256 * 256); t.p1 = take(80 * 256);
+    return t;
+}
+static int pack_train_weights(l2s_model* m, float* wbuf, hipStream_t s) {
+    TrainW t = train_w(wbuf);
+    const std::string D = "decoder.";
+    auto P = [&](const std::string& k) { return m->canon(D + k); };
+    const PackSeg none{nullptr, 0, 0, 0, 0, 0};
+    L2S_REQUIRE(P("fc_out.linear_layer.weight") && P("decoder_rnn.weight_ih_l0") && P("prenet.0.linear_layer.weight"), "decoder parameters not bound");
+    if (pack_fragT(t.fc, 512, 96, PackSeg{P("fc_out.linear_layer.weight"), 512, 0, 512, 0, 80}, PackSeg{P("stop_token_layer.linear_layer.weight"), 1024, 0, 512, 80, 81}, none, s)) return 1;
+    if (pack_fragT(t.l1, 1024, 2048, PackSeg{P("decoder_rnn.weight_ih_l1"), 512, 0, 512, 0, 2048}, PackSeg{P("decoder_rnn.weight_hh_l1"), 512, 512, 1024, 0, 2048}, none, s)) return 1;
+    if (pack_fragT(t.l0, 1024, 2048, PackSeg{P("decoder_rnn.weight_ih_l0"), 512, 0, 512, 0, 2048}, PackSeg{P("decoder_rnn.weight_hh_l0"), 512, 512, 1024, 0, 2048}, none, s)) return 1;
+    if (pack_fragT(t.ap, 512, 256, PackSeg{P("attention_proj.linear_layer.weight"), 512, 0, 512, 0, 256}, none, none, s)) return 1;
+    if (pack_fragT(t.q, 1024, 512, PackSeg{P("Q.0.linear_layer.weight"), 1024, 0, 1024, 0, 512}, none, none, s)) return 1;
+    if (pack_fragT(t.cq, 1024, 256, PackSeg{P("content.Q.0.weight"), 1024, 0, 1024, 0, 256}, none, none, s)) return 1;
+    if (pack_fragT(t.p2, 256, 256, PackSeg{P("prenet.3.linear_layer.weight"), 256, 0, 256, 0, 256}, none, none, s)) return 1;
+    if (pack_fragT(t.p1, 80, 256, PackSeg{P("prenet.0.linear_layer.weight"), 80, 0, 80, 0, 256}, none, none, s)) return 1;
+    return 0;
+}
+
+// small helpers of the backward loop
+static SkinnyP bsk(const float* Wfrag, int N, int K, int B, const float* afrag, float* out, int ldo, const float* add = nullptr, int ld_add = 0) {
+    SkinnyP p{};
+    p.W = Wfrag; p.B = B; p.N = N; p.K = K; p.act = ACT_NONE; p.epi = SK_PLAIN;
+    p.seg[0] = {afrag, K / 16}; p.nseg = 1; p.out = out; p.ldo = ldo; p.add = add; p.ld_add = ld_add;
+    return p;
+}
+static int run1(const SkinnyP& p, hipStream_t s, const char* name) {
+    SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+    sb.p[0] = p; sb.ntiles[0] = (p.N + 15) / 16; sb.count = 1;
+    return launch_train_skinny(sb, tb, s, name);
+}
+static int ew(int n) { return (n + 255) / 256; }
+
+__global__ __launch_bounds__(256) void psine_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t rows, int C, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) out[i] = sinf(z[i]) * w[i % C];
+}
+// de_c[b][j] = (sum_i dstop[b][i]) * ws[512 + j];  d ws[512 + j] = sum_b (sum_i dstop[b][i]) * e_c[b][j]
+__global__ __launch_bounds__(512) void stop_tail_bwd_kernel(const float* __restrict__ dstop, int B, int S, const float* __restrict__ ws, const float* __restrict__ ecell,
+                                                            float* __restrict__ de_c, float* __restrict__ dws_tail) {
+    __shared__ float sb[128];
+    const int j = threadIdx.x;
+    for (int b = j; b < B; b += 512) { float a = 0.f; for (int i = 0; i < S; ++i) a += dstop[(int64_t)b * S + i]; sb[b] = a; }
+    __syncthreads();
+    float g = 0.f;
+    for (int b = 0; b < B; ++b) { de_c[(int64_t)b * 512 + j] = sb[b] * ws[512 + j]; g += sb[b] * ecell[(int64_t)b * 512 + j]; }
+    if (dws_tail) dws_tail[j] = g;
+}
+__global__ void sum_small_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {   // one thread: n <= a few thousand
+    if (blockIdx.x == 0 && threadIdx.x == 0) { double a = 0.0; for (int i = 0; i < n; ++i) a += x[i]; out[0] = (float)a; }
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int rows, int cols) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < rows * cols) dst[(int64_t)(idx / cols) * ld_dst + idx % cols] = src[(int64_t)(idx / cols) * ld_src + idx % cols];
+}
+
+static int64_t step_bwd_ws_floats(int B, int S) {
+    const int64_t Bp = pad16(B), SB = (int64_t)S * B;
+    return SB * (96 + 2048 * 3 + 256 * 3 + 512 + 2 + 256 + 256) + Bp * (96 + 2048 * 2 + 256 * 4 + 512) + (int64_t)B * (512 * 6 + 1024 * 4 + 256 + 80) +
+           (int64_t)AB_RS * 3 * 2048 + (int64_t)96 * 512 + 4096 + 64 * 60;
+}
+
+// Back-propagation through the S steps.  Inputs: dmel (B,S,80) total gradient of the pre-postnet frames, dstop (B,S).
+// Outputs: parameter gradients (bound slots), dk/dv (B,T,512), dckey/dcval (B,m,256), dh_init (2,B,512), de_c (B,512).
+static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* mask, float* tape_base, const float* attn_logits,
+                            const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
+                            float* de_c, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    StepTape tp = step_tape(tape_base, B, S);
+    TrainW tw = train_w(wbuf);
+    const int Bp = pad16(B);
+    const int64_t SB = (int64_t)S * B;
+    Bump bp(ws, ws_bytes);
+    // stacks (time-major)
+    float* st_dyt = bp.f(SB * 96); float* st_dg1 = bp.f(SB * 2048); float* st_dg0 = bp.f(SB * 2048); float* st_du = bp.f(SB * 256);
+    float* st_dq = bp.f(SB * 512); float* st_dqc = bp.f(SB * 256); float* st_dp1 = bp.f(SB * 256); float* st_dtau = bp.f(SB); float* st_dtauc = bp.f(SB);
+    float* st_tmp = bp.f(SB * 2048); float* st_p1 = bp.f(SB * 256);
+    // per-step fragments and plain buffers
+    float* f_dyt = bp.f((int64_t)Bp * 96); float* f_dg1 = bp.f((int64_t)Bp * 2048); float* f_dg0 = bp.f((int64_t)Bp * 2048);
+    float* f_du = bp.f((int64_t)Bp * 256); float* f_dzq = bp.f((int64_t)Bp * 512); float* f_dzc = bp.f((int64_t)Bp * 256);
+    float* f_dz2 = bp.f((int64_t)Bp * 256); float* f_dz1 = bp.f((int64_t)Bp * 256);
+    float* dh1lin = bp.f((int64_t)B * 512); float* d01 = bp.f((int64_t)B * 1024); float* d0x = bp.f((int64_t)B * 1024); float* dav = bp.f((int64_t)B * 512);
+    float* dhq = bp.f((int64_t)B * 1024); float* dcq = bp.f((int64_t)B * 1024); float* dp1 = bp.f((int64_t)B * 256); float* dyc = bp.f((int64_t)B * 80);
+    float* dh0c = bp.f((int64_t)B * 512); float* dh1c = bp.f((int64_t)B * 512); float* dc0c = bp.f((int64_t)B * 512); float* dc1c = bp.f((int64_t)B * 512);
+    float* partials = bp.f((int64_t)AB_RS * 3 * 2048); float* tmp96 = bp.f((int64_t)96 * 512); float* small = bp.f(4096);
+    L2S_REQUIRE(!bp.overflow, "training backward workspace too small");
+    for (float* z : {dh0c, dh1c, dc0c, dc1c}) if (launch_fill(z, (int64_t)B * 512, 0.f, s)) return 1;
+    for (float* z : {f_dyt}) if (launch_fill(z, (int64_t)Bp * 96, 0.f, s)) return 1;
+    if (launch_fill(dk, (int64_t)B * T * 512, 0.f, s) || launch_fill(dv, (int64_t)B * T * 512, 0.f, s)) return 1;
+    if (launch_fill(dckey, (int64_t)B * sl.m * 256, 0.f, s) || launch_fill(dcval, (int64_t)B * sl.m * 256, 0.f, s)) return 1;
+    const std::string D = "decoder.";
+    const float* wq = m->canon(D + "Q.1.w"); const float* w1 = m->canon(D + "prenet.1.w"); const float* w2 = m->canon(D + "prenet.4.w");
+    L2S_REQUIRE(wq && w1 && w2, "decoder parameters not bound");
+
+    bool use_carry = false;
+    for (int i = S - 1; i >= 0; --i) {
+        const int64_t r256 = (int64_t)i * B * 256, r512 = (int64_t)i * B * 512, r2048 = (int64_t)i * B * 2048;
+        hipLaunchKernelGGL(build_dy_kernel, dim3(ew(Bp * 96)), dim3(256), 0, s, dmel, dstop, dyc, use_carry ? 1 : 0, B, S, i, f_dyt, st_dyt + (int64_t)i * B * 96);
+        if (run1(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 512), s, "train_bwd_fc")) return 1;
+        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh1lin, 512, (const float*)nullptr, 0, dc1c, tp.g1 + r2048,
+                           tp.c1 + r512, tp.c1 + r512 + (int64_t)B * 512, B, 512, f_dg1, st_dg1 + r2048);
+        if (run1(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), s, "train_bwd_lstm_dx")) return 1;
+        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh0c, 512, d01, 1024, dc0c, tp.g0 + r2048, tp.c0 + r512,
+                           tp.c0 + r512 + (int64_t)B * 512, B, 512, f_dg0, st_dg0 + r2048);
+        if (run1(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), s, "train_bwd_lstm_dx")) return 1;
+        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x + 256, 1024, (const float*)nullptr, (int)ACT_NONE, (const float*)nullptr, B, 256,
+                           f_du, st_du + r256);
+        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x + 256, 1024, tp.z2 + r256, (int)ACT_PSINE, w2, B, 256, f_dz2, (float*)nullptr);
+        if (run1(bsk(tw.ap, 512, 256, B, f_du, dav, 512), s, "train_bwd_attention_proj")) return 1;
+        {
+            AttnBwdP a{};
+            a.dav = dav; a.dcc = d0x; a.ld_dcc = 1024; a.logits = attn_logits + (int64_t)i * T; a.ld_logit_b = (int64_t)S * T;
+            a.k = state + sl.k; a.v = state + sl.v; a.zq = tp.zq + r512; a.wq = wq; a.pos = w.pos + (int64_t)i * 512; a.tau = w.tau;
+            a.alpha = tp.alpha + (int64_t)i * B * 16; a.ckey = state + sl.ckey; a.cval = state + sl.cval; a.zc = tp.zc + r256; a.tau_c = w.tau_c;
+            a.dk = dk; a.dv = dv; a.dckey = dckey; a.dcval = dcval; a.dzq_frag = f_dzq; a.dq_stack = st_dq + r512; a.dzc_frag = f_dzc;
+            a.dqc_stack = st_dqc + r256; a.dtau_part = st_dtau + (int64_t)i * B; a.dtauc_part = st_dtauc + (int64_t)i * B;
+            a.B = B; a.T = T; a.m = sl.m;
+            hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(512), 0, s, a);
+        }
+        {
+            SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+            sb.p[0] = bsk(tw.q, 1024, 512, B, f_dzq, dhq, 1024); sb.ntiles[0] = 64;
+            sb.p[1] = bsk(tw.cq, 1024, 256, B, f_dzc, dcq, 1024); sb.ntiles[1] = 64;
+            sb.p[2] = bsk(tw.p2, 256, 256, B, f_dz2, dp1, 256); sb.ntiles[2] = 16;
+            sb.count = 3;
+            if (launch_train_skinny(sb, tb, s, "train_bwd_q_cq_prenet2")) return 1;
+        }
+        hipLaunchKernelGGL(carry_update_kernel, dim3(ew(B * 512)), dim3(256), 0, s, d0x, d01, dhq, dcq, B, dh0c, dh1c, dc0c, dc1c);
+        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, dp1, 256, tp.z1 + r256, (int)ACT_PSINE, w1, B, 256, f_dz1, st_dp1 + r256);
+        if (run1(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), s, "train_bwd_prenet1")) return 1;
+        const bool forced = (i == 0) || (mask && mask[i]);
+        use_carry = !forced;
+        L2S_CHECK_HIP(hipGetLastError());
+    }
+    // ---- state gradients
+    L2S_CHECK_HIP(hipMemcpyAsync(dh_init, dh0c, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(dh_init + (int64_t)B * 512, dh1c, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+    const float* ws_can = m->canon(D + "stop_token_layer.linear_layer.weight");
+    float* g_ws = m->grad(D + "stop_token_layer.linear_layer.weight");
+    hipLaunchKernelGGL(stop_tail_bwd_kernel, dim3(1), dim3(512), 0, s, dstop, B, S, ws_can, state + sl.ecell, de_c, g_ws ? g_ws + 512 : nullptr);
+    // ---- parameter gradients from the stacks
+    auto dw = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int cin, float* out, int ldc) -> int {
+        if (!out) return 0;
+        BwdGemmP p = bwd_dw(dz, ldz, x, ldx, out, 1, (int)SB, (int)SB, nout, cin, 1, 1, 0, false);
+        p.ldc = ldc;
+        return launch_gemm_bwd(p, s, "train_bwd_step_dw");
+    };
+    const float* h0prev = tp.h0; const float* h0new = tp.h0 + (int64_t)B * 512; const float* h1prev = tp.h1; const float* h1new = tp.h1 + (int64_t)B * 512;
+    // fc_out + stop (h1 half): (96 x 512) product, rows 0..79 -> fc_out.weight, row 80 -> stop weight[:512]
+    if (dw(st_dyt, 96, 96, h1new, 512, 512, tmp96, 512)) return 1;
+    if (float* g = m->grad(D + "fc_out.linear_layer.weight")) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(80 * 512)), dim3(256), 0, s, tmp96, 512, g, 512, 80, 512);
+    if (g_ws) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(512)), dim3(256), 0, s, tmp96 + 80 * 512, 512, g_ws, 512, 1, 512);
+    if (colsum(st_dyt, SB, 96, partials, st_tmp, small, false, s)) return 1;
+    if (float* g = m->grad(D + "fc_out.linear_layer.bias")) hipLaunchKernelGGL(copy_rows_kernel, dim3(1), dim3(256), 0, s, small, 96, g, 80, 1, 80);
+    if (float* g = m->grad(D + "stop_token_layer.linear_layer.bias")) hipLaunchKernelGGL(copy_rows_kernel, dim3(1), dim3(256), 0, s, small + 80, 96, g, 1, 1, 1);
+    // LSTM layers
+    if (dw(st_dg1, 2048, 2048, h0new, 512, 512, m->grad(D + "decoder_rnn.weight_ih_l1"), 512)) return 1;
+    if (dw(st_dg1, 2048, 2048, h1prev, 512, 512, m->grad(D + "decoder_rnn.weight_hh_l1"), 512)) return 1;
+    if (colsum(st_dg1, SB, 2048, partials, st_tmp, small, false, s)) return 1;
+    for (const char* k : {"decoder_rnn.bias_ih_l1", "decoder_rnn.bias_hh_l1"})
+        if (float* g = m->grad(D + k)) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(2048)), dim3(256), 0, s, small, 2048, g, 2048, 1, 2048);
+    if (float* g = m->grad(D + "decoder_rnn.weight_ih_l0")) {
+        if (dw(st_dg0, 2048, 2048, tp.cc, 256, 256, g, 512)) return 1;
+        if (dw(st_dg0, 2048, 2048, tp.u, 256, 256, g + 256, 512)) return 1;
+    }
+    if (dw(st_dg0, 2048, 2048, h0prev, 512, 512, m->grad(D + "decoder_rnn.weight_hh_l0"), 512)) return 1;
+    if (colsum(st_dg0, SB, 2048, partials, st_tmp, small, false, s)) return 1;
+    for (const char* k : {"decoder_rnn.bias_ih_l0", "decoder_rnn.bias_hh_l0"})
+        if (float* g = m->grad(D + k)) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(2048)), dim3(256), 0, s, small, 2048, g, 2048, 1, 2048);
+    // attention_proj
+    if (dw(st_du, 256, 256, tp.av, 512, 512, m->grad(D + "attention_proj.linear_layer.weight"), 512)) return 1;
+    if (colsum(st_du, SB, 256, partials, st_tmp, m->grad(D + "attention_proj.linear_layer.bias") ? m->grad(D + "attention_proj.linear_layer.bias") : small, false, s)) return 1;
+    // Q (PSine): dz stack + bias + w gradients, then the weight
+    {
+        ActBwdP a{}; a.dy = st_dq; a.z = tp.zq; a.dconv = st_tmp; a.rows = SB; a.C = 512; a.act = ACT_PSINE; a.actw = wq; a.partials = partials;
+        if (act_bwd(a, m->grad(D + "Q.0.linear_layer.bias"), nullptr, m->grad(D + "Q.1.w"), nullptr, false, s)) return 1;
+        if (float* g = m->grad(D + "Q.0.linear_layer.weight")) {
+            if (dw(st_tmp, 512, 512, h0prev, 512, 512, g, 1024)) return 1;
+            if (dw(st_tmp, 512, 512, h1prev, 512, 512, g + 512, 1024)) return 1;
+        }
+    }
+    {   // content Q (SiLU)
+        ActBwdP a{}; a.dy = st_dqc; a.z = tp.zc; a.dconv = st_tmp; a.rows = SB; a.C = 256; a.act = ACT_SILU; a.partials = partials;
+        if (act_bwd(a, m->grad(D + "content.Q.0.bias"), nullptr, nullptr, nullptr, false, s)) return 1;
+        if (float* g = m->grad(D + "content.Q.0.weight")) {
+            if (dw(st_tmp, 256, 256, tp.c0, 512, 512, g, 1024)) return 1;
+            if (dw(st_tmp, 256, 256, tp.c1, 512, 512, g + 512, 1024)) return 1;
+        }
+    }
+    {   // prenet layer 2: input p1 = PSine(z1)
+        hipLaunchKernelGGL(psine_fwd_kernel, dim3(2048), dim3(256), 0, s, tp.z1, w1, SB, 256, st_p1);
+        ActBwdP a{}; a.dy = st_du; a.z = tp.z2; a.dconv = st_tmp; a.rows = SB; a.C = 256; a.act = ACT_PSINE; a.actw = w2; a.partials = partials;
+        if (act_bwd(a, m->grad(D + "prenet.3.linear_layer.bias"), nullptr, m->grad(D + "prenet.4.w"), nullptr, false, s)) return 1;
+        if (dw(st_tmp, 256, 256, st_p1, 256, 256, m->grad(D + "prenet.3.linear_layer.weight"), 256)) return 1;
+    }
+    {   // prenet layer 1: input = the frame fed at each step
+        ActBwdP a{}; a.dy = st_dp1; a.z = tp.z1; a.dconv = st_tmp; a.rows = SB; a.C = 256; a.act = ACT_PSINE; a.actw = w1; a.partials = partials;
+        if (act_bwd(a, m->grad(D + "prenet.0.linear_layer.bias"), nullptr, m->grad(D + "prenet.1.w"), nullptr, false, s)) return 1;
+        if (dw(st_tmp, 256, 256, tp.yprev, 96, 80, m->grad(D + "prenet.0.linear_layer.weight"), 80)) return 1;
+    }
+    // BOS: the frame of step 0; dyc now holds the gradient wrt that frame
+    if (float* g = m->grad(D + "BOS")) { if (colsum(dyc, B, 80, partials, st_tmp, g, false, s)) return 1; }
+    if (float* g = m->grad(D + "temperature")) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(1), 0, s, st_dtau, (int)SB, g);
+    if (float* g = m->grad(D + "content.temperature")) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(1), 0, s, st_dtauc, (int)SB, g);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s
+
 // ================================================================================================ C ABI
 using namespace l2s;
 
@@ -216,6 +872,33 @@ int l2s_train_bind(l2s_model* m, const char* key, float* param_dev, float* grad_
     L2S_REQUIRE(m && key && param_dev, "bad arguments");
     m->bound[key] = {param_dev, grad_dev};
     return 0;
+}
+
+int64_t l2s_train_steps_tape_floats(int B, int S) { return step_tape_floats(B, S); }
+int64_t l2s_train_steps_weights_floats(void) { return train_w_floats(); }
+int64_t l2s_train_steps_ws_bytes(int B, int S) { return (std::max(step_fwd_ws_floats(B), step_bwd_ws_floats(B, S)) + 1024) * (int64_t)sizeof(float); }
+
+int l2s_train_steps_pack_weights(l2s_model* m, float* wbuf, void* stream) {
+    L2S_REQUIRE(m && wbuf, "bad arguments");
+    return pack_train_weights(m, wbuf, (hipStream_t)stream);
+}
+
+int l2s_train_steps_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
+                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes,
+                        void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_dec && state && tape && mel && stop && attn_logits && ws, "bad arguments");
+    L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS && B <= 96, "sizes");
+    L2S_REQUIRE(!teacher || (teacher_mask && teacher_mask_dev), "teacher frames need the step mask on host and device");
+    return decode_train_fwd(m, state, B, T, S, teacher, teacher_mask, teacher_mask_dev, tape, mel, stop, attn_logits, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* teacher_mask, float* tape, const float* attn_logits,
+                        const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
+                        float* de_c, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_dec && state && tape && attn_logits && dmel && dstop && wbuf && dk && dv && dckey && dcval && dh_init && de_c && ws,
+                "bad arguments");
+    return decode_train_bwd(m, state, B, T, S, teacher_mask, tape, attn_logits, dmel, dstop, wbuf, dk, dv, dckey, dcval, dh_init, de_c, ws, ws_bytes,
+                            (hipStream_t)stream);
 }
 
 int64_t l2s_train_postnet_tape_floats(int B, int S) { return post_tape_floats(B, S); }

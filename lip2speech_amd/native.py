@@ -27,6 +27,8 @@ ABI_SYMBOLS = (
     "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
+    "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
+    "l2s_train_steps_fwd", "l2s_train_steps_bwd",
     "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
@@ -85,6 +87,14 @@ def lib() -> ctypes.CDLL:
     L.l2s_train_postnet_ws_bytes.restype = _i64
     L.l2s_train_postnet_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _vp]
     L.l2s_train_postnet_bwd.argtypes = [_vp, _fp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_steps_tape_floats.argtypes = [_i, _i]
+    L.l2s_train_steps_tape_floats.restype = _i64
+    L.l2s_train_steps_weights_floats.restype = _i64
+    L.l2s_train_steps_ws_bytes.argtypes = [_i, _i]
+    L.l2s_train_steps_ws_bytes.restype = _i64
+    L.l2s_train_steps_pack_weights.argtypes = [_vp, _fp, _vp]
+    L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_scratch_bytes.restype = _i64
     L.l2s_loss.argtypes = [_fp] * 6 + [_i, _i, _i] + [_fp] * 5 + [_vp, _vp]
     L.l2s_grad_norm.argtypes = [_fp, _i64, _vp, _fp, _vp]
@@ -249,6 +259,32 @@ class NativeModel:
         ws = torch.empty(int(L.l2s_train_postnet_ws_bytes(B, S)), dtype=torch.uint8, device=mel.device)
         check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(ws), ws.numel(), _stream()))
         return out, dmel
+
+    def train_steps(self, state, B, T, S, dmel, dstop, teacher=None, teacher_mask=None):
+        """Loop forward-with-tape + BPTT (stage 2 of the training path).  Returns (mel, stop, attn_logits) and the state gradients."""
+        L, dev = lib(), state.device
+        tape = torch.zeros(int(L.l2s_train_steps_tape_floats(B, S)), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.l2s_train_steps_ws_bytes(B, S)), dtype=torch.uint8, device=dev)
+        wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=dev)
+        mel = torch.empty(B, S, 80, dtype=torch.float32, device=dev)
+        stop = torch.empty(B, S, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, S, T, dtype=torch.float32, device=dev)
+        mask_np = mask_dev = mask_ptr = None
+        if teacher is not None:
+            teacher = _f32(teacher)
+            mask_np = np.ascontiguousarray(np.asarray(teacher_mask, dtype=np.uint8))
+            mask_dev = torch.from_numpy(mask_np).to(dev)
+            mask_ptr = mask_np.ctypes.data_as(_vp)
+        check(L.l2s_train_steps_fwd(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_ptr, _ptr(mask_dev) if mask_dev is not None else None,
+                                    _ptr(tape), _ptr(mel), _ptr(stop), _ptr(logits), _ptr(ws), ws.numel(), _stream()))
+        m = min_T(T)
+        out = {"dk": torch.empty(B, T, 512, device=dev), "dv": torch.empty(B, T, 512, device=dev), "dckey": torch.empty(B, m, 256, device=dev),
+               "dcval": torch.empty(B, m, 256, device=dev), "dh_init": torch.empty(2, B, 512, device=dev), "de_c": torch.empty(B, 512, device=dev)}
+        check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
+        check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, mask_ptr, _ptr(tape), _ptr(logits), _ptr(_f32(dmel)), _ptr(_f32(dstop)), _ptr(wbuf),
+                                    _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
+                                    _ptr(ws), ws.numel(), _stream()))
+        return (mel, stop, logits), out
 
     def lstm_cell_chain_us(self, B: int, n_pairs: int = 300) -> float:
         """Average duration of the decoder LSTM-cell kernel, one HIP-event pair around 2*n_pairs chained launches."""

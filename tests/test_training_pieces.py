@@ -139,3 +139,67 @@ def test_postnet_backward_matches_autograd(synth_sd):
         ref = sd64[k].grad
         assert ref is not None, k
         assert pc.maxdiff(g, ref.reshape(g.shape)) < 3e-4 * max(1.0, ref.abs().max().item()), k
+
+
+STEP_KEYS = ["fc_out.linear_layer.weight", "fc_out.linear_layer.bias", "stop_token_layer.linear_layer.weight", "stop_token_layer.linear_layer.bias",
+             "decoder_rnn.weight_ih_l0", "decoder_rnn.weight_hh_l0", "decoder_rnn.bias_ih_l0", "decoder_rnn.bias_hh_l0",
+             "decoder_rnn.weight_ih_l1", "decoder_rnn.weight_hh_l1", "decoder_rnn.bias_ih_l1", "decoder_rnn.bias_hh_l1",
+             "attention_proj.linear_layer.weight", "attention_proj.linear_layer.bias", "Q.0.linear_layer.weight", "Q.0.linear_layer.bias", "Q.1.w",
+             "content.Q.0.weight", "content.Q.0.bias", "prenet.0.linear_layer.weight", "prenet.0.linear_layer.bias", "prenet.1.w",
+             "prenet.3.linear_layer.weight", "prenet.3.linear_layer.bias", "prenet.4.w", "BOS", "temperature", "content.temperature"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,forced", [(9, False), (12, True)])
+def test_decode_loop_bptt_matches_autograd(synth_sd, S, forced):
+    """Stage 2 of the training path: the S-step loop with a tape and its back-propagation through time against autograd through
+    the oracle's decode loop in fp64 - every step parameter and every state tensor the prologue produced."""
+    import parity_common as pc
+    from lip2speech_amd import native, synth
+    from oracle import l2s_oracle as orc
+    g, _, emb = pc.lrw2_inputs()
+    B, T = 2, 29
+    nm = pc.native_model(synth_sd)
+    vis = native.build_visual(g["feat"].cuda(), emb.cuda())
+    state, _ = nm.decoder_prologue(vis, emb.cuda(), g["gumbel"].cuda())
+    torch.manual_seed(S)
+    Gm, Gs = torch.randn(B, S, 80), torch.randn(B, S)
+    mels = synth.synth_mels(B, S, tag="mel-lrw2")
+    mask = None
+    teacher = None
+    if forced:
+        mask = torch.zeros(S, dtype=torch.bool)
+        mask[[0, 3, 4, 9]] = True
+        teacher = torch.cat([synth_sd["decoder.BOS"].expand(B, 1, -1), mels.permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
+    keys = ["decoder." + k for k in STEP_KEYS] + ["decoder.positional_encodings.pos_table"]
+    sd64 = {k: synth_sd[k].double().requires_grad_(k != "decoder.positional_encodings.pos_table") for k in keys}
+    st = {"k": g["oracle_k"], "v": g["oracle_v"], "key": g["oracle_key"], "value": g["oracle_value"], "hidden": g["oracle_hidden"],
+          "encoder_cell": g["oracle_encoder_cell"]}
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items()}
+    # the reference builds teacher_input = cat(BOS, mels) from the BOS parameter itself (decoder.py:349), so its gradient reaches BOS
+    teacher64 = torch.cat([sd64["decoder.BOS"].expand(B, 1, -1), mels.double().permute(0, 2, 1)[:, :S - 1]], dim=1) if forced else None
+    mel_o, stop_o, logit_o = orc.decode_loop(sd64, st64, S, teacher=teacher64, teacher_mask=mask, return_logits=True)
+    ((mel_o * Gm.double()).sum() + (stop_o * Gs.double()).sum()).backward()
+    params = {k: synth_sd[k].cuda() for k in keys if k != "decoder.positional_encodings.pos_table"}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    nm.train_bind(params, grads)
+    (mel, stop, logits), sg = nm.train_steps(state, B, T, S, Gm.cuda(), Gs.cuda(), teacher=teacher.cuda() if forced else None,
+                                             teacher_mask=mask.numpy() if forced else None)
+    assert pc.maxdiff(mel, mel_o) < 1e-4 and pc.maxdiff(stop, stop_o) < 1e-4
+    assert pc.maxdiff(logits, logit_o) / logit_o.abs().max().item() < 1e-5
+
+    def close(name, got, ref, rel=2e-3):
+        ref = ref.reshape(got.shape)
+        scale = max(1e-6, ref.abs().max().item())
+        err = pc.maxdiff(got, ref) / scale
+        assert err < rel, f"{name}: relative error {err:.2e} (scale {scale:.2e})"
+
+    close("dk", sg["dk"], st64["k"].grad.permute(0, 2, 1))
+    close("dv", sg["dv"], st64["v"].grad)
+    close("dckey", sg["dckey"], st64["key"].grad.permute(0, 2, 1))
+    close("dcval", sg["dcval"], st64["value"].grad)
+    close("dh_init", sg["dh_init"], st64["hidden"].grad)
+    close("de_c", sg["de_c"], st64["encoder_cell"].grad)
+    for k in grads:
+        assert sd64[k].grad is not None, k
+        close(k, grads[k], sd64[k].grad)
