@@ -180,6 +180,18 @@ int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const u
                         const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
                         float* de_c, void* ws, int64_t ws_bytes, void* stream);
 
+/* Stage 3: the decoder prologue with a tape (decoder.py:321-351 / 383-410) and its backward down to the visual features.
+ * Forward = l2s_decoder_prologue (same `state` buffer, same arguments) plus the tape.  Backward: the gradients of the state the loop
+ * consumed (the outputs of l2s_train_steps_bwd; dcontent_dis dev (B*min_T,501) = gradient of the content distribution, may be NULL)
+ * -> every prologue parameter gradient into the bound slots and dvis dev (B,T,1024). */
+int64_t l2s_train_prologue_tape_floats(int B, int T);
+int64_t l2s_train_prologue_ws_bytes(int B, int T);
+int l2s_train_prologue_fwd(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T, float* state, float* content_dis,
+                           float* tape, void* ws, int64_t ws_bytes, void* stream);
+int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int B, int T, float* state, float* tape, float* wbuf, const float* dk,
+                           const float* dv, const float* dckey, const float* dcval, const float* dh_init, const float* de_c, const float* dcontent_dis,
+                           float* dvis, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
 /* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,

@@ -18,7 +18,8 @@ namespace l2s {
 constexpr int AB_RS = 32;     // row splits
 
 struct ActBwdP {
-    const float* dy; const float* z; float* dconv;     // [rows][C]
+    const float* dy; const float* z; float* dconv;     // [rows][ld]
+    int ld_dy, ld_z, ld_dconv;                          // 0 = C
     int64_t rows; int C;
     int act;                                            // ACT_NONE / ACT_SILU / ACT_PSINE / ACT_RELU
     const float* actw;                                  // psine w
@@ -33,19 +34,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
     const int64_t chunk = (p.rows + AB_RS - 1) / AB_RS;
     const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < p.rows ? r_begin + chunk : p.rows;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int64_t ldy = p.ld_dy ? p.ld_dy : p.C, ldz = p.ld_z ? p.ld_z : p.C, ldc = p.ld_dconv ? p.ld_dconv : p.C;
     if (col < p.C) {
         const float s = p.scale ? p.scale[col] : 1.f;
         const float w = p.act == ACT_PSINE ? p.actw[col] : 0.f;
         const float be = p.beta ? p.beta[col] : 0.f, ig = p.gamma ? 1.f / p.gamma[col] : 0.f;
         for (int64_t r = r_begin + rl; r < r_end; r += 4) {
-            const float z = p.z[r * p.C + col], dy = p.dy[r * p.C + col];
+            const float z = p.z[r * ldz + col], dy = p.dy[r * ldy + col];
             float dpre = dy;
             if (p.act == ACT_PSINE) { dpre = dy * cosf(z) * w; a2 += dy * sinf(z); }
             else if (p.act == ACT_SILU) { const float sg = 1.f / (1.f + expf(-z)); dpre = dy * sg * (1.f + z * (1.f - sg)); }
             else if (p.act == ACT_RELU) { dpre = z > 0.f ? dy : 0.f; }
             a0 += dpre;
             a1 += dpre * (z - be) * ig;
-            p.dconv[r * p.C + col] = dpre * s;
+            p.dconv[r * ldc + col] = dpre * s;
         }
     }
     sh[0][rl][threadIdx.x & 63] = a0; sh[1][rl][threadIdx.x & 63] = a1; sh[2][rl][threadIdx.x & 63] = a2;
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(256) void build_yprev_kernel(const float* __restric
 // LSTM cell backward: dh = dh_a (+ dh_b); dc = dc_carry + dh*o*(1-tanh(c_new)^2); pre-activation gate gradients in canonical order
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh_a, int ld_a, const float* __restrict__ dh_b, int ld_b,
                                                        float* __restrict__ dc_carry, const float* __restrict__ gates, const float* __restrict__ c_prev,
-                                                       const float* __restrict__ c_new, int B, int H, float* __restrict__ dg_frag, float* __restrict__ dg_stack) {
+                                                       const float* __restrict__ c_new, int B, int H, float* __restrict__ dg_frag, float* __restrict__ dg_stack,
+                                                       float* __restrict__ dg_stack2 = nullptr, int64_t ld_stack2_b = 0) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * H) return;
     const int b = idx / H, u = idx - b * H;
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int k = 0; k < 4; ++k) {
         dg_frag[frag16_index(b, k * H + u, 4 * H)] = vals[k];
         dg_stack[(int64_t)b * 4 * H + k * H + u] = vals[k];
+        if (dg_stack2) dg_stack2[(int64_t)b * ld_stack2_b + k * H + u] = vals[k];
     }
 }
 
@@ -646,13 +650,14 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
 }
 
 // ---- transposed step weights for the backward products, packed on the device from the canonical parameters
-struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1; };
-static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 64 * 10; }
+struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1, *bhh[2], *fc4; };
+static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 2 * (int64_t)512 * 2048 + 504 * 256 + 64 * 14; }
 static TrainW train_w(float* base) {
     TrainW t; int64_t o = 0;
     auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
     t.fc = take((int64_t)512 * 96); t.l1 = take((int64_t)1024 * 2048); t.l0 = take((int64_t)1024 * 2048); t.ap = take((int64_t)512 * 256);
     t.q = take((int64_t)1024 * 512); t.cq = take((int64_t)1024 * 256); t.p2 = take(256 * 256); t.p1 = take(80 * 256);
+    t.bhh[0] = take((int64_t)512 * 2048); t.bhh[1] = take((int64_t)512 * 2048); t.fc4 = take(504 * 256);
     return t;
 }
 static int pack_train_weights(l2s_model* m, float* wbuf, hipStream_t s) {
@@ -669,6 +674,12 @@ static int pack_train_weights(l2s_model* m, float* wbuf, hipStream_t s) {
     if (pack_fragT(t.cq, 1024, 256, PackSeg{P("content.Q.0.weight"), 1024, 0, 1024, 0, 256}, none, none, s)) return 1;
     if (pack_fragT(t.p2, 256, 256, PackSeg{P("prenet.3.linear_layer.weight"), 256, 0, 256, 0, 256}, none, none, s)) return 1;
     if (pack_fragT(t.p1, 80, 256, PackSeg{P("prenet.0.linear_layer.weight"), 80, 0, 80, 0, 256}, none, none, s)) return 1;
+    if (P("encoder_rnn.weight_hh_l0") && P("content.location_fc.4.weight")) {     // prologue backward operands
+        if (pack_fragT(t.bhh[0], 512, 2048, PackSeg{P("encoder_rnn.weight_hh_l0"), 512, 0, 512, 0, 2048}, none, none, s)) return 1;
+        if (pack_fragT(t.bhh[1], 512, 2048, PackSeg{P("encoder_rnn.weight_hh_l0_reverse"), 512, 0, 512, 0, 2048}, none, none, s)) return 1;
+        if (launch_fill(t.fc4, 504 * 256, 0.f, s)) return 1;
+        L2S_CHECK_HIP(hipMemcpyAsync(t.fc4, P("content.location_fc.4.weight"), sizeof(float) * 501 * 256, hipMemcpyDeviceToDevice, s));
+    }
     return 0;
 }
 
@@ -863,6 +874,431 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
 
 }  // namespace l2s
 
+// =====================================================================================================================
+// Stage 3: the decoder prologue (decoder.py:321-351): forward with a tape, and its backward down to the visual features.
+// =====================================================================================================================
+namespace l2s {
+
+struct ProTape {
+    float *resid, *z_se, *s_e, *z_sa, *s_a;                 // (BT,512), (B,512) x 4
+    float *gin;                                             // (BT,4096) BiLSTM input gates (both directions)
+    float *rnn;                                             // (B,T,1024) BiLSTM outputs
+    float *gates[2], *cproc[2], *hproc[2];                  // per direction, in processing order: (T,B,2048), (T+1,B,512), (T+1,B,512)
+    float *cellcat;                                         // (B,1024)
+    float *cat;                                             // (BT,4608) [x | K branches | V branches] (post-activation)
+    float *zcat;                                            // (BT,4608): pre-SiLU (post-BN) of the 8 MultiHop branches, same columns as cat
+    float *zkv[2];                                          // (BT,512) pre-PSine bottleneck outputs
+    float *zagg[4], *cmap[4];                               // (B*L_j,512)
+    float *pooled, *wv, *zk0, *tA, *zk2, *zf0, *tB, *zf2, *tC, *zf4, *logits, *zsoft, *dis;
+    int L[4], m;
+};
+static int64_t pro_tape_floats(int B, int T) {
+    int L[4]; const int m = content_lens(T, L);
+    const int64_t BT = (int64_t)B * T, R = (int64_t)B * m;
+    int64_t n = BT * (512 + 4096 + 1024 + 4608 * 2 + 512 * 2) + (int64_t)B * 512 * 4 + 2 * ((int64_t)T * B * 2048 + 2 * (int64_t)(T + 1) * B * 512) + (int64_t)B * 1024;
+    for (int j = 0; j < 4; ++j) n += 2 * (int64_t)B * L[j] * 512;
+    n += R * (2560 + 256 * 8 + 504 * 4);
+    return n + 64 * 64;
+}
+static ProTape pro_tape(float* base, int B, int T) {
+    ProTape t; int64_t o = 0;
+    auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
+    t.m = content_lens(T, t.L);
+    const int64_t BT = (int64_t)B * T, R = (int64_t)B * t.m;
+    t.resid = take(BT * 512); t.z_se = take((int64_t)B * 512); t.s_e = take((int64_t)B * 512); t.z_sa = take((int64_t)B * 512); t.s_a = take((int64_t)B * 512);
+    t.gin = take(BT * 4096); t.rnn = take(BT * 1024);
+    for (int d = 0; d < 2; ++d) { t.gates[d] = take((int64_t)T * B * 2048); t.cproc[d] = take((int64_t)(T + 1) * B * 512); t.hproc[d] = take((int64_t)(T + 1) * B * 512); }
+    t.cellcat = take((int64_t)B * 1024); t.cat = take(BT * 4608);
+    t.zcat = take(BT * 4608);
+    for (int j = 0; j < 2; ++j) t.zkv[j] = take(BT * 512);
+    for (int j = 0; j < 4; ++j) { t.zagg[j] = take((int64_t)B * t.L[j] * 512); t.cmap[j] = take((int64_t)B * t.L[j] * 512); }
+    t.pooled = take(R * 2560); t.wv = take(R * 256); t.zk0 = take(R * 256); t.tA = take(R * 256); t.zk2 = take(R * 256);
+    t.zf0 = take(R * 256); t.tB = take(R * 256); t.zf2 = take(R * 256); t.tC = take(R * 256); t.zf4 = take(R * 504); t.logits = take(R * 504); t.zsoft = take(R * 504); t.dis = take(R * 504);
+    return t;
+}
+
+static GemmP tconv(const float* X, int lda, int B, int Tin, int Cin, const ConvW& c, int Cout, int taps, int stride, int pad, float* out, int ldc, int act, float* zout) {
+    const int Tout = (Tin + 2 * pad - taps) / stride + 1;
+    GemmP p = gemm_plain(X, lda, c.W, out, ldc, B * Tout, Cout, taps * Cin);
+    p.Tout = Tout; p.Tin = Tin; p.taps = taps; p.stride = stride; p.pad = pad; p.Cin = Cin;
+    p.scale = c.scale; p.shift = c.shift; p.actw = c.actw; p.act = act; p.Zout = zout;
+    return p;
+}
+static GemmP tlin(const float* A, int lda, const ConvW& c, float* out, int ldc, int M, int N, int K, int act, float* zout) {
+    GemmP p = gemm_plain(A, lda, c.W, out, ldc, M, N, K);
+    p.shift = c.shift; p.actw = c.actw; p.act = act; p.Zout = zout;
+    return p;
+}
+
+static int64_t pro_fwd_ws_floats(int B) { return (int64_t)pad16(B) * 512 * 6 + 64 * 8; }
+
+static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T, float* state, float* content_dis,
+                              float* tape_base, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    ProTape tp = pro_tape(tape_base, B, T);
+    L2S_REQUIRE(T >= 7 && T <= L2S_MAX_STEPS, "T must be in [7, 300]");
+    const int BT = B * T, Bp = pad16(B), R = B * tp.m;
+    Bump bp(ws, ws_bytes);
+    float* hf[2][2]; float* cf[2];
+    for (int d = 0; d < 2; ++d) { hf[d][0] = bp.f((int64_t)Bp * 512); hf[d][1] = bp.f((int64_t)Bp * 512); cf[d] = bp.f((int64_t)Bp * 512); }
+    L2S_REQUIRE(!bp.overflow, "training prologue workspace too small");
+    {
+        GemmP p = gemm_plain(vis, 1024, w.resid.W, tp.resid, 512, BT, 512, 1024); p.shift = w.resid.shift;
+        if (launch_gemm1(p, s, "train_prologue_gemm")) return 1;
+        GemmBatch gb{};
+        gb.p[0] = tlin(emb, 256, w.enc_site, tp.s_e, 512, B, 512, 256, ACT_PSINE, tp.z_se);
+        gb.p[1] = tlin(emb, 256, w.attn_site, tp.s_a, 512, B, 512, 256, ACT_PSINE, tp.z_sa);
+        gb.count = 2;
+        if (launch_gemm(gb, s, "train_prologue_gemm")) return 1;
+        GemmP g = gemm_plain(vis, 1024, w.wih_cat, tp.gin, 4096, BT, 4096, 1024); g.shift = w.bih_cat;
+        if (launch_gemm1(g, s, "train_bilstm_input_gemm")) return 1;
+    }
+    for (int d = 0; d < 2; ++d) {
+        if (launch_to_frag(tp.s_e, 512, B, 512, hf[d][0], 512, 0, 0, s)) return 1;
+        if (launch_to_frag(tp.s_e, 512, B, 512, cf[d], 512, 0, 0, s)) return 1;
+        if (launch_fill(hf[d][1], (int64_t)Bp * 512, 0.f, s)) return 1;
+        L2S_CHECK_HIP(hipMemcpyAsync(tp.hproc[d], tp.s_e, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+        L2S_CHECK_HIP(hipMemcpyAsync(tp.cproc[d], tp.s_e, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+    }
+    for (int step = 0; step < T; ++step) {
+        SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+        const int cur = step & 1, nxt = cur ^ 1;
+        for (int d = 0; d < 2; ++d) {
+            const int t = d == 0 ? step : T - 1 - step;
+            SkinnyP p = tsk(w.whh[d], B);
+            p.seg[0] = {hf[d][cur], 32}; p.nseg = 1; p.epi = SK_LSTM; p.H = 512;
+            p.pre = tp.gin + (int64_t)t * 4096 + d * 2048; p.ld_pre = (int64_t)T * 4096;
+            p.c_in = cf[d]; p.c_out = cf[d]; p.h_out = hf[d][nxt]; p.h_out_K = 512; p.h_out_off = 0;
+            p.h_seq = tp.rnn + (int64_t)t * 1024 + d * 512; p.ld_hseq = (int64_t)T * 1024;
+            p.h_plain = tp.hproc[d] + (int64_t)(step + 1) * B * 512; p.ld_hplain = 512;
+            tb.t[d].gates = tp.gates[d] + (int64_t)step * B * 2048; tb.t[d].ld_gates = 2048;
+            tb.t[d].c_new = tp.cproc[d] + (int64_t)(step + 1) * B * 512; tb.t[d].ld_c = 512;
+            sb.p[d] = p; sb.ntiles[d] = w.whh[d].tiles;
+        }
+        sb.count = 2;
+        if (launch_train_skinny(sb, tb, s, "train_bilstm_step")) return 1;
+    }
+    const int fin = T & 1;
+    L2S_CHECK_HIP(hipMemcpyAsync(state + sl.h, hf[0][fin], sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    L2S_CHECK_HIP(hipMemcpyAsync(state + sl.h + (int64_t)Bp * 512, hf[1][fin], sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
+    if (launch_from_frag(cf[0], 512, B, 512, tp.cellcat, 1024, 0, s)) return 1;
+    if (launch_from_frag(cf[1], 512, B, 512, tp.cellcat, 1024, 512, s)) return 1;
+    {
+        GemmP p = gemm_plain(tp.cellcat, 1024, w.e_c.W, state + sl.ecell, 512, B, 512, 1024); p.shift = w.e_c.shift;
+        if (launch_gemm1(p, s, "train_prologue_gemm")) return 1;
+        if (launch_stop_const(state + sl.ecell, w.stop_tail, w.stop_bias, B, state + sl.stopc, s)) return 1;
+        GemmP e = gemm_plain(tp.rnn, 1024, w.enc_proj.W, tp.cat, 4608, BT, 512, 1024);
+        e.shift = w.enc_proj.shift; e.R1 = tp.resid; e.ldr1 = 512; e.R2 = tp.s_a; e.ldr2 = 512; e.r2_div = T;
+        if (launch_gemm1(e, s, "train_prologue_gemm")) return 1;
+        if (launch_copy_cols(tp.cat, 4608, 0, state + sl.enc, 512, 0, 1, BT, 512, s)) return 1;
+    }
+    {
+        GemmBatch gb{};
+        for (int kv = 0; kv < 2; ++kv)
+            for (int j = 0; j < 4; ++j)
+                gb.p[kv * 4 + j] = tconv(tp.cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2, tp.cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU, nullptr);
+        gb.count = 8;
+        for (int q = 0; q < 8; ++q) gb.p[q].Zout = tp.zcat + 512 + q * 512;       // Zout shares C's addressing (ld 4608)
+        if (launch_gemm(gb, s, "train_multihop_conv_gemm")) return 1;
+        GemmBatch bb{};
+        for (int kv = 0; kv < 2; ++kv) {
+            GemmP p = gemm_plain(tp.cat, 4608, w.mh_bott[kv].W, state + (kv == 0 ? sl.k : sl.v), 512, BT, 512, 2560);
+            if (kv == 1) { p.a_split = 512; p.a_gap = 2048; }
+            p.shift = w.mh_bott[kv].shift; p.act = ACT_PSINE; p.actw = w.mh_bott[kv].actw; p.R1 = w.pos; p.ldr1 = 512; p.r1_mod = T; p.Zout = tp.zkv[kv];
+            bb.p[kv] = p;
+        }
+        bb.count = 2;
+        if (launch_gemm(bb, s, "train_multihop_bottleneck_gemm")) return 1;
+    }
+    {
+        GemmBatch gb{};
+        for (int j = 0; j < 4; ++j)
+            gb.p[j] = tconv(tp.cat, 4608, B, T, 512, w.ct_branch[j], 512, CT_KS[j], CT_KS[j], 0, tp.cmap[j], 512, ACT_SILU, tp.zagg[j]);
+        gb.count = 4;
+        if (launch_gemm(gb, s, "train_content_agg_gemm")) return 1;
+        PoolCatP pc{};
+        pc.x[0] = tp.cat; pc.L[0] = T; pc.ld[0] = 4608;
+        for (int j = 0; j < 4; ++j) { pc.x[j + 1] = tp.cmap[j]; pc.L[j + 1] = tp.L[j]; pc.ld[j + 1] = 512; }
+        pc.nmaps = 5; pc.B = B; pc.m = tp.m; pc.C = 512; pc.out = tp.pooled;
+        if (launch_pool_cat(pc, s)) return 1;
+        if (launch_gemm1(tlin(tp.pooled, 2560, w.ct_bott, tp.wv, 256, R, 256, 2560, ACT_NONE, nullptr), s, "train_content_gemm")) return 1;
+        GemmBatch g1{};
+        g1.p[0] = tlin(tp.wv, 256, w.ct_k0, tp.tA, 256, R, 256, 256, ACT_SILU, tp.zk0);
+        g1.p[1] = tlin(tp.wv, 256, w.ct_fc0, tp.tB, 256, R, 256, 256, ACT_SILU, tp.zf0);
+        g1.count = 2;
+        if (launch_gemm(g1, s, "train_content_gemm")) return 1;
+        GemmBatch g2{};
+        g2.p[0] = tlin(tp.tA, 256, w.ct_k2, state + sl.ckey, 256, R, 256, 256, ACT_SILU, tp.zk2);
+        g2.p[1] = tlin(tp.tB, 256, w.ct_fc2, tp.tC, 256, R, 256, 256, ACT_SILU, tp.zf2);
+        g2.count = 2;
+        if (launch_gemm(g2, s, "train_content_gemm")) return 1;
+        GemmP p3 = tlin(tp.tC, 256, w.ct_fc4, tp.logits, VOC, R, VOC, 256, ACT_SILU, tp.zf4);
+        if (launch_gemm1(p3, s, "train_content_gemm")) return 1;
+        if (launch_gumbel_softmax(tp.logits, gumbel, R, VOC, 0.1f, tp.zsoft, VOCP, content_dis ? content_dis : tp.dis, s)) return 1;
+        if (content_dis) L2S_CHECK_HIP(hipMemcpyAsync(tp.dis, content_dis, sizeof(float) * R * VOC, hipMemcpyDeviceToDevice, s));
+        if (launch_gemm1(gemm_plain(tp.zsoft, VOCP, w.ct_emb.W, state + sl.cval, 256, R, 256, VOCP), s, "train_content_gemm")) return 1;
+    }
+    if (launch_fill(state + sl.c, (int64_t)Bp * 512 * 2, 0.f, s)) return 1;
+    return 0;
+}
+
+}  // namespace l2s
+
+namespace l2s {
+
+// d logits of Content.encode: y = softmax((l+g)/tau) (gumbel) and dis = softmax(l):
+//   dl = y*(dy - sum y dy)/tau + dis*(ddis - sum dis ddis);  one block per row; output ld 504 (padding columns zeroed)
+__global__ __launch_bounds__(256) void content_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, int ldy, const float* __restrict__ dis,
+                                                                  const float* __restrict__ ddis, int n, float inv_tau, float* __restrict__ dl, int ldl) {
+    __shared__ float sh[8];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        s1 += y[(int64_t)row * ldy + j] * dy[(int64_t)row * ldy + j];
+        if (ddis) s2 += dis[(int64_t)row * n + j] * ddis[(int64_t)row * n + j];
+    }
+    s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    if ((tid & 63) == 0) { sh[tid >> 6] = s1; sh[4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    s1 = (sh[0] + sh[1]) + (sh[2] + sh[3]); s2 = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    for (int j = tid; j < ldl; j += 256) {
+        float v = 0.f;
+        if (j < n) {
+            v = y[(int64_t)row * ldy + j] * (dy[(int64_t)row * ldy + j] - s1) * inv_tau;
+            if (ddis) v += dis[(int64_t)row * n + j] * (ddis[(int64_t)row * n + j] - s2);
+        }
+        dl[(int64_t)row * ldl + j] = v;
+    }
+}
+
+// backward of the adaptive average pooling + concatenation: dpooled (B,m,nmaps*C) -> d map_j[b][t][c] (+)= sum over bins containing t of dpooled / binsize
+struct PoolBwdP { float* dx[5]; int L[5]; int ld[5]; int acc[5]; int nmaps; int B, m, C; const float* dp; };
+__global__ __launch_bounds__(256) void pool_cat_bwd_kernel(const PoolBwdP p) {
+    int64_t total = 0;
+    for (int j = 0; j < p.nmaps; ++j) total += (int64_t)p.B * p.L[j] * p.C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx; int j = 0;
+        while (r >= (int64_t)p.B * p.L[j] * p.C) { r -= (int64_t)p.B * p.L[j] * p.C; ++j; }
+        const int c = r % p.C; r /= p.C;
+        const int L = p.L[j];
+        const int t = r % L, b = r / L;
+        float g = 0.f;
+        for (int i = 0; i < p.m; ++i) {
+            const int st = (i * L) / p.m, en = ((i + 1) * L + p.m - 1) / p.m;
+            if (t >= st && t < en) g += p.dp[((int64_t)b * p.m + i) * (p.nmaps * p.C) + j * p.C + c] / (float)(en - st);
+        }
+        float* dst = p.dx[j] + ((int64_t)b * L + t) * p.ld[j] + c;
+        *dst = p.acc[j] ? *dst + g : g;
+    }
+}
+// out[b][c] = sum_t x[b][t][c]
+__global__ __launch_bounds__(256) void sum_time_kernel(const float* __restrict__ x, int B, int T, int C, int ld, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += x[((int64_t)b * T + t) * ld + c];
+    out[idx] = a;
+}
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ out, int ldo, int64_t rows, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) {
+        const int c = i % C; const int64_t r = i / C;
+        out[r * ldo + c] = a[r * lda + c] + (b ? b[r * ldb + c] : 0.f);
+    }
+}
+
+static int64_t pro_bwd_ws_floats(int B, int T) {
+    int L[4]; const int m = content_lens(T, L);
+    const int64_t BT = (int64_t)B * T, R = (int64_t)B * m, Bp = pad16(B);
+    int64_t n = BT * (4608 + 512 * 4 + 1024 + 2048 * 3) + (int64_t)512 * 11 * 512 + (int64_t)AB_RS * 3 * 4608 + R * (2560 + 504 * 3 + 256 * 6) + 504 * 256 +
+                (int64_t)B * (512 * 8 + 1024 * 2) + Bp * 2048 + 4 * BT * 512 + 8192;
+    return n + 64 * 64;
+}
+
+// Inputs: gradients of the state the loop consumed.  Outputs: every prologue parameter gradient (bound slots) and dvis (B,T,1024).
+static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, int B, int T, float* state, float* tape_base, float* wbuf,
+                              const float* dk, const float* dv, const float* dckey, const float* dcval, const float* dh_init, const float* de_c,
+                              const float* ddis, float* dvis, void* ws, int64_t ws_bytes, hipStream_t s) {
+    const Weights& w = m->w;
+    ProTape tp = pro_tape(tape_base, B, T);
+    TrainW tw = train_w(wbuf);
+    const int BT = B * T, Bp = pad16(B), R = B * tp.m, mT = tp.m;
+    const std::string D = "decoder.";
+    Bump bp(ws, ws_bytes);
+    float* dcat = bp.f((int64_t)BT * 4608); float* gk = bp.f((int64_t)BT * 512); float* gconv = bp.f((int64_t)BT * 512);
+    float* dxc = bp.f((int64_t)BT * 512); float* denc = bp.f((int64_t)BT * 512);
+    float* drnn = bp.f((int64_t)BT * 1024); float* dgbt[2] = {bp.f((int64_t)BT * 2048), bp.f((int64_t)BT * 2048)};
+    float* dgk = bp.f((int64_t)BT * 2048);                      // processing-order stack (one direction at a time)
+    float* dwp = bp.f((int64_t)512 * 11 * 512); float* partials = bp.f((int64_t)AB_RS * 3 * 4608);
+    float* dpooled = bp.f((int64_t)R * 2560); float* dzs = bp.f((int64_t)R * 504); float* dl = bp.f((int64_t)R * 504); float* dz4 = bp.f((int64_t)R * 504);
+    float* r256[6]; for (auto& q : r256) q = bp.f((int64_t)R * 256);
+    float* tmpE = bp.f(504 * 256);
+    float* ds_a = bp.f((int64_t)B * 512); float* ds_e = bp.f((int64_t)B * 512); float* dzs_site = bp.f((int64_t)B * 512);
+    float* dcellcat = bp.f((int64_t)B * 1024); float* dhc = bp.f((int64_t)B * 512); float* dcc = bp.f((int64_t)B * 512); float* dhn = bp.f((int64_t)B * 512);
+    float* f_dg = bp.f((int64_t)Bp * 2048);
+    float* dmap[4]; for (int j = 0; j < 4; ++j) dmap[j] = bp.f((int64_t)B * tp.L[j] * 512);
+    float* small = bp.f(8192);
+    L2S_REQUIRE(!bp.overflow, "training prologue backward workspace too small");
+    auto G = [&](const std::string& k) { return m->grad(D + k); };
+    auto Cn = [&](const std::string& k) { return m->canon(D + k); };
+    auto dW = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int cin, int rows, float* out, int ldc) -> int {   // linear weight gradient
+        if (!out) return 0;
+        BwdGemmP p = bwd_dw(dz, ldz, x, ldx, out, 1, rows, rows, nout, cin, 1, 1, 0, false);
+        p.ldc = ldc;
+        return launch_gemm_bwd(p, s, "train_bwd_prologue_dw");
+    };
+    auto dX = [&](const float* dz, int ldz, int nout, const float* Wf, int ldw, float* out, int ldo, int cin, int rows, bool acc) -> int {   // linear input gradient
+        BwdGemmP p = bwd_dx(dz, ldz, Wf, out, ldo, 1, rows, rows, nout, cin, 1, 0, acc);
+        p.ldb = ldw;
+        return launch_gemm_bwd(p, s, "train_bwd_prologue_dx");
+    };
+    auto act = [&](const float* dy, int ldy, const float* z, int ldz, float* dconv, int ldc, int64_t rows, int C, int actk, const float* aw, const float* scale,
+                   const float* gamma, const float* beta, float* g_shift, float* g_gamma, float* g_aw, float* g_cb) -> int {
+        ActBwdP a{}; a.dy = dy; a.ld_dy = ldy; a.z = z; a.ld_z = ldz; a.dconv = dconv; a.ld_dconv = ldc; a.rows = rows; a.C = C; a.act = actk; a.actw = aw;
+        a.scale = scale; a.gamma = gamma; a.beta = beta; a.partials = partials;
+        return act_bwd(a, g_shift, g_gamma, g_aw, g_cb, false, s);
+    };
+
+    // ---- A. K / V bottlenecks: k = PSine(bott([x | branches])) + pos
+    for (int kv = 0; kv < 2; ++kv) {
+        const std::string kn = kv == 0 ? "K" : "V";
+        if (act(kv == 0 ? dk : dv, 512, tp.zkv[kv], 512, gk, 512, BT, 512, ACT_PSINE, Cn(kn + ".1.w"), nullptr, nullptr, nullptr, G(kn + ".0.bottleneck.bias"), nullptr,
+                G(kn + ".1.w"), nullptr)) return 1;
+        float* gw = G(kn + ".0.bottleneck.weight");
+        if (kv == 0) {
+            if (dW(gk, 512, 512, tp.cat, 4608, 2560, BT, gw, 2560)) return 1;
+            if (dX(gk, 512, 512, w.mh_bott[0].W, 2560, dcat, 4608, 2560, BT, false)) return 1;
+        } else {
+            if (dW(gk, 512, 512, tp.cat, 4608, 512, BT, gw, 2560)) return 1;
+            if (dW(gk, 512, 512, tp.cat + 2560, 4608, 2048, BT, gw ? gw + 512 : nullptr, 2560)) return 1;
+            if (dX(gk, 512, 512, w.mh_bott[1].W, 2560, dcat, 4608, 512, BT, true)) return 1;
+            if (dX(gk, 512, 512, w.mh_bott[1].W + 512, 2560, dcat + 2560, 4608, 2048, BT, false)) return 1;
+        }
+    }
+    // ---- B. the 8 MultiHop branches: SiLU(BN(conv_k(x)))
+    for (int q = 0; q < 8; ++q) {
+        const int kv = q / 4, j = q % 4, k = MH_KS[j];
+        const std::string c = std::string(kv == 0 ? "K" : "V") + ".0.conv." + std::to_string(j);
+        if (act(dcat + 512 + q * 512, 4608, tp.zcat + 512 + q * 512, 4608, gconv, 512, BT, 512, ACT_SILU, nullptr, w.mh_branch[kv][j].scale, Cn(c + ".1.weight"),
+                Cn(c + ".1.bias"), G(c + ".1.bias"), G(c + ".1.weight"), nullptr, G(c + ".0.bias"))) return 1;
+        if (float* gw = G(c + ".0.weight")) {
+            if (launch_gemm_bwd(bwd_dw(gconv, 512, tp.cat, 4608, dwp, B, T, T, 512, 512, k, 1, k / 2, false), s, "train_bwd_multihop_dw")) return 1;
+            if (conv1d_grad_to_canonical(dwp, 512, 512, k, gw, false, s)) return 1;
+        }
+        BwdGemmP px = bwd_dx(gconv, 512, w.mh_branch[kv][j].W, dcat, 4608, B, T, T, 512, 512, k, k / 2, true);
+        if (launch_gemm_bwd(px, s, "train_bwd_multihop_dx")) return 1;
+    }
+    // ---- C. Content.encode
+    if (launch_fill(dxc, (int64_t)BT * 512, 0.f, s)) return 1;
+    {
+        float *dtC = r256[0], *dtB = r256[1], *dwv = r256[2], *dtA = r256[3], *dzt = r256[4];
+        // value = zsoft @ word_embeddings
+        if (launch_fill(dzs, (int64_t)R * 504, 0.f, s)) return 1;
+        if (launch_gemm1(gemm_plain(dcval, 256, Cn("content.word_embeddings"), dzs, 504, R, VOC, 256), s, "train_bwd_content_gemm")) return 1;
+        if (float* g = G("content.word_embeddings")) {
+            if (dW(tp.zsoft, 504, 504, dcval, 256, 256, R, tmpE, 256)) return 1;
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(VOC * 256)), dim3(256), 0, s, tmpE, 256, g, 256, VOC, 256);
+        }
+        hipLaunchKernelGGL(content_softmax_bwd_kernel, dim3(R), dim3(256), 0, s, tp.zsoft, dzs, 504, tp.dis, ddis, VOC, 10.0f, dl, 504);
+        // location_fc.4 (+SiLU): dz4 padded to 504 columns
+        if (launch_fill(dz4, (int64_t)R * 504, 0.f, s)) return 1;
+        if (act(dl, 504, tp.zf4, VOC, dz4, 504, R, VOC, ACT_SILU, nullptr, nullptr, nullptr, nullptr, G("content.location_fc.4.bias"), nullptr, nullptr, nullptr)) return 1;
+        if (float* g = G("content.location_fc.4.weight")) {
+            if (dW(dz4, 504, 504, tp.tC, 256, 256, R, tmpE, 256)) return 1;
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(VOC * 256)), dim3(256), 0, s, tmpE, 256, g, 256, VOC, 256);
+        }
+        if (dX(dz4, 504, 504, tw.fc4, 256, dtC, 256, 256, R, false)) return 1;
+        // location_fc.2, .0
+        if (act(dtC, 256, tp.zf2, 256, dzt, 256, R, 256, ACT_SILU, nullptr, nullptr, nullptr, nullptr, G("content.location_fc.2.bias"), nullptr, nullptr, nullptr)) return 1;
+        if (dW(dzt, 256, 256, tp.tB, 256, 256, R, G("content.location_fc.2.weight"), 256)) return 1;
+        if (dX(dzt, 256, 256, w.ct_fc2.W, 256, dtB, 256, 256, R, false)) return 1;
+        if (act(dtB, 256, tp.zf0, 256, dzt, 256, R, 256, ACT_SILU, nullptr, nullptr, nullptr, nullptr, G("content.location_fc.0.bias"), nullptr, nullptr, nullptr)) return 1;
+        if (dW(dzt, 256, 256, tp.wv, 256, 256, R, G("content.location_fc.0.weight"), 256)) return 1;
+        if (dX(dzt, 256, 256, w.ct_fc0.W, 256, dwv, 256, 256, R, false)) return 1;
+        // key = SiLU(K.2(SiLU(K.0(w))))
+        if (act(dckey, 256, tp.zk2, 256, dzt, 256, R, 256, ACT_SILU, nullptr, nullptr, nullptr, nullptr, G("content.K.2.bias"), nullptr, nullptr, nullptr)) return 1;
+        if (dW(dzt, 256, 256, tp.tA, 256, 256, R, G("content.K.2.weight"), 256)) return 1;
+        if (dX(dzt, 256, 256, w.ct_k2.W, 256, dtA, 256, 256, R, false)) return 1;
+        if (act(dtA, 256, tp.zk0, 256, dzt, 256, R, 256, ACT_SILU, nullptr, nullptr, nullptr, nullptr, G("content.K.0.bias"), nullptr, nullptr, nullptr)) return 1;
+        if (dW(dzt, 256, 256, tp.wv, 256, 256, R, G("content.K.0.weight"), 256)) return 1;
+        if (dX(dzt, 256, 256, w.ct_k0.W, 256, dwv, 256, 256, R, true)) return 1;
+        // bottleneck over the pooled concatenation
+        if (dW(dwv, 256, 256, tp.pooled, 2560, 2560, R, G("content.bottleneck.weight"), 2560)) return 1;
+        if (float* g = G("content.bottleneck.bias")) { if (colsum(dwv, R, 256, partials, dzt, g, false, s)) return 1; }
+        if (dX(dwv, 256, 256, w.ct_bott.W, 2560, dpooled, 2560, 2560, R, false)) return 1;
+        PoolBwdP pb{};
+        pb.dx[0] = dcat; pb.L[0] = T; pb.ld[0] = 4608; pb.acc[0] = 1;
+        for (int j = 0; j < 4; ++j) { pb.dx[j + 1] = dmap[j]; pb.L[j + 1] = tp.L[j]; pb.ld[j + 1] = 512; pb.acc[j + 1] = 0; }
+        pb.nmaps = 5; pb.B = B; pb.m = mT; pb.C = 512; pb.dp = dpooled;
+        hipLaunchKernelGGL(pool_cat_bwd_kernel, dim3(2048), dim3(256), 0, s, pb);
+        for (int j = 0; j < 4; ++j) {
+            const int k = CT_KS[j], Lj = tp.L[j];
+            const std::string c = "content.agg." + std::to_string(j);
+            if (act(dmap[j], 512, tp.zagg[j], 512, gconv, 512, (int64_t)B * Lj, 512, ACT_SILU, nullptr, w.ct_branch[j].scale, Cn(c + ".1.weight"), Cn(c + ".1.bias"),
+                    G(c + ".1.bias"), G(c + ".1.weight"), nullptr, G(c + ".0.bias"))) return 1;
+            if (float* gw = G(c + ".0.weight")) {
+                if (launch_gemm_bwd(bwd_dw(gconv, 512, tp.cat, 4608, dwp, B, Lj, T, 512, 512, k, k, 0, false), s, "train_bwd_content_agg_dw")) return 1;
+                if (conv1d_grad_to_canonical(dwp, 512, 512, k, gw, false, s)) return 1;
+            }
+            // stride = kernel, no padding: each input frame belongs to one window -> a plain linear map on the (B*L, k*512) view of x
+            BwdGemmP px{};
+            px.mode = BWD_DX; px.A = gconv; px.lda = 512; px.B = w.ct_branch[j].W; px.ldb = k * 512; px.C = dxc; px.ldc = k * 512;
+            px.M = B * Lj; px.N = k * 512; px.K = 512; px.Tx = B * Lj; px.Tz = B * Lj; px.taps = 1; px.stride = 1; px.pad = 0; px.padp = 0; px.Nout = 512; px.Cin = k * 512;
+            px.c_T = Lj; px.c_seq_stride = (int64_t)T * 512; px.alpha = 1.f; px.accumulate = 1;
+            if (launch_gemm_bwd(px, s, "train_bwd_content_agg_dx")) return 1;
+        }
+    }
+    // ---- D. enc = encoder_proj(rnn_out) + s_a + residual_bottleneck(vis)
+    hipLaunchKernelGGL(add3_kernel, dim3(2048), dim3(256), 0, s, dcat, 4608, dxc, 512, denc, 512, (int64_t)BT, 512);
+    if (dW(denc, 512, 512, tp.rnn, 1024, 1024, BT, G("encoder_proj.linear_layer.weight"), 1024)) return 1;
+    if (dW(denc, 512, 512, vis, 1024, 1024, BT, G("residual_bottleneck.weight"), 1024)) return 1;
+    if (colsum(denc, BT, 512, partials, gconv, small, false, s)) return 1;
+    for (const char* k : {"encoder_proj.linear_layer.bias", "residual_bottleneck.bias"})
+        if (float* g = G(k)) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(512)), dim3(256), 0, s, small, 512, g, 512, 1, 512);
+    if (dX(denc, 512, 512, w.enc_proj.W, 1024, drnn, 1024, 1024, BT, false)) return 1;
+    if (dX(denc, 512, 512, w.resid.W, 1024, dvis, 1024, 1024, BT, false)) return 1;
+    hipLaunchKernelGGL(sum_time_kernel, dim3(ew(B * 512)), dim3(256), 0, s, denc, B, T, 512, 512, ds_a);
+    if (act(ds_a, 512, tp.z_sa, 512, dzs_site, 512, B, 512, ACT_PSINE, Cn("attention_site.1.w"), nullptr, nullptr, nullptr, G("attention_site.0.linear_layer.bias"), nullptr,
+            G("attention_site.1.w"), nullptr)) return 1;
+    if (dW(dzs_site, 512, 512, emb, 256, 256, B, G("attention_site.0.linear_layer.weight"), 256)) return 1;
+    // ---- E. encoder_cell = E_C(cat(c_fwd, c_bwd))
+    if (dW(de_c, 512, 512, tp.cellcat, 1024, 1024, B, G("E_C.linear_layer.weight"), 1024)) return 1;
+    if (float* g = G("E_C.linear_layer.bias")) { if (colsum(de_c, B, 512, partials, gconv, g, false, s)) return 1; }
+    if (dX(de_c, 512, 512, w.e_c.W, 1024, dcellcat, 1024, 1024, B, false)) return 1;
+    // ---- F. BiLSTM back-propagation through time (both directions; the decoder's initial hidden states are its final hidden states)
+    if (launch_fill(ds_e, (int64_t)B * 512, 0.f, s)) return 1;
+    for (int d = 0; d < 2; ++d) {
+        const std::string suf = d == 0 ? "l0" : "l0_reverse";
+        L2S_CHECK_HIP(hipMemcpyAsync(dhc, dh_init + (int64_t)d * B * 512, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dcellcat + d * 512, 1024, dcc, 512, B, 512);
+        for (int step = T - 1; step >= 0; --step) {
+            const int t = d == 0 ? step : T - 1 - step;
+            hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dhc, 512, drnn + (int64_t)t * 1024 + d * 512, T * 1024, dcc,
+                               tp.gates[d] + (int64_t)step * B * 2048, tp.cproc[d] + (int64_t)step * B * 512, tp.cproc[d] + (int64_t)(step + 1) * B * 512, B, 512, f_dg,
+                               dgk + (int64_t)step * B * 2048, dgbt[d] + (int64_t)t * 2048, (int64_t)T * 2048);
+            if (run1(bsk(tw.bhh[d], 512, 2048, B, f_dg, dhn, 512), s, "train_bwd_bilstm_dx")) return 1;
+            std::swap(dhc, dhn);
+        }
+        hipLaunchKernelGGL(add3_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dhc, 512, dcc, 512, dhn, 512, (int64_t)B, 512);      // h0 = c0 = s_e
+        if (add_into(dhn, ds_e, (int64_t)B * 512, s)) return 1;
+        if (dW(dgk, 2048, 2048, tp.hproc[d], 512, 512, BT, G("encoder_rnn.weight_hh_" + suf), 512)) return 1;
+        if (dW(dgbt[d], 2048, 2048, vis, 1024, 1024, BT, G("encoder_rnn.weight_ih_" + suf), 1024)) return 1;
+        if (colsum(dgk, BT, 2048, partials, dcat /*scratch: dcat is dead by now*/, small, false, s)) return 1;
+        for (const std::string& k : {"encoder_rnn.bias_ih_" + suf, "encoder_rnn.bias_hh_" + suf})
+            if (float* g = G(k)) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(2048)), dim3(256), 0, s, small, 2048, g, 2048, 1, 2048);
+        if (dX(dgbt[d], 2048, 2048, w.wih_cat + (int64_t)d * 2048 * 1024, 1024, dvis, 1024, 1024, BT, true)) return 1;
+    }
+    // ---- G. encoder_site embedding (initial h and c of both directions)
+    if (act(ds_e, 512, tp.z_se, 512, dzs_site, 512, B, 512, ACT_PSINE, Cn("encoder_site.1.w"), nullptr, nullptr, nullptr, G("encoder_site.0.linear_layer.bias"), nullptr,
+            G("encoder_site.1.w"), nullptr)) return 1;
+    if (dW(dzs_site, 512, 512, emb, 256, 256, B, G("encoder_site.0.linear_layer.weight"), 256)) return 1;
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s
+
 // ================================================================================================ C ABI
 using namespace l2s;
 
@@ -899,6 +1335,25 @@ int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const u
                 "bad arguments");
     return decode_train_bwd(m, state, B, T, S, teacher_mask, tape, attn_logits, dmel, dstop, wbuf, dk, dv, dckey, dcval, dh_init, de_c, ws, ws_bytes,
                             (hipStream_t)stream);
+}
+
+int64_t l2s_train_prologue_tape_floats(int B, int T) { return pro_tape_floats(B, T); }
+int64_t l2s_train_prologue_ws_bytes(int B, int T) { return (std::max(pro_fwd_ws_floats(B), pro_bwd_ws_floats(B, T)) + 1024) * (int64_t)sizeof(float); }
+
+int l2s_train_prologue_fwd(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T, float* state, float* content_dis,
+                           float* tape, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_dec && vis && emb && gumbel && state && tape && ws, "bad arguments");
+    L2S_REQUIRE(B >= 1 && B <= 96, "sizes");
+    return prologue_train_fwd(m, vis, emb, gumbel, B, T, state, content_dis, tape, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int B, int T, float* state, float* tape, float* wbuf, const float* dk,
+                           const float* dv, const float* dckey, const float* dcval, const float* dh_init, const float* de_c, const float* dcontent_dis,
+                           float* dvis, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_dec && vis && emb && state && tape && wbuf && dk && dv && dckey && dcval && dh_init && de_c && dvis && ws, "bad arguments");
+    L2S_REQUIRE(B >= 1 && B <= 96 && T >= 7 && T <= L2S_MAX_STEPS, "sizes");
+    L2S_REQUIRE(m->canon("decoder.encoder_rnn.weight_hh_l0") != nullptr, "parameters not bound (l2s_train_bind)");
+    return prologue_train_bwd(m, vis, emb, B, T, state, tape, wbuf, dk, dv, dckey, dcval, dh_init, de_c, dcontent_dis, dvis, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int64_t l2s_train_postnet_tape_floats(int B, int S) { return post_tape_floats(B, S); }

@@ -29,6 +29,7 @@ ABI_SYMBOLS = (
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
+    "l2s_train_prologue_tape_floats", "l2s_train_prologue_ws_bytes", "l2s_train_prologue_fwd", "l2s_train_prologue_bwd",
     "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
@@ -95,6 +96,12 @@ def lib() -> ctypes.CDLL:
     L.l2s_train_steps_pack_weights.argtypes = [_vp, _fp, _vp]
     L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_prologue_tape_floats.argtypes = [_i, _i]
+    L.l2s_train_prologue_tape_floats.restype = _i64
+    L.l2s_train_prologue_ws_bytes.argtypes = [_i, _i]
+    L.l2s_train_prologue_ws_bytes.restype = _i64
+    L.l2s_train_prologue_fwd.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_prologue_bwd.argtypes = [_vp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_scratch_bytes.restype = _i64
     L.l2s_loss.argtypes = [_fp] * 6 + [_i, _i, _i] + [_fp] * 5 + [_vp, _vp]
     L.l2s_grad_norm.argtypes = [_fp, _i64, _vp, _fp, _vp]
@@ -285,6 +292,36 @@ class NativeModel:
                                     _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
                                     _ptr(ws), ws.numel(), _stream()))
         return (mel, stop, logits), out
+
+    def train_prologue_fwd(self, vis, emb, gumbel):
+        """Prologue forward with a tape (stage 3).  Returns (state, content_dis, tape)."""
+        vis, emb, gumbel = _f32(vis), _f32(emb), _f32(gumbel)
+        B, T, _ = vis.shape
+        L, dev = lib(), vis.device
+        state = torch.zeros(int(L.l2s_state_floats(B, T)), dtype=torch.float32, device=dev)
+        dis = torch.empty(B * min_T(T), 501, dtype=torch.float32, device=dev)
+        tape = torch.zeros(int(L.l2s_train_prologue_tape_floats(B, T)), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.l2s_train_prologue_ws_bytes(B, T)), dtype=torch.uint8, device=dev)
+        check(L.l2s_train_prologue_fwd(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
+        return state, dis, tape
+
+    def train_prologue_bwd(self, vis, emb, state, tape, g, dcontent_dis=None, wbuf=None):
+        """Prologue backward: g = the state gradients of train_steps (dk, dv, dckey, dcval, dh_init, de_c).  Returns dvis (B,T,1024);
+        parameter gradients land in the bound slots."""
+        vis, emb = _f32(vis), _f32(emb)
+        B, T, _ = vis.shape
+        L, dev = lib(), vis.device
+        if wbuf is None:
+            wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=dev)
+            check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
+        ws = torch.empty(int(L.l2s_train_prologue_ws_bytes(B, T)), dtype=torch.uint8, device=dev)
+        dvis = torch.empty(B, T, 1024, dtype=torch.float32, device=dev)
+        gg = {k: _f32(v) for k, v in g.items()}
+        dd = _f32(dcontent_dis) if dcontent_dis is not None else None
+        check(L.l2s_train_prologue_bwd(self._h, _ptr(vis), _ptr(emb), B, T, _ptr(state), _ptr(tape), _ptr(wbuf), _ptr(gg["dk"]), _ptr(gg["dv"]),
+                                       _ptr(gg["dckey"]), _ptr(gg["dcval"]), _ptr(gg["dh_init"]), _ptr(gg["de_c"]), _ptr(dd), _ptr(dvis),
+                                       _ptr(ws), ws.numel(), _stream()))
+        return dvis
 
     def lstm_cell_chain_us(self, B: int, n_pairs: int = 300) -> float:
         """Average duration of the decoder LSTM-cell kernel, one HIP-event pair around 2*n_pairs chained launches."""

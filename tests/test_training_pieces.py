@@ -203,3 +203,67 @@ def test_decode_loop_bptt_matches_autograd(synth_sd, S, forced):
     for k in grads:
         assert sd64[k].grad is not None, k
         close(k, grads[k], sd64[k].grad)
+
+
+PROLOGUE_PREFIXES = ("residual_bottleneck.", "encoder_site.", "attention_site.", "encoder_rnn.", "E_C.", "encoder_proj.", "K.", "V.", "content.")
+PROLOGUE_SKIP = ("content.Q.0.", "content.temperature")          # used by the loop, not by the prologue
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [29, 40])
+def test_prologue_backward_matches_autograd(synth_sd, T):
+    """Stage 3 of the training path: decoder prologue (site embeddings, BiLSTM, MultiHop K/V, Content.encode with the Gumbel
+    soft-max) forward-with-tape and backward against autograd through the oracle's prologue in fp64: the gradient wrt the visual
+    features and every prologue parameter."""
+    import parity_common as pc
+    from lip2speech_amd import native, synth
+    from oracle import l2s_oracle as orc
+    B = 2
+    m = native.min_T(T)
+    torch.manual_seed(T)
+    feat = torch.nn.functional.normalize(torch.randn(B, T, 768), dim=-1)
+    emb = synth.synth_speaker_embedding(B, tag="pro-train")
+    gumbel = synth.synth_gumbel(B * m, tag="pro-train")
+    vis = orc.build_visual(feat, emb).contiguous()
+    dec = [k for k in synth_sd if k.startswith("decoder.") and synth_sd[k].is_floating_point() and not k.startswith("decoder.postnet.")]
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "pos_table"))
+    pro = [k for k in dec if k[len("decoder."):].startswith(PROLOGUE_PREFIXES) and not k[len("decoder."):].startswith(PROLOGUE_SKIP) and not is_buf(k)]
+    sd64 = {k: synth_sd[k].double().requires_grad_(k in pro) for k in dec}
+    vis64 = vis.double().requires_grad_(True)
+    st = orc.decoder_prologue(sd64, vis64, emb.double(), gumbel.double())
+    names = ["k", "v", "key", "value", "hidden", "encoder_cell", "content_dis"]
+    cot = {n: torch.randn(st[n].shape, dtype=torch.float64) for n in names}
+    cot["content_dis"] *= 50.0            # the distribution is nearly uniform over 501 words; give its path a visible gradient
+    sum((st[n] * cot[n]).sum() for n in names).backward()
+
+    nm = pc.native_model(synth_sd)
+    params = {k: synth_sd[k].cuda() for k in dec if not is_buf(k)}
+    grads = {k: torch.zeros_like(params[k]) for k in pro}
+    nm.train_bind(params, grads)
+    state, dis, tape = nm.train_prologue_fwd(vis.cuda(), emb.cuda(), gumbel.cuda())
+    sf = lambda f, shape: native.state_field(state, B, T, f, shape)      # noqa: E731
+    assert pc.maxdiff(sf(native.ST_K, (B, T, 512)), st["k"].permute(0, 2, 1)) < 2e-4
+    assert pc.maxdiff(sf(native.ST_V, (B, T, 512)), st["v"]) < 2e-4
+    assert pc.maxdiff(sf(native.ST_CKEY, (B, m, 256)), st["key"].permute(0, 2, 1)) < 2e-4
+    assert pc.maxdiff(sf(native.ST_CVAL, (B, m, 256)), st["value"]) < 2e-4
+    assert pc.maxdiff(sf(native.ST_ECELL, (B, 512)), st["encoder_cell"]) < 2e-4
+    assert pc.maxdiff(dis, st["content_dis"]) < 1e-6
+    g = {"dk": cot["k"].permute(0, 2, 1).contiguous().cuda(), "dv": cot["v"].cuda(), "dckey": cot["key"].permute(0, 2, 1).contiguous().cuda(),
+         "dcval": cot["value"].cuda(), "dh_init": cot["hidden"].cuda(), "de_c": cot["encoder_cell"].cuda()}
+    dvis = nm.train_prologue_bwd(vis.cuda(), emb.cuda(), state, tape, g, dcontent_dis=cot["content_dis"].cuda())
+
+    def close(name, got, ref, rel=2e-3):
+        ref = ref.reshape(got.shape)
+        scale = max(1e-6, ref.abs().max().item())
+        err = pc.maxdiff(got, ref) / scale
+        assert err < rel, f"{name}: relative error {err:.2e} (scale {scale:.2e})"
+
+    close("dvis", dvis, vis64.grad)
+    bad = []
+    for k in pro:
+        assert sd64[k].grad is not None, k
+        try:
+            close(k, grads[k], sd64[k].grad)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad)
