@@ -254,25 +254,43 @@ class NativeModel:
             g = grads.get(key)
             check(lib().l2s_train_bind(self._h, key.encode(), _ptr(p), _ptr(g) if g is not None else None))
 
-    def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor):
-        """Post-net forward + backward (stage 1 of the training path): returns mel_post (B,80,S) and dmel (B,S,80)."""
-        mel, dmel_post = _f32(mel), _f32(dmel_post)
+    def train_postnet_fwd(self, mel: torch.Tensor):
+        """Post-net forward with a tape: mel (B,S,80) -> (mel_post (B,80,S), tape)."""
+        mel = _f32(mel)
         B, S, _ = mel.shape
         L = lib()
         tape = torch.zeros(int(L.l2s_train_postnet_tape_floats(B, S)), dtype=torch.float32, device=mel.device)
         out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
         check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _stream()))
+        return out, tape
+
+    def train_postnet_bwd(self, mel: torch.Tensor, dmel_post: torch.Tensor, tape: torch.Tensor) -> torch.Tensor:
+        """Post-net backward: dmel_post (B,80,S) -> dmel (B,S,80) (residual path included); parameter gradients into the bound slots."""
+        mel, dmel_post = _f32(mel), _f32(dmel_post)
+        B, S, _ = mel.shape
+        L = lib()
         dmel = torch.zeros_like(mel)
         ws = torch.empty(int(L.l2s_train_postnet_ws_bytes(B, S)), dtype=torch.uint8, device=mel.device)
         check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(ws), ws.numel(), _stream()))
-        return out, dmel
+        return dmel
 
-    def train_steps(self, state, B, T, S, dmel, dstop, teacher=None, teacher_mask=None):
-        """Loop forward-with-tape + BPTT (stage 2 of the training path).  Returns (mel, stop, attn_logits) and the state gradients."""
+    def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor):
+        """Post-net forward + backward (stage 1 of the training path): returns mel_post (B,80,S) and dmel (B,S,80)."""
+        out, tape = self.train_postnet_fwd(mel)
+        return out, self.train_postnet_bwd(mel, dmel_post, tape)
+
+    def train_pack_weights(self, device) -> torch.Tensor:
+        """Transposed step / prologue weights for the backward GEMMs, packed on the device from the bound parameters."""
+        L = lib()
+        wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=device)
+        check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
+        return wbuf
+
+    def train_steps_fwd(self, state, B, T, S, teacher=None, teacher_mask=None):
+        """Loop forward with a tape.  Returns (mel (B,S,80), stop (B,S), attn_logits (B,S,T)) and the context for train_steps_bwd."""
         L, dev = lib(), state.device
         tape = torch.zeros(int(L.l2s_train_steps_tape_floats(B, S)), dtype=torch.float32, device=dev)
         ws = torch.empty(int(L.l2s_train_steps_ws_bytes(B, S)), dtype=torch.uint8, device=dev)
-        wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=dev)
         mel = torch.empty(B, S, 80, dtype=torch.float32, device=dev)
         stop = torch.empty(B, S, dtype=torch.float32, device=dev)
         logits = torch.empty(B, S, T, dtype=torch.float32, device=dev)
@@ -284,14 +302,28 @@ class NativeModel:
             mask_ptr = mask_np.ctypes.data_as(_vp)
         check(L.l2s_train_steps_fwd(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_ptr, _ptr(mask_dev) if mask_dev is not None else None,
                                     _ptr(tape), _ptr(mel), _ptr(stop), _ptr(logits), _ptr(ws), ws.numel(), _stream()))
+        ctx = dict(state=state, B=B, T=T, S=S, tape=tape, ws=ws, logits=logits, mask_np=mask_np, mask_ptr=mask_ptr, teacher=teacher, mask_dev=mask_dev)
+        return (mel, stop, logits), ctx
+
+    def train_steps_bwd(self, ctx, dmel, dstop, wbuf=None):
+        """BPTT through the loop: dmel (B,S,80), dstop (B,S) -> gradients of the prologue state; parameter gradients into the bound slots."""
+        L, state = lib(), ctx["state"]
+        B, T, S, dev = ctx["B"], ctx["T"], ctx["S"], state.device
         m = min_T(T)
         out = {"dk": torch.empty(B, T, 512, device=dev), "dv": torch.empty(B, T, 512, device=dev), "dckey": torch.empty(B, m, 256, device=dev),
                "dcval": torch.empty(B, m, 256, device=dev), "dh_init": torch.empty(2, B, 512, device=dev), "de_c": torch.empty(B, 512, device=dev)}
-        check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
-        check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, mask_ptr, _ptr(tape), _ptr(logits), _ptr(_f32(dmel)), _ptr(_f32(dstop)), _ptr(wbuf),
-                                    _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
+        if wbuf is None:
+            wbuf = self.train_pack_weights(dev)
+        ws = ctx["ws"]
+        check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, ctx["mask_ptr"], _ptr(ctx["tape"]), _ptr(ctx["logits"]), _ptr(_f32(dmel)), _ptr(_f32(dstop)),
+                                    _ptr(wbuf), _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
                                     _ptr(ws), ws.numel(), _stream()))
-        return (mel, stop, logits), out
+        return out
+
+    def train_steps(self, state, B, T, S, dmel, dstop, teacher=None, teacher_mask=None):
+        """Loop forward-with-tape + BPTT (stage 2 of the training path).  Returns (mel, stop, attn_logits) and the state gradients."""
+        outs, ctx = self.train_steps_fwd(state, B, T, S, teacher, teacher_mask)
+        return outs, self.train_steps_bwd(ctx, dmel, dstop)
 
     def train_prologue_fwd(self, vis, emb, gumbel):
         """Prologue forward with a tape (stage 3).  Returns (state, content_dis, tape)."""
@@ -312,8 +344,7 @@ class NativeModel:
         B, T, _ = vis.shape
         L, dev = lib(), vis.device
         if wbuf is None:
-            wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=dev)
-            check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
+            wbuf = self.train_pack_weights(dev)
         ws = torch.empty(int(L.l2s_train_prologue_ws_bytes(B, T)), dtype=torch.uint8, device=dev)
         dvis = torch.empty(B, T, 1024, dtype=torch.float32, device=dev)
         gg = {k: _f32(v) for k, v in g.items()}

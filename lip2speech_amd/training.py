@@ -89,6 +89,36 @@ def loss_terms(mel, mel_post, stop, content_dis, mel_target, gate_target, want_g
     return out, grads
 
 
+def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None):
+    """Forward + backward of the decoder half of `Lip2Speech.forward` + `Loss.forward` (reference: model.py:34-41 -> decoder.py:320-379,
+    losses.py:69-77, train.py:172-184) with eval-mode statistics (running BN stats, no dropout): prologue -> S-step loop -> post-net ->
+    4-term loss, then back through the post-net, the loop (BPTT) and the prologue.  Parameter gradients land in the slots bound with
+    `nm.train_bind`; returns the outputs, the loss terms and the gradient wrt the visual features `vis` (B,T,1024).
+
+    teacher_mask (S,) bool marks the steps whose input frame is the ground-truth previous frame (scheduled sampling made explicit,
+    decoder.py:355-359); `bos` is the device BOS parameter (needed only with a mask)."""
+    B, T, _ = vis.shape
+    S = mel_target.shape[2]
+    state, dis, ptape = nm.train_prologue_fwd(vis, emb, gumbel)
+    teacher = None
+    if teacher_mask is not None and bool(torch.as_tensor(teacher_mask).any()):
+        assert bos is not None, "teacher forcing needs the BOS parameter"
+        teacher = torch.cat([bos.reshape(1, 1, 80).expand(B, 1, 80), mel_target.permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
+        teacher_mask = torch.as_tensor(teacher_mask).cpu().numpy()
+    else:
+        teacher_mask = None
+    (mel, stop, logits), ctx = nm.train_steps_fwd(state, B, T, S, teacher, teacher_mask)
+    mel_post, post_tape = nm.train_postnet_fwd(mel)
+    mel_cf = mel.permute(0, 2, 1).contiguous()
+    loss, g = loss_terms(mel_cf, mel_post, stop, dis, mel_target, gate_target)
+    wbuf = nm.train_pack_weights(vis.device)
+    dmel = nm.train_postnet_bwd(mel, g["mel_post"], post_tape)
+    dmel += g["mel"].permute(0, 2, 1)
+    sg = nm.train_steps_bwd(ctx, dmel, g["stop"], wbuf=wbuf)
+    dvis = nm.train_prologue_bwd(vis, emb, state, ptape, sg, dcontent_dis=g["content_dis"], wbuf=wbuf)
+    return {"loss": loss, "mel": mel_cf, "mel_post": mel_post, "stop": stop, "attn_logits": logits, "content_dis": dis, "dvis": dvis}
+
+
 class GradAllReducer:
     """Sum all-reduce of a flat gradient buffer in fixed-size buckets (default 25 MB), issued asynchronously in order;
     `wait()` blocks on all of them.  The division by world size is NOT done here - AdamWAmsgrad.step(grad_mul=1/world)

@@ -322,6 +322,16 @@ def forward_eval(sd: SD, video: torch.Tensor, emb: torch.Tensor, mels: torch.Ten
     return [mel_cf, postnet(sd, mel_cf) + mel_cf, stop.unsqueeze(2), emb, attn, st["content_dis"]]
 
 
+def loss_terms(outs, mel_target: torch.Tensor, gate_target: torch.Tensor):
+    """Loss.forward (train_utils/losses.py:69-77) + train.py:175: returns (mel_loss, postnet_mel_loss, gate_loss, KLD, total)."""
+    mel, mel_post, stop, qy = outs[0], outs[1], outs[2], outs[5]
+    kld = torch.sum(qy * torch.log(qy * qy.shape[-1] + 1e-20), dim=-1).mean()
+    mel_loss = F.mse_loss(mel, mel_target)
+    post_loss = 10 * F.mse_loss(mel_post, mel_target)
+    gate_loss = F.binary_cross_entropy_with_logits(stop.reshape(-1, 1), gate_target.reshape(-1, 1))
+    return mel_loss, post_loss, gate_loss, kld, kld + mel_loss + post_loss + gate_loss
+
+
 # ----------------------------------------------------------------------------------
 # speaker encoder  (audio.py:110-150).  The mel front-end is torchaudio's (absent here): its published algorithm is
 # restated below - PARITY UNPINNED for that piece; the LSTM/Linear tail is plain nn.LSTM math.
