@@ -192,6 +192,16 @@ int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int
                            const float* dv, const float* dckey, const float* dcval, const float* dh_init, const float* de_c, const float* dcontent_dis,
                            float* dvis, void* ws, int64_t ws_bytes, void* stream);
 
+/* Visual encoder with a tape (video.py:76-87, shufflenetv2.py:42-152) and its backward.  Forward = l2s_encoder_fwd (same outputs:
+ * vis dev (B,T,1024) and/or feat dev (B,T,768)) plus the tape.  Backward: dfeat = gradient wrt the normalised features, row stride
+ * ld_dfeat floats (pass the dvis of l2s_train_prologue_bwd with ld_dfeat = 1024) -> every encoder parameter gradient into the bound
+ * slots (the reference computes no gradient wrt the video). */
+int64_t l2s_train_encoder_tape_floats(int B, int T, int H);
+int64_t l2s_train_encoder_ws_bytes(int B, int T, int H);
+int l2s_train_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* emb, float* vis, float* feat, float* tape, void* stream);
+int l2s_train_encoder_bwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* dfeat, int ld_dfeat, float* tape, void* ws, int64_t ws_bytes,
+                          void* stream);
+
 /* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
 /* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,

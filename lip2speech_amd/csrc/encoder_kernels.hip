@@ -21,9 +21,9 @@ constexpr int FE_XLD = 104;                 // LDS row stride (floats); data col
 constexpr int FE_KP = 50;                   // taps per slab, padded (kh*7+kw; tap 49 has zero weight)
 constexpr int FE_CO = 24;
 
-template <int HW>
+template <int HW, bool SAVE_Z>
 __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, const float* __restrict__ video,
-                                                            int T, float* __restrict__ out) {
+                                                            int T, float* __restrict__ out, float* __restrict__ zout) {
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
     constexpr int P = FE_CR * Wc;                    // conv pixels per strip
     constexpr int NT = (P + 31) / 32;                // 32-pixel MFMA row tiles
@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
                     const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
                     if (p < P) {
                         float v = acc[j][r] * sc + sh;
+                        if (SAVE_Z) {                // training tape: pre-PReLU map (B*T, H/2, W/2, 24); the halo row belongs to the strip above
+                            const int lr = p / Wc, crow = 2 * p0 - 1 + lr;
+                            if (lr >= 1 && crow < Hc) zout[(((int64_t)f * Hc + crow) * Wc + (p - lr * Wc)) * FE_CO + li] = v;
+                        }
                         v = v >= 0.f ? v : sl * v;
                         Cs[p * FE_CO + li] = v;
                     }
@@ -141,16 +145,19 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     }
 }
 
-int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s) {
+int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
     L2S_REQUIRE((reinterpret_cast<uintptr_t>(video) & 15u) == 0, "video must be 16-byte aligned");
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     ProfScope ps("frontend3d_conv_bn_prelu_pool", s);
-    if (H == 96)
-        hipLaunchKernelGGL(frontend3d_kernel<96>, grid, dim3(256), 0, s, w, video, T, out);
-    else
-        hipLaunchKernelGGL(frontend3d_kernel<88>, grid, dim3(256), 0, s, w, video, T, out);
+    if (zout) {
+        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, true>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        else hipLaunchKernelGGL((frontend3d_kernel<88, true>), grid, dim3(256), 0, s, w, video, T, out, zout);
+    } else {
+        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, false>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        else hipLaunchKernelGGL((frontend3d_kernel<88, false>), grid, dim3(256), 0, s, w, video, T, out, zout);
+    }
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -9,6 +9,8 @@
 // Reference semantics: autograd of nn.Linear / nn.Conv1d in /root/reference/model/modules/decoder.py (train.py:184 loss.backward()).
 #include "l2s_common.h"
 
+#include <algorithm>
+
 namespace l2s {
 
 constexpr int TB = 64, TK = 32, TLD = TK + 4;
@@ -29,8 +31,26 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nkt = (p.K + TK - 1) / TK;
+    const int nkt_all = (p.K + TK - 1) / TK;
+    int kt_begin = 0, kt_end = nkt_all;
+    float* Cout = p.C;
+    if (p.ksplit > 1) {                                // split-K (DW mode): slice z of the reduction -> its own partial matrix
+        const int per = (nkt_all + p.ksplit - 1) / p.ksplit;
+        kt_begin = blockIdx.z * per;
+        kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
+        Cout += (int64_t)blockIdx.z * p.c_split_stride;
+    }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vec = p.vec != 0;
+    auto ld4 = [&](const float* q, int nvalid) -> float4 {      // vec: dimensions and strides are multiples of 4, pointers 16-byte aligned
+        if (vec) return *reinterpret_cast<const float4*>(q);
+        float4 v = zero4;
+        if (nvalid > 0) v.x = q[0];
+        if (nvalid > 1) v.y = q[1];
+        if (nvalid > 2) v.z = q[2];
+        if (nvalid > 3) v.w = q[3];
+        return v;
+    };
 
     // ---- per-mode loaders ------------------------------------------------------------------------------------------------
     // DX: A = dZ gathered (row-major staging: thread -> row lr (+32), k-quad kq), B = Wp transposed staging
@@ -46,19 +66,19 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
         if (p.taps > 1) { tap = k / p.Nout; n = k - tap * p.Nout; }
         const int tz = t + tap - p.padp;
         if (tz < 0 || tz >= p.Tz) return zero4;
-        return *reinterpret_cast<const float4*>(p.A + ((int64_t)b * p.Tz + tz) * p.lda + n);
+        return ld4(p.A + ((int64_t)b * p.Tz + tz) * p.lda + n, p.K - k);
     };
     auto load_dx_b = [&](int j, int k0) -> float4 {    // Wp[n(r)][(taps-1-tap')*Cin + col..col+3] for reduction row r = k0 + r0 + 16j
         const int r = k0 + r0 + 16 * j, col = n0 + c4;
         if (r >= p.K || col >= p.N) return zero4;
         int tap = 0, n = r;
         if (p.taps > 1) { tap = r / p.Nout; n = r - tap * p.Nout; }
-        return *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + (p.taps - 1 - tap) * p.Cin + col);
+        return ld4(p.B + (int64_t)n * p.ldb + (p.taps - 1 - tap) * p.Cin + col, p.N - col);
     };
     auto load_dw_a = [&](int j, int k0) -> float4 {    // dZ[m][n0 + c4 ..], m = k0 + r0 + 16j
         const int m = k0 + r0 + 16 * j, col = m0 + c4;
         if (m >= p.K || col >= p.M) return zero4;
-        return *reinterpret_cast<const float4*>(p.A + (int64_t)m * p.lda + col);
+        return ld4(p.A + (int64_t)m * p.lda + col, p.M - col);
     };
     auto load_dw_b = [&](int j, int k0) -> float4 {    // Xcol(m, jcol..jcol+3), jcol = (tap, ci)
         const int m = k0 + r0 + 16 * j, col = n0 + c4;
@@ -68,16 +88,16 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
         if (p.taps > 1) { tap = col / p.Cin; ci = col - tap * p.Cin; }
         const int tx = t * p.stride + tap - p.pad;
         if (tx < 0 || tx >= p.Tx) return zero4;
-        return *reinterpret_cast<const float4*>(p.B + ((int64_t)b * p.Tx + tx) * p.ldb + ci);
+        return ld4(p.B + ((int64_t)b * p.Tx + tx) * p.ldb + ci, p.N - col);
     };
 
     float4 ra[2], rb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        if (MODE == BWD_DX) { ra[j] = load_dx_a(j, kq); rb[j] = load_dx_b(j, 0); }
-        else { ra[j] = load_dw_a(j, 0); rb[j] = load_dw_b(j, 0); }
+        if (MODE == BWD_DX) { ra[j] = load_dx_a(j, kt_begin * TK + kq); rb[j] = load_dx_b(j, kt_begin * TK); }
+        else { ra[j] = load_dw_a(j, kt_begin * TK); rb[j] = load_dw_b(j, kt_begin * TK); }
     }
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
         if (MODE == BWD_DX) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(lr + 32 * j) * TLD + kq]) = ra[j];
@@ -86,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
         }
         stage_transposed(Bs, r0, c4, rb[0], rb[1]);
         __syncthreads();
-        if (kt + 1 < nkt) {
+        if (kt + 1 < kt_end) {
             const int k0 = (kt + 1) * TK;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
         if (p.c_T > 0) { const int b = row / p.c_T; off = (int64_t)b * p.c_seq_stride + (int64_t)(row - b * p.c_T) * p.ldc + col; }
         else off = (int64_t)row * p.ldc + col;
         const float v = acc[r] * p.alpha;
-        p.C[off] = p.accumulate ? p.C[off] + v : v;
+        Cout[off] = p.accumulate ? Cout[off] + v : v;
     }
 }
 
@@ -125,13 +145,48 @@ static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) 
 
 int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
     L2S_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "bwd gemm dims");
-    L2S_REQUIRE(al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0, "bwd gemm operands must be 16-byte aligned with ld % 4 == 0");
-    if (p.mode == BWD_DX) L2S_REQUIRE(p.Nout % 4 == 0 && p.N % 4 == 0 && p.Cin % 4 == 0, "dX gemm: channel counts must be multiples of 4");
-    else L2S_REQUIRE(p.M % 4 == 0 && p.Cin % 4 == 0, "dW gemm: channel counts must be multiples of 4");
-    dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB);
+    BwdGemmP q = p;
+    bool vec = al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+    if (p.mode == BWD_DX) vec = vec && p.Nout % 4 == 0 && p.N % 4 == 0 && p.Cin % 4 == 0;
+    else vec = vec && p.M % 4 == 0 && p.Cin % 4 == 0 && p.N % 4 == 0;
+    q.vec = vec ? 1 : 0;
+    L2S_REQUIRE(vec || p.taps == 1, "bwd gemm: unaligned operands are supported for 1x1 layers only");
+    L2S_REQUIRE(p.ksplit <= 1 || (p.mode == BWD_DW && !p.accumulate), "split-K is a dW-mode feature (partials are reduced by launch_gemm_bwd_splitk)");
+    dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB, p.ksplit > 1 ? p.ksplit : 1);
     ProfScope ps(name, s);
-    if (p.mode == BWD_DX) hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DX>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DW>, grid, dim3(256), 0, s, p);
+    if (p.mode == BWD_DX) hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DX>, grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DW>, grid, dim3(256), 0, s, q);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// C[m][n] (+)= sum_z partial[z][m][n]
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ partials, int nsplit, int64_t stride, int M, int N, int ldp,
+                                                            float* __restrict__ C, int ldc, int accumulate) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int n = idx % N; const int64_t m = idx / N;
+        float a = 0.f;
+        for (int z = 0; z < nsplit; ++z) a += partials[(int64_t)z * stride + m * ldp + n];
+        float* dst = C + m * ldc + n;
+        *dst = accumulate ? *dst + a : a;
+    }
+}
+
+int64_t gemm_bwd_splitk_floats(const BwdGemmP& p, int splits) { return (int64_t)splits * p.M * p.N; }
+
+// dW-mode GEMM with the (long) reduction split over gridDim.z; partials [splits][M][N] are summed in a fixed order
+int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipStream_t s, const char* name) {
+    L2S_REQUIRE(p.mode == BWD_DW && p.c_T == 0, "split-K: dW mode only");
+    const int nkt = (p.K + TK - 1) / TK;
+    if (splits > nkt) splits = nkt;
+    if (splits <= 1) return launch_gemm_bwd(p, s, name);
+    BwdGemmP q = p;
+    q.C = partials; q.ldc = p.N; q.ksplit = splits; q.c_split_stride = (int64_t)p.M * p.N; q.accumulate = 0;
+    if (launch_gemm_bwd(q, s, name)) return 1;
+    const int64_t total = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, partials, splits, q.c_split_stride, p.M, p.N,
+                       p.N, p.C, p.ldc, p.accumulate);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

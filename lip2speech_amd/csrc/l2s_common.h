@@ -38,7 +38,7 @@ struct ProfScope {
     ~ProfScope() { prof_end(s); }
 };
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_PSINE = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_PSINE = 3, ACT_PRELU = 4 /* backward only */ };
 
 // ---------------------------------------------------------------- tiled fp32 MFMA GEMM (gemm_nt.hip)
 // C[m, n] = epilogue( sum_k A(m,k) * W[n*K + k] ), A addressed as an implicit Conv1d over channel-last
@@ -85,10 +85,31 @@ struct BwdGemmP {
     int Tx, Tz, taps, stride, pad, padp, Nout, Cin;
     int c_T; int64_t c_seq_stride;   // c_T > 0: C row = (m / c_T) * c_seq_stride + (m % c_T) * ldc
     float alpha; int accumulate;
+    int vec;                     // set by launch_gemm_bwd: operands allow 16-byte loads
+    int ksplit; int64_t c_split_stride;   // DW: reduction split over gridDim.z into partial matrices (launch_gemm_bwd_splitk)
 };
 BwdGemmP bwd_dx(const float* dZ, int ldz, const float* Wp, float* dX, int ldx, int B, int Tz, int Tx, int Nout, int Cin, int taps, int pad, bool accumulate);
 BwdGemmP bwd_dw(const float* dZ, int ldz, const float* X, int ldx, float* dWp, int B, int Tz, int Tx, int Nout, int Cin, int taps, int stride, int pad, bool accumulate);
 int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name);
+int64_t gemm_bwd_splitk_floats(const BwdGemmP& p, int splits);
+int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipStream_t s, const char* name);
+
+// Backward of a fused GEMM epilogue  y = act(z) [+ residual],  z = conv * s + shift  (s, shift = eval-mode BatchNorm and/or bias):
+//   dpre = dy * act'(z);  dconv = dpre * s;  per-column sums  r0 = sum dpre,  r1 = sum dpre * (z - beta)/gamma,
+//   r2 = sum dy * sin(z) (PSine) or sum dy * min(z, 0) (PReLU).  Two-stage column reduction, deterministic (train_decoder.hip).
+constexpr int AB_RS = 32;     // row splits
+struct ActBwdP {
+    const float* dy; const float* z; float* dconv;     // [rows][ld]
+    int ld_dy, ld_z, ld_dconv;                          // 0 = C
+    int64_t rows; int C;
+    int act;                                            // ACT_NONE / ACT_SILU / ACT_PSINE / ACT_RELU / ACT_PRELU
+    const float* actw;                                  // PSine w / PReLU slope
+    const float* scale;                                 // BN scale s (null = 1)
+    const float* gamma; const float* beta;              // BN affine (null = no BN)
+    float* partials;                                    // [AB_RS][3][C]
+    int cs_dy, co_dy, cs_z, co_z;                       // column stride (0 = 1) and offset of dy / z (shuffled channel positions)
+};
+int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
 struct FrontendW {          // device pointers into the weight blob
@@ -97,7 +118,7 @@ struct FrontendW {          // device pointers into the weight blob
     const float* shift;     // [24]
     const float* slope;     // [24] PReLU
 };
-int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s);
+int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout = nullptr);
 
 // depthwise 3x3, pad 1, channel-last: in (N,Hi,Wi,ldi) channels [ci_off, ci_off+C) -> out (N,Ho,Wo,ldo) at co_off
 int launch_dwconv(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,

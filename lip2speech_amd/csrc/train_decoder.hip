@@ -15,19 +15,6 @@ namespace l2s {
 // Backward of a fused GEMM epilogue  y = act(z) [+ residual],  z = conv * s + shift  (s, shift = eval-mode BatchNorm and/or bias):
 //   dpre = dy * act'(z);  dconv = dpre * s;  per-column sums  r0 = sum dpre,  r1 = sum dpre * (z - beta)/gamma,  r2 = sum dy * sin(z)
 // Two-stage column reduction (row splits -> partials -> final), deterministic.
-constexpr int AB_RS = 32;     // row splits
-
-struct ActBwdP {
-    const float* dy; const float* z; float* dconv;     // [rows][ld]
-    int ld_dy, ld_z, ld_dconv;                          // 0 = C
-    int64_t rows; int C;
-    int act;                                            // ACT_NONE / ACT_SILU / ACT_PSINE / ACT_RELU
-    const float* actw;                                  // psine w
-    const float* scale;                                 // BN scale s (null = 1)
-    const float* gamma; const float* beta;              // BN affine (null = no BN)
-    float* partials;                                    // [AB_RS][3][C]
-};
-
 __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
     __shared__ float sh[3][4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
@@ -35,16 +22,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
     const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < p.rows ? r_begin + chunk : p.rows;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int64_t ldy = p.ld_dy ? p.ld_dy : p.C, ldz = p.ld_z ? p.ld_z : p.C, ldc = p.ld_dconv ? p.ld_dconv : p.C;
+    const int csy = p.cs_dy ? p.cs_dy : 1, csz = p.cs_z ? p.cs_z : 1;
     if (col < p.C) {
         const float s = p.scale ? p.scale[col] : 1.f;
-        const float w = p.act == ACT_PSINE ? p.actw[col] : 0.f;
+        const float w = (p.act == ACT_PSINE || p.act == ACT_PRELU) ? p.actw[col] : 0.f;
         const float be = p.beta ? p.beta[col] : 0.f, ig = p.gamma ? 1.f / p.gamma[col] : 0.f;
         for (int64_t r = r_begin + rl; r < r_end; r += 4) {
-            const float z = p.z[r * ldz + col], dy = p.dy[r * ldy + col];
+            const float z = p.z[r * ldz + p.co_z + col * csz], dy = p.dy[r * ldy + p.co_dy + col * csy];
             float dpre = dy;
             if (p.act == ACT_PSINE) { dpre = dy * cosf(z) * w; a2 += dy * sinf(z); }
             else if (p.act == ACT_SILU) { const float sg = 1.f / (1.f + expf(-z)); dpre = dy * sg * (1.f + z * (1.f - sg)); }
             else if (p.act == ACT_RELU) { dpre = z > 0.f ? dy : 0.f; }
+            else if (p.act == ACT_PRELU) { dpre = z >= 0.f ? dy : dy * w; a2 += z >= 0.f ? 0.f : dy * z; }
             a0 += dpre;
             a1 += dpre * (z - be) * ig;
             p.dconv[r * ldc + col] = dpre * s;
@@ -77,7 +66,7 @@ __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restr
     put(d_convbias, r[0] * (scale ? scale[col] : 1.f));
 }
 
-static int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s) {
+int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s) {
     ProfScope ps("train_act_bn_bwd", s);
     hipLaunchKernelGGL(act_bwd_kernel, dim3((p.C + 63) / 64, AB_RS), dim3(256), 0, s, p);
     hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p.partials, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,

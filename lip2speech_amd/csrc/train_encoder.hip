@@ -1,0 +1,470 @@
+// Training path of the visual encoder (reference: VideoExtractor.forward /root/reference/model/modules/video.py:76-87 and
+// shufflenetv2.py:42-152 under loss.backward(), train.py:184): forward with a tape (every unit's intermediate maps are kept - 288 GB
+// of HBM make recomputation pointless) and the backward down to the Conv3d weight.  Eval-mode normalisation statistics (the
+// configuration the gradient goldens pin).
+//
+//   conv_last/pool/normalise : L2-normalise + AvgPool backward in one kernel, then the generic epilogue/BN backward + dX/dW GEMMs
+//   ShuffleNet units         : 1x1 convs = dX / split-K dW GEMMs (gemm_bwd.hip) around the shared epilogue backward (act_bwd, column
+//                              strides pick the shuffled channel positions); depthwise 3x3 = transposed depthwise conv for dX and a
+//                              two-stage per-tap reduction for dW
+//   front-end                : MaxPool argmax gather + PReLU + BN backward fused in one pass over the saved pre-activation map, then
+//                              dW of the Conv3d as a split-K GEMM over an explicit im2col of the clip (chunks of frames)
+#include "../../include/l2s.h"
+#include "l2s_common.h"
+#include "l2s_model.h"
+
+#include <algorithm>
+#include <string>
+
+namespace l2s {
+
+// ------------------------------------------------------------------------------------------------------------ tape
+struct EncTape {
+    float* z0;                 // (NF, H/2, W/2, 24) pre-PReLU front-end map
+    float* x[N_UNITS + 1];     // x[0] = pooled front-end map (NF, H/4, W/4, 24); x[u+1] = output of unit u (channel-last)
+    float* t1[N_UNITS];        // banch2 first 1x1 conv output (post-ReLU)
+    float* t2[N_UNITS];        // banch2 depthwise output (post-BN)
+    float* b1[N_UNITS];        // stride-2 units: banch1 depthwise output (post-BN)
+    float* last;               // conv_last output (NF*h*h, 768), post-ReLU
+    int h[N_UNITS + 1];        // spatial size of x[u]
+    int NF;
+};
+static int64_t enc_tape_layout(EncTape* t, float* base, int B, int T, int H) {
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* r = base ? base + o : nullptr; o += align_up(n, 64); return r; };
+    const int NF = B * T;
+    if (t) t->NF = NF;
+    float* z0 = take((int64_t)NF * (H / 2) * (H / 2) * 24);
+    int h = H / 4, cin = STAGE_CH[0], u = 0;
+    float* x0 = take((int64_t)NF * h * h * cin);
+    if (t) { t->z0 = z0; t->x[0] = x0; t->h[0] = h; }
+    for (int st = 0; st < 3; ++st) {
+        const int cout = STAGE_CH[st + 1], half = cout / 2;
+        for (int r = 0; r < STAGE_REP[st]; ++r, ++u) {
+            const bool s2 = r == 0;
+            const int ho = s2 ? (h + 1) / 2 : h;
+            const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
+            float* t1 = take(in_px * half); float* t2 = take(out_px * half);
+            float* b1 = s2 ? take(out_px * cin) : nullptr;
+            float* y = take(out_px * cout);
+            if (t) { t->t1[u] = t1; t->t2[u] = t2; t->b1[u] = b1; t->x[u + 1] = y; t->h[u + 1] = ho; }
+            h = ho; cin = cout;
+        }
+    }
+    float* last = take((int64_t)NF * h * h * LAST_CH);
+    if (t) t->last = last;
+    return o + 64;
+}
+
+static GemmP pw(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride, int64_t M, int N, int K) {
+    GemmP p = gemm_plain(A + a_off, lda, c.W, C + c_off, ldc, (int)M, N, K);
+    p.scale = c.scale; p.shift = c.shift; p.act = ACT_RELU; p.c_cstride = cstride;
+    return p;
+}
+
+static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* emb, float* vis, float* feat, float* tape_base,
+                             hipStream_t s) {
+    const Weights& w = m->w;
+    EncTape tp; enc_tape_layout(&tp, tape_base, B, T, H);
+    const int NF = tp.NF;
+    if (launch_frontend(w.fe, video, B, T, H, W, tp.x[0], s, tp.z0)) return 1;
+    for (int u = 0; u < N_UNITS; ++u) {
+        const UnitW& U = w.unit[u];
+        const int half = U.half, cout = 2 * half, h = tp.h[u], ho = tp.h[u + 1];
+        const float* x = tp.x[u]; float* y = tp.x[u + 1];
+        const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
+        if (U.stride2) {
+            const int cin = U.cin;
+            if (launch_dwconv(x, NF, h, h, cin, 0, cin, 2, U.b1_dw.w9, U.b1_dw.scale, U.b1_dw.shift, tp.b1[u], cin, 0, s)) return 1;
+            if (launch_gemm1(pw(tp.b1[u], cin, 0, U.b1_pw, y, cout, 0, 2, out_px, half, cin), s, "train_shuffle_pw_gemm")) return 1;
+            if (launch_gemm1(pw(x, cin, 0, U.pw1, tp.t1[u], half, 0, 1, in_px, half, cin), s, "train_shuffle_pw_gemm")) return 1;
+            if (launch_dwconv(tp.t1[u], NF, h, h, half, 0, half, 2, U.dw.w9, U.dw.scale, U.dw.shift, tp.t2[u], half, 0, s)) return 1;
+            if (launch_gemm1(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, out_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
+        } else {
+            if (launch_copy_cols(x, cout, 0, y, cout, 0, 2, in_px, half, s)) return 1;
+            if (launch_gemm1(pw(x, cout, half, U.pw1, tp.t1[u], half, 0, 1, in_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
+            if (launch_dwconv(tp.t1[u], NF, h, h, half, 0, half, 1, U.dw.w9, U.dw.scale, U.dw.shift, tp.t2[u], half, 0, s)) return 1;
+            if (launch_gemm1(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, in_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
+        }
+    }
+    const int hl = tp.h[N_UNITS];
+    const int64_t px = (int64_t)NF * hl * hl;
+    if (launch_gemm1(pw(tp.x[N_UNITS], STAGE_CH[3], 0, w.conv_last, tp.last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3]), s, "train_conv_last_gemm")) return 1;
+    if (launch_pool_norm_cat(tp.last, NF, hl * hl, LAST_CH, emb, L2S_D_EMB, T, vis, L2S_D_VIS, feat, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward kernels
+// feat = v / max(|v|, eps), v = mean over the P pixels: dlast[f][p][c] = ((df - feat*(feat.df)) / max(|v|, eps))[c] / P   (video.py:81-85)
+__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* __restrict__ last, int P, int C, const float* __restrict__ dfeat, int ld_df,
+                                                            float* __restrict__ dlast) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[8];
+    float v[4], g[4];
+    float ss = 0.f, dot = 0.f;
+    int cnt = 0;
+    for (int c = tid; c < C; c += 256, ++cnt) {
+        float acc = 0.f;
+        for (int p = 0; p < P; ++p) acc += last[((int64_t)f * P + p) * C + c];
+        acc /= (float)P;
+        v[cnt] = acc; g[cnt] = dfeat[(int64_t)f * ld_df + c];
+        ss += acc * acc; dot += acc * g[cnt];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+    if ((tid & 63) == 0) { red[tid >> 6] = ss; red[4 + (tid >> 6)] = dot; }
+    __syncthreads();
+    ss = (red[0] + red[1]) + (red[2] + red[3]); dot = (red[4] + red[5]) + (red[6] + red[7]);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < 1e-12f;
+    const float inv = 1.f / (clamped ? 1e-12f : nrm);
+    cnt = 0;
+    for (int c = tid; c < C; c += 256, ++cnt) {
+        // d(v/n): (g - v (v.g)/n^2)/n ; when the norm is clamped the denominator is the constant eps
+        const float dv = clamped ? g[cnt] * inv : (g[cnt] - v[cnt] * dot * inv * inv) * inv;
+        for (int p = 0; p < P; ++p) dlast[((int64_t)f * P + p) * C + c] = dv / (float)P;
+    }
+}
+
+// transposed depthwise 3x3 (pad 1): dx[n][ih][iw][c] (+)= sum_{kh,kw} gd[n][oh][ow][c] * w9[kh*3+kw][c], oh*stride + kh - 1 = ih
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restrict__ gd, int N, int Ho, int Wo, int C, int stride, const float* __restrict__ w9,
+                                                            float* __restrict__ dx, int Hi, int Wi, int ldx, int xoff, int accumulate) {
+    const int64_t total = (int64_t)N * Hi * Wi * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = idx % C;
+        int64_t r = idx / C;
+        const int iw = r % Wi; r /= Wi;
+        const int ih = r % Hi;
+        const int n = r / Hi;
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = ih + 1 - kh;
+            if (th < 0 || th % stride) continue;
+            const int oh = th / stride;
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = iw + 1 - kw;
+                if (tw < 0 || tw % stride) continue;
+                const int ow = tw / stride;
+                if (ow >= Wo) continue;
+                acc = fmaf(gd[(((int64_t)n * Ho + oh) * Wo + ow) * C + c], w9[(kh * 3 + kw) * C + c], acc);
+            }
+        }
+        float* dst = dx + (((int64_t)n * Hi + ih) * Wi + iw) * ldx + xoff + c;
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+
+constexpr int DW_RS = 64;      // row splits of the per-tap reductions
+// partial[rs][k][c] = sum over this split's output pixels of gd[.][c] * x[shifted by tap k][c]
+__global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restrict__ gd, const float* __restrict__ x, int N, int Hi, int Wi, int ldx, int xoff,
+                                                            int Ho, int Wo, int C, int stride, float* __restrict__ partials) {
+    __shared__ float sh[9][4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
+    const int64_t rows = (int64_t)N * Ho * Wo, chunk = (rows + DW_RS - 1) / DW_RS;
+    const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+    float a[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = 0.f;
+    if (col < C) {
+        for (int64_t r = r_begin + rl; r < r_end; r += 4) {
+            const int ow = r % Wo; const int64_t q = r / Wo;
+            const int oh = q % Ho, n = q / Ho;
+            const float g = gd[r * C + col];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * stride + kh - 1;
+                if (ih < 0 || ih >= Hi) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow * stride + kw - 1;
+                    if (iw < 0 || iw >= Wi) continue;
+                    a[kh * 3 + kw] = fmaf(g, x[(((int64_t)n * Hi + ih) * Wi + iw) * ldx + xoff + col], a[kh * 3 + kw]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sh[k][rl][threadIdx.x & 63] = a[k];
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        const int c = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) partials[((int64_t)rs * 9 + k) * C + col] = (sh[k][0][c] + sh[k][1][c]) + (sh[k][2][c] + sh[k][3][c]);
+    }
+}
+// out[c*so_c + k*so_k] (+)= sum_blk partials[blk*blk_stride + k*C + c]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int blk_stride, int K, int C, float* __restrict__ out, int so_k,
+                                                              int so_c, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= K * C) return;
+    const int c = idx % C, k = idx / C;
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += partials[(int64_t)b * blk_stride + k * C + c];
+    float* dst = out + (int64_t)c * so_c + (int64_t)k * so_k;
+    *dst = accumulate ? *dst + a : a;
+}
+
+// Front-end backward: MaxPool(1x3x3, s 2, p 1) argmax gather + PReLU + BN(eval) backward over the saved pre-PReLU map z (NF,Hc,Wc,24).
+//   dy(pixel) = sum over the <= 4 pool windows that contain it and whose first maximum it is;  dz = dy * (z >= 0 ? 1 : slope)
+//   dconv = dz * bn_scale;  partial sums per block: [0] sum dz, [1] sum dz (z - beta)/gamma, [2] sum dy * min(z, 0)
+constexpr int FB_BLOCKS = 2048;
+__global__ __launch_bounds__(192) void frontend_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool, int NF, int Hc, int Wc,
+                                                           const float* __restrict__ slope, const float* __restrict__ scale, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dconv, float* __restrict__ partials) {
+    __shared__ float sh[3][8][24];
+    const int ch = threadIdx.x % 24, pl = threadIdx.x / 24;
+    const int Hp = Hc / 2, Wp = Wc / 2;
+    const float sl = slope[ch], sc = scale[ch], be = beta[ch], ig = 1.f / gamma[ch];
+    auto act = [&](float v) { return v >= 0.f ? v : sl * v; };
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int64_t total = (int64_t)NF * Hc * Wc;
+    for (int64_t px = (int64_t)blockIdx.x * 8 + pl; px < total; px += (int64_t)gridDim.x * 8) {
+        const int c = px % Wc; const int64_t q = px / Wc;
+        const int r = q % Hc; const int64_t f = q / Hc;
+        const float* zf = z + f * Hc * Wc * 24 + ch;
+        const float zv = zf[(r * Wc + c) * 24];
+        const float yv = act(zv);
+        float dy = 0.f;
+        const int pr0 = r >> 1, pr1 = (r & 1) ? pr0 + 1 : pr0;         // pool rows whose window holds conv row r
+        const int pc0 = c >> 1, pc1 = (c & 1) ? pc0 + 1 : pc0;
+        for (int pr = pr0; pr <= pr1; ++pr) {
+            if (pr >= Hp) continue;
+            for (int pc = pc0; pc <= pc1; ++pc) {
+                if (pc >= Wp) continue;
+                // is (r,c) the first maximum of window (pr,pc) in row-major scan order?
+                bool mine = true;
+                for (int dr = -1; dr <= 1 && mine; ++dr) {
+                    const int rr = 2 * pr + dr;
+                    if (rr < 0 || rr >= Hc) continue;
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const int cc = 2 * pc + dc;
+                        if (cc < 0 || cc >= Wc || (rr == r && cc == c)) continue;
+                        const float o = act(zf[(rr * Wc + cc) * 24]);
+                        const bool before = rr < r || (rr == r && cc < c);
+                        if (o > yv || (before && o == yv)) { mine = false; break; }
+                    }
+                }
+                if (mine) dy += dpool[((f * Hp + pr) * Wp + pc) * 24 + ch];
+            }
+        }
+        const float dz = zv >= 0.f ? dy : dy * sl;
+        a0 += dz; a1 += dz * (zv - be) * ig; a2 += zv >= 0.f ? 0.f : dy * zv;
+        dconv[px * 24 + ch] = dz * sc;
+    }
+    sh[0][pl][ch] = a0; sh[1][pl][ch] = a1; sh[2][pl][ch] = a2;
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+            for (int j = 0; j < 8; ++j) t += sh[k][j][ch];
+            partials[((int64_t)blockIdx.x * 3 + k) * 24 + ch] = t;
+        }
+    }
+}
+
+// explicit im2col of frames [f0, f0+nf) for the Conv3d weight gradient: col[(f-f0)*Hc*Wc + r*Wc + c][j], j = (ci*5 + kt)*49 + kh*7 + kw (735 -> ld 736)
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ video, int T, int H, int W, int f0, int nf, float* __restrict__ col) {
+    const int Hc = H / 2, Wc = W / 2;
+    const int64_t total = (int64_t)nf * Hc * Wc * 736;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = idx % 736; int64_t q = idx / 736;
+        const int c = q % Wc; q /= Wc;
+        const int r = q % Hc; const int fl = q / Hc;
+        float v = 0.f;
+        if (j < 735) {
+            const int f = f0 + fl, b = f / T, t = f - b * T;
+            const int tap = j % 49, slab = j / 49, ci = slab / 5, kt = slab - ci * 5;
+            const int kh = tap / 7, kw = tap - kh * 7;
+            const int tt = t + kt - 2, y = 2 * r + kh - 3, x = 2 * c + kw - 3;
+            if (tt >= 0 && tt < T && y >= 0 && y < H && x >= 0 && x < W) v = video[(((int64_t)(b * 3 + ci) * T + tt) * H + y) * W + x];
+        }
+        col[idx] = v;
+    }
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int ld_src, int so, int cs, float* __restrict__ dst, int ld_dst, int dof, int64_t rows, int cols,
+                                                     int accumulate) {
+    // dst[r*ld_dst + dof + c] (+)= src[r*ld_src + so + c*cs]
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * 256) {
+        const int c = i % cols; const int64_t r = i / cols;
+        const float v = src[r * ld_src + so + (int64_t)c * cs];
+        float* d = dst + r * ld_dst + dof + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward driver
+constexpr int IM2COL_FRAMES = 64;
+static int64_t enc_bwd_ws_floats(int B, int T, int H) {
+    const int64_t NF = (int64_t)B * T, Hc = H / 2, Hp = H / 4;
+    const int64_t maxact = std::max<int64_t>(NF * Hp * Hp * 24, NF * ((Hp + 1) / 2) * ((Hp + 1) / 2) * 116);   // largest unit map
+    const int64_t maxhalf = NF * Hp * Hp * 58;                                                                    // largest t1
+    int64_t n = 2 * maxact + 4 * maxhalf + NF * 9 * LAST_CH * 2;      // dy/dx ping-pong; g, dt, gd, db1; dlast, gconv
+    n += NF * Hc * Hc * 24;                                            // dconv of the front-end
+    n += (int64_t)std::min<int64_t>(NF, IM2COL_FRAMES) * Hc * Hc * 736; // im2col chunk
+    n += (int64_t)64 * LAST_CH * STAGE_CH[3] + (int64_t)24 * 736;      // split-K partials (largest: conv_last with <= 64 splits ... bounded below), dW staging
+    n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + (int64_t)FB_BLOCKS * 3 * 24;
+    return n + 64 * 32;
+}
+
+static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* dfeat, int ld_df, float* tape_base, void* ws, int64_t ws_bytes,
+                             hipStream_t s) {
+    const Weights& w = m->w;
+    EncTape tp; enc_tape_layout(&tp, tape_base, B, T, H);
+    const int NF = tp.NF, Hc = H / 2, Hp = H / 4;
+    const std::string E = "encoder.";
+    Bump bp(ws, ws_bytes);
+    const int64_t maxact = std::max<int64_t>((int64_t)NF * Hp * Hp * 24, (int64_t)NF * ((Hp + 1) / 2) * ((Hp + 1) / 2) * 116);
+    const int64_t maxhalf = (int64_t)NF * Hp * Hp * 58;
+    float* dA = bp.f(maxact); float* dB = bp.f(maxact);
+    float* g = bp.f(maxhalf); float* dt = bp.f(maxhalf); float* gd = bp.f(maxhalf); float* dt1 = bp.f(maxhalf);
+    float* dlast = bp.f((int64_t)NF * 9 * LAST_CH); float* gconv = bp.f((int64_t)NF * 9 * LAST_CH);
+    float* dconv = bp.f((int64_t)NF * Hc * Hc * 24);
+    const int chunkF = std::min(NF, IM2COL_FRAMES);
+    float* col = bp.f((int64_t)chunkF * Hc * Hc * 736);
+    const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];
+    float* skp = bp.f(splitk_cap); float* dw3 = bp.f(24 * 736);
+    float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)FB_BLOCKS * 3 * 24);
+    L2S_REQUIRE(!bp.overflow, "encoder training backward workspace too small");
+    auto G = [&](const std::string& k) { return m->grad(E + k); };
+    auto Cn = [&](const std::string& k) { return m->canon(E + k); };
+
+    // 1x1 conv weight gradient: dW[N][K] = dz^T x, reduction over `rows` pixels split so that the grid fills the chip
+    auto dW = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int cin, int64_t rows, float* out) -> int {
+        if (!out) return 0;
+        BwdGemmP p = bwd_dw(dz, ldz, x, ldx, out, 1, (int)rows, (int)rows, nout, cin, 1, 1, 0, false);
+        const int tiles = ((nout + 63) / 64) * ((cin + 63) / 64);
+        int splits = std::max(1, std::min(64, 1024 / tiles));
+        while (splits > 1 && gemm_bwd_splitk_floats(p, splits) > splitk_cap) --splits;
+        return launch_gemm_bwd_splitk(p, splits, skp, s, "train_bwd_encoder_dw");
+    };
+    auto dX = [&](const float* dz, int ldz, int nout, const float* Wf, float* out, int ldo, int cin, int64_t rows, bool acc) -> int {
+        return launch_gemm_bwd(bwd_dx(dz, ldz, Wf, out, ldo, 1, (int)rows, (int)rows, nout, cin, 1, 0, acc), s, "train_bwd_encoder_dx");
+    };
+    // epilogue backward of "conv (+BN) (+ReLU)": dy/z may sit at shuffled channel positions
+    auto epi = [&](const float* dy, int ldy, int csy, int coy, const float* z, int ldz, int csz, int coz, float* out, int64_t rows, int C, int act, const float* scale,
+                   const std::string& bn) -> int {
+        ActBwdP a{}; a.dy = dy; a.ld_dy = ldy; a.cs_dy = csy; a.co_dy = coy; a.z = z; a.ld_z = ldz; a.cs_z = csz; a.co_z = coz; a.dconv = out; a.ld_dconv = C;
+        a.rows = rows; a.C = C; a.act = act; a.scale = scale; a.gamma = Cn(bn + ".weight"); a.beta = Cn(bn + ".bias"); a.partials = abp;
+        L2S_REQUIRE(a.gamma && a.beta, "encoder parameters not bound (l2s_train_bind)");
+        return act_bwd(a, G(bn + ".bias"), G(bn + ".weight"), nullptr, nullptr, false, s);
+    };
+    auto dwconv_bwd = [&](const float* gdz, const float* x, int ldx, int xoff, int hi, int ho, int C, int stride, const float* w9, float* dx, int ld_dx, int dxoff,
+                          bool acc, float* gw) -> int {
+        const int64_t total = (int64_t)NF * hi * hi * C;
+        {
+            ProfScope ps("train_bwd_dwconv_dx", s);
+            hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, gdz, NF, ho, ho, C, stride, w9, dx, hi, hi,
+                               ld_dx, dxoff, acc ? 1 : 0);
+        }
+        if (gw) {
+            ProfScope ps("train_bwd_dwconv_dw", s);
+            hipLaunchKernelGGL(dwconv_bwd_dw_kernel, dim3((C + 63) / 64, DW_RS), dim3(256), 0, s, gdz, x, NF, hi, hi, ldx, xoff, ho, ho, C, stride, dwp);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, s, dwp, DW_RS, 9 * C, 9, C, gw, 1, 9, 0);     // canonical (C,1,3,3)
+        }
+        L2S_CHECK_HIP(hipGetLastError());
+        return 0;
+    };
+    auto blocks = [](int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)); };
+
+    // ---- normalise + AvgPool + conv_last
+    const int hl = tp.h[N_UNITS], P = hl * hl;
+    const int64_t pxl = (int64_t)NF * P;
+    {
+        ProfScope ps("train_bwd_pool_norm", s);
+        hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(NF), dim3(256), 0, s, tp.last, P, LAST_CH, dfeat, ld_df, dlast);
+    }
+    if (epi(dlast, LAST_CH, 1, 0, tp.last, LAST_CH, 1, 0, gconv, pxl, LAST_CH, ACT_RELU, w.conv_last.scale, "trunk.1.1")) return 1;
+    if (dW(gconv, LAST_CH, LAST_CH, tp.x[N_UNITS], STAGE_CH[3], STAGE_CH[3], pxl, G("trunk.1.0.weight"))) return 1;
+    float* dy = dA; float* dx = dB;
+    if (dX(gconv, LAST_CH, LAST_CH, w.conv_last.W, dy, STAGE_CH[3], STAGE_CH[3], pxl, false)) return 1;
+
+    // ---- ShuffleNet units, last to first
+    for (int u = N_UNITS - 1; u >= 0; --u) {
+        const UnitW& U = w.unit[u];
+        const int half = U.half, cout = 2 * half, h = tp.h[u], ho = tp.h[u + 1];
+        const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
+        const std::string p = "trunk.0." + std::to_string(u) + ".";
+        const float* y = tp.x[u + 1];
+        // banch2 tail: pw2 (+BN+ReLU) at the odd output channels, then the depthwise conv (+BN)
+        if (epi(dy, cout, 2, 1, y, cout, 2, 1, g, out_px, half, ACT_RELU, U.pw2.scale, p + "banch2.6")) return 1;
+        if (dW(g, half, half, tp.t2[u], half, half, out_px, G(p + "banch2.5.weight"))) return 1;
+        if (dX(g, half, half, U.pw2.W, dt, half, half, out_px, false)) return 1;
+        if (epi(dt, half, 1, 0, tp.t2[u], half, 1, 0, gd, out_px, half, ACT_NONE, U.dw.scale, p + "banch2.4")) return 1;
+        if (dwconv_bwd(gd, tp.t1[u], half, 0, h, ho, half, U.stride2 ? 2 : 1, U.dw.w9, dt1, half, 0, false, G(p + "banch2.3.weight"))) return 1;
+        if (epi(dt1, half, 1, 0, tp.t1[u], half, 1, 0, g, in_px, half, ACT_RELU, U.pw1.scale, p + "banch2.1")) return 1;
+        if (U.stride2) {
+            const int cin = U.cin;
+            if (dW(g, half, half, tp.x[u], cin, cin, in_px, G(p + "banch2.0.weight"))) return 1;
+            if (dX(g, half, half, U.pw1.W, dx, cin, cin, in_px, false)) return 1;
+            // banch1: dw (+BN) -> pw (+BN+ReLU) at the even output channels
+            if (epi(dy, cout, 2, 0, y, cout, 2, 0, g, out_px, half, ACT_RELU, U.b1_pw.scale, p + "banch1.3")) return 1;
+            if (dW(g, half, half, tp.b1[u], cin, cin, out_px, G(p + "banch1.2.weight"))) return 1;
+            if (dX(g, half, half, U.b1_pw.W, dt, cin, cin, out_px, false)) return 1;
+            if (epi(dt, cin, 1, 0, tp.b1[u], cin, 1, 0, gd, out_px, cin, ACT_NONE, U.b1_dw.scale, p + "banch1.1")) return 1;
+            if (dwconv_bwd(gd, tp.x[u], cin, 0, h, ho, cin, 2, U.b1_dw.w9, dx, cin, 0, true, G(p + "banch1.0.weight"))) return 1;
+        } else {
+            if (dW(g, half, half, tp.x[u] + half, cout, half, in_px, G(p + "banch2.0.weight"))) return 1;
+            if (dX(g, half, half, U.pw1.W, dx + half, cout, half, in_px, false)) return 1;
+            // passthrough half: out[2k] = x1[k]
+            hipLaunchKernelGGL(copy2d_kernel, blocks(in_px * half), dim3(256), 0, s, dy, cout, 0, 2, dx, cout, 0, in_px, half, 0);
+        }
+        std::swap(dy, dx);
+    }
+
+    // ---- front-end: MaxPool + PReLU + BN backward, then the Conv3d weight gradient
+    {
+        const float* gamma = Cn("frontend3D.1.weight"); const float* beta = Cn("frontend3D.1.bias");
+        L2S_REQUIRE(gamma && beta, "encoder parameters not bound (l2s_train_bind)");
+        ProfScope ps("train_bwd_frontend_pool_prelu_bn", s);
+        hipLaunchKernelGGL(frontend_bwd_kernel, dim3(FB_BLOCKS), dim3(192), 0, s, tp.z0, dy, NF, Hc, Hc, w.fe.slope, w.fe.scale, gamma, beta, dconv, fbp);
+        float* outs[3] = {G("frontend3D.1.bias"), G("frontend3D.1.weight"), G("frontend3D.2.weight")};
+        for (int k = 0; k < 3; ++k)
+            if (outs[k]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, outs[k], 0, 1, 0);
+    }
+    L2S_CHECK_HIP(hipGetLastError());
+    if (float* gw = G("frontend3D.0.weight")) {
+        const int64_t ppf = (int64_t)Hc * Hc;
+        for (int f0 = 0; f0 < NF; f0 += chunkF) {
+            const int nf = std::min(chunkF, NF - f0);
+            {
+                ProfScope ps("train_bwd_frontend_im2col", s);
+                hipLaunchKernelGGL(im2col3d_kernel, dim3(8192), dim3(256), 0, s, video, T, H, W, f0, nf, col);
+            }
+            BwdGemmP p = bwd_dw(dconv + (int64_t)f0 * ppf * 24, 24, col, 736, dw3, 1, (int)(nf * ppf), (int)(nf * ppf), 24, 736, 1, 1, 0, f0 > 0);
+            if (launch_gemm_bwd_splitk(p, 64, skp, s, "train_bwd_frontend_dw")) return 1;
+        }
+        hipLaunchKernelGGL(copy2d_kernel, blocks(24 * 735), dim3(256), 0, s, dw3, 736, 0, 1, gw, 735, 0, (int64_t)24, 735, 0);
+    }
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s
+
+// ================================================================================================ C ABI
+using namespace l2s;
+
+extern "C" {
+
+int64_t l2s_train_encoder_tape_floats(int B, int T, int H) { return enc_tape_layout(nullptr, nullptr, B, T, H); }
+int64_t l2s_train_encoder_ws_bytes(int B, int T, int H) { return (enc_bwd_ws_floats(B, T, H) + 1024) * (int64_t)sizeof(float); }
+
+int l2s_train_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* emb, float* vis, float* feat, float* tape, void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_enc && video && tape && (vis || feat), "bad arguments");
+    L2S_REQUIRE(B >= 1 && T >= 1 && H == W && (H == 96 || H == 88), "sizes");
+    L2S_REQUIRE(!vis || emb, "the visual sequence needs the speaker embedding");
+    return encoder_train_fwd(m, video, B, T, H, W, emb, vis, feat, tape, (hipStream_t)stream);
+}
+
+int l2s_train_encoder_bwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* dfeat, int ld_dfeat, float* tape, void* ws, int64_t ws_bytes,
+                          void* stream) {
+    L2S_REQUIRE(m && m->finalized && m->has_enc && video && dfeat && tape && ws, "bad arguments");
+    L2S_REQUIRE(B >= 1 && T >= 1 && H == W && (H == 96 || H == 88) && ld_dfeat >= LAST_CH, "sizes");
+    return encoder_train_bwd(m, video, B, T, H, W, dfeat, ld_dfeat, tape, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -29,6 +29,7 @@ ABI_SYMBOLS = (
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
+    "l2s_train_encoder_tape_floats", "l2s_train_encoder_ws_bytes", "l2s_train_encoder_fwd", "l2s_train_encoder_bwd",
     "l2s_train_prologue_tape_floats", "l2s_train_prologue_ws_bytes", "l2s_train_prologue_fwd", "l2s_train_prologue_bwd",
     "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
@@ -96,6 +97,12 @@ def lib() -> ctypes.CDLL:
     L.l2s_train_steps_pack_weights.argtypes = [_vp, _fp, _vp]
     L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_encoder_tape_floats.argtypes = [_i, _i, _i]
+    L.l2s_train_encoder_tape_floats.restype = _i64
+    L.l2s_train_encoder_ws_bytes.argtypes = [_i, _i, _i]
+    L.l2s_train_encoder_ws_bytes.restype = _i64
+    L.l2s_train_encoder_fwd.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp]
+    L.l2s_train_encoder_bwd.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _i, _fp, _vp, _i64, _vp]
     L.l2s_train_prologue_tape_floats.argtypes = [_i, _i]
     L.l2s_train_prologue_tape_floats.restype = _i64
     L.l2s_train_prologue_ws_bytes.argtypes = [_i, _i]
@@ -324,6 +331,26 @@ class NativeModel:
         """Loop forward-with-tape + BPTT (stage 2 of the training path).  Returns (mel, stop, attn_logits) and the state gradients."""
         outs, ctx = self.train_steps_fwd(state, B, T, S, teacher, teacher_mask)
         return outs, self.train_steps_bwd(ctx, dmel, dstop)
+
+    def train_encoder_fwd(self, video, emb=None):
+        """Encoder forward with a tape.  Returns (vis (B,T,1024) or None, feat (B,T,768), tape)."""
+        video = _f32(video)
+        B, _, T, H, W = video.shape
+        L, dev = lib(), video.device
+        tape = torch.empty(int(L.l2s_train_encoder_tape_floats(B, T, H)), dtype=torch.float32, device=dev)
+        feat = torch.empty(B, T, 768, dtype=torch.float32, device=dev)
+        vis = torch.empty(B, T, 1024, dtype=torch.float32, device=dev) if emb is not None else None
+        check(L.l2s_train_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(_f32(emb)) if emb is not None else None, _ptr(vis), _ptr(feat), _ptr(tape), _stream()))
+        return vis, feat, tape
+
+    def train_encoder_bwd(self, video, dfeat, tape) -> None:
+        """Encoder backward: dfeat (B,T,>=768) (e.g. dvis, row stride 1024); parameter gradients land in the bound slots."""
+        video = _f32(video)
+        B, _, T, H, W = video.shape
+        L = lib()
+        assert dfeat.is_cuda and dfeat.dtype == torch.float32 and dfeat.stride(-1) == 1 and dfeat.stride(0) == T * dfeat.stride(1)
+        ws = torch.empty(int(L.l2s_train_encoder_ws_bytes(B, T, H)), dtype=torch.uint8, device=video.device)
+        check(L.l2s_train_encoder_bwd(self._h, _ptr(video), B, T, H, W, dfeat.data_ptr(), int(dfeat.stride(1)), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
 
     def train_prologue_fwd(self, vis, emb, gumbel):
         """Prologue forward with a tape (stage 3).  Returns (state, content_dis, tape)."""

@@ -93,6 +93,7 @@ def test_fused_adamw_amsgrad_clip_matches_torch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T,Ci,Co,k,st,pad", [(2, 29, 512, 512, 11, 1, 5), (3, 40, 80, 512, 5, 1, 2), (2, 75, 512, 80, 5, 1, 2),
+                                                (3, 144, 58, 58, 1, 1, 0), (2, 100, 24, 58, 1, 1, 0), (1, 333, 58, 116, 1, 1, 0),
                                                  (2, 29, 512, 512, 7, 7, 0), (4, 1, 1024, 512, 1, 1, 0), (2, 29, 2560, 256, 1, 1, 0)])
 def test_conv1d_backward_gemms(B, T, Ci, Co, k, st, pad):
     """dX (flipped-tap implicit GEMM) and dW (reduction over rows) of the Conv1d/Linear layers vs autograd in fp64."""
@@ -266,4 +267,49 @@ def test_prologue_backward_matches_autograd(synth_sd, T):
             close(k, grads[k], sd64[k].grad)
         except AssertionError as e:
             bad.append(str(e))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(2, 9), (1, 29)])
+def test_encoder_backward_matches_autograd(synth_sd, B, T):
+    """Visual encoder forward-with-tape and backward (front-end MaxPool/PReLU/BN + Conv3d weight gradient, the 16 ShuffleNet units,
+    conv_last, AvgPool, L2-normalise) against autograd through the oracle's encoder: every encoder parameter.  The comparison runs
+    the oracle in fp32: ReLU / MaxPool decisions on pre-activations within rounding of zero (or of each other) differ between an fp32
+    and an fp64 forward and move single gradient entries by ~1e-2 (tools/dbg_enc_bwd.py: HIP vs fp32 oracle 1e-6, fp32 vs fp64 oracle
+    1e-2 on the same entries); the fp64 oracle bounds the result at that level."""
+    import parity_common as pc
+    from lip2speech_amd import synth
+    from oracle import l2s_oracle as orc
+    video = synth.synth_video(B, T, tag=f"enc-train{T}")
+    torch.manual_seed(T)
+    cot = torch.randn(B, T, 768, dtype=torch.float64)
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))      # noqa: E731
+    enc = [k for k in synth_sd if k.startswith("encoder.")]
+    par = [k for k in enc if synth_sd[k].is_floating_point() and not is_buf(k)]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        sdx = {k: (synth_sd[k].to(dt).requires_grad_(k in par) if synth_sd[k].is_floating_point() else synth_sd[k]) for k in enc}
+        feat_o = orc.encoder_forward(sdx, video.to(dt))
+        (feat_o * cot.to(dt)).sum().backward()
+        ref[dt] = {k: sdx[k].grad.double() for k in par}
+        if dt == torch.float64:
+            feat64 = feat_o.detach()
+    nm = pc.native_model(synth_sd)
+    params = {k: synth_sd[k].cuda() for k in par}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    nm.train_bind(params, grads)
+    _, feat, tape = nm.train_encoder_fwd(video.cuda())
+    assert pc.maxdiff(feat, feat64) < 2e-5
+    dvis = torch.zeros(B, T, 1024, device="cuda")
+    dvis[:, :, :768] = cot.float().cuda()
+    nm.train_encoder_bwd(video.cuda(), dvis, tape)
+    bad = []
+    for k in par:
+        r32, r64 = ref[torch.float32][k].reshape(grads[k].shape), ref[torch.float64][k].reshape(grads[k].shape)
+        scale = max(1e-9, r64.abs().max().item())
+        e32, e64 = pc.maxdiff(grads[k], r32) / scale, pc.maxdiff(grads[k], r64) / scale
+        if not (e32 < 2e-4 and e64 < 5e-2):
+            bad.append(f"{k}: relative error vs fp32 oracle {e32:.2e}, vs fp64 oracle {e64:.2e} (scale {scale:.2e})")
     assert not bad, "\n".join(bad)
