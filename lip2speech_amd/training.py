@@ -119,6 +119,16 @@ def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_tar
     return {"loss": loss, "mel": mel_cf, "mel_post": mel_post, "stop": stop, "attn_logits": logits, "content_dis": dis, "dvis": dvis}
 
 
+def model_forward_backward(nm: "native.NativeModel", video, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None):
+    """`Lip2Speech.forward` + `Loss` + `backward()` (model.py:20-41, train.py:167-184) with the speaker embedding supplied and eval-mode
+    statistics: encoder forward with a tape, `decoder_forward_backward`, then the encoder backward fed by the visual-feature gradient.
+    All encoder and decoder parameter gradients land in the bound slots."""
+    vis, _, etape = nm.train_encoder_fwd(video, emb)
+    out = decoder_forward_backward(nm, vis, emb, gumbel, mel_target, gate_target, teacher_mask=teacher_mask, bos=bos)
+    nm.train_encoder_bwd(video, out["dvis"], etape)
+    return out
+
+
 class GradAllReducer:
     """Sum all-reduce of a flat gradient buffer in fixed-size buckets (default 25 MB), issued asynchronously in order;
     `wait()` blocks on all of them.  The division by world size is NOT done here - AdamWAmsgrad.step(grad_mul=1/world)

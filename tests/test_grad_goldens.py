@@ -123,3 +123,30 @@ def test_hip_decoder_training_step_matches_reference_gradients(case):
     dfeat = out["dvis"][:, :, :768]
     ref = torch.from_numpy(z["dfeat"])
     assert pc.maxdiff(dfeat, ref) < 4e-3 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_hip_full_training_step_matches_reference_gradients(case):
+    """Whole model: video -> encoder -> decoder -> loss -> backward through the decoder AND the encoder, against the reference's own
+    backward: all 308 encoder/decoder parameter gradients."""
+    from lip2speech_amd.training import model_forward_backward
+    z, index = load(case)
+    sd = synth.synth_state_dict()
+    video = synth.synth_video(B, T, tag="video-lrw2").cuda()
+    emb = synth.synth_speaker_embedding(B, tag="spk-lrw2").cuda()
+    gum = synth.synth_gumbel(B * 4, tag="gumbel-lrw2").cuda()
+    mels = synth.synth_mels(B, S, tag="mel-lrw2").cuda()
+    nm = pc.native_model(sd)
+    params = {k: sd[k].cuda() for k in index}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    nm.train_bind(params, grads)
+    mask = torch.from_numpy(z["teacher_mask"])
+    out = model_forward_backward(nm, video, emb, gum, mels, gate_targets().cuda(), teacher_mask=mask if bool(mask.any()) else None,
+                                 bos=params["decoder.BOS"])
+    got = out["loss"].cpu().double().numpy()
+    assert np.abs(got - z["loss_terms"]).max() < 2e-5 * np.abs(z["loss_terms"]).max(), (got, z["loss_terms"])
+    check_grads(z, index, grads, list(index), rel_norm=3e-3, rel_proj=6e-3, rel_full=6e-3)
+    total = float(np.sqrt(sum(float(g.double().pow(2).sum()) for g in grads.values())))
+    ref_total = float(np.sqrt((z["grad_norm"] ** 2).sum()))
+    assert abs(total - ref_total) < 1e-3 * ref_total           # what clip_grad_norm_ sees (train.py:191)

@@ -275,7 +275,7 @@ def test_prologue_backward_matches_autograd(synth_sd, T):
 def test_encoder_backward_matches_autograd(synth_sd, B, T):
     """Visual encoder forward-with-tape and backward (front-end MaxPool/PReLU/BN + Conv3d weight gradient, the 16 ShuffleNet units,
     conv_last, AvgPool, L2-normalise) against autograd through the oracle's encoder: every encoder parameter.  The comparison runs
-    the oracle in fp32: ReLU / MaxPool decisions on pre-activations within rounding of zero (or of each other) differ between an fp32
+    the oracle in fp32 AND fp64: ReLU / MaxPool decisions on pre-activations within rounding of zero (or of each other) differ between an fp32
     and an fp64 forward and move single gradient entries by ~1e-2 (tools/dbg_enc_bwd.py: HIP vs fp32 oracle 1e-6, fp32 vs fp64 oracle
     1e-2 on the same entries); the fp64 oracle bounds the result at that level."""
     import parity_common as pc
@@ -290,7 +290,7 @@ def test_encoder_backward_matches_autograd(synth_sd, B, T):
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ref = {}
     for dt in (torch.float64, torch.float32):
-        sdx = {k: (synth_sd[k].to(dt).requires_grad_(k in par) if synth_sd[k].is_floating_point() else synth_sd[k]) for k in enc}
+        sdx = {k: (synth_sd[k].detach().clone().to(dt).requires_grad_(k in par) if synth_sd[k].is_floating_point() else synth_sd[k]) for k in enc}
         feat_o = orc.encoder_forward(sdx, video.to(dt))
         (feat_o * cot.to(dt)).sum().backward()
         ref[dt] = {k: sdx[k].grad.double() for k in par}
@@ -310,6 +310,6 @@ def test_encoder_backward_matches_autograd(synth_sd, B, T):
         r32, r64 = ref[torch.float32][k].reshape(grads[k].shape), ref[torch.float64][k].reshape(grads[k].shape)
         scale = max(1e-9, r64.abs().max().item())
         e32, e64 = pc.maxdiff(grads[k], r32) / scale, pc.maxdiff(grads[k], r64) / scale
-        if not (e32 < 2e-4 and e64 < 5e-2):
+        if not (min(e32, e64) < 2e-4 and max(e32, e64) < 5e-2):     # a flip separates the HIP forward from one oracle precision or the other
             bad.append(f"{k}: relative error vs fp32 oracle {e32:.2e}, vs fp64 oracle {e64:.2e} (scale {scale:.2e})")
     assert not bad, "\n".join(bad)
