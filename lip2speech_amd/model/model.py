@@ -19,6 +19,52 @@ from .modules._tree import NativeBacked
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+class _HipTrainStep(torch.autograd.Function):
+    """`Lip2Speech.forward` as ONE autograd node (reference: model.py:20-41 + decoder.py:320-379 under loss.backward(), train.py:184):
+    forward runs the HIP kernels with tapes; backward runs the HIP backward (post-net, BPTT through the loop, prologue, encoder) and
+    deposits every encoder/decoder parameter gradient in the flat gradient buffer the parameters' `.grad` alias.  `anchor` is any
+    parameter of the model - it only makes autograd call `backward`."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, video, emb, gumbel, mels, mask):
+        nm = model.native_model()
+        B, _, T, _, _ = video.shape
+        S = mels.shape[2]
+        vis, _, etape = nm.train_encoder_fwd(video, emb)
+        state, dis, ptape = nm.train_prologue_fwd(vis, emb, gumbel)
+        teacher = None
+        if mask is not None:
+            bos = model.decoder.BOS.detach().to(torch.float32).reshape(1, 1, -1).expand(B, 1, -1)
+            teacher = torch.cat([bos, mels.detach().to(torch.float32).permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
+        (mel, stop, logits), sctx = nm.train_steps_fwd(state, B, T, S, teacher, mask)
+        mel_post, post_tape = nm.train_postnet_fwd(mel)
+        ctx.model, ctx.tapes = model, (video, emb, vis, etape, state, ptape, sctx, mel, post_tape)
+        ctx.mark_non_differentiable(logits)
+        return mel.permute(0, 2, 1).contiguous(), mel_post, stop.unsqueeze(2), logits, dis
+
+    @staticmethod
+    def backward(ctx, dmel_cf, dmel_post, dstop, _dlogits, ddis):
+        model = ctx.model
+        nm = model.native_model()
+        video, emb, vis, etape, state, ptape, sctx, mel, post_tape = ctx.tapes
+        B, S = mel.shape[0], mel.shape[1]
+        flat = model._flat
+        live = model._grads_live()
+        prev = flat.grad.clone() if live else None                    # gradient accumulation across backward() calls
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g  # noqa: E731
+        wbuf = nm.train_pack_weights(video.device)
+        dmel = nm.train_postnet_bwd(mel, z(dmel_post, mel.permute(0, 2, 1)), post_tape)
+        if dmel_cf is not None:
+            dmel += dmel_cf.permute(0, 2, 1)
+        sg = nm.train_steps_bwd(sctx, dmel, z(dstop, mel[:, :, :1]).reshape(B, S), wbuf=wbuf)
+        dvis = nm.train_prologue_bwd(vis, emb, state, ptape, sg, dcontent_dis=ddis, wbuf=wbuf)
+        nm.train_encoder_bwd(video, dvis, etape)
+        if prev is not None:
+            flat.grad += prev
+        model._attach_grads()
+        return (None,) * 7
+
+
 class Lip2Speech(NativeBacked):
     _key_prefix = ""
 
@@ -36,6 +82,36 @@ class Lip2Speech(NativeBacked):
         sd = self.state_dict(keep_vars=True)
         return {k: v for k, v in sd.items() if k.startswith(("encoder.", "decoder."))}
 
+    # ------------------------------------------------------------------ training state
+    def trainable_groups(self):
+        """The optimizer's parameter groups as train.py:102-104 builds them: decoder, then encoder."""
+        return [list(self.decoder.parameters()), list(self.encoder.parameters())]
+
+    def _train_state(self):
+        """Lazy: re-home the decoder/encoder parameters into one flat fp32 buffer (+ a flat gradient buffer) and bind both to the library."""
+        if self.__dict__.get("_flat") is None:
+            from ..training import FlatBuffer
+            flat = FlatBuffer(self.trainable_groups())
+            self.__dict__["_flat"] = flat
+            names = {id(p): "decoder." + n for n, p in self.decoder.named_parameters()}
+            names.update({id(p): "encoder." + n for n, p in self.encoder.named_parameters()})
+            self.__dict__["_flat_names"] = [names[id(p)] for p in flat.params]
+            grads = {}
+            for p, key in zip(flat.params, self._flat_names):
+                off = flat.offsets[id(p)]
+                grads[key] = flat.grad[off:off + p.numel()].view_as(p)
+                p.grad = None
+            self.__dict__["_grad_views"] = grads
+            self.native_model().train_bind({k: p.data for k, p in zip(self._flat_names, flat.params)}, grads)
+        return self._flat
+
+    def _grads_live(self) -> bool:
+        return any(p.grad is not None for p in self._flat.params)
+
+    def _attach_grads(self):
+        for p, key in zip(self._flat.params, self._flat_names):
+            p.grad = self._grad_views[key]
+
     def _speaker(self, face_frames, speaker_embedding):
         if speaker_embedding is not None:
             return speaker_embedding
@@ -43,12 +119,34 @@ class Lip2Speech(NativeBacked):
 
     def forward(self, video_frames, face_frames, audio_frames, melspecs, video_lengths, audio_lengths, melspec_lengths,
                 tf_ratio, speaker_embedding=None, gumbel_noise=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.decoder.parameters()):
+            return self._forward_train(video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise)
         video_features = F.dropout(self.encoder(video_frames), 0.1, self.training)
         emb = self._speaker(face_frames, speaker_embedding)
         vis = native.build_visual(video_features, emb)
         face = emb.unsqueeze(1).expand(-1, vis.shape[1], -1)
         outputs = self.decoder(vis, face, melspecs, video_lengths, melspec_lengths, tf_ratio, gumbel_noise=gumbel_noise)
         return outputs + [video_lengths]
+
+    def _forward_train(self, video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise):
+        """The differentiable route (train.py:167-184): same outputs as `forward`, attached to autograd through `_HipTrainStep`.
+        Normalisation layers use their running statistics and the dropout sites are the identity in this build (the configuration the
+        reference gradient goldens pin); batch-statistics BatchNorm and dropout masks are the next increment."""
+        self._train_state()
+        with torch.no_grad():
+            emb = self._speaker(face_frames, speaker_embedding).to(torch.float32).contiguous()
+        B, _, T, _, _ = video_frames.shape
+        S = melspecs.shape[2]
+        if gumbel_noise is None:
+            gumbel_noise = Decoder.draw_gumbel(B * native.min_T(T), video_frames.device)
+        mask, consumed = [], 0
+        for _ in range(S):                                   # scheduled sampling, one torch.rand(1) per step (decoder.py:355-357)
+            take = bool(torch.rand(1) > tf_ratio) and consumed < int(tf_ratio * S)
+            consumed += int(take)
+            mask.append(1 if take else 0)
+        mel, mel_post, stop, attn, dis = _HipTrainStep.apply(self.decoder.BOS, self, video_frames.detach().to(torch.float32).contiguous(), emb,
+                                                             gumbel_noise.detach().to(torch.float32).contiguous(), melspecs, mask if any(mask) else None)
+        return [mel, mel_post, stop, emb, attn, dis, video_lengths]
 
     def inference(self, video_frames, face_frames, speaker_embedding=None, return_attention_map=False, gumbel_noise=None):
         with torch.no_grad():

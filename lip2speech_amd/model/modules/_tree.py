@@ -64,8 +64,14 @@ class NativeBacked(nn.Module):
         if self.__dict__["_native"] is None or sig != self.__dict__["_native_sig"]:
             if not next(iter(tensors.values())).is_cuda:
                 raise RuntimeError("the Lip2Speech hot path runs on the GPU: call .to('cuda') first (no CPU fallback)")
-            nm = native.NativeModel()
+            nm = self.__dict__["_native"] or native.NativeModel()       # re-pack into the same handle: training bindings stay valid
             nm.load(tensors, list(tensors.keys()))
             self.__dict__["_native"] = nm
             self.__dict__["_native_sig"] = sig
         return self.__dict__["_native"]
+
+    def mark_weights_changed(self):
+        """Call after updating parameters behind autograd's back (the fused optimizer writes the flat buffer directly): the packed
+        blob is rebuilt on the next use."""
+        target = self.__dict__.get("_native_parent") or self
+        target.__dict__["_native_sig"] = None

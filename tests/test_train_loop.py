@@ -1,0 +1,90 @@
+"""End-to-end training loop through the drop-in boundary (reference flow: train.py:102-104,167-193): `net(...)` -> 4-term loss ->
+`loss.backward()` -> `clip_grad_norm_` -> AdamW(amsgrad).  The HIP model runs under a stock torch optimizer (drop-in) and under the
+fused flat-buffer optimizer; both are compared, step by step, with the same loop driven by autograd through the CPU oracle."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity_common as pc              # noqa: E402
+from lip2speech_amd import synth        # noqa: E402
+from oracle import l2s_oracle as orc    # noqa: E402
+
+B, T, S, STEPS = 2, 29, 24, 3
+LR, WD, CLIP = 1e-4, 1e-6, 1.0
+
+
+def inputs():
+    video = synth.synth_video(B, T, tag="video-lrw2")
+    emb = synth.synth_speaker_embedding(B, tag="spk-lrw2")
+    gum = synth.synth_gumbel(B * 4, tag="gumbel-lrw2")
+    mels = synth.synth_mels(B, S, tag="mel-loop")
+    gate = torch.zeros(B, S)
+    gate[:, S - 1] = 1.0
+    return video, emb, gum, mels, gate
+
+
+@pytest.fixture(scope="module")
+def oracle_loop():
+    """[(loss terms (5,), total grad norm)] of STEPS steps of the reference flow driven by autograd through the oracle (fp32, CPU)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = synth.synth_state_dict()
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked", "pos_table"))      # noqa: E731
+    keys = [k for k in sd if k.startswith(("encoder.", "decoder."))]
+    work = {k: (sd[k].clone().requires_grad_(sd[k].is_floating_point() and not is_buf(k))) for k in keys}
+    dec = [work[k] for k in keys if k.startswith("decoder.") and work[k].requires_grad]
+    enc = [work[k] for k in keys if k.startswith("encoder.") and work[k].requires_grad]
+    opt = torch.optim.AdamW([{"params": dec}, {"params": enc}], lr=LR, weight_decay=WD, amsgrad=True)
+    video, emb, gum, mels, gate = inputs()
+    hist = []
+    for _ in range(STEPS):
+        outs = orc.forward_eval(work, video, emb, mels, gum)
+        terms = orc.loss_terms(outs, mels, gate)
+        opt.zero_grad()
+        terms[-1].backward()
+        gn = torch.nn.utils.clip_grad_norm_(dec + enc, CLIP)
+        opt.step()
+        hist.append((torch.stack([t.detach() for t in terms]), float(gn)))
+    return hist
+
+
+def run_hip_loop(fused: bool):
+    from model.model import get_network
+    from lip2speech_amd.training import AdamWAmsgrad
+    net = get_network("train").cuda()
+    net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
+    video, emb, gum, mels, gate = (t.cuda() for t in inputs())
+    lens = torch.full((B,), T, device="cuda")
+    if fused:
+        flat = net._train_state()
+        opt = AdamWAmsgrad(flat, lr=LR, weight_decay=WD)
+    else:
+        dec, enc = net.trainable_groups()
+        opt = torch.optim.AdamW([{"params": dec}, {"params": enc}], lr=LR, weight_decay=WD, amsgrad=True)
+    hist = []
+    for _ in range(STEPS):
+        outs = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+        terms = orc.loss_terms(outs, mels, gate)
+        opt.zero_grad()
+        terms[-1].backward()
+        if fused:
+            gn = float(opt.step(max_norm=CLIP))
+            net.mark_weights_changed()
+        else:
+            gn = float(torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP))
+            opt.step()
+        hist.append((torch.stack([t.detach() for t in terms]).cpu(), gn))
+    return hist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_loop_tracks_oracle_loop(oracle_loop, fused):
+    hist = run_hip_loop(fused)
+    for step, ((terms, gn), (o_terms, o_gn)) in enumerate(zip(hist, oracle_loop)):
+        rel = 2e-5 if step == 0 else 2e-3          # later steps: Adam's sign-like first updates amplify rounding of near-zero gradients
+        assert (terms.double() - o_terms.double()).abs().max() < rel * o_terms.abs().max().item(), (step, terms, o_terms)
+        assert abs(gn - o_gn) < max(rel, 1e-3) * o_gn, (step, gn, o_gn)
+    assert hist[-1][0][4] < hist[0][0][4], "the loss does not decrease"
