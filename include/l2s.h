@@ -151,10 +151,17 @@ int l2s_adamw_amsgrad_step(float* params, const float* grads, float* exp_avg, fl
                            float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm,
                            float grad_mul, float max_norm, void* stream);
 
-/* ---- training path of the model (in progress: stage 1 = post-net) -------------------------------------------------------------
+/* ---- training path of the model (forward with tapes + backward of encoder, prologue, loop, post-net) ---------------------------
  * l2s_train_bind: device pointers of a parameter in its canonical (checkpoint) layout and of its gradient slot (may be NULL), by key.
  * The backward entry points write parameter gradients into the bound slots (overwrite, not accumulate). */
 int l2s_train_bind(l2s_model* m, const char* key, float* param_dev, float* grad_dev);
+/* After an optimizer step: rebuild the packed blob ON THE DEVICE from the bound tensors (l2s_train_bind; bind the BatchNorm running
+ * statistics and the other buffers as well, grad_dev = NULL).  Needs l2s_set_option("refresh_map", 1) before l2s_model_finalize: finalize
+ * then records, for every blob float that copies a checkpoint element verbatim, where it comes from; BatchNorm folds and bias sums are
+ * recomputed by small kernels; the phase-merged step weights (fp64 products) are marked stale and l2s_decode_steps / l2s_inference use
+ * the literal step until the next l2s_model_finalize.  Replaces the host re-pack (~190 ms) by ~1 ms of device work. */
+int l2s_train_refresh_weights(l2s_model* m, void* stream);
+
 /* Post-net forward with a tape (decoder.py:143-156, eval-mode BatchNorm statistics, no dropout) and its backward:
  * mel dev (B,S,80) -> mel_post dev (B,80,S);  dmel_post dev (B,80,S) -> dmel dev (B,S,80) is ACCUMULATED into. */
 int64_t l2s_train_postnet_tape_floats(int B, int S);
@@ -228,7 +235,8 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
  *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
  *   "use_graph"         (0)  replay the decode loop from a captured hipGraph
  *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
- *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop */
+ *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
+ *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
 int l2s_set_option(const char* name, int value);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */

@@ -98,7 +98,9 @@ struct Packer {
     void bind(const float** slot, int64_t off) { fixups.emplace_back(slot, off); }
 
     // BatchNorm (eval) as scale/shift, optionally absorbing a conv bias: v = (acc + b - mu) * s + beta
-    void bn(const std::string& p, int c, const std::vector<float>* bias, const float** scale, const float** shift) {
+    std::vector<l2s_model::RefreshBn> bn_rec;
+    std::vector<l2s_model::RefreshSum> sum_rec;
+    void bn(const std::string& p, int c, const std::vector<float>* bias, const float** scale, const float** shift, const std::string& bias_key = std::string()) {
         auto g = get(p + ".weight", c), b = get(p + ".bias", c), mu = get(p + ".running_mean", c), var = get(p + ".running_var", c);
         if (!g || !b || !mu || !var) return;
         int64_t so = blob.alloc(c), ho = blob.alloc(c);
@@ -110,6 +112,7 @@ struct Packer {
         }
         bind(scale, so);
         bind(shift, ho);
+        bn_rec.push_back({p, bias_key, c, so, ho});
     }
     void copy(const std::string& key, int64_t n, const float** slot) {
         auto v = get(key, n);
@@ -160,8 +163,9 @@ static int lstm_perm_row(int np, int H) {      // packed row (unit-major: 4*unit
     return gate * H + unit;
 }
 
-static int pack_model(l2s_model* m, hipStream_t stream) {
-    Packer P{m};
+static int g_opt_refresh_map = 0;     // build the device-side refresh map at finalize (training)
+
+static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bool& want_spk) {
     m->w = Weights{};
     Weights& w = m->w;
     const std::string E = "encoder.", Dk = "decoder.";
@@ -172,7 +176,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         return false;
     };
     const std::string Sk = "speaker_encoder.";
-    const bool want_enc = has_prefix(E), want_dec = has_prefix(Dk), want_spk = has_prefix(Sk);
+    want_enc = has_prefix(E); want_dec = has_prefix(Dk); want_spk = has_prefix(Sk);
     if (!want_enc && !want_dec && !want_spk) { set_error("l2s_model_finalize: no encoder.* / decoder.* / speaker_encoder.* tensors were set"); return 1; }
     if (want_enc) {
 
@@ -260,6 +264,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
             if (!wi || !bi || !bh || !wh) continue;
             std::memcpy(&P.blob.data[wo + (int64_t)d * 2048 * 1024], wi->data(), sizeof(float) * 2048 * 1024);
             for (int i = 0; i < 2048; ++i) P.blob.data[bo + d * 2048 + i] = (*bi)[i] + (*bh)[i];
+            P.sum_rec.push_back({Dk + "encoder_rnn.bias_ih_" + suf[d], Dk + "encoder_rnn.bias_hh_" + suf[d], 2048, 0, bo + d * 2048});
             P.frag16(2048, 512, [&](int np, float* row) {
                 std::memcpy(row, wh->data() + (int64_t)lstm_perm_row(np, 512) * 512, sizeof(float) * 512);
                 return true;
@@ -274,7 +279,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         for (int j = 0; j < 4; ++j) {
             std::string c = p + ".0.conv." + std::to_string(j);
             P.conv1d_w(c + ".0.weight", D, D, MH_KS[j], &w.mh_branch[kv][j].W);
-            P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.mh_branch[kv][j].scale, &w.mh_branch[kv][j].shift);
+            P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.mh_branch[kv][j].scale, &w.mh_branch[kv][j].shift, c + ".0.bias");
         }
         P.conv1d_w(p + ".0.bottleneck.weight", D, 5 * D, 1, &w.mh_bott[kv].W);
         P.copy(p + ".0.bottleneck.bias", D, &w.mh_bott[kv].shift);
@@ -284,7 +289,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     for (int j = 0; j < 4; ++j) {
         std::string c = Dk + "content.agg." + std::to_string(j);
         P.conv1d_w(c + ".0.weight", D, D, CT_KS[j], &w.ct_branch[j].W);
-        P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.ct_branch[j].scale, &w.ct_branch[j].shift);
+        P.bn(c + ".1", D, P.get(c + ".0.bias", D), &w.ct_branch[j].scale, &w.ct_branch[j].shift, c + ".0.bias");
     }
     P.conv1d_w(Dk + "content.bottleneck.weight", 256, 5 * D, 1, &w.ct_bott.W);
     P.copy(Dk + "content.bottleneck.bias", 256, &w.ct_bott.shift);
@@ -343,6 +348,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         int64_t o = P.blob.alloc(2048);
         for (int np = 0; np < 2048; ++np) { int r = lstm_perm_row(np, 512); P.blob.data[o + np] = (*bi)[r] + (*bh)[r]; }
         P.bind(&s.bias, o);
+        P.sum_rec.push_back({Dk + "decoder_rnn.bias_ih_" + sl, Dk + "decoder_rnn.bias_hh_" + sl, 2048, 512, o});
         s.N = 2048; s.K = 1024; s.tiles = 128;
     }
     {   // fc_out (80 rows) + stop-token row over h1 (row 80) in one weight: [96][512]
@@ -432,7 +438,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         int ci = i == 0 ? NM : D, co = i == 4 ? NM : D;
         std::string c = Dk + "postnet.convolutions." + std::to_string(i);
         P.conv1d_w(c + ".0.conv.weight", co, ci, 5, &w.post[i].W);
-        P.bn(c + ".1", co, P.get(c + ".0.conv.bias", co), &w.post[i].scale, &w.post[i].shift);
+        P.bn(c + ".1", co, P.get(c + ".0.conv.bias", co), &w.post[i].scale, &w.post[i].shift, c + ".0.conv.bias");
         if (i < 4) P.copy(Dk + "postnet.sin_activation." + std::to_string(i) + ".w", D, &w.post[i].actw);
     }
     }   // want_dec
@@ -485,6 +491,17 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
         P.copy(Sk + "linear.bias", 256, &w.spk_linear.shift);
     }   // want_spk
     if (!P.missing.empty()) { set_error("l2s_model_finalize: " + P.missing); return 1; }
+    return 0;
+}
+
+static int build_refresh_map(l2s_model* m, const Packer& P, hipStream_t stream);
+
+static int pack_model(l2s_model* m, hipStream_t stream) {
+    Packer P{m};
+    bool want_enc = false, want_dec = false, want_spk = false;
+    if (pack_host(m, P, want_enc, want_dec, want_spk)) return 1;
+    if (g_opt_refresh_map && build_refresh_map(m, P, stream)) return 1;
+    m->folded_valid = true;
 
     // upload and patch pointers
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -499,6 +516,139 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     m->has_enc = want_enc;
     m->has_dec = want_dec;
     m->has_spk = want_spk;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ device-side refresh (training)
+// Which checkpoint element does each blob float copy?  Pack a shadow checkpoint whose elements carry their own global id as raw bits
+// (ids < 2^31 - 2^23 are finite positive floats, so plain copies preserve them; arithmetic on them produces other patterns), then keep an
+// entry only if the real blob holds exactly the value of the element the id names.  Computed entries (BatchNorm folds, bias sums) are
+// refreshed from the records the packer left; the phase-merged step weights are fp64 products and are invalidated instead.
+static int build_refresh_map(l2s_model* m, const Packer& P, hipStream_t stream) {
+    std::vector<std::string> keys;
+    for (auto& kv : m->host) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    std::vector<int64_t> base(keys.size() + 1, 0);
+    for (size_t i = 0; i < keys.size(); ++i) base[i + 1] = base[i] + (int64_t)m->host[keys[i]].size();
+    L2S_REQUIRE(base.back() < 0x7F000000LL, "too many checkpoint elements for the refresh map");
+    std::unordered_map<std::string, std::vector<float>> shadow;
+    for (size_t i = 0; i < keys.size(); ++i) {
+        std::vector<float> v(m->host[keys[i]].size());
+        for (size_t j = 0; j < v.size(); ++j) { const uint32_t id = (uint32_t)(base[i] + (int64_t)j + 1); std::memcpy(&v[j], &id, 4); }
+        shadow.emplace(keys[i], std::move(v));
+    }
+    Weights saved = m->w;
+    m->host.swap(shadow);
+    Packer P2{m};
+    bool e = false, d = false, k = false;
+    const int rc = pack_host(m, P2, e, d, k);
+    m->host.swap(shadow);
+    m->w = saved;
+    if (rc) return 1;
+    L2S_REQUIRE(P2.blob.data.size() == P.blob.data.size(), "refresh map: shadow pack differs in size");
+    const int64_t n = (int64_t)P.blob.data.size();
+    std::vector<int32_t> rk(n, -1), ri(n, 0);
+    size_t cur = 0;
+    int64_t copies = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t id; std::memcpy(&id, &P2.blob.data[i], 4);
+        if (id == 0 || (int64_t)id > base.back()) continue;
+        const int64_t g = (int64_t)id - 1;
+        if (!(g >= base[cur] && g < base[cur + 1])) cur = (size_t)(std::upper_bound(base.begin(), base.end(), g) - base.begin()) - 1;
+        const std::vector<float>& src = m->host[keys[cur]];
+        const int64_t j = g - base[cur];
+        uint32_t a, b; std::memcpy(&a, &P.blob.data[i], 4); std::memcpy(&b, &src[j], 4);
+        if (a != b) continue;
+        rk[i] = (int32_t)cur; ri[i] = (int32_t)j; ++copies;
+    }
+    if (m->r_key) { (void)hipFree(m->r_key); m->r_key = nullptr; }
+    if (m->r_idx) { (void)hipFree(m->r_idx); m->r_idx = nullptr; }
+    L2S_CHECK_HIP(hipMalloc(&m->r_key, n * sizeof(int32_t)));
+    L2S_CHECK_HIP(hipMalloc(&m->r_idx, n * sizeof(int32_t)));
+    L2S_CHECK_HIP(hipMemcpyAsync(m->r_key, rk.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    L2S_CHECK_HIP(hipMemcpyAsync(m->r_idx, ri.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    L2S_CHECK_HIP(hipStreamSynchronize(stream));
+    m->r_keys = keys;
+    m->r_bn = P.bn_rec;
+    m->r_sum = P.sum_rec;
+    (void)copies;
+    return 0;
+}
+
+struct RBn { const float *g, *b, *mu, *var, *bias; float *scale, *shift; int c; };
+struct RSum { const float *a, *b; float* dst; int n, perm_H; };
+
+__global__ __launch_bounds__(256) void refresh_gather_kernel(float* __restrict__ blob, const int32_t* __restrict__ rk, const int32_t* __restrict__ ri,
+                                                             const float* const* __restrict__ ptrs, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int k = rk[i];
+        if (k < 0) continue;
+        const float* src = ptrs[k];
+        if (src) blob[i] = src[ri[i]];
+    }
+}
+__global__ __launch_bounds__(256) void refresh_bn_kernel(const RBn* __restrict__ recs) {
+    const RBn r = recs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r.c) return;
+    const float s = __fdiv_rn(r.g[i], __fsqrt_rn(r.var[i] + BN_EPS));   // correctly rounded, like the host packer's expression
+    const float cb = r.bias ? r.bias[i] : 0.f;
+    r.scale[i] = s;
+    r.shift[i] = (cb - r.mu[i]) * s + r.b[i];
+}
+__global__ __launch_bounds__(256) void refresh_sum_kernel(const RSum* __restrict__ recs) {
+    const RSum r = recs[blockIdx.y];
+    const int np = blockIdx.x * 256 + threadIdx.x;
+    if (np >= r.n) return;
+    const int src = r.perm_H ? (np & 3) * r.perm_H + (np >> 2) : np;
+    r.dst[np] = r.a[src] + r.b[src];
+}
+
+static int refresh_weights(l2s_model* m, hipStream_t s) {
+    L2S_REQUIRE(m->finalized && m->r_key && m->r_idx, "no refresh map: set option refresh_map=1 before l2s_model_finalize");
+    const size_t nk = m->r_keys.size(), nb = m->r_bn.size(), ns = m->r_sum.size();
+    const size_t off_bn = align_up((int64_t)(nk * sizeof(float*)), 64), off_sum = off_bn + align_up((int64_t)(nb * sizeof(RBn)), 64);
+    const size_t total = off_sum + ns * sizeof(RSum) + 64;
+    m->r_tables_host.assign(total, 0);
+    const float** ptrs = reinterpret_cast<const float**>(m->r_tables_host.data());
+    for (size_t i = 0; i < nk; ++i) ptrs[i] = m->canon(m->r_keys[i]);
+    RBn* bn = reinterpret_cast<RBn*>(m->r_tables_host.data() + off_bn);
+    size_t nb_live = 0;
+    int maxc = 1;
+    for (const auto& r : m->r_bn) {
+        RBn d{m->canon(r.p + ".weight"), m->canon(r.p + ".bias"), m->canon(r.p + ".running_mean"), m->canon(r.p + ".running_var"),
+              r.bias_key.empty() ? nullptr : m->canon(r.bias_key), m->blob + r.so, m->blob + r.ho, r.c};
+        if (!d.g && !d.b && !d.mu && !d.var) continue;                   // a module that is not bound at all (e.g. frozen) keeps its packed values
+        L2S_REQUIRE(d.g && d.b && d.mu && d.var && (r.bias_key.empty() || d.bias), "refresh: BatchNorm tensors of a layer are only partly bound");
+        bn[nb_live++] = d; maxc = std::max(maxc, r.c);
+    }
+    RSum* sm = reinterpret_cast<RSum*>(m->r_tables_host.data() + off_sum);
+    size_t ns_live = 0;
+    int maxn = 1;
+    for (const auto& r : m->r_sum) {
+        RSum d{m->canon(r.a), m->canon(r.b), m->blob + r.dst, r.n, r.perm_H};
+        if (!d.a && !d.b) continue;
+        L2S_REQUIRE(d.a && d.b, "refresh: bias pair only partly bound");
+        sm[ns_live++] = d; maxn = std::max(maxn, r.n);
+    }
+    if ((int64_t)total > m->r_tables_bytes) {
+        if (m->r_tables) (void)hipFree(m->r_tables);
+        L2S_CHECK_HIP(hipMalloc(&m->r_tables, total));
+        m->r_tables_bytes = (int64_t)total;
+    }
+    L2S_CHECK_HIP(hipMemcpyAsync(m->r_tables, m->r_tables_host.data(), total, hipMemcpyHostToDevice, s));
+    L2S_CHECK_HIP(hipStreamSynchronize(s));                             // pageable staging buffer: the copy must have left the host vector
+    char* T = (char*)m->r_tables;
+    {
+        ProfScope ps("train_refresh_gather", s);
+        hipLaunchKernelGGL(refresh_gather_kernel, dim3(4096), dim3(256), 0, s, m->blob, m->r_key, m->r_idx, reinterpret_cast<const float* const*>(T), m->blob_floats);
+    }
+    if (nb_live) hipLaunchKernelGGL(refresh_bn_kernel, dim3((maxc + 255) / 256, (unsigned)nb_live), dim3(256), 0, s, reinterpret_cast<const RBn*>(T + off_bn));
+    if (ns_live) hipLaunchKernelGGL(refresh_sum_kernel, dim3((maxn + 255) / 256, (unsigned)ns_live), dim3(256), 0, s, reinterpret_cast<const RSum*>(T + off_sum));
+    L2S_CHECK_HIP(hipGetLastError());
+    m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are fp64 products of the old parameters: the loop falls back to the literal step
+    for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    m->graphs.clear();
     return 0;
 }
 
@@ -904,7 +1054,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
 static int decode_run(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
                       float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
-    const bool fold = g_opt_fold != 0;
+    const bool fold = g_opt_fold != 0 && m->folded_valid;
     const bool use_graph = g_opt_graph && !teacher && !g_prof_on;
     if (!use_graph) return decode_launches(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, s, fold);
 
@@ -1063,6 +1213,9 @@ int l2s_model_destroy(l2s_model* m) {
     if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_in); (void)hipEventDestroy(m->ev_out); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->blob) (void)hipFree(m->blob);
+    if (m->r_key) (void)hipFree(m->r_key);
+    if (m->r_idx) (void)hipFree(m->r_idx);
+    if (m->r_tables) (void)hipFree(m->r_tables);
     delete m;
     return 0;
 }
@@ -1198,7 +1351,7 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
         // the side stream must not start before earlier work on `s` (previous users of these buffers) is done
         L2S_CHECK_HIP(hipEventRecord(m->ev_in, s));
         L2S_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_in, 0));
-        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, g_opt_fold != 0, &on_frames)) return 1;
+        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, g_opt_fold != 0 && m->folded_valid, &on_frames)) return 1;
         L2S_CHECK_HIP(hipEventRecord(m->ev_out, m->side));
         L2S_CHECK_HIP(hipStreamWaitEvent(s, m->ev_out, 0));
     }
@@ -1234,8 +1387,14 @@ int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W
     return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);
 }
 
+int l2s_train_refresh_weights(l2s_model* m, void* stream) {
+    L2S_REQUIRE(m != nullptr, "null model");
+    return refresh_weights(m, (hipStream_t)stream);
+}
+
 int l2s_set_option(const char* name, int value) {
     L2S_REQUIRE(name != nullptr, "null option name");
+    if (!std::strcmp(name, "refresh_map")) { g_opt_refresh_map = value; return 0; }
     if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;

@@ -81,6 +81,18 @@ struct l2s_model {
     std::vector<hipEvent_t> ev_pool;
     // training: device pointers of the canonical (PyTorch-layout) parameters and of their gradient slots, bound by key
     std::unordered_map<std::string, std::pair<float*, float*>> bound;
+    // training: device-side refresh of the packed blob from the bound tensors (l2s_train_refresh_weights).  Built by l2s_model_finalize
+    // when the "refresh_map" option is on: for every blob float that is a verbatim copy of a checkpoint element, its source (key index,
+    // element index); plus the records of the entries that are computed (eval-BatchNorm folds, bias sums).
+    struct RefreshBn { std::string p, bias_key; int c; int64_t so, ho; };
+    struct RefreshSum { std::string a, b; int n, perm_H; int64_t dst; };
+    std::vector<RefreshBn> r_bn;
+    std::vector<RefreshSum> r_sum;
+    std::vector<std::string> r_keys;
+    int32_t* r_key = nullptr; int32_t* r_idx = nullptr;      // device [blob_floats]
+    void* r_tables = nullptr; int64_t r_tables_bytes = 0;     // device scratch for the pointer / descriptor tables
+    std::vector<char> r_tables_host;
+    bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
     const float* canon(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.first; }
     float* grad(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.second; }
 };

@@ -102,7 +102,13 @@ class Lip2Speech(NativeBacked):
                 grads[key] = flat.grad[off:off + p.numel()].view_as(p)
                 p.grad = None
             self.__dict__["_grad_views"] = grads
-            self.native_model().train_bind({k: p.data for k, p in zip(self._flat_names, flat.params)}, grads)
+            native.set_option("refresh_map", 1)                  # the (re)load below also builds the device-side refresh map
+            self.__dict__["_native_sig"] = None
+            nm = self.native_model()
+            bound = {k: p.data for k, p in zip(self._flat_names, flat.params)}
+            bound.update({k: v for k, v in self._tensors().items() if k not in bound and v.is_floating_point()})   # buffers: BN statistics, pos_table
+            nm.train_bind(bound, grads)
+            self.__dict__["_refresh_on_device"] = True
         return self._flat
 
     def _grads_live(self) -> bool:

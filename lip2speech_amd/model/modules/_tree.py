@@ -55,12 +55,21 @@ class NativeBacked(nn.Module):
     def _signature(self, tensors):
         return tuple((t.data_ptr(), t._version) for t in tensors.values())
 
+    def _same_storage(self, tensors) -> bool:
+        """True when only tensor versions changed since the last pack (same device addresses): the bound pointers are still right."""
+        old = self.__dict__.get("_native_sig")
+        return old is not None and len(old) == len(tensors) and all(o[0] == t.data_ptr() for o, t in zip(old, tensors.values()))
+
     def native_model(self) -> native.NativeModel:
         parent = self.__dict__.get("_native_parent")
         if parent is not None:
             return parent.native_model()
         tensors = self._tensors()
         sig = self._signature(tensors)
+        if self.__dict__["_native"] is not None and sig != self.__dict__["_native_sig"] and self.__dict__.get("_refresh_on_device") \
+                and self._same_storage(tensors):
+            self.__dict__["_native"].train_refresh_weights()           # in-place parameter updates (a torch optimizer stepped)
+            self.__dict__["_native_sig"] = sig
         if self.__dict__["_native"] is None or sig != self.__dict__["_native_sig"]:
             if not next(iter(tensors.values())).is_cuda:
                 raise RuntimeError("the Lip2Speech hot path runs on the GPU: call .to('cuda') first (no CPU fallback)")
@@ -72,6 +81,10 @@ class NativeBacked(nn.Module):
 
     def mark_weights_changed(self):
         """Call after updating parameters behind autograd's back (the fused optimizer writes the flat buffer directly): the packed
-        blob is rebuilt on the next use."""
+        blob is rebuilt - on the device when the training state is set up (l2s_train_refresh_weights), else from the host on next use."""
         target = self.__dict__.get("_native_parent") or self
-        target.__dict__["_native_sig"] = None
+        if target.__dict__.get("_refresh_on_device") and target.__dict__.get("_native") is not None:
+            target.__dict__["_native"].train_refresh_weights()
+            target.__dict__["_native_sig"] = target._signature(target._tensors())
+        else:
+            target.__dict__["_native_sig"] = None

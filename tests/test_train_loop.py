@@ -88,3 +88,42 @@ def test_training_loop_tracks_oracle_loop(oracle_loop, fused):
         assert (terms.double() - o_terms.double()).abs().max() < rel * o_terms.abs().max().item(), (step, terms, o_terms)
         assert abs(gn - o_gn) < max(rel, 1e-3) * o_gn, (step, gn, o_gn)
     assert hist[-1][0][4] < hist[0][0][4], "the loss does not decrease"
+
+
+@pytest.mark.gpu
+def test_device_refresh_equals_host_repack():
+    """After parameters (and BatchNorm statistics) change, l2s_train_refresh_weights rebuilds the packed blob on the device; the model
+    must then compute exactly what a model packed from scratch on the host computes from the same tensors."""
+    from model.model import get_network
+    from lip2speech_amd import native
+    net = get_network("train").cuda()
+    net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
+    net._train_state()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for name, t in net.state_dict(keep_vars=True).items():
+            if not t.is_floating_point() or name.endswith("pos_table"):
+                continue
+            if name.endswith("running_var"):
+                t.mul_(1.0 + 0.2 * torch.rand_like(t))
+            else:
+                t.add_(0.02 * t.abs().mean() * torch.randn_like(t))
+    net.mark_weights_changed()
+    video, emb, gum, _, _ = (t.cuda() for t in inputs())
+    native.set_option("fold_step_weights", 0)          # the refreshed model runs the literal step; compare like with like
+    try:
+        net.eval()
+        mel, lengths, attn = net.inference(video, None, speaker_embedding=emb, return_attention_map=True, gumbel_noise=gum)
+        ref = native.NativeModel()
+        tensors = {k: v.detach() for k, v in net.state_dict().items() if k.startswith(("encoder.", "decoder."))}
+        ref.load(tensors, list(tensors.keys()))
+        mel_r, len_r, attn_r = ref.inference(video, emb, gum, S=300, want_attn=True)
+    finally:
+        native.set_option("fold_step_weights", 1)
+        native.set_option("refresh_map", 0)
+    assert torch.equal(lengths, len_r)
+    assert pc.maxdiff(mel, mel_r) < 1e-4 and pc.maxdiff(attn, attn_r) < 1e-4, (pc.maxdiff(mel, mel_r), pc.maxdiff(attn, attn_r))
+    # and the untouched synthetic checkpoint gives a different answer (the refresh really happened)
+    base = pc.native_model()
+    mel_b, _, _ = base.inference(video, emb, gum, S=300)
+    assert pc.maxdiff(mel, mel_b) > 1e-3
