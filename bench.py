@@ -94,13 +94,92 @@ def cpu_baseline(seconds_budget=12.0):
                       f"thread-count probe (S=20 pass, seconds): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
 
 
+def train_main(args):
+    """Secondary bench line: training throughput.  One step = `Lip2Speech.forward` (encoder + decoder, S=77 targets) + 4-term loss +
+    backward through everything + bucketed gradient all-reduce (RCCL, N>1) + global-norm clip + fused AdamW(amsgrad) + device-side
+    re-pack of the weight blob, on B=8 clips per GPU, fp32, eval-mode normalisation statistics."""
+    from model.model import get_network
+    from lip2speech_amd.training import AdamWAmsgrad, GradAllReducer, model_forward_backward
+    Bt, St = 8, 77
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    net = get_network("train").cuda()
+    net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
+    flat = net._train_state()
+    nm = net.native_model()
+    opt = AdamWAmsgrad(flat, lr=1e-4, weight_decay=1e-6)
+    reducer = GradAllReducer(flat.grad)
+    tag = f"train{rank}"
+    video = synth.synth_video(Bt, T, tag=tag).cuda()
+    emb = synth.synth_speaker_embedding(Bt, tag=tag).cuda()
+    gum = synth.synth_gumbel(Bt * native.min_T(T), tag=tag).cuda()
+    mels = synth.synth_mels(Bt, St, tag=tag).cuda()
+    gate = torch.zeros(Bt, St, device="cuda")
+    gate[:, -1] = 1.0
+    bos = dict(net.decoder.named_parameters())["BOS"]
+    mask = torch.zeros(St, dtype=torch.bool)
+    mask[1::2] = True                                   # half of the steps teacher-forced (tf_ratio 0.5 regime)
+
+    def step():
+        out = model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bos.detach())
+        reducer.start()
+        mul = reducer.wait()
+        opt.step(max_norm=1.0, grad_mul=mul)
+        nm.train_refresh_weights()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = out["loss"].cpu()
+    assert torch.isfinite(loss).all(), "non-finite loss"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training clips/sec (forward + loss + backward + all-reduce + clip + AdamW-amsgrad + weight re-pack)",
+            "value": world * Bt * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "LRW training step, batch=8 per GPU, 29x96x96 clips, S=77 mel targets, half of the steps teacher-forced, "
+                                   "38.4 M parameters, eval-mode BatchNorm statistics / no dropout", "batch_per_gpu": Bt, "frames": T,
+                       "decode_steps": St, "parallelism": f"dp{world} (one bucketed gradient all-reduce of 153.7 MB per step)"},
+            "final_loss": float(loss[4])}), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    ap.add_argument("--mode", choices=["inference", "train"], default="inference",
+                    help="inference = the headline metric (default); train = one data-parallel training step per 'step' (SURVEY.md §8 config 3)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

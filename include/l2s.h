@@ -231,6 +231,8 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
 /* launch-floor probe: n dependent launches of an empty kernel (kind 0) or of a kernel in which each of `blocks` 512-thread
  * blocks streams n_per_block x 8 KiB from `in` (kind 1) - the cost model of a latency-bound decode phase (tools/launch_floor.py) */
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream);
+/* the same chain issued alternately on two streams (two independent dependency chains): does a second chain hide the launch floor? */
+int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b);
 /* run-time options (A/B switches kept for measurement; defaults are the fastest measured):
  *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
  *   "use_graph"         (0)  replay the decode loop from a captured hipGraph

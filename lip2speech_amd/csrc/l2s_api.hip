@@ -1456,6 +1456,14 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
     return 0;
 }
 
+int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b) {
+    for (int i = 0; i < n_launches; ++i) {
+        if (launch_probe(kind, blocks, n_per_block, in, out, (hipStream_t)stream_a)) return 1;
+        if (launch_probe(kind, blocks, n_per_block, in + (int64_t)(1 << 24), out + 2048, (hipStream_t)stream_b)) return 1;
+    }
+    return 0;
+}
+
 int l2s_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 int l2s_profile_reset(void) { prof_drain(); g_prof.clear(); g_prof_idx.clear(); return 0; }
 int l2s_profile_count(void) { prof_drain(); return (int)g_prof.size(); }

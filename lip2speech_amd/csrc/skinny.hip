@@ -97,8 +97,16 @@ __global__ __launch_bounds__(512) void probe_touch_kernel(const float* __restric
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
     if (threadIdx.x == 0) out[blockIdx.x] = acc.x;
 }
+// every block spins for `ticks` periods of the 100 MHz constant clock: a kernel of known duration, to expose the GPU-side gap between
+// dependent launches when the host enqueues faster than the GPU drains
+__global__ __launch_bounds__(512) void probe_spin_kernel(float* out, int ticks) {
+    const uint64_t t0 = wall_clock64();
+    while ((int64_t)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
+    if (threadIdx.x == 1023) out[0] = 0.f;
+}
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s) {
-    if (kind == 0) hipLaunchKernelGGL(probe_empty_kernel, dim3(blocks), dim3(512), 0, s, out);
+    if (kind == 2) hipLaunchKernelGGL(probe_spin_kernel, dim3(blocks), dim3(512), 0, s, out, n_per_block);
+    else if (kind == 0) hipLaunchKernelGGL(probe_empty_kernel, dim3(blocks), dim3(512), 0, s, out);
     else hipLaunchKernelGGL(probe_touch_kernel, dim3(blocks), dim3(512), 0, s, in, out, n_per_block);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

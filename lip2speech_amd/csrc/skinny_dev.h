@@ -76,7 +76,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
             else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
             a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
-            w[j] = wbase[(int64_t)c * 64];
+            w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
         }
     }
     // ---- epilogue operands have launch-time addresses too: fetch them under the same round trip
