@@ -54,8 +54,8 @@ class Decoder(ParamTree, NativeBacked):
 
     def _no_training(self):
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training (dropout + backward through the 300-step loop) on the HIP decoder is "
-                                      "not implemented yet; call .eval() (SURVEY.md §8(f) row 2)")
+            raise NotImplementedError("a stand-alone Decoder is forward-only: train through Lip2Speech.forward (one autograd node over "
+                                      "the HIP forward/backward of encoder + decoder) or call .eval() / torch.no_grad()")
 
     def forward(self, encoder_outputs, face_features, mels, text_lengths, output_lengths, tf_ratio,
                 gumbel_noise: Optional[torch.Tensor] = None):

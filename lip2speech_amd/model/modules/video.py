@@ -2,8 +2,9 @@
 
 Same constructor defaults, same ``state_dict`` keys (``frontend3D.*``, ``trunk.0.<unit>.banch*``,
 ``trunk.1.*``), same call contract ``(B,3,T,H,W) -> (B,T,768)`` L2-normalised; the arithmetic is
-``l2s_encoder_fwd`` (fused Conv3d front-end + ShuffleNetV2 trunk in HIP).  Inference only:
-gradients are a later row of SURVEY.md §8(f).
+``l2s_encoder_fwd`` (fused Conv3d front-end + ShuffleNetV2 trunk in HIP).  Called on its own the module is
+forward-only; gradients flow when it runs inside ``Lip2Speech.forward`` (``l2s_train_encoder_fwd/_bwd``, one autograd
+node for the whole model).
 """
 from __future__ import annotations
 
@@ -29,6 +30,6 @@ class VideoExtractor(ParamTree, NativeBacked):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("training (backward) through the HIP encoder is not implemented yet; "
-                                      "use .eval() / torch.no_grad() (SURVEY.md §8(f) row 2)")
+            raise NotImplementedError("a stand-alone VideoExtractor is forward-only: train through Lip2Speech.forward (one autograd "
+                                      "node over the HIP forward/backward of encoder + decoder) or call .eval() / torch.no_grad()")
         return self.native_model().encoder_fwd(x)

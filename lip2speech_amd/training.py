@@ -1,9 +1,8 @@
 """Training-side pieces of the data-parallel step (reference: /root/reference/train.py:102-104,172-193 and
-train_utils/losses.py:35-79), built so far: the 4-term loss (with its gradients), global-norm clipping + AdamW(amsgrad)
-as one fused HIP update over a flat parameter buffer, and the bucketed gradient all-reduce over RCCL (SURVEY.md §8(e):
-one all-reduce of 38 436 836 fp32 gradients per step, in ~25 MB buckets so the first buckets travel over xGMI while later
-ones are still being produced).  The backward kernels of the model itself are the next row; these pieces
-are independent of how the gradient buffer gets filled and are tested on their own.
+train_utils/losses.py:35-79): the 4-term loss (with its gradients), the forward+backward drivers of the decoder and of the whole
+model over the HIP kernels, global-norm clipping + AdamW(amsgrad) as one fused HIP update over a flat parameter buffer, and the
+bucketed gradient all-reduce over RCCL (one all-reduce of 38 436 836 fp32 gradients per step, in ~25 MB buckets).
+DESIGN.md §9 describes the path; tests/test_grad_goldens.py pins it to the reference's own backward.
 """
 from __future__ import annotations
 
