@@ -162,12 +162,14 @@ int l2s_train_bind(l2s_model* m, const char* key, float* param_dev, float* grad_
  * the literal step until the next l2s_model_finalize.  Replaces the host re-pack (~190 ms) by ~1 ms of device work. */
 int l2s_train_refresh_weights(l2s_model* m, void* stream);
 
-/* Post-net forward with a tape (decoder.py:143-156, eval-mode BatchNorm statistics, no dropout) and its backward:
- * mel dev (B,S,80) -> mel_post dev (B,80,S);  dmel_post dev (B,80,S) -> dmel dev (B,S,80) is ACCUMULATED into. */
+/* Post-net forward with a tape (decoder.py:143-156, eval-mode BatchNorm statistics) and its backward:
+ * mel dev (B,S,80) -> mel_post dev (B,80,S);  dmel_post dev (B,80,S) -> dmel dev (B,S,80) is ACCUMULATED into.
+ * drop: NULL (no dropout) or the five dropout multipliers (0 or 1/(1-p), p = 0.5; decoder.py:152,154) channel-last and back to back:
+ * layers 0..3 (B*S,512) each at offset l*B*S*512, layer 4 (B*S,80) at offset 4*B*S*512 - explicit inputs, like the Gumbel noise. */
 int64_t l2s_train_postnet_tape_floats(int B, int S);
 int64_t l2s_train_postnet_ws_bytes(int B, int S);
-int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, void* stream);
-int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel,
+int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, void* stream);
+int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel, const float* drop,
                           void* ws, int64_t ws_bytes, void* stream);
 
 /* Stage 2: the autoregressive loop with a tape and its back-propagation through time (decoder.py:353-375; the literal 6-phase
@@ -175,17 +177,22 @@ int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post
  * attn_logits dev (B,S,T) (also read by the backward).  Backward: dmel dev (B,S,80) = total gradient of the pre-postnet frames,
  * dstop dev (B,S); wbuf = l2s_train_steps_weights_floats() floats filled by l2s_train_steps_pack_weights (transposed step weights packed on
  * the device from the bound canonical parameters - repack after every optimizer step).  Outputs: parameter gradients into the bound
- * slots, dk / dv dev (B,T,512), dckey / dcval dev (B,min_T,256), dh_init dev (2,B,512), de_c dev (B,512). */
+ * slots, dk / dv dev (B,T,512), dckey / dcval dev (B,min_T,256), dh_init dev (2,B,512), de_c dev (B,512).
+ * Train-mode dropout sites of the loop as explicit multiplier inputs (0 or 1/(1-p); NULL = site off), the same tensors for fwd and bwd:
+ * drop_prenet dev (S,B,256) after the first prenet PSine (p 0.2, decoder.py:308); drop_attn dev (S,B,T) on the attention logits (p 0.1,
+ * :363 - the returned attn_logits are the dropped ones, as in the reference); drop_rnn dev (S,B,512) on h0 as input of LSTM layer 1
+ * (p 0.1, nn.LSTM(dropout=0.1), :312). */
 int64_t l2s_train_steps_tape_floats(int B, int S);
 int64_t l2s_train_steps_weights_floats(void);
 int64_t l2s_train_steps_ws_bytes(int B, int S);
 int l2s_train_steps_pack_weights(l2s_model* m, float* wbuf, void* stream);
 int l2s_train_steps_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
-                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes,
-                        void* stream);
+                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, const float* drop_prenet,
+                        const float* drop_attn, const float* drop_rnn, void* ws, int64_t ws_bytes, void* stream);
 int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* teacher_mask, float* tape, const float* attn_logits,
                         const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
-                        float* de_c, void* ws, int64_t ws_bytes, void* stream);
+                        float* de_c, const float* drop_prenet, const float* drop_attn, const float* drop_rnn, void* ws, int64_t ws_bytes,
+                        void* stream);
 
 /* Stage 3: the decoder prologue with a tape (decoder.py:321-351 / 383-410) and its backward down to the visual features.
  * Forward = l2s_decoder_prologue (same `state` buffer, same arguments) plus the tape.  Backward: the gradients of the state the loop

@@ -159,8 +159,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         float v = acc[r] * sc + sh;
         if (p.Zout) p.Zout[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
         v = apply_act(v, p.act, p.actw, col);
+        if (p.mask && p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
         if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];
         if (p.R2) v += p.R2[(int64_t)(p.r2_div ? row / p.r2_div : (p.r2_mod ? row % p.r2_mod : row)) * p.ldr2 + col];
+        if (p.mask && !p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
         if (p.c_tr_T > 0) {
             const int b = row / p.c_tr_T, t = row - b * p.c_tr_T;
             p.C[((int64_t)b * p.N + col) * p.c_tr_T + t] = v;

@@ -64,6 +64,8 @@ struct GemmP {
     int win_T, win_off;   // win_T > 0: rows cover the time window [win_off, win_off + Tout) of sequences of length win_T:
                           //   input frame = (win_off + t)*stride + tap - pad, output/residual row = b*win_T + win_off + t
     int vec;              // 4: float4 operand loads (K, Cin, lda, offsets multiples of 4); 1: scalar loads
+    const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
+    int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
 };
 constexpr int GEMM_MAX_GROUP = 8;
 struct GemmBatch {

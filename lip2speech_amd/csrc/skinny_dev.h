@@ -11,8 +11,11 @@ struct SkinnyTrain {               // training-side stores of one skinny group (
     float* gates; int64_t ld_gates;    // SK_LSTM: post-nonlinearity i,f,g,o at [b*ld_gates + gate*H + unit]
     float* c_new; int64_t ld_c;        // SK_LSTM: plain copy of the new cell state [b*ld_c + unit]
     float* out_plain; int ld_out;      // SK_FRAG: plain copy of the output [b*ld_out + n]
+    const float* out_mask; int ld_mask; // dropout multiplier (0 or 1/(1-p)) applied to the activated output [b*ld_mask + n]
+    float* h_drop; int h_drop_K; const float* h_mask; int ld_hmask;   // SK_LSTM: second frag16 copy of the new hidden state times a dropout mask
 };
 struct AttnTrain {
+    const float* logit_mask; int ld_lmask;   // dropout multiplier on the attention logits [b*ld_lmask + t] (decoder.py:363)
     float* alpha; int ld_alpha;        // content attention weights [b*ld_alpha + j]
     float* av_plain;                   // [b*512 + c]
     float* cc_plain;                   // [b*256 + c]
@@ -150,6 +153,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
                         gs[0] = sigmoidf_(gi); gs[H] = sigmoidf_(gf); gs[2 * H] = tanhf(gg); gs[3 * H] = sigmoidf_(go);
                     }
                     if (tr->c_new) tr->c_new[(int64_t)b2 * tr->ld_c + unit2] = cn;
+                    if (tr->h_drop) tr->h_drop[frag16_index(b2, unit2, tr->h_drop_K)] = tr->h_mask ? hn * tr->h_mask[(int64_t)b2 * tr->ld_hmask + unit2] : hn;
                 }
                 if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
                 if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
@@ -171,6 +175,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
     if constexpr (TRAIN) { if (tr->zsave) tr->zsave[(int64_t)b * tr->ld_z + np] = v; }
     v = act_apply(v, act, p.actw, np);
     v += pf_extra;
+    if constexpr (TRAIN) { if (tr->out_mask) v *= tr->out_mask[(int64_t)b * tr->ld_mask + np]; }
     if constexpr (TRAIN) { if (tr->out_plain) tr->out_plain[(int64_t)b * tr->ld_out + np] = v; }
     if (epi == SK_FRAG)
         p.out[frag16_index(b, np, p.ldo)] = v;
@@ -276,7 +281,8 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     __syncthreads();
     // ---- softmax over T (T <= 320 < 512: one element per thread)
     const bool on = tid < T;
-    const float x = on ? sc[tid] : -INFINITY;
+    float x = on ? sc[tid] : -INFINITY;
+    if constexpr (TRAIN) { if (on && tr->logit_mask) x *= tr->logit_mask[(int64_t)b * tr->ld_lmask + tid]; }
     const float mx = block_max8(x, scratch);
     const float ex = on ? expf(x - mx) : 0.f;
     const float tot = block_sum8(ex, scratch);

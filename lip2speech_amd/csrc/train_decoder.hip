@@ -137,7 +137,10 @@ static PostTape post_tape(float* base, int B, int S) {
     return t;
 }
 
-static int postnet_train_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, hipStream_t s) {
+// dropout masks of the post-net (decoder.py:152,154), channel-last like the activations: layers 0..3 (B*S,512) each, layer 4 (B*S,80)
+static const float* post_mask(const float* drop, int B, int S, int l) { return drop ? drop + (int64_t)l * B * S * 512 : nullptr; }
+
+static int postnet_train_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, hipStream_t s) {
     const Weights& w = m->w;
     PostTape t = post_tape(tape, B, S);
     for (int l = 0; l < 5; ++l) {
@@ -150,13 +153,27 @@ static int postnet_train_fwd(l2s_model* m, const float* mel, int B, int S, float
         if (l < 4) { p.act = ACT_PSINE; p.actw = w.post[l].actw; }
         if (l >= 1 && l <= 3) { p.R1 = in; p.ldr1 = 512; }
         if (l == 4) { p.R1 = mel; p.ldr1 = NM_; p.c_tr_T = S; }
+        p.mask = post_mask(drop, B, S, l); p.ldmask = cout; p.mask_pre = l == 4;     // the mel residual is added outside the Postnet module
         if (launch_gemm1(p, s, "train_postnet_conv_gemm")) return 1;
     }
     return 0;
 }
 
 // dmel_post (B,80,S) channel-first -> accumulates into dmel (B,S,80); parameter gradients into the bound slots
-static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_post_cf, int B, int S, float* tape, float* dmel, void* ws,
+__global__ __launch_bounds__(256) void mul_inplace_kernel(float* __restrict__ x, const float* __restrict__ m, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= m[i];
+}
+__global__ __launch_bounds__(256) void mul_out_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ m, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] * m[i];
+}
+static int mul_inplace(float* x, const float* m, int64_t n, hipStream_t s) {
+    ProfScope ps("train_dropout_mask", s);
+    hipLaunchKernelGGL(mul_inplace_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, x, m, n);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_post_cf, int B, int S, float* tape, float* dmel, const float* drop, void* ws,
                              int64_t ws_bytes, hipStream_t s) {
     const Weights& w = m->w;
     PostTape t = post_tape(tape, B, S);
@@ -176,6 +193,7 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
         const int cin = l == 0 ? NM_ : 512, cout = l == 4 ? NM_ : 512;
         const float* xin = l == 0 ? mel : t.x[l - 1];
         const std::string c = P + "convolutions." + std::to_string(l);
+        if (drop) { if (mul_inplace(g, post_mask(drop, B, S, l), R * cout, s)) return 1; }     // dropout sits after the residual add (layers 0..3) / after the last conv
         ActBwdP a{};
         a.dy = g; a.z = t.z[l]; a.dconv = gconv; a.rows = R; a.C = cout;
         a.act = l < 4 ? ACT_PSINE : ACT_NONE; a.actw = w.post[l].actw;
@@ -286,12 +304,13 @@ __global__ __launch_bounds__(256) void build_yprev_kernel(const float* __restric
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh_a, int ld_a, const float* __restrict__ dh_b, int ld_b,
                                                        float* __restrict__ dc_carry, const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                        const float* __restrict__ c_new, int B, int H, float* __restrict__ dg_frag, float* __restrict__ dg_stack,
-                                                       float* __restrict__ dg_stack2 = nullptr, int64_t ld_stack2_b = 0) {
+                                                       float* __restrict__ dg_stack2 = nullptr, int64_t ld_stack2_b = 0,
+                                                       const float* __restrict__ mask_b = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * H) return;
     const int b = idx / H, u = idx - b * H;
     float dh = dh_a[(int64_t)b * ld_a + u];
-    if (dh_b) dh += dh_b[(int64_t)b * ld_b + u];
+    if (dh_b) dh += dh_b[(int64_t)b * ld_b + u] * (mask_b ? mask_b[idx] : 1.f);     // mask_b: inter-layer dropout on the path into the next layer
     const float* g = gates + (int64_t)b * 4 * H + u;
     const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
     const float tc = tanhf(c_new[idx]);
@@ -329,14 +348,15 @@ __global__ __launch_bounds__(256) void build_dy_kernel(const float* __restrict__
 // generic: dz = dy * f'(z) with f = PSine(w) / SiLU / identity; writes dz as frag16 (K = C) and dy to a stack (for the parameter sums)
 __global__ __launch_bounds__(256) void act_bwd_small_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int act,
                                                             const float* __restrict__ actw, int B, int C, float* __restrict__ dz_frag,
-                                                            float* __restrict__ dy_stack) {
+                                                            float* __restrict__ dy_stack, const float* __restrict__ mask = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int Bp = (B + 15) & ~15;
     if (idx >= Bp * C) return;
     const int b = idx / C, c = idx - b * C;
     float dzv = 0.f;
     if (b < B) {
-        const float d = dy[(int64_t)b * ld_dy + c];
+        float d = dy[(int64_t)b * ld_dy + c];
+        if (mask) d *= mask[idx];                         // dropout on the activated output: [b*C + c]
         if (dy_stack) dy_stack[idx] = d;
         dzv = d;
         if (act == ACT_PSINE) dzv = d * cosf(z[idx]) * actw[c];
@@ -362,7 +382,8 @@ __global__ __launch_bounds__(256) void carry_update_kernel(const float* __restri
 struct AttnBwdP {
     const float* dav;                 // [B][512]
     const float* dcc; int ld_dcc;     // [B][ld]
-    const float* logits; int64_t ld_logit_b;   // logits of this step: [b*ld + t]
+    const float* logits; int64_t ld_logit_b;   // logits of this step (after dropout): [b*ld + t]
+    const float* lmask; int ld_lmask;          // dropout multiplier of the logits [b*ld + t] or null
     const float* k; const float* v;   // [B][T][512]
     const float* zq; const float* wq; const float* pos; const float* tau;
     const float* alpha;               // [B][16]
@@ -428,6 +449,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnBwdP p) {
     if (lane == 0) s_red[wave] = pt;
     __syncthreads();
     if (tid == 0) { float tt = 0.f; for (int i = 0; i < 8; ++i) tt += s_red[i]; p.dtau_part[b] = tt; }
+    // stored logit L = mask * tau q.k: the sum above is already d tau (mask*L_raw = L); q and k see the masked gradient
+    if (on && p.lmask) s_dl[tid] = dlt * p.lmask[(int64_t)b * p.ld_lmask + tid];
+    __syncthreads();
     // per column c = tid: q, dq, dk, dv
     {
         const float zq = p.zq[(int64_t)b * 512 + tid], wq = p.wq[tid];
@@ -534,10 +558,14 @@ static SkinnyP tsk(const SkW& sw, int B) {
 }
 
 // ---- forward of the loop with the tape (the literal 6-phase step; eval-mode statistics, no dropout)
-static int64_t step_fwd_ws_floats(int B) { return (int64_t)pad16(B) * (512 * 7 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 20; }
+static int64_t step_fwd_ws_floats(int B) { return (int64_t)pad16(B) * (512 * 8 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 20; }
+
+// dropout multipliers of the loop (train mode; any may be null): prenet (S,B,256) after the first PSine (decoder.py:308), attention
+// logits (S,B,T) (:363), inter-layer LSTM dropout (S,B,512) on h0 as the input of layer 1 (:312)
+struct StepDrop { const float* prenet; const float* attn; const float* rnn; };
 
 static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* mask, const uint8_t* mask_dev,
-                            float* tape_base, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
+                            float* tape_base, float* mel, float* stop, float* attn_logits, StepDrop drop, void* ws, int64_t ws_bytes, hipStream_t s) {
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     StepTape tp = step_tape(tape_base, B, S);
@@ -549,7 +577,9 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
     float* p1 = bp.f((int64_t)Bp * 256); float* cc = bp.f((int64_t)Bp * 256); float* uu = bp.f((int64_t)Bp * 256);
     float* yf = bp.f((int64_t)Bp * 96);
     float* q = bp.f((int64_t)B * 512); float* qc = bp.f((int64_t)B * 256); float* p2 = bp.f((int64_t)B * 256);
+    float* h0d = bp.f((int64_t)Bp * 512);
     L2S_REQUIRE(!bp.overflow, "training decode workspace too small");
+    if (launch_fill(h0d, (int64_t)Bp * 512, 0.f, s)) return 1;
     L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
     L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
     for (float* z : {h0[1], h1[1], c0, c1, av}) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
@@ -571,6 +601,7 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             SkinnyP a = tsk(w.pre1, B);
             a.seg[0] = {yf, 5}; a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
             tb.t[0].zsave = tp.z1 + r256; tb.t[0].ld_z = 256;
+            if (drop.prenet) { tb.t[0].out_mask = drop.prenet + r256; tb.t[0].ld_mask = 256; }
             SkinnyP b = tsk(w.q, B);
             b.seg[0] = {h0[cur], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2; b.act = ACT_PSINE; b.out = q; b.ldo = 512;
             b.addrow = w.pos + (int64_t)i * 512;
@@ -588,6 +619,7 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             at.attn_out = attn_logits + (int64_t)i * T; at.ld_attn_b = (int64_t)S * T; at.attn_logits = 1;
             at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
             at.B = B; at.T = T; at.m = sl.m;
+            if (drop.attn) { sb.att.logit_mask = drop.attn + (int64_t)i * B * T; sb.att.ld_lmask = T; }
             sb.att.alpha = tp.alpha + (int64_t)i * B * 16; sb.att.ld_alpha = 16; sb.att.av_plain = tp.av + r512; sb.att.cc_plain = tp.cc + r256;
             sb.pre2 = tsk(w.pre2, B);
             sb.pre2.seg[0] = {p1, 16}; sb.pre2.nseg = 1; sb.pre2.act = ACT_PSINE; sb.pre2.out = p2; sb.pre2.ldo = 256;
@@ -609,8 +641,9 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
             SkinnyP a = tsk(layer == 0 ? w.lstm0 : w.lstm1, B);
             if (layer == 0) { a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3; }
-            else { a.seg[0] = {h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2; }
+            else { a.seg[0] = {drop.rnn ? h0d : h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2; }
             a.epi = SK_LSTM; a.H = 512;
+            if (layer == 0 && drop.rnn) { tb.t[0].h_drop = h0d; tb.t[0].h_drop_K = 512; tb.t[0].h_mask = drop.rnn + r512; tb.t[0].ld_hmask = 512; }
             a.c_in = layer == 0 ? c0 : c1; a.c_out = a.c_in == c0 ? c0 : c1;
             a.h_out = layer == 0 ? h0[nxt] : h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             a.h_seq = (layer == 0 ? tp.h0 : tp.h1) + (int64_t)(i + 1) * B * 512; a.ld_hseq = 512;
@@ -718,7 +751,7 @@ static int64_t step_bwd_ws_floats(int B, int S) {
 // Outputs: parameter gradients (bound slots), dk/dv (B,T,512), dckey/dcval (B,m,256), dh_init (2,B,512), de_c (B,512).
 static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* mask, float* tape_base, const float* attn_logits,
                             const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
-                            float* de_c, void* ws, int64_t ws_bytes, hipStream_t s) {
+                            float* de_c, StepDrop drop, void* ws, int64_t ws_bytes, hipStream_t s) {
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     StepTape tp = step_tape(tape_base, B, S);
@@ -756,7 +789,7 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
                            tp.c1 + r512, tp.c1 + r512 + (int64_t)B * 512, B, 512, f_dg1, st_dg1 + r2048);
         if (run1(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), s, "train_bwd_lstm_dx")) return 1;
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh0c, 512, d01, 1024, dc0c, tp.g0 + r2048, tp.c0 + r512,
-                           tp.c0 + r512 + (int64_t)B * 512, B, 512, f_dg0, st_dg0 + r2048);
+                           tp.c0 + r512 + (int64_t)B * 512, B, 512, f_dg0, st_dg0 + r2048, (float*)nullptr, (int64_t)0, drop.rnn ? drop.rnn + r512 : nullptr);
         if (run1(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), s, "train_bwd_lstm_dx")) return 1;
         hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x + 256, 1024, (const float*)nullptr, (int)ACT_NONE, (const float*)nullptr, B, 256,
                            f_du, st_du + r256);
@@ -765,6 +798,7 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
         {
             AttnBwdP a{};
             a.dav = dav; a.dcc = d0x; a.ld_dcc = 1024; a.logits = attn_logits + (int64_t)i * T; a.ld_logit_b = (int64_t)S * T;
+            if (drop.attn) { a.lmask = drop.attn + (int64_t)i * B * T; a.ld_lmask = T; }
             a.k = state + sl.k; a.v = state + sl.v; a.zq = tp.zq + r512; a.wq = wq; a.pos = w.pos + (int64_t)i * 512; a.tau = w.tau;
             a.alpha = tp.alpha + (int64_t)i * B * 16; a.ckey = state + sl.ckey; a.cval = state + sl.cval; a.zc = tp.zc + r256; a.tau_c = w.tau_c;
             a.dk = dk; a.dv = dv; a.dckey = dckey; a.dcval = dcval; a.dzq_frag = f_dzq; a.dq_stack = st_dq + r512; a.dzc_frag = f_dzc;
@@ -781,7 +815,8 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
             if (launch_train_skinny(sb, tb, s, "train_bwd_q_cq_prenet2")) return 1;
         }
         hipLaunchKernelGGL(carry_update_kernel, dim3(ew(B * 512)), dim3(256), 0, s, d0x, d01, dhq, dcq, B, dh0c, dh1c, dc0c, dc1c);
-        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, dp1, 256, tp.z1 + r256, (int)ACT_PSINE, w1, B, 256, f_dz1, st_dp1 + r256);
+        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, dp1, 256, tp.z1 + r256, (int)ACT_PSINE, w1, B, 256, f_dz1, st_dp1 + r256,
+                           drop.prenet ? drop.prenet + r256 : nullptr);
         if (run1(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), s, "train_bwd_prenet1")) return 1;
         const bool forced = (i == 0) || (mask && mask[i]);
         use_carry = !forced;
@@ -809,7 +844,12 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     if (float* g = m->grad(D + "fc_out.linear_layer.bias")) hipLaunchKernelGGL(copy_rows_kernel, dim3(1), dim3(256), 0, s, small, 96, g, 80, 1, 80);
     if (float* g = m->grad(D + "stop_token_layer.linear_layer.bias")) hipLaunchKernelGGL(copy_rows_kernel, dim3(1), dim3(256), 0, s, small + 80, 96, g, 1, 1, 1);
     // LSTM layers
-    if (dw(st_dg1, 2048, 2048, h0new, 512, 512, m->grad(D + "decoder_rnn.weight_ih_l1"), 512)) return 1;
+    const float* l1_in = h0new;
+    if (drop.rnn) {                                     // layer 1 saw the dropped h0
+        hipLaunchKernelGGL(mul_out_kernel, dim3(4096), dim3(256), 0, s, st_tmp, h0new, drop.rnn, SB * 512);
+        l1_in = st_tmp;
+    }
+    if (dw(st_dg1, 2048, 2048, l1_in, 512, 512, m->grad(D + "decoder_rnn.weight_ih_l1"), 512)) return 1;
     if (dw(st_dg1, 2048, 2048, h1prev, 512, 512, m->grad(D + "decoder_rnn.weight_hh_l1"), 512)) return 1;
     if (colsum(st_dg1, SB, 2048, partials, st_tmp, small, false, s)) return 1;
     for (const char* k : {"decoder_rnn.bias_ih_l1", "decoder_rnn.bias_hh_l1"})
@@ -844,6 +884,7 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     }
     {   // prenet layer 2: input p1 = PSine(z1)
         hipLaunchKernelGGL(psine_fwd_kernel, dim3(2048), dim3(256), 0, s, tp.z1, w1, SB, 256, st_p1);
+        if (drop.prenet) { if (mul_inplace(st_p1, drop.prenet, SB * 256, s)) return 1; }
         ActBwdP a{}; a.dy = st_du; a.z = tp.z2; a.dconv = st_tmp; a.rows = SB; a.C = 256; a.act = ACT_PSINE; a.actw = w2; a.partials = partials;
         if (act_bwd(a, m->grad(D + "prenet.3.linear_layer.bias"), nullptr, m->grad(D + "prenet.4.w"), nullptr, false, s)) return 1;
         if (dw(st_tmp, 256, 256, st_p1, 256, 256, m->grad(D + "prenet.3.linear_layer.weight"), 256)) return 1;
@@ -1309,21 +1350,22 @@ int l2s_train_steps_pack_weights(l2s_model* m, float* wbuf, void* stream) {
 }
 
 int l2s_train_steps_fwd(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
-                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, void* ws, int64_t ws_bytes,
-                        void* stream) {
+                        const uint8_t* teacher_mask_dev, float* tape, float* mel, float* stop, float* attn_logits, const float* drop_prenet,
+                        const float* drop_attn, const float* drop_rnn, void* ws, int64_t ws_bytes, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && state && tape && mel && stop && attn_logits && ws, "bad arguments");
     L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS && B <= 96, "sizes");
     L2S_REQUIRE(!teacher || (teacher_mask && teacher_mask_dev), "teacher frames need the step mask on host and device");
-    return decode_train_fwd(m, state, B, T, S, teacher, teacher_mask, teacher_mask_dev, tape, mel, stop, attn_logits, ws, ws_bytes, (hipStream_t)stream);
+    return decode_train_fwd(m, state, B, T, S, teacher, teacher_mask, teacher_mask_dev, tape, mel, stop, attn_logits, StepDrop{drop_prenet, drop_attn, drop_rnn}, ws,
+                            ws_bytes, (hipStream_t)stream);
 }
 
 int l2s_train_steps_bwd(l2s_model* m, float* state, int B, int T, int S, const uint8_t* teacher_mask, float* tape, const float* attn_logits,
                         const float* dmel, const float* dstop, float* wbuf, float* dk, float* dv, float* dckey, float* dcval, float* dh_init,
-                        float* de_c, void* ws, int64_t ws_bytes, void* stream) {
+                        float* de_c, const float* drop_prenet, const float* drop_attn, const float* drop_rnn, void* ws, int64_t ws_bytes, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && state && tape && attn_logits && dmel && dstop && wbuf && dk && dv && dckey && dcval && dh_init && de_c && ws,
                 "bad arguments");
-    return decode_train_bwd(m, state, B, T, S, teacher_mask, tape, attn_logits, dmel, dstop, wbuf, dk, dv, dckey, dcval, dh_init, de_c, ws, ws_bytes,
-                            (hipStream_t)stream);
+    return decode_train_bwd(m, state, B, T, S, teacher_mask, tape, attn_logits, dmel, dstop, wbuf, dk, dv, dckey, dcval, dh_init, de_c,
+                            StepDrop{drop_prenet, drop_attn, drop_rnn}, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int64_t l2s_train_prologue_tape_floats(int B, int T) { return pro_tape_floats(B, T); }
@@ -1350,16 +1392,16 @@ int64_t l2s_train_postnet_ws_bytes(int B, int S) {
     return ((int64_t)B * S * 512 * 3 + (int64_t)512 * 5 * 512 + (int64_t)AB_RS * 3 * 512 + 64 * 8) * (int64_t)sizeof(float);
 }
 
-int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, void* stream) {
+int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && mel && tape && mel_post, "bad arguments");
-    return postnet_train_fwd(m, mel, B, S, tape, mel_post, (hipStream_t)stream);
+    return postnet_train_fwd(m, mel, B, S, tape, mel_post, drop, (hipStream_t)stream);
 }
 
-int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel, void* ws,
+int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post, int B, int S, float* tape, float* dmel, const float* drop, void* ws,
                           int64_t ws_bytes, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && mel && dmel_post && tape && dmel && ws, "bad arguments");
     L2S_REQUIRE(m->canon("decoder.postnet.convolutions.0.1.weight") != nullptr, "parameters not bound (l2s_train_bind)");
-    return postnet_train_bwd(m, mel, dmel_post, B, S, tape, dmel, ws, ws_bytes, (hipStream_t)stream);
+    return postnet_train_bwd(m, mel, dmel_post, B, S, tape, dmel, drop, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

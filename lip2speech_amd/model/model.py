@@ -26,19 +26,23 @@ class _HipTrainStep(torch.autograd.Function):
     parameter of the model - it only makes autograd call `backward`."""
 
     @staticmethod
-    def forward(ctx, anchor, model, video, emb, gumbel, mels, mask):
+    def forward(ctx, anchor, model, video, emb, gumbel, mels, mask, drop):
         nm = model.native_model()
         B, _, T, _, _ = video.shape
         S = mels.shape[2]
+        drop = drop or {}
+        pdrop = native.postnet_drop_pack(drop["post"]) if drop.get("post") is not None else None
         vis, _, etape = nm.train_encoder_fwd(video, emb)
+        if drop.get("feat") is not None:
+            vis[:, :, :768] *= drop["feat"]                 # F.dropout(self.encoder(video_frames), 0.1, self.training), model.py:26
         state, dis, ptape = nm.train_prologue_fwd(vis, emb, gumbel)
         teacher = None
         if mask is not None:
             bos = model.decoder.BOS.detach().to(torch.float32).reshape(1, 1, -1).expand(B, 1, -1)
             teacher = torch.cat([bos, mels.detach().to(torch.float32).permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
-        (mel, stop, logits), sctx = nm.train_steps_fwd(state, B, T, S, teacher, mask)
-        mel_post, post_tape = nm.train_postnet_fwd(mel)
-        ctx.model, ctx.tapes = model, (video, emb, vis, etape, state, ptape, sctx, mel, post_tape)
+        (mel, stop, logits), sctx = nm.train_steps_fwd(state, B, T, S, teacher, mask, drop=drop)
+        mel_post, post_tape = nm.train_postnet_fwd(mel, pdrop)
+        ctx.model, ctx.tapes = model, (video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, drop.get("feat"))
         ctx.mark_non_differentiable(logits)
         return mel.permute(0, 2, 1).contiguous(), mel_post, stop.unsqueeze(2), logits, dis
 
@@ -46,23 +50,25 @@ class _HipTrainStep(torch.autograd.Function):
     def backward(ctx, dmel_cf, dmel_post, dstop, _dlogits, ddis):
         model = ctx.model
         nm = model.native_model()
-        video, emb, vis, etape, state, ptape, sctx, mel, post_tape = ctx.tapes
+        video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, fdrop = ctx.tapes
         B, S = mel.shape[0], mel.shape[1]
         flat = model._flat
         live = model._grads_live()
         prev = flat.grad.clone() if live else None                    # gradient accumulation across backward() calls
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g  # noqa: E731
         wbuf = nm.train_pack_weights(video.device)
-        dmel = nm.train_postnet_bwd(mel, z(dmel_post, mel.permute(0, 2, 1)), post_tape)
+        dmel = nm.train_postnet_bwd(mel, z(dmel_post, mel.permute(0, 2, 1)), post_tape, pdrop)
         if dmel_cf is not None:
             dmel += dmel_cf.permute(0, 2, 1)
         sg = nm.train_steps_bwd(sctx, dmel, z(dstop, mel[:, :, :1]).reshape(B, S), wbuf=wbuf)
         dvis = nm.train_prologue_bwd(vis, emb, state, ptape, sg, dcontent_dis=ddis, wbuf=wbuf)
+        if fdrop is not None:
+            dvis[:, :, :768] *= fdrop
         nm.train_encoder_bwd(video, dvis, etape)
         if prev is not None:
             flat.grad += prev
         model._attach_grads()
-        return (None,) * 7
+        return (None,) * 8
 
 
 class Lip2Speech(NativeBacked):
@@ -124,9 +130,9 @@ class Lip2Speech(NativeBacked):
         return self.vgg_face.inference(face_frames[:, 0, :, :, :])
 
     def forward(self, video_frames, face_frames, audio_frames, melspecs, video_lengths, audio_lengths, melspec_lengths,
-                tf_ratio, speaker_embedding=None, gumbel_noise=None):
+                tf_ratio, speaker_embedding=None, gumbel_noise=None, dropout_masks=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.decoder.parameters()):
-            return self._forward_train(video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise)
+            return self._forward_train(video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise, dropout_masks)
         video_features = F.dropout(self.encoder(video_frames), 0.1, self.training)
         emb = self._speaker(face_frames, speaker_embedding)
         vis = native.build_visual(video_features, emb)
@@ -134,10 +140,12 @@ class Lip2Speech(NativeBacked):
         outputs = self.decoder(vis, face, melspecs, video_lengths, melspec_lengths, tf_ratio, gumbel_noise=gumbel_noise)
         return outputs + [video_lengths]
 
-    def _forward_train(self, video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise):
+    def _forward_train(self, video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise, dropout_masks=None):
         """The differentiable route (train.py:167-184): same outputs as `forward`, attached to autograd through `_HipTrainStep`.
-        Normalisation layers use their running statistics and the dropout sites are the identity in this build (the configuration the
-        reference gradient goldens pin); batch-statistics BatchNorm and dropout masks are the next increment."""
+        In `train()` mode the five dropout sites of the reference are active (multipliers drawn on the device by `training.draw_dropout`
+        and handed to the kernels as inputs, or supplied through `dropout_masks=`); in `eval()` mode they are off (the configuration the
+        reference gradient goldens pin).  Normalisation layers use their running statistics in both modes in this build; batch-statistics
+        BatchNorm is the next increment."""
         self._train_state()
         with torch.no_grad():
             emb = self._speaker(face_frames, speaker_embedding).to(torch.float32).contiguous()
@@ -150,8 +158,12 @@ class Lip2Speech(NativeBacked):
             take = bool(torch.rand(1) > tf_ratio) and consumed < int(tf_ratio * S)
             consumed += int(take)
             mask.append(1 if take else 0)
+        drop = dropout_masks
+        if drop is None and self.training:
+            from ..training import draw_dropout
+            drop = draw_dropout(B, T, S, video_frames.device)
         mel, mel_post, stop, attn, dis = _HipTrainStep.apply(self.decoder.BOS, self, video_frames.detach().to(torch.float32).contiguous(), emb,
-                                                             gumbel_noise.detach().to(torch.float32).contiguous(), melspecs, mask if any(mask) else None)
+                                                             gumbel_noise.detach().to(torch.float32).contiguous(), melspecs, mask if any(mask) else None, drop)
         return [mel, mel_post, stop, emb, attn, dis, video_lengths]
 
     def inference(self, video_frames, face_frames, speaker_embedding=None, return_attention_map=False, gumbel_noise=None):

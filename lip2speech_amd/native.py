@@ -88,16 +88,16 @@ def lib() -> ctypes.CDLL:
     L.l2s_train_postnet_tape_floats.restype = _i64
     L.l2s_train_postnet_ws_bytes.argtypes = [_i, _i]
     L.l2s_train_postnet_ws_bytes.restype = _i64
-    L.l2s_train_postnet_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _vp]
-    L.l2s_train_postnet_bwd.argtypes = [_vp, _fp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_postnet_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _fp, _fp, _vp]
+    L.l2s_train_postnet_bwd.argtypes = [_vp, _fp, _fp, _i, _i, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_steps_tape_floats.argtypes = [_i, _i]
     L.l2s_train_steps_tape_floats.restype = _i64
     L.l2s_train_steps_weights_floats.restype = _i64
     L.l2s_train_steps_ws_bytes.argtypes = [_i, _i]
     L.l2s_train_steps_ws_bytes.restype = _i64
     L.l2s_train_steps_pack_weights.argtypes = [_vp, _fp, _vp]
-    L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
-    L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_refresh_weights.argtypes = [_vp, _vp]
     L.l2s_train_encoder_tape_floats.argtypes = [_i, _i, _i]
     L.l2s_train_encoder_tape_floats.restype = _i64
@@ -267,30 +267,30 @@ class NativeModel:
         """Device-side re-pack of the weight blob from the bound tensors (needs set_option('refresh_map', 1) before load())."""
         check(lib().l2s_train_refresh_weights(self._h, _stream()))
 
-    def train_postnet_fwd(self, mel: torch.Tensor):
-        """Post-net forward with a tape: mel (B,S,80) -> (mel_post (B,80,S), tape)."""
+    def train_postnet_fwd(self, mel: torch.Tensor, drop: Optional[torch.Tensor] = None):
+        """Post-net forward with a tape: mel (B,S,80) -> (mel_post (B,80,S), tape).  drop: packed dropout multipliers (postnet_drop_pack)."""
         mel = _f32(mel)
         B, S, _ = mel.shape
         L = lib()
         tape = torch.zeros(int(L.l2s_train_postnet_tape_floats(B, S)), dtype=torch.float32, device=mel.device)
         out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
-        check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _stream()))
+        check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _ptr(drop), _stream()))
         return out, tape
 
-    def train_postnet_bwd(self, mel: torch.Tensor, dmel_post: torch.Tensor, tape: torch.Tensor) -> torch.Tensor:
+    def train_postnet_bwd(self, mel: torch.Tensor, dmel_post: torch.Tensor, tape: torch.Tensor, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Post-net backward: dmel_post (B,80,S) -> dmel (B,S,80) (residual path included); parameter gradients into the bound slots."""
         mel, dmel_post = _f32(mel), _f32(dmel_post)
         B, S, _ = mel.shape
         L = lib()
         dmel = torch.zeros_like(mel)
         ws = torch.empty(int(L.l2s_train_postnet_ws_bytes(B, S)), dtype=torch.uint8, device=mel.device)
-        check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(ws), ws.numel(), _stream()))
+        check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(drop), _ptr(ws), ws.numel(), _stream()))
         return dmel
 
-    def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor):
+    def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor, drop: Optional[torch.Tensor] = None):
         """Post-net forward + backward (stage 1 of the training path): returns mel_post (B,80,S) and dmel (B,S,80)."""
-        out, tape = self.train_postnet_fwd(mel)
-        return out, self.train_postnet_bwd(mel, dmel_post, tape)
+        out, tape = self.train_postnet_fwd(mel, drop)
+        return out, self.train_postnet_bwd(mel, dmel_post, tape, drop)
 
     def train_pack_weights(self, device) -> torch.Tensor:
         """Transposed step / prologue weights for the backward GEMMs, packed on the device from the bound parameters."""
@@ -299,8 +299,14 @@ class NativeModel:
         check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
         return wbuf
 
-    def train_steps_fwd(self, state, B, T, S, teacher=None, teacher_mask=None):
-        """Loop forward with a tape.  Returns (mel (B,S,80), stop (B,S), attn_logits (B,S,T)) and the context for train_steps_bwd."""
+    def train_steps_fwd(self, state, B, T, S, teacher=None, teacher_mask=None, drop=None):
+        """Loop forward with a tape.  Returns (mel (B,S,80), stop (B,S), attn_logits (B,S,T)) and the context for train_steps_bwd.
+        drop: dict of dropout multipliers (any subset): 'prenet' (S,B,256), 'attn' (S,B,T), 'rnn' (S,B,512)."""
+        drop = {k: _f32(v) for k, v in (drop or {}).items() if k in ("prenet", "attn", "rnn") and v is not None}
+        dp, da, dr = drop.get("prenet"), drop.get("attn"), drop.get("rnn")
+        assert dp is None or tuple(dp.shape) == (S, B, 256)
+        assert da is None or tuple(da.shape) == (S, B, T)
+        assert dr is None or tuple(dr.shape) == (S, B, 512)
         L, dev = lib(), state.device
         tape = torch.zeros(int(L.l2s_train_steps_tape_floats(B, S)), dtype=torch.float32, device=dev)
         ws = torch.empty(int(L.l2s_train_steps_ws_bytes(B, S)), dtype=torch.uint8, device=dev)
@@ -314,8 +320,9 @@ class NativeModel:
             mask_dev = torch.from_numpy(mask_np).to(dev)
             mask_ptr = mask_np.ctypes.data_as(_vp)
         check(L.l2s_train_steps_fwd(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_ptr, _ptr(mask_dev) if mask_dev is not None else None,
-                                    _ptr(tape), _ptr(mel), _ptr(stop), _ptr(logits), _ptr(ws), ws.numel(), _stream()))
-        ctx = dict(state=state, B=B, T=T, S=S, tape=tape, ws=ws, logits=logits, mask_np=mask_np, mask_ptr=mask_ptr, teacher=teacher, mask_dev=mask_dev)
+                                    _ptr(tape), _ptr(mel), _ptr(stop), _ptr(logits), _ptr(dp), _ptr(da), _ptr(dr), _ptr(ws), ws.numel(), _stream()))
+        ctx = dict(state=state, B=B, T=T, S=S, tape=tape, ws=ws, logits=logits, mask_np=mask_np, mask_ptr=mask_ptr, teacher=teacher, mask_dev=mask_dev,
+                   drop=(dp, da, dr))
         return (mel, stop, logits), ctx
 
     def train_steps_bwd(self, ctx, dmel, dstop, wbuf=None):
@@ -330,12 +337,12 @@ class NativeModel:
         ws = ctx["ws"]
         check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, ctx["mask_ptr"], _ptr(ctx["tape"]), _ptr(ctx["logits"]), _ptr(_f32(dmel)), _ptr(_f32(dstop)),
                                     _ptr(wbuf), _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
-                                    _ptr(ws), ws.numel(), _stream()))
+                                    _ptr(ctx["drop"][0]), _ptr(ctx["drop"][1]), _ptr(ctx["drop"][2]), _ptr(ws), ws.numel(), _stream()))
         return out
 
-    def train_steps(self, state, B, T, S, dmel, dstop, teacher=None, teacher_mask=None):
+    def train_steps(self, state, B, T, S, dmel, dstop, teacher=None, teacher_mask=None, drop=None):
         """Loop forward-with-tape + BPTT (stage 2 of the training path).  Returns (mel, stop, attn_logits) and the state gradients."""
-        outs, ctx = self.train_steps_fwd(state, B, T, S, teacher, teacher_mask)
+        outs, ctx = self.train_steps_fwd(state, B, T, S, teacher, teacher_mask, drop=drop)
         return outs, self.train_steps_bwd(ctx, dmel, dstop)
 
     def train_encoder_fwd(self, video, emb=None):
@@ -400,6 +407,19 @@ class NativeModel:
         out = torch.empty(B * T, H // 4, W // 4, 24, dtype=torch.float32, device=video.device)
         check(lib().l2s_op_frontend(self._h, _ptr(video), B, T, H, W, _ptr(out), _stream()))
         return out
+
+
+def postnet_drop_pack(masks) -> torch.Tensor:
+    """Five post-net dropout multipliers in the reference's layout - (B,512,S) x4 and (B,80,S) - packed channel-last, back to back
+    (the layout l2s_train_postnet_fwd/_bwd read)."""
+    assert len(masks) == 5
+    B, _, S = masks[0].shape
+    out = torch.zeros(4 * B * S * 512 + B * S * 80, dtype=torch.float32, device=masks[0].device)
+    for l, mk in enumerate(masks):
+        C = 512 if l < 4 else 80
+        assert tuple(mk.shape) == (B, C, S)
+        out[l * B * S * 512: l * B * S * 512 + B * S * C] = mk.to(torch.float32).permute(0, 2, 1).reshape(-1)
+    return out
 
 
 def build_visual(feat: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:

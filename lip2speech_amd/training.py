@@ -88,7 +88,20 @@ def loss_terms(mel, mel_post, stop, content_dis, mel_target, gate_target, want_g
     return out, grads
 
 
-def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None):
+def draw_dropout(B: int, T: int, S: int, device, generator=None) -> dict:
+    """The train-mode dropout multipliers of one `Lip2Speech.forward` (0 or 1/(1-p)) as explicit tensors, in the order the reference
+    consumes its RNG: features p 0.1 (model.py:26), per step prenet p 0.2 / attention logits p 0.1 / LSTM inter-layer
+    p 0.1 (decoder.py:308,363,312), post-net p 0.5 x5 (:152,154).  torch's own Philox streams are not reproduced bit for bit (that
+    would need the reference's exact draw shapes on its device); the masks are inputs, like the Gumbel noise, so a run is reproducible
+    and comparable against the oracle."""
+    def mk(shape, p):
+        return (torch.rand(shape, device=device, generator=generator) >= p).to(torch.float32) / (1.0 - p)
+    d = {"feat": mk((B, T, 768), 0.1), "prenet": mk((S, B, 256), 0.2), "attn": mk((S, B, T), 0.1), "rnn": mk((S, B, 512), 0.1)}
+    d["post"] = [mk((B, 512 if l < 4 else 80, S), 0.5) for l in range(5)]
+    return d
+
+
+def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None, drop=None):
     """Forward + backward of the decoder half of `Lip2Speech.forward` + `Loss.forward` (reference: model.py:34-41 -> decoder.py:320-379,
     losses.py:69-77, train.py:172-184) with eval-mode statistics (running BN stats, no dropout): prologue -> S-step loop -> post-net ->
     4-term loss, then back through the post-net, the loop (BPTT) and the prologue.  Parameter gradients land in the slots bound with
@@ -98,6 +111,11 @@ def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_tar
     decoder.py:355-359); `bos` is the device BOS parameter (needed only with a mask)."""
     B, T, _ = vis.shape
     S = mel_target.shape[2]
+    drop = drop or {}
+    pdrop = native.postnet_drop_pack(drop["post"]) if drop.get("post") is not None else None
+    if drop.get("feat") is not None:                      # F.dropout on the encoder features (model.py:26); the embedding columns pass
+        vis = vis.clone()
+        vis[:, :, :768] *= drop["feat"]
     state, dis, ptape = nm.train_prologue_fwd(vis, emb, gumbel)
     teacher = None
     if teacher_mask is not None and bool(torch.as_tensor(teacher_mask).any()):
@@ -106,24 +124,26 @@ def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_tar
         teacher_mask = torch.as_tensor(teacher_mask).cpu().numpy()
     else:
         teacher_mask = None
-    (mel, stop, logits), ctx = nm.train_steps_fwd(state, B, T, S, teacher, teacher_mask)
-    mel_post, post_tape = nm.train_postnet_fwd(mel)
+    (mel, stop, logits), ctx = nm.train_steps_fwd(state, B, T, S, teacher, teacher_mask, drop=drop)
+    mel_post, post_tape = nm.train_postnet_fwd(mel, pdrop)
     mel_cf = mel.permute(0, 2, 1).contiguous()
     loss, g = loss_terms(mel_cf, mel_post, stop, dis, mel_target, gate_target)
     wbuf = nm.train_pack_weights(vis.device)
-    dmel = nm.train_postnet_bwd(mel, g["mel_post"], post_tape)
+    dmel = nm.train_postnet_bwd(mel, g["mel_post"], post_tape, pdrop)
     dmel += g["mel"].permute(0, 2, 1)
     sg = nm.train_steps_bwd(ctx, dmel, g["stop"], wbuf=wbuf)
     dvis = nm.train_prologue_bwd(vis, emb, state, ptape, sg, dcontent_dis=g["content_dis"], wbuf=wbuf)
+    if drop.get("feat") is not None:
+        dvis[:, :, :768] *= drop["feat"]
     return {"loss": loss, "mel": mel_cf, "mel_post": mel_post, "stop": stop, "attn_logits": logits, "content_dis": dis, "dvis": dvis}
 
 
-def model_forward_backward(nm: "native.NativeModel", video, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None):
+def model_forward_backward(nm: "native.NativeModel", video, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None, drop=None):
     """`Lip2Speech.forward` + `Loss` + `backward()` (model.py:20-41, train.py:167-184) with the speaker embedding supplied and eval-mode
     statistics: encoder forward with a tape, `decoder_forward_backward`, then the encoder backward fed by the visual-feature gradient.
     All encoder and decoder parameter gradients land in the bound slots."""
     vis, _, etape = nm.train_encoder_fwd(video, emb)
-    out = decoder_forward_backward(nm, vis, emb, gumbel, mel_target, gate_target, teacher_mask=teacher_mask, bos=bos)
+    out = decoder_forward_backward(nm, vis, emb, gumbel, mel_target, gate_target, teacher_mask=teacher_mask, bos=bos, drop=drop)
     nm.train_encoder_bwd(video, out["dvis"], etape)
     return out
 

@@ -229,9 +229,12 @@ def decoder_prologue(sd: SD, vis: torch.Tensor, emb: torch.Tensor, gumbel: torch
 
 
 def decode_loop(sd: SD, st: dict, S: int, p: str = "decoder.", teacher: Optional[torch.Tensor] = None,
-                teacher_mask: Optional[torch.Tensor] = None, return_logits: bool = False):
+                teacher_mask: Optional[torch.Tensor] = None, return_logits: bool = False, drop: Optional[dict] = None):
     """decoder.py:412-429 (inference) / 353-375 (forward).  ``teacher`` (B,S,80) with boolean ``teacher_mask`` (S,)
-    substitutes the previous frame at the marked steps (scheduled sampling made explicit).  Returns
+    substitutes the previous frame at the marked steps (scheduled sampling made explicit).  ``drop`` holds the train-mode dropout
+    multipliers (0 or 1/(1-p)) as explicit tensors: 'prenet' (S,B,256) nn.Dropout(0.2) :308, 'attn' (S,B,T) F.dropout(logits, 0.1) :363
+    (the returned logits are the dropped ones, as the reference appends after the dropout), 'rnn' (S,B,512) nn.LSTM(dropout=0.1) :312
+    between the two layers.  Returns
     mel (B,S,80), stop logits (B,S), attention (B,S,T) (post-softmax, or tau*q.k logits if return_logits)."""
     k, v, key, value = st["k"], st["v"], st["key"], st["value"]
     h0, h1 = st["hidden"][0], st["hidden"][1]
@@ -245,10 +248,15 @@ def decode_loop(sd: SD, st: dict, S: int, p: str = "decoder.", teacher: Optional
     for i in range(S):
         if teacher is not None and teacher_mask is not None and bool(teacher_mask[i]):
             y = teacher[:, i]
+        drop = drop or {}
         pr = psine_last(linear(y, sd, p + "prenet.0.linear_layer"), sd[p + "prenet.1.w"])
+        if drop.get("prenet") is not None:
+            pr = pr * drop["prenet"][i]
         pr = psine_last(linear(pr, sd, p + "prenet.3.linear_layer"), sd[p + "prenet.4.w"])
         q = psine_last(linear(torch.cat([h0, h1], dim=1), sd, p + "Q.0.linear_layer"), sd[p + "Q.1.w"]) + pos[i]
         logits = torch.bmm((q * tau).unsqueeze(1), k).squeeze(1)                  # (B,T)
+        if drop.get("attn") is not None:
+            logits = logits * drop["attn"][i]
         a = torch.softmax(logits, dim=-1)
         attns.append(logits if return_logits else a)
         o = linear(torch.bmm(a.unsqueeze(1), v).squeeze(1), sd, p + "attention_proj.linear_layer")
@@ -259,7 +267,7 @@ def decode_loop(sd: SD, st: dict, S: int, p: str = "decoder.", teacher: Optional
         h0, c0 = lstm_cell(torch.cat([cc, u], dim=1), h0, c0,
                            sd[p + "decoder_rnn.weight_ih_l0"], sd[p + "decoder_rnn.weight_hh_l0"],
                            sd[p + "decoder_rnn.bias_ih_l0"], sd[p + "decoder_rnn.bias_hh_l0"])
-        h1, c1 = lstm_cell(h0, h1, c1,
+        h1, c1 = lstm_cell(h0 if drop.get("rnn") is None else h0 * drop["rnn"][i], h1, c1,
                            sd[p + "decoder_rnn.weight_ih_l1"], sd[p + "decoder_rnn.weight_hh_l1"],
                            sd[p + "decoder_rnn.bias_ih_l1"], sd[p + "decoder_rnn.bias_hh_l1"])
         y = linear(h1, sd, p + "fc_out.linear_layer")
@@ -275,8 +283,9 @@ def output_lengths_from_stop(stop_logits: torch.Tensor, S: int) -> torch.Tensor:
     return first.to(torch.int64)
 
 
-def postnet(sd: SD, mel: torch.Tensor, p: str = "decoder.postnet.") -> torch.Tensor:
-    """decoder.py:143-156: mel (B,80,S) -> residual correction (B,80,S) (caller adds mel)."""
+def postnet(sd: SD, mel: torch.Tensor, p: str = "decoder.postnet.", drop=None) -> torch.Tensor:
+    """decoder.py:143-156: mel (B,80,S) -> residual correction (B,80,S) (caller adds mel).  ``drop``: the five train-mode dropout
+    multipliers (p 0.5, :152,154) as explicit tensors (B,C,S), applied after the residual add / after the last conv."""
     x = mel
     for i in range(5):
         y = F.conv1d(x, sd[f"{p}convolutions.{i}.0.conv.weight"], sd[f"{p}convolutions.{i}.0.conv.bias"], padding=2)
@@ -285,6 +294,8 @@ def postnet(sd: SD, mel: torch.Tensor, p: str = "decoder.postnet.") -> torch.Ten
             y = psine_channels_first(y, sd[f"{p}sin_activation.{i}.w"])
             if i != 0:
                 y = y + x
+        if drop is not None:
+            y = y * drop[i]
         x = y
     return x
 

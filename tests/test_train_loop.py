@@ -53,7 +53,7 @@ def oracle_loop():
 def run_hip_loop(fused: bool):
     from model.model import get_network
     from lip2speech_amd.training import AdamWAmsgrad
-    net = get_network("train").cuda()
+    net = get_network("train").cuda().eval()       # eval(): dropout off - the deterministic configuration the oracle loop runs
     net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
     video, emb, gum, mels, gate = (t.cuda() for t in inputs())
     lens = torch.full((B,), T, device="cuda")
@@ -127,3 +127,26 @@ def test_device_refresh_equals_host_repack():
     base = pc.native_model()
     mel_b, _, _ = base.inference(video, emb, gum, S=300)
     assert pc.maxdiff(mel, mel_b) > 1e-3
+
+
+@pytest.mark.gpu
+def test_train_mode_applies_dropout():
+    """`net.train()`: the dropout sites are live (statistically pinned): ~10 % of the returned attention logits are
+    exactly zero, two forward passes differ, the backward runs; `net.eval()` with autograd stays deterministic."""
+    from model.model import get_network
+    net = get_network("train").cuda()
+    net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
+    video, emb, gum, mels, gate = (t.cuda() for t in inputs())
+    lens = torch.full((B,), T, device="cuda")
+    torch.manual_seed(0)
+    o1 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+    o2 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+    frac = float((o1[4] == 0).float().mean())
+    assert 0.05 < frac < 0.16, frac
+    assert pc.maxdiff(o1[0], o2[0]) > 1e-3
+    orc.loss_terms(o1, mels, gate)[-1].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.decoder.parameters())
+    net.eval()
+    e1 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+    e2 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+    assert torch.equal(e1[0], e2[0]) and float((e1[4] == 0).float().mean()) == 0.0

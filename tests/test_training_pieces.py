@@ -313,3 +313,59 @@ def test_encoder_backward_matches_autograd(synth_sd, B, T):
         if not (min(e32, e64) < 2e-4 and max(e32, e64) < 5e-2):     # a flip separates the HIP forward from one oracle precision or the other
             bad.append(f"{k}: relative error vs fp32 oracle {e32:.2e}, vs fp64 oracle {e64:.2e} (scale {scale:.2e})")
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.gpu
+def test_dropout_sites_match_oracle(synth_sd):
+    """Train-mode dropout as explicit multiplier inputs at the five sites of the reference (features, prenet, attention logits, LSTM
+    inter-layer, post-net x5): the HIP decoder step with masks against autograd through the oracle with the same masks - outputs,
+    loss terms, every decoder parameter gradient and the gradient wrt the visual features."""
+    import parity_common as pc
+    from lip2speech_amd import synth
+    from lip2speech_amd.training import decoder_forward_backward, draw_dropout
+    from oracle import l2s_oracle as orc
+    B, T, S = 2, 29, 20
+    gen = torch.Generator().manual_seed(77)
+    drop = draw_dropout(B, T, S, "cpu", generator=gen)
+    feat = torch.nn.functional.normalize(torch.randn(B, T, 768, generator=gen), dim=-1)
+    emb = synth.synth_speaker_embedding(B, tag="drop")
+    gum = synth.synth_gumbel(B * 4, tag="drop")
+    mels = synth.synth_mels(B, S, tag="drop")
+    gate = torch.zeros(B, S)
+    gate[:, -1] = 1.0
+    mask = torch.zeros(S, dtype=torch.bool)
+    mask[[2, 3, 11]] = True
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked", "pos_table"))      # noqa: E731
+    dec = [k for k in synth_sd if k.startswith("decoder.") and synth_sd[k].is_floating_point()]
+    par = [k for k in dec if not is_buf(k)]
+    sd64 = {k: synth_sd[k].detach().clone().double().requires_grad_(k in par) for k in dec}
+    vis64 = orc.build_visual(feat, emb).double().requires_grad_(True)
+    d64 = {k: ([m.double() for m in v] if isinstance(v, list) else v.double()) for k, v in drop.items()}
+    vis_in = torch.cat([vis64[:, :, :768] * d64["feat"], vis64[:, :, 768:]], dim=2)
+    st = orc.decoder_prologue(sd64, vis_in, emb.double(), gum.double())
+    teacher = torch.cat([sd64["decoder.BOS"].view(1, 1, -1).expand(B, -1, -1), mels.double().permute(0, 2, 1)], dim=1)
+    mel_o, stop_o, logit_o = orc.decode_loop(sd64, st, S, teacher=teacher, teacher_mask=mask, return_logits=True, drop=d64)
+    mel_cf = mel_o.permute(0, 2, 1)
+    post_o = orc.postnet(sd64, mel_cf, drop=d64["post"]) + mel_cf
+    terms = orc.loss_terms([mel_cf, post_o, stop_o.unsqueeze(2), None, logit_o, st["content_dis"]], mels.double(), gate.double())
+    terms[-1].backward()
+
+    nm = pc.native_model(synth_sd)
+    params = {k: synth_sd[k].cuda() for k in par}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    nm.train_bind(params, grads)
+    cdrop = {k: ([m.cuda() for m in v] if isinstance(v, list) else v.cuda()) for k, v in drop.items()}
+    out = decoder_forward_backward(nm, orc.build_visual(feat, emb).cuda(), emb.cuda(), gum.cuda(), mels.cuda(), gate.cuda(), teacher_mask=mask,
+                                   bos=params["decoder.BOS"], drop=cdrop)
+    assert pc.maxdiff(out["mel"], mel_cf) < 2e-4 and pc.maxdiff(out["mel_post"], post_o) < 5e-4
+    assert pc.maxdiff(out["attn_logits"], logit_o) / logit_o.abs().max().item() < 1e-5
+    want = torch.stack([t.detach() for t in terms])
+    assert (out["loss"].cpu().double() - want).abs().max() < 2e-5 * want.abs().max()
+
+    def rel(got, ref):
+        ref = ref.reshape(got.shape)
+        return pc.maxdiff(got, ref) / max(1e-6, ref.abs().max().item())
+    assert rel(out["dvis"], vis64.grad) < 3e-3
+    bad = [f"{k}: {rel(grads[k], sd64[k].grad):.2e}" for k in par if not k.startswith(("decoder.K.", "decoder.temperature", "decoder.Q."))
+           and rel(grads[k], sd64[k].grad) > 3e-3]
+    assert not bad, "\n".join(bad)
