@@ -155,6 +155,10 @@ int l2s_adamw_amsgrad_step(float* params, const float* grads, float* exp_avg, fl
  * l2s_train_bind: device pointers of a parameter in its canonical (checkpoint) layout and of its gradient slot (may be NULL), by key.
  * The backward entry points write parameter gradients into the bound slots (overwrite, not accumulate). */
 int l2s_train_bind(l2s_model* m, const char* key, float* param_dev, float* grad_dev);
+/* BatchNorm behaviour of the l2s_train_* entry points: batch_stats = 1 -> nn.Module.train() semantics (normalise with the statistics of
+ * this batch, update the BOUND running_mean / running_var in place with `momentum`, unbiased running variance; per process - no cross-rank
+ * synchronisation, like the single-device reference); 0 (default) -> running statistics (eval()). */
+int l2s_train_set_bn(l2s_model* m, int batch_stats, float momentum);
 /* After an optimizer step: rebuild the packed blob ON THE DEVICE from the bound tensors (l2s_train_bind; bind the BatchNorm running
  * statistics and the other buffers as well, grad_dev = NULL).  Needs l2s_set_option("refresh_map", 1) before l2s_model_finalize: finalize
  * then records, for every blob float that copies a checkpoint element verbatim, where it comes from; BatchNorm folds and bias sums are

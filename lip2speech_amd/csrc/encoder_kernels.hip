@@ -21,9 +21,12 @@ constexpr int FE_XLD = 104;                 // LDS row stride (floats); data col
 constexpr int FE_KP = 50;                   // taps per slab, padded (kh*7+kw; tap 49 has zero weight)
 constexpr int FE_CO = 24;
 
-template <int HW, bool SAVE_Z>
+// MODE 0: inference; 1: also save the pre-PReLU map (training tape); 2: batch-statistics pass (training): nothing is stored but the
+// per-channel sum / sum of squares of the RAW conv output over this block's own conv rows -> zout[(block*2 + k)*24 + ch]
+template <int HW, int MODE>
 __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, const float* __restrict__ video,
                                                             int T, float* __restrict__ out, float* __restrict__ zout) {
+    constexpr bool SAVE_Z = MODE == 1;
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
     constexpr int P = FE_CR * Wc;                    // conv pixels per strip
     constexpr int NT = (P + 31) / 32;                // 32-pixel MFMA row tiles
@@ -96,6 +99,31 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     }
     __syncthreads();                                 // slabs dead; reuse LDS as the conv tile
 
+    if (MODE == 2) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            if (wave + 4 * j < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    const int lr = p / Wc, crow = 2 * p0 - 1 + lr;
+                    if (p < P && lr >= 1 && crow < Hc) { s1 += acc[j][r]; s2 += acc[j][r] * acc[j][r]; }    // the halo row belongs to the strip above
+                }
+            }
+        }
+        float* red = smem;                                   // [2][wave 4][lg 2][32]
+        red[((0 * 4 + wave) * 2 + lg) * 32 + li] = s1;
+        red[((1 * 4 + wave) * 2 + lg) * 32 + li] = s2;
+        __syncthreads();
+        if (tid < 2 * FE_CO) {
+            const int k = tid / FE_CO, ch = tid - k * FE_CO;
+            float t = 0.f;
+            for (int q = 0; q < 8; ++q) t += red[(k * 8 + q) * 32 + ch];
+            zout[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + k) * FE_CO + ch] = t;
+        }
+        return;
+    }
     // BN + PReLU, conv tile Cs[pixel][24]
     float* Cs = smem;
     if (li < FE_CO) {
@@ -152,12 +180,24 @@ int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H,
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     ProfScope ps("frontend3d_conv_bn_prelu_pool", s);
     if (zout) {
-        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, true>), grid, dim3(256), 0, s, w, video, T, out, zout);
-        else hipLaunchKernelGGL((frontend3d_kernel<88, true>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        else hipLaunchKernelGGL((frontend3d_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);
     } else {
-        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, false>), grid, dim3(256), 0, s, w, video, T, out, zout);
-        else hipLaunchKernelGGL((frontend3d_kernel<88, false>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 0>), grid, dim3(256), 0, s, w, video, T, out, zout);
+        else hipLaunchKernelGGL((frontend3d_kernel<88, 0>), grid, dim3(256), 0, s, w, video, T, out, zout);
     }
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials, int* nblocks, hipStream_t s) {
+    L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
+    const int Hp = H / 4;
+    dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
+    *nblocks = (int)(grid.x * grid.y);
+    ProfScope ps("train_frontend3d_stats", s);
+    if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 2>), grid, dim3(256), 0, s, w, video, T, (float*)nullptr, partials);
+    else hipLaunchKernelGGL((frontend3d_kernel<88, 2>), grid, dim3(256), 0, s, w, video, T, (float*)nullptr, partials);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

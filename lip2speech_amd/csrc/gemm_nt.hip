@@ -146,6 +146,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         __syncthreads();
     }
 
+    if (p.stats) {      // batch-statistics pass: per-column sum and sum of squares of this tile's rows, nothing stored
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+            if (row < p.M) { s1 += acc[r]; s2 += acc[r] * acc[r]; }
+        }
+        float* red = As;                                   // [2][wm 2][lg 2][64 cols]
+        red[((0 * 2 + wm) * 2 + lg) * 64 + wn * 32 + li] = s1;
+        red[((1 * 2 + wm) * 2 + lg) * 64 + wn * 32 + li] = s2;
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            if (n0 + c < p.N) {
+                const float* q = red + k * 256 + c;
+                p.stats[((int64_t)blockIdx.y * 2 + k) * p.N + n0 + c] = (q[0] + q[64]) + (q[128] + q[192]);
+            }
+        }
+        return;
+    }
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;

@@ -1387,6 +1387,13 @@ int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W
     return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);
 }
 
+int l2s_train_set_bn(l2s_model* m, int batch_stats, float momentum) {
+    L2S_REQUIRE(m != nullptr && momentum >= 0.f && momentum <= 1.f, "bad arguments");
+    m->bn_batch = batch_stats != 0;
+    m->bn_momentum = momentum;
+    return 0;
+}
+
 int l2s_train_refresh_weights(l2s_model* m, void* stream) {
     L2S_REQUIRE(m != nullptr, "null model");
     return refresh_weights(m, (hipStream_t)stream);

@@ -66,7 +66,10 @@ struct GemmP {
     int vec;              // 4: float4 operand loads (K, Cin, lda, offsets multiples of 4); 1: scalar loads
     const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
     int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
+    float* stats;         // training, batch-statistics BatchNorm: STATS PASS - nothing is stored; per-column sums of the raw product
+                          //   (no scale/shift) go to stats[(blockIdx.y*2 + {0: sum, 1: sum of squares})*N + n]
 };
+inline int64_t gemm_stats_floats(int M, int N) { return (int64_t)((M + 63) / 64) * 2 * N; }
 constexpr int GEMM_MAX_GROUP = 8;
 struct GemmBatch {
     GemmP p[GEMM_MAX_GROUP];
@@ -111,7 +114,24 @@ struct ActBwdP {
     float* partials;                                    // [AB_RS][3][C]
     int cs_dy, co_dy, cs_z, co_z;                       // column stride (0 = 1) and offset of dy / z (shuffled channel positions)
 };
-int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s);
+int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s, float* totals = nullptr);
+
+// ---- batch-statistics BatchNorm (train mode), train_kernels.hip.  The forward kernels keep their fused "acc*scale + shift" epilogues:
+// a STATS PASS of the same kernel first reduces the raw conv output per channel, bn_stats_finalize turns the sums into this batch's
+// scale/shift (and updates the running statistics like nn.BatchNorm, momentum 0.1, unbiased running variance), then the real pass runs
+// with them.  Backward: act_bwd as for eval statistics (dconv = dpre*scale, totals r0 = sum dpre, r1 = sum dpre*xhat), then
+// bn_train_fix subtracts scale*(r0/n + xhat*r1/n).
+struct BnLayer {
+    const float* gamma; const float* beta; float* rmean; float* rvar; const float* conv_bias;   // canonical tensors (bias may be null)
+    float* scale; float* shift;                                                                  // outputs [C] (kept on the tape)
+    int C;
+};
+int bn_stats_finalize(const float* partials, int nblk, int blk_stride, int64_t count, const BnLayer& L, float momentum, hipStream_t s);
+int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z, int co_z, const float* gamma, const float* beta, const float* scale,
+                 const float* totals, int64_t rows, int C, hipStream_t s);
+// depthwise 3x3 stats pass: partials[(rs*2 + k)*C + c], DWS_RS row splits
+constexpr int DWS_RS = 64;
+int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
 struct FrontendW {          // device pointers into the weight blob
@@ -121,6 +141,8 @@ struct FrontendW {          // device pointers into the weight blob
     const float* slope;     // [24] PReLU
 };
 int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout = nullptr);
+// batch-statistics pass of the front-end conv (training): partials[(block*2 + k)*24 + ch], *nblocks blocks
+int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials /*[blocks][2][24]*/, int* nblocks, hipStream_t s);
 
 // depthwise 3x3, pad 1, channel-last: in (N,Hi,Wi,ldi) channels [ci_off, ci_off+C) -> out (N,Ho,Wo,ldo) at co_off
 int launch_dwconv(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,

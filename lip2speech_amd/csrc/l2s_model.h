@@ -93,6 +93,8 @@ struct l2s_model {
     void* r_tables = nullptr; int64_t r_tables_bytes = 0;     // device scratch for the pointer / descriptor tables
     std::vector<char> r_tables_host;
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
+    // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics
+    bool bn_batch = false; float bn_momentum = 0.1f;
     const float* canon(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.first; }
     float* grad(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.second; }
 };

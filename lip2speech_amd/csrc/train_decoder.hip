@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
 // final stage: out_k[col] (+)= mul_k(col) * sum_rs partial[rs][k][col];   k=0 -> shift-like grad (BN beta or plain bias), conv bias = s * r0
 __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restrict__ partials, int C, const float* __restrict__ scale,
                                                             float* __restrict__ d_shift, float* __restrict__ d_gamma, float* __restrict__ d_actw,
-                                                            float* __restrict__ d_convbias, int accumulate) {
+                                                            float* __restrict__ d_convbias, int accumulate, float* __restrict__ totals) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= C) return;
     float r[3] = {0.f, 0.f, 0.f};
@@ -64,13 +64,14 @@ __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restr
     put(d_gamma, r[1]);
     put(d_actw, r[2]);
     put(d_convbias, r[0] * (scale ? scale[col] : 1.f));
+    if (totals) { totals[col] = r[0]; totals[C + col] = r[1]; }
 }
 
-int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s) {
+int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s, float* totals) {
     ProfScope ps("train_act_bn_bwd", s);
     hipLaunchKernelGGL(act_bwd_kernel, dim3((p.C + 63) / 64, AB_RS), dim3(256), 0, s, p);
     hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p.partials, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, totals);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -26,9 +26,25 @@ struct EncTape {
     float* t2[N_UNITS];        // banch2 depthwise output (post-BN)
     float* b1[N_UNITS];        // stride-2 units: banch1 depthwise output (post-BN)
     float* last;               // conv_last output (NF*h*h, 768), post-ReLU
+    float* t1z[N_UNITS];       // batch-statistics mode only: pre-ReLU values of t1 / of the branch columns of x[u+1] / of last (the batch-stat
+    float* yz[N_UNITS];        //   backward needs xhat on every row, also where the ReLU is off)
+    float* lastz;
+    float* bn;                 // batch-statistics BatchNorm: this batch's (scale, shift) per layer, slot id * 2*768 floats
+    float* stats; int64_t stats_floats;   // scratch of the statistics passes
     int h[N_UNITS + 1];        // spatial size of x[u]
     int NF;
 };
+// BatchNorm layer ids: 0 front-end; 1 + 5u + {0: banch1.1, 1: banch1.3, 2: banch2.1, 3: banch2.4, 4: banch2.6}; 81 conv_last
+constexpr int ENC_BN_SLOTS = 82, ENC_BN_SLOT = 2 * LAST_CH;
+static float* bn_scale(const EncTape& t, int id) { return t.bn + (int64_t)id * ENC_BN_SLOT; }
+static float* bn_shift(const EncTape& t, int id) { return t.bn + (int64_t)id * ENC_BN_SLOT + LAST_CH; }
+static BnLayer enc_bn_layer(const l2s_model* m, const EncTape& t, int id, const std::string& key, int C) {
+    BnLayer L{};
+    L.gamma = m->canon("encoder." + key + ".weight"); L.beta = m->canon("encoder." + key + ".bias");
+    L.rmean = const_cast<float*>(m->canon("encoder." + key + ".running_mean")); L.rvar = const_cast<float*>(m->canon("encoder." + key + ".running_var"));
+    L.scale = bn_scale(t, id); L.shift = bn_shift(t, id); L.C = C;
+    return L;
+}
 static int64_t enc_tape_layout(EncTape* t, float* base, int B, int T, int H) {
     int64_t o = 0;
     auto take = [&](int64_t n) { float* r = base ? base + o : nullptr; o += align_up(n, 64); return r; };
@@ -47,12 +63,18 @@ static int64_t enc_tape_layout(EncTape* t, float* base, int B, int T, int H) {
             float* t1 = take(in_px * half); float* t2 = take(out_px * half);
             float* b1 = s2 ? take(out_px * cin) : nullptr;
             float* y = take(out_px * cout);
-            if (t) { t->t1[u] = t1; t->t2[u] = t2; t->b1[u] = b1; t->x[u + 1] = y; t->h[u + 1] = ho; }
+            float* t1z = take(in_px * half); float* yz = take(out_px * cout);
+            if (t) { t->t1[u] = t1; t->t2[u] = t2; t->b1[u] = b1; t->x[u + 1] = y; t->h[u + 1] = ho; t->t1z[u] = t1z; t->yz[u] = yz; }
             h = ho; cin = cout;
         }
     }
     float* last = take((int64_t)NF * h * h * LAST_CH);
-    if (t) t->last = last;
+    float* lastz = take((int64_t)NF * h * h * LAST_CH);
+    if (t) t->lastz = lastz;
+    float* bn = take((int64_t)ENC_BN_SLOTS * ENC_BN_SLOT);
+    const int64_t sf = std::max<int64_t>((int64_t)NF * (H / 4) * (H / 4) * 116 / 16 + 8192, (int64_t)NF * 8 * 48 + (int64_t)DWS_RS * 2 * 512);
+    float* stats = take(sf);
+    if (t) { t->last = last; t->bn = bn; t->stats = stats; t->stats_floats = sf; }
     return o + 64;
 }
 
@@ -67,29 +89,66 @@ static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int
     const Weights& w = m->w;
     EncTape tp; enc_tape_layout(&tp, tape_base, B, T, H);
     const int NF = tp.NF;
-    if (launch_frontend(w.fe, video, B, T, H, W, tp.x[0], s, tp.z0)) return 1;
+    const bool bnb = m->bn_batch;
+    // 1x1 conv + BN + ReLU; with batch statistics: stats pass -> finalize -> the same fused kernel with this batch's scale/shift
+    auto run_pw = [&](GemmP p, float* zbuf, int id, const std::string& key, const char* name) -> int {
+        if (bnb) {
+            p.Zout = zbuf;
+            L2S_REQUIRE(gemm_stats_floats(p.M, p.N) <= tp.stats_floats, "statistics scratch too small");
+            GemmP q = p; q.stats = tp.stats; q.scale = nullptr; q.shift = nullptr;
+            if (launch_gemm1(q, s, "train_pw_gemm_stats")) return 1;
+            BnLayer L = enc_bn_layer(m, tp, id, key, p.N);
+            if (bn_stats_finalize(tp.stats, (p.M + 63) / 64, 2 * p.N, p.M, L, m->bn_momentum, s)) return 1;
+            p.scale = L.scale; p.shift = L.shift;
+        }
+        return launch_gemm1(p, s, name);
+    };
+    auto run_dw = [&](const float* in, int h, int ldi, int C, int stride, const DwW& d, float* out, int id, const std::string& key) -> int {
+        const float* sc = d.scale; const float* sh = d.shift;
+        if (bnb) {
+            const int ho = (h + 2 - 3) / stride + 1;
+            if (launch_dwconv_stats(in, NF, h, h, ldi, 0, C, stride, d.w9, tp.stats, s)) return 1;
+            BnLayer L = enc_bn_layer(m, tp, id, key, C);
+            if (bn_stats_finalize(tp.stats, DWS_RS, 2 * C, (int64_t)NF * ho * ho, L, m->bn_momentum, s)) return 1;
+            sc = L.scale; sh = L.shift;
+        }
+        return launch_dwconv(in, NF, h, h, ldi, 0, C, stride, d.w9, sc, sh, out, C, 0, s);
+    };
+    {
+        FrontendW fe = w.fe;
+        if (bnb) {
+            int nblk = 0;
+            if (launch_frontend_stats(w.fe, video, B, T, H, W, tp.stats, &nblk, s)) return 1;
+            BnLayer L = enc_bn_layer(m, tp, 0, "frontend3D.1", 24);
+            if (bn_stats_finalize(tp.stats, nblk, 48, (int64_t)NF * (H / 2) * (W / 2), L, m->bn_momentum, s)) return 1;
+            fe.scale = L.scale; fe.shift = L.shift;
+        }
+        if (launch_frontend(fe, video, B, T, H, W, tp.x[0], s, tp.z0)) return 1;
+    }
     for (int u = 0; u < N_UNITS; ++u) {
         const UnitW& U = w.unit[u];
         const int half = U.half, cout = 2 * half, h = tp.h[u], ho = tp.h[u + 1];
         const float* x = tp.x[u]; float* y = tp.x[u + 1];
         const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
+        const std::string p = "trunk.0." + std::to_string(u) + ".";
+        const int id = 1 + 5 * u;
         if (U.stride2) {
             const int cin = U.cin;
-            if (launch_dwconv(x, NF, h, h, cin, 0, cin, 2, U.b1_dw.w9, U.b1_dw.scale, U.b1_dw.shift, tp.b1[u], cin, 0, s)) return 1;
-            if (launch_gemm1(pw(tp.b1[u], cin, 0, U.b1_pw, y, cout, 0, 2, out_px, half, cin), s, "train_shuffle_pw_gemm")) return 1;
-            if (launch_gemm1(pw(x, cin, 0, U.pw1, tp.t1[u], half, 0, 1, in_px, half, cin), s, "train_shuffle_pw_gemm")) return 1;
-            if (launch_dwconv(tp.t1[u], NF, h, h, half, 0, half, 2, U.dw.w9, U.dw.scale, U.dw.shift, tp.t2[u], half, 0, s)) return 1;
-            if (launch_gemm1(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, out_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
+            if (run_dw(x, h, cin, cin, 2, U.b1_dw, tp.b1[u], id + 0, p + "banch1.1")) return 1;
+            if (run_pw(pw(tp.b1[u], cin, 0, U.b1_pw, y, cout, 0, 2, out_px, half, cin), tp.yz[u], id + 1, p + "banch1.3", "train_shuffle_pw_gemm")) return 1;
+            if (run_pw(pw(x, cin, 0, U.pw1, tp.t1[u], half, 0, 1, in_px, half, cin), tp.t1z[u], id + 2, p + "banch2.1", "train_shuffle_pw_gemm")) return 1;
+            if (run_dw(tp.t1[u], h, half, half, 2, U.dw, tp.t2[u], id + 3, p + "banch2.4")) return 1;
+            if (run_pw(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, out_px, half, half), tp.yz[u] + 1, id + 4, p + "banch2.6", "train_shuffle_pw_gemm")) return 1;
         } else {
             if (launch_copy_cols(x, cout, 0, y, cout, 0, 2, in_px, half, s)) return 1;
-            if (launch_gemm1(pw(x, cout, half, U.pw1, tp.t1[u], half, 0, 1, in_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
-            if (launch_dwconv(tp.t1[u], NF, h, h, half, 0, half, 1, U.dw.w9, U.dw.scale, U.dw.shift, tp.t2[u], half, 0, s)) return 1;
-            if (launch_gemm1(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, in_px, half, half), s, "train_shuffle_pw_gemm")) return 1;
+            if (run_pw(pw(x, cout, half, U.pw1, tp.t1[u], half, 0, 1, in_px, half, half), tp.t1z[u], id + 2, p + "banch2.1", "train_shuffle_pw_gemm")) return 1;
+            if (run_dw(tp.t1[u], h, half, half, 1, U.dw, tp.t2[u], id + 3, p + "banch2.4")) return 1;
+            if (run_pw(pw(tp.t2[u], half, 0, U.pw2, y, cout, 1, 2, in_px, half, half), tp.yz[u] + 1, id + 4, p + "banch2.6", "train_shuffle_pw_gemm")) return 1;
         }
     }
     const int hl = tp.h[N_UNITS];
     const int64_t px = (int64_t)NF * hl * hl;
-    if (launch_gemm1(pw(tp.x[N_UNITS], STAGE_CH[3], 0, w.conv_last, tp.last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3]), s, "train_conv_last_gemm")) return 1;
+    if (run_pw(pw(tp.x[N_UNITS], STAGE_CH[3], 0, w.conv_last, tp.last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3]), tp.lastz, 81, "trunk.1.1", "train_conv_last_gemm")) return 1;
     if (launch_pool_norm_cat(tp.last, NF, hl * hl, LAST_CH, emb, L2S_D_EMB, T, vis, L2S_D_VIS, feat, s)) return 1;
     return 0;
 }
@@ -306,7 +365,7 @@ static int64_t enc_bwd_ws_floats(int B, int T, int H) {
     n += NF * Hc * Hc * 24;                                            // dconv of the front-end
     n += (int64_t)std::min<int64_t>(NF, IM2COL_FRAMES) * Hc * Hc * 736; // im2col chunk
     n += (int64_t)64 * LAST_CH * STAGE_CH[3] + (int64_t)24 * 736;      // split-K partials (largest: conv_last with <= 64 splits ... bounded below), dW staging
-    n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + (int64_t)FB_BLOCKS * 3 * 24;
+    n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + (int64_t)FB_BLOCKS * 3 * 24 + 2 * 1024;
     return n + 64 * 32;
 }
 
@@ -328,6 +387,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];
     float* skp = bp.f(splitk_cap); float* dw3 = bp.f(24 * 736);
     float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)FB_BLOCKS * 3 * 24);
+    float* totals = bp.f(2 * 1024);
     L2S_REQUIRE(!bp.overflow, "encoder training backward workspace too small");
     auto G = [&](const std::string& k) { return m->grad(E + k); };
     auto Cn = [&](const std::string& k) { return m->canon(E + k); };
@@ -345,12 +405,15 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         return launch_gemm_bwd(bwd_dx(dz, ldz, Wf, out, ldo, 1, (int)rows, (int)rows, nout, cin, 1, 0, acc), s, "train_bwd_encoder_dx");
     };
     // epilogue backward of "conv (+BN) (+ReLU)": dy/z may sit at shuffled channel positions
+    const bool bnb = m->bn_batch;
     auto epi = [&](const float* dy, int ldy, int csy, int coy, const float* z, int ldz, int csz, int coz, float* out, int64_t rows, int C, int act, const float* scale,
-                   const std::string& bn) -> int {
+                   const std::string& bn, int id) -> int {
         ActBwdP a{}; a.dy = dy; a.ld_dy = ldy; a.cs_dy = csy; a.co_dy = coy; a.z = z; a.ld_z = ldz; a.cs_z = csz; a.co_z = coz; a.dconv = out; a.ld_dconv = C;
-        a.rows = rows; a.C = C; a.act = act; a.scale = scale; a.gamma = Cn(bn + ".weight"); a.beta = Cn(bn + ".bias"); a.partials = abp;
+        a.rows = rows; a.C = C; a.act = act; a.scale = bnb ? bn_scale(tp, id) : scale; a.gamma = Cn(bn + ".weight"); a.beta = Cn(bn + ".bias"); a.partials = abp;
         L2S_REQUIRE(a.gamma && a.beta, "encoder parameters not bound (l2s_train_bind)");
-        return act_bwd(a, G(bn + ".bias"), G(bn + ".weight"), nullptr, nullptr, false, s);
+        if (act_bwd(a, G(bn + ".bias"), G(bn + ".weight"), nullptr, nullptr, false, s, bnb ? totals : nullptr)) return 1;
+        if (bnb) return bn_train_fix(out, C, z, ldz, csz, coz, a.gamma, a.beta, a.scale, totals, rows, C, s);      // batch statistics depend on the input too
+        return 0;
     };
     auto dwconv_bwd = [&](const float* gdz, const float* x, int ldx, int xoff, int hi, int ho, int C, int stride, const float* w9, float* dx, int ld_dx, int dxoff,
                           bool acc, float* gw) -> int {
@@ -377,7 +440,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         ProfScope ps("train_bwd_pool_norm", s);
         hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(NF), dim3(256), 0, s, tp.last, P, LAST_CH, dfeat, ld_df, dlast);
     }
-    if (epi(dlast, LAST_CH, 1, 0, tp.last, LAST_CH, 1, 0, gconv, pxl, LAST_CH, ACT_RELU, w.conv_last.scale, "trunk.1.1")) return 1;
+    if (epi(dlast, LAST_CH, 1, 0, bnb ? tp.lastz : tp.last, LAST_CH, 1, 0, gconv, pxl, LAST_CH, ACT_RELU, w.conv_last.scale, "trunk.1.1", 81)) return 1;
     if (dW(gconv, LAST_CH, LAST_CH, tp.x[N_UNITS], STAGE_CH[3], STAGE_CH[3], pxl, G("trunk.1.0.weight"))) return 1;
     float* dy = dA; float* dx = dB;
     if (dX(gconv, LAST_CH, LAST_CH, w.conv_last.W, dy, STAGE_CH[3], STAGE_CH[3], pxl, false)) return 1;
@@ -388,23 +451,25 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         const int half = U.half, cout = 2 * half, h = tp.h[u], ho = tp.h[u + 1];
         const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
         const std::string p = "trunk.0." + std::to_string(u) + ".";
-        const float* y = tp.x[u + 1];
+        const float* y = bnb ? tp.yz[u] : tp.x[u + 1];          // pre-ReLU values in batch-statistics mode, post-ReLU (same sign test) otherwise
+        const float* t1v = bnb ? tp.t1z[u] : tp.t1[u];
+        const int id = 1 + 5 * u;
         // banch2 tail: pw2 (+BN+ReLU) at the odd output channels, then the depthwise conv (+BN)
-        if (epi(dy, cout, 2, 1, y, cout, 2, 1, g, out_px, half, ACT_RELU, U.pw2.scale, p + "banch2.6")) return 1;
+        if (epi(dy, cout, 2, 1, y, cout, 2, 1, g, out_px, half, ACT_RELU, U.pw2.scale, p + "banch2.6", id + 4)) return 1;
         if (dW(g, half, half, tp.t2[u], half, half, out_px, G(p + "banch2.5.weight"))) return 1;
         if (dX(g, half, half, U.pw2.W, dt, half, half, out_px, false)) return 1;
-        if (epi(dt, half, 1, 0, tp.t2[u], half, 1, 0, gd, out_px, half, ACT_NONE, U.dw.scale, p + "banch2.4")) return 1;
+        if (epi(dt, half, 1, 0, tp.t2[u], half, 1, 0, gd, out_px, half, ACT_NONE, U.dw.scale, p + "banch2.4", id + 3)) return 1;
         if (dwconv_bwd(gd, tp.t1[u], half, 0, h, ho, half, U.stride2 ? 2 : 1, U.dw.w9, dt1, half, 0, false, G(p + "banch2.3.weight"))) return 1;
-        if (epi(dt1, half, 1, 0, tp.t1[u], half, 1, 0, g, in_px, half, ACT_RELU, U.pw1.scale, p + "banch2.1")) return 1;
+        if (epi(dt1, half, 1, 0, t1v, half, 1, 0, g, in_px, half, ACT_RELU, U.pw1.scale, p + "banch2.1", id + 2)) return 1;
         if (U.stride2) {
             const int cin = U.cin;
             if (dW(g, half, half, tp.x[u], cin, cin, in_px, G(p + "banch2.0.weight"))) return 1;
             if (dX(g, half, half, U.pw1.W, dx, cin, cin, in_px, false)) return 1;
             // banch1: dw (+BN) -> pw (+BN+ReLU) at the even output channels
-            if (epi(dy, cout, 2, 0, y, cout, 2, 0, g, out_px, half, ACT_RELU, U.b1_pw.scale, p + "banch1.3")) return 1;
+            if (epi(dy, cout, 2, 0, y, cout, 2, 0, g, out_px, half, ACT_RELU, U.b1_pw.scale, p + "banch1.3", id + 1)) return 1;
             if (dW(g, half, half, tp.b1[u], cin, cin, out_px, G(p + "banch1.2.weight"))) return 1;
             if (dX(g, half, half, U.b1_pw.W, dt, cin, cin, out_px, false)) return 1;
-            if (epi(dt, cin, 1, 0, tp.b1[u], cin, 1, 0, gd, out_px, cin, ACT_NONE, U.b1_dw.scale, p + "banch1.1")) return 1;
+            if (epi(dt, cin, 1, 0, tp.b1[u], cin, 1, 0, gd, out_px, cin, ACT_NONE, U.b1_dw.scale, p + "banch1.1", id + 0)) return 1;
             if (dwconv_bwd(gd, tp.x[u], cin, 0, h, ho, cin, 2, U.b1_dw.w9, dx, cin, 0, true, G(p + "banch1.0.weight"))) return 1;
         } else {
             if (dW(g, half, half, tp.x[u] + half, cout, half, in_px, G(p + "banch2.0.weight"))) return 1;
@@ -420,10 +485,15 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         const float* gamma = Cn("frontend3D.1.weight"); const float* beta = Cn("frontend3D.1.bias");
         L2S_REQUIRE(gamma && beta, "encoder parameters not bound (l2s_train_bind)");
         ProfScope ps("train_bwd_frontend_pool_prelu_bn", s);
-        hipLaunchKernelGGL(frontend_bwd_kernel, dim3(FB_BLOCKS), dim3(192), 0, s, tp.z0, dy, NF, Hc, Hc, w.fe.slope, w.fe.scale, gamma, beta, dconv, fbp);
+        const float* fscale = bnb ? bn_scale(tp, 0) : w.fe.scale;
+        hipLaunchKernelGGL(frontend_bwd_kernel, dim3(FB_BLOCKS), dim3(192), 0, s, tp.z0, dy, NF, Hc, Hc, w.fe.slope, fscale, gamma, beta, dconv, fbp);
         float* outs[3] = {G("frontend3D.1.bias"), G("frontend3D.1.weight"), G("frontend3D.2.weight")};
-        for (int k = 0; k < 3; ++k)
-            if (outs[k]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, outs[k], 0, 1, 0);
+        for (int k = 0; k < 3; ++k) {
+            float* dst = k < 2 ? totals + k * 24 : outs[2];                  // r0, r1 are needed by the batch-statistics correction as well
+            if (dst) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, dst, 0, 1, 0);
+            if (k < 2 && outs[k]) L2S_CHECK_HIP(hipMemcpyAsync(outs[k], totals + k * 24, 24 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        if (bnb) { if (bn_train_fix(dconv, 24, tp.z0, 24, 1, 0, gamma, beta, fscale, totals, (int64_t)NF * Hc * Hc, 24, s)) return 1; }
     }
     L2S_CHECK_HIP(hipGetLastError());
     if (float* gw = G("frontend3D.0.weight")) {

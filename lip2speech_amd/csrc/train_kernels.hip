@@ -5,6 +5,8 @@
 // deterministic - no floating-point atomics.
 #include "l2s_common.h"
 
+#include <algorithm>
+
 namespace l2s {
 
 constexpr int RED_BLOCKS = 1024;
@@ -152,6 +154,105 @@ int launch_loss(const LossP& p, double* partials /*[4*RED_BLOCKS]*/, float* out5
 
 // ================================================================================================ C ABI
 #include "../../include/l2s.h"
+namespace l2s {
+
+// ------------------------------------------------------------------------------------------------ batch-statistics BatchNorm
+// partials[blk*blk_stride + k*C + c], k = 0: sum, 1: sum of squares of the raw conv output over the rows of block blk
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partials, int nblk, int blk_stride, double inv_n, double unbias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, const float* __restrict__ conv_bias, float momentum, int C,
+                                                             float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
+    const double mean = s1 * inv_n;
+    double var = s2 * inv_n - mean * mean;                   // biased (the normaliser); fp64 combination of fp32 tile sums
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)1e-5f));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;                  // a conv bias cancels against its own mean
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mean + (conv_bias ? conv_bias[c] : 0.f));
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
+}
+int bn_stats_finalize(const float* partials, int nblk, int blk_stride, int64_t count, const BnLayer& L, float momentum, hipStream_t s) {
+    L2S_REQUIRE(L.gamma && L.beta && L.scale && L.shift && count > 1, "batch-norm layer not bound (l2s_train_bind incl. running statistics)");
+    ProfScope ps("train_bn_stats_finalize", s);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((L.C + 255) / 256), dim3(256), 0, s, partials, nblk, blk_stride, 1.0 / (double)count,
+                       (double)count / (double)(count - 1), L.gamma, L.beta, L.rmean, L.rvar, L.conv_bias, momentum, L.C, L.scale, L.shift);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// dconv[r][c] -= scale[c] * (r0[c]/n + xhat[r][c] * r1[c]/n),  xhat = (z - beta)/gamma   (totals = [r0 | r1])
+__global__ __launch_bounds__(256) void bn_train_fix_kernel(float* __restrict__ dconv, int ld_dconv, const float* __restrict__ z, int ld_z, int cs_z, int co_z,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+                                                           const float* __restrict__ totals, float inv_n, int64_t rows, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) {
+        const int c = i % C; const int64_t r = i / C;
+        const float xh = (z[r * ld_z + co_z + (int64_t)c * cs_z] - beta[c]) / gamma[c];
+        dconv[r * ld_dconv + c] -= scale[c] * (totals[c] + xh * totals[C + c]) * inv_n;
+    }
+}
+int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z, int co_z, const float* gamma, const float* beta, const float* scale,
+                 const float* totals, int64_t rows, int C, hipStream_t s) {
+    ProfScope ps("train_bn_batchstat_bwd", s);
+    const int64_t n = rows * C;
+    hipLaunchKernelGGL(bn_train_fix_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, dconv, ld_dconv ? ld_dconv : C, z, ld_z ? ld_z : C,
+                       cs_z ? cs_z : 1, co_z, gamma, beta, scale, totals, 1.f / (float)rows, rows, C);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// depthwise 3x3 (pad 1) statistics pass over channel-last maps: raw conv recomputed per output element, two-stage column sums
+__global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restrict__ in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,
+                                                           const float* __restrict__ w9, int Ho, int Wo, float* __restrict__ partials) {
+    __shared__ float sh[2][4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
+    const int64_t rows = (int64_t)N * Ho * Wo, chunk = (rows + DWS_RS - 1) / DWS_RS;
+    const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+    float s1 = 0.f, s2 = 0.f;
+    if (col < C) {
+        float wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = w9[k * C + col];
+        for (int64_t r = r_begin + rl; r < r_end; r += 4) {
+            const int ow = r % Wo; const int64_t q = r / Wo;
+            const int oh = q % Ho, n = q / Ho;
+            float acc = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * stride + kh - 1;
+                if (ih < 0 || ih >= Hi) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow * stride + kw - 1;
+                    if (iw < 0 || iw >= Wi) continue;
+                    acc = fmaf(in[(((int64_t)n * Hi + ih) * Wi + iw) * ldi + ci_off + col], wk[kh * 3 + kw], acc);
+                }
+            }
+            s1 += acc; s2 += acc * acc;
+        }
+    }
+    sh[0][rl][threadIdx.x & 63] = s1; sh[1][rl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        const int c = threadIdx.x & 63;
+        partials[((int64_t)rs * 2 + 0) * C + col] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+        partials[((int64_t)rs * 2 + 1) * C + col] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    }
+}
+int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s) {
+    const int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
+    ProfScope ps("train_dwconv_stats", s);
+    hipLaunchKernelGGL(dwconv_stats_kernel, dim3((C + 63) / 64, DWS_RS), dim3(256), 0, s, in, N, Hi, Wi, ldi, ci_off, C, stride, w9, Ho, Wo, partials);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s
+
 using namespace l2s;
 
 extern "C" {

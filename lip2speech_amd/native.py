@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
-    "l2s_train_refresh_weights", "l2s_train_encoder_tape_floats", "l2s_train_encoder_ws_bytes", "l2s_train_encoder_fwd", "l2s_train_encoder_bwd",
+    "l2s_train_set_bn", "l2s_train_refresh_weights", "l2s_train_encoder_tape_floats", "l2s_train_encoder_ws_bytes", "l2s_train_encoder_fwd", "l2s_train_encoder_bwd",
     "l2s_train_prologue_tape_floats", "l2s_train_prologue_ws_bytes", "l2s_train_prologue_fwd", "l2s_train_prologue_bwd",
     "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
@@ -98,6 +98,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_train_steps_pack_weights.argtypes = [_vp, _fp, _vp]
     L.l2s_train_steps_fwd.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_train_steps_bwd.argtypes = [_vp, _fp, _i, _i, _i, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_train_set_bn.argtypes = [_vp, _i, ctypes.c_float]
     L.l2s_train_refresh_weights.argtypes = [_vp, _vp]
     L.l2s_train_encoder_tape_floats.argtypes = [_i, _i, _i]
     L.l2s_train_encoder_tape_floats.restype = _i64
@@ -262,6 +263,10 @@ class NativeModel:
                 continue
             g = grads.get(key)
             check(lib().l2s_train_bind(self._h, key.encode(), _ptr(p), _ptr(g) if g is not None else None))
+
+    def train_set_bn(self, batch_stats: bool, momentum: float = 0.1) -> None:
+        """BatchNorm of the training entry points: batch statistics + running-stat updates (nn.Module.train()) or running statistics."""
+        check(lib().l2s_train_set_bn(self._h, 1 if batch_stats else 0, float(momentum)))
 
     def train_refresh_weights(self) -> None:
         """Device-side re-pack of the weight blob from the bound tensors (needs set_option('refresh_map', 1) before load())."""

@@ -41,9 +41,41 @@ BN_EPS = 1e-5
 # ----------------------------------------------------------------------------------
 # small pieces
 # ----------------------------------------------------------------------------------
+class batch_statistics:
+    """Context manager: BatchNorm layers behave as in nn.Module.train() (the reference's nn.BatchNorm{1,2,3}d at video.py:70,
+    shufflenetv2.py:46-69, decoder.py:118-140,166-226 under train.py:150 `net.train()`): normalise with this batch's mean and biased
+    variance; the running statistics a real module would hold afterwards (momentum 0.1, unbiased variance) are recorded in
+    ``updates[prefix] = (running_mean, running_var)`` instead of being written into ``sd``."""
+    active = None
+
+    def __init__(self, momentum: float = 0.1):
+        self.momentum, self.updates = momentum, {}
+
+    def __enter__(self):
+        batch_statistics.active = self
+        return self
+
+    def __exit__(self, *a):
+        batch_statistics.active = None
+
+
 def batchnorm_eval(x: torch.Tensor, sd: SD, prefix: str) -> torch.Tensor:
-    """Eval-mode BatchNorm{1,2,3}d over channel dim 1: (x-mu)/sqrt(var+eps)*gamma+beta."""
+    """BatchNorm{1,2,3}d over channel dim 1: (x-mu)/sqrt(var+eps)*gamma+beta with the running statistics (eval), or with the batch's
+    own statistics inside a ``batch_statistics()`` block."""
     shape = [1, -1] + [1] * (x.dim() - 2)
+    ctx = batch_statistics.active
+    if ctx is not None:
+        dims = [d for d in range(x.dim()) if d != 1]
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=dims)
+        var_b = x.var(dim=dims, unbiased=False)
+        m = ctx.momentum
+        with torch.no_grad():
+            ctx.updates[prefix] = ((1 - m) * sd[prefix + ".running_mean"] + m * mean.detach(),
+                                   (1 - m) * sd[prefix + ".running_var"] + m * var_b.detach() * n / (n - 1))
+        g = sd[prefix + ".weight"].view(shape)
+        b = sd[prefix + ".bias"].view(shape)
+        return (x - mean.view(shape)) / torch.sqrt(var_b.view(shape) + BN_EPS) * g + b
     mu = sd[prefix + ".running_mean"].view(shape)
     var = sd[prefix + ".running_var"].view(shape)
     g = sd[prefix + ".weight"].view(shape)

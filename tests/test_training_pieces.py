@@ -369,3 +369,79 @@ def test_dropout_sites_match_oracle(synth_sd):
     bad = [f"{k}: {rel(grads[k], sd64[k].grad):.2e}" for k in par if not k.startswith(("decoder.K.", "decoder.temperature", "decoder.Q."))
            and rel(grads[k], sd64[k].grad) > 3e-3]
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.gpu
+def test_encoder_batchnorm_train_mode(synth_sd):
+    """nn.Module.train() semantics of the 56 BatchNorm layers of the encoder: forward with batch statistics (stats pass -> finalize -> fused
+    kernel) and the running-statistics update against the oracle; the backward (a) is the gradient of that forward - central difference
+    of the HIP forward along the HIP gradient, the direction with the largest signal - and (b) agrees with autograd through the oracle at
+    the level at which the oracle agrees with itself across precisions: with statistics over 18 frames every ReLU / MaxPool decision
+    that rounding flips moves the batch statistics of everything downstream (fp32 vs fp64 oracle: ~0.5 % L2 per tensor)."""
+    import parity_common as pc
+    from lip2speech_amd import native, synth
+    from oracle import l2s_oracle as orc
+    B, T = 2, 9
+    video = synth.synth_video(B, T, tag="enc-bn-train")
+    torch.manual_seed(11)
+    cot = torch.randn(B, T, 768, dtype=torch.float64)
+    enc = [k for k in synth_sd if k.startswith("encoder.")]
+    is_stat = lambda k: k.endswith(("running_mean", "running_var"))      # noqa: E731
+    par = [k for k in enc if synth_sd[k].is_floating_point() and not is_stat(k)]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref, upd = {}, None
+    for dt in (torch.float64, torch.float32):
+        sdx = {k: (synth_sd[k].detach().clone().to(dt).requires_grad_(k in par) if synth_sd[k].is_floating_point() else synth_sd[k]) for k in enc}
+        with orc.batch_statistics() as bs:
+            feat_o = orc.encoder_forward(sdx, video.to(dt))
+        (feat_o * cot.to(dt)).sum().backward()
+        ref[dt] = {k: sdx[k].grad.double() for k in par}
+        if dt == torch.float64:
+            feat64, upd = feat_o.detach(), bs.updates
+    native.set_option("refresh_map", 1)
+    try:
+        nm = native.NativeModel()
+        nm.load({k: synth_sd[k].cuda() for k in enc}, enc)
+    finally:
+        native.set_option("refresh_map", 0)
+    params = {k: synth_sd[k].clone().cuda() for k in enc if synth_sd[k].is_floating_point()}      # incl. the running statistics (updated in place)
+    grads = {k: torch.zeros_like(params[k]) for k in par}
+    nm.train_bind(params, grads)
+    nm.train_set_bn(True, 0.1)
+    vid, cotc = video.cuda(), cot.float().cuda()
+    _, feat, tape = nm.train_encoder_fwd(vid)
+    dvis = torch.zeros(B, T, 1024, device="cuda")
+    dvis[:, :, :768] = cotc
+    nm.train_encoder_bwd(vid, dvis, tape)
+    assert pc.maxdiff(feat, feat64) < 5e-5
+    assert len(upd) == 56
+    for prefix, (rm, rv) in upd.items():
+        assert pc.maxdiff(params[prefix + ".running_mean"], rm) < 1e-5 * max(1.0, rm.abs().max().item()), prefix
+        assert pc.maxdiff(params[prefix + ".running_var"], rv) < 1e-5 * max(1.0, rv.abs().max().item()), prefix
+    # (b) against the oracle
+    worst = 0.0
+    for k in par:
+        r64, r32 = ref[torch.float64][k].reshape(grads[k].shape), ref[torch.float32][k].reshape(grads[k].shape)
+        if r64.norm() < 1e-6 * max(1.0, ref[torch.float64]["encoder.trunk.1.0.weight"].norm().item()):
+            continue                                     # exactly-zero gradients (a BN bias in front of another batch-stat BN): rounding residue
+        err = min((grads[k].cpu().double() - r).norm().item() for r in (r64, r32)) / r64.norm().item()
+        worst = max(worst, err)
+        assert err < 4e-2, f"{k}: L2-relative error {err:.2e}"
+    # the last layer sees no upstream flips: tight
+    for k in ("encoder.trunk.1.0.weight", "encoder.trunk.1.1.weight", "encoder.trunk.1.1.bias"):
+        r32 = ref[torch.float32][k].reshape(grads[k].shape)
+        assert pc.maxdiff(grads[k], r32) < 1e-3 * r32.abs().max().item(), k
+    # (a) central difference of the HIP forward along the HIP gradient
+    g = {k: grads[k].clone() for k in par}
+    base = {k: params[k].clone() for k in par}
+    d = {k: g[k] * (base[k].pow(2).mean().sqrt() / (g[k].pow(2).mean().sqrt() + 1e-20)) for k in par}
+    ana = sum(float((g[k].double() * d[k].double()).sum()) for k in par)
+    eps, vals = 3e-6, []
+    for sgn in (+1, -1):
+        for k in par:
+            params[k].copy_(base[k] + sgn * eps * d[k])
+        nm.train_refresh_weights()
+        _, f2, _ = nm.train_encoder_fwd(vid)
+        vals.append(float((f2.double() * cotc.double()).sum()))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - ana) < 2e-2 * abs(ana), (fd, ana, worst)
