@@ -128,14 +128,24 @@ static int add_into(const float* x, float* y, int64_t n, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Post-net.  Tape: z_l (B*S, C_l) for l = 0..3 (pre-PSine), x_l (layer outputs) for l = 0..3.
-struct PostTape { float* z[5]; float* x[4]; };
-static int64_t post_tape_floats(int B, int S) { return (int64_t)B * S * 512 * 9 + 64 * 9; }
+struct PostTape { float* z[5]; float* x[4]; float* bn; float* stats; };    // bn: this batch's (scale, shift) per layer, 2*512 floats each
+static int64_t post_tape_floats(int B, int S) { return (int64_t)B * S * 512 * 9 + 5 * 1024 + gemm_stats_floats(B * S, 512) + 64 * 12; }
 static PostTape post_tape(float* base, int B, int S) {
     PostTape t;
     const int64_t n = align_up((int64_t)B * S * 512, 64);
     for (int l = 0; l < 4; ++l) { t.z[l] = base + (2 * l) * n; t.x[l] = base + (2 * l + 1) * n; }
     t.z[4] = base + 8 * n;                  // (B*S, 80): output of the last BatchNorm, before the residual
+    t.bn = base + 9 * n;
+    t.stats = t.bn + 5 * 1024 + 64;
     return t;
+}
+static BnLayer dec_bn_layer(const l2s_model* m, const std::string& bn_key, const std::string& bias_key, float* slot, int C) {
+    BnLayer L{};
+    L.gamma = m->canon(bn_key + ".weight"); L.beta = m->canon(bn_key + ".bias");
+    L.rmean = const_cast<float*>(m->canon(bn_key + ".running_mean")); L.rvar = const_cast<float*>(m->canon(bn_key + ".running_var"));
+    L.conv_bias = bias_key.empty() ? nullptr : m->canon(bias_key);
+    L.scale = slot; L.shift = slot + 512; L.C = C;
+    return L;
 }
 
 // dropout masks of the post-net (decoder.py:152,154), channel-last like the activations: layers 0..3 (B*S,512) each, layer 4 (B*S,80)
@@ -155,6 +165,14 @@ static int postnet_train_fwd(l2s_model* m, const float* mel, int B, int S, float
         if (l >= 1 && l <= 3) { p.R1 = in; p.ldr1 = 512; }
         if (l == 4) { p.R1 = mel; p.ldr1 = NM_; p.c_tr_T = S; }
         p.mask = post_mask(drop, B, S, l); p.ldmask = cout; p.mask_pre = l == 4;     // the mel residual is added outside the Postnet module
+        if (m->bn_batch) {                     // batch statistics: stats pass of the same conv, then this batch's scale/shift in the fused epilogue
+            const std::string c = "decoder.postnet.convolutions." + std::to_string(l);
+            GemmP q = p; q.stats = t.stats; q.scale = nullptr; q.shift = nullptr;
+            if (launch_gemm1(q, s, "train_postnet_conv_stats")) return 1;
+            BnLayer L = dec_bn_layer(m, c + ".1", c + ".0.conv.bias", t.bn + l * 1024, cout);
+            if (bn_stats_finalize(t.stats, (B * S + 63) / 64, 2 * cout, (int64_t)B * S, L, m->bn_momentum, s)) return 1;
+            p.scale = L.scale; p.shift = L.shift;
+        }
         if (launch_gemm1(p, s, "train_postnet_conv_gemm")) return 1;
     }
     return 0;
@@ -185,7 +203,9 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
     float* gprev = bp.f(R * 512);
     float* dwp = bp.f((int64_t)512 * 5 * 512);
     float* partials = bp.f((int64_t)AB_RS * 3 * 512);
+    float* totals = bp.f(1024);
     L2S_REQUIRE(!bp.overflow, "post-net backward workspace too small");
+    const bool bnb = m->bn_batch;
     const std::string P = "decoder.postnet.";
     // mel_post = z4 + mel, channel-first: g4 (B*S,80) = transpose(dmel_post); dmel += g4
     if (add_transposed_bcs(dmel_post_cf, B, NM_, S, g, false, s)) return 1;
@@ -198,10 +218,14 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
         ActBwdP a{};
         a.dy = g; a.z = t.z[l]; a.dconv = gconv; a.rows = R; a.C = cout;
         a.act = l < 4 ? ACT_PSINE : ACT_NONE; a.actw = w.post[l].actw;
-        a.scale = w.post[l].scale; a.gamma = m->canon(c + ".1.weight"); a.beta = m->canon(c + ".1.bias");
+        a.scale = bnb ? t.bn + l * 1024 : w.post[l].scale; a.gamma = m->canon(c + ".1.weight"); a.beta = m->canon(c + ".1.bias");
         a.partials = partials;
         if (act_bwd(a, m->grad(c + ".1.bias"), m->grad(c + ".1.weight"), l < 4 ? m->grad(P + "sin_activation." + std::to_string(l) + ".w") : nullptr,
-                    m->grad(c + ".0.conv.bias"), false, s)) return 1;
+                    bnb ? nullptr : m->grad(c + ".0.conv.bias"), false, s, bnb ? totals : nullptr)) return 1;
+        if (bnb) {      // batch statistics: the mean subtraction removes the conv bias (zero gradient) and couples every row of a channel
+            if (bn_train_fix(gconv, cout, t.z[l], cout, 1, 0, a.gamma, a.beta, a.scale, totals, R, cout, s)) return 1;
+            if (float* gb = m->grad(c + ".0.conv.bias")) { if (launch_fill(gb, cout, 0.f, s)) return 1; }
+        }
         // weight gradient (tap-major) -> canonical layout
         if (launch_gemm_bwd(bwd_dw(gconv, cout, xin, cin, dwp, B, S, S, cout, cin, 5, 1, 2, false), s, "train_postnet_dw")) return 1;
         if (float* gw = m->grad(c + ".0.conv.weight")) { if (conv1d_grad_to_canonical(dwp, cout, cin, 5, gw, false, s)) return 1; }
@@ -921,6 +945,8 @@ struct ProTape {
     float *zkv[2];                                          // (BT,512) pre-PSine bottleneck outputs
     float *zagg[4], *cmap[4];                               // (B*L_j,512)
     float *pooled, *wv, *zk0, *tA, *zk2, *zf0, *tB, *zf2, *tC, *zf4, *logits, *zsoft, *dis;
+    float* bn;                                              // batch-statistics BatchNorm: (scale, shift) of the 8 MultiHop + 4 content branches, 1024 floats each
+    float* stats; int64_t stats_group;                      // statistics scratch: one region of stats_group floats per grouped conv
     int L[4], m;
 };
 static int64_t pro_tape_floats(int B, int T) {
@@ -929,6 +955,7 @@ static int64_t pro_tape_floats(int B, int T) {
     int64_t n = BT * (512 + 4096 + 1024 + 4608 * 2 + 512 * 2) + (int64_t)B * 512 * 4 + 2 * ((int64_t)T * B * 2048 + 2 * (int64_t)(T + 1) * B * 512) + (int64_t)B * 1024;
     for (int j = 0; j < 4; ++j) n += 2 * (int64_t)B * L[j] * 512;
     n += R * (2560 + 256 * 8 + 504 * 4);
+    n += 12 * 1024 + 8 * align_up(gemm_stats_floats((int)BT, 512), 64);
     return n + 64 * 64;
 }
 static ProTape pro_tape(float* base, int B, int T) {
@@ -945,6 +972,9 @@ static ProTape pro_tape(float* base, int B, int T) {
     for (int j = 0; j < 4; ++j) { t.zagg[j] = take((int64_t)B * t.L[j] * 512); t.cmap[j] = take((int64_t)B * t.L[j] * 512); }
     t.pooled = take(R * 2560); t.wv = take(R * 256); t.zk0 = take(R * 256); t.tA = take(R * 256); t.zk2 = take(R * 256);
     t.zf0 = take(R * 256); t.tB = take(R * 256); t.zf2 = take(R * 256); t.tC = take(R * 256); t.zf4 = take(R * 504); t.logits = take(R * 504); t.zsoft = take(R * 504); t.dis = take(R * 504);
+    t.bn = take(12 * 1024);
+    t.stats_group = align_up(gemm_stats_floats((int)BT, 512), 64);
+    t.stats = take(8 * t.stats_group);
     return t;
 }
 
@@ -1031,6 +1061,17 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
                 gb.p[kv * 4 + j] = tconv(tp.cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2, tp.cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU, nullptr);
         gb.count = 8;
         for (int q = 0; q < 8; ++q) gb.p[q].Zout = tp.zcat + 512 + q * 512;       // Zout shares C's addressing (ld 4608)
+        if (m->bn_batch) {
+            GemmBatch sbt = gb;
+            for (int q = 0; q < 8; ++q) { sbt.p[q].stats = tp.stats + q * tp.stats_group; sbt.p[q].scale = nullptr; sbt.p[q].shift = nullptr; }
+            if (launch_gemm(sbt, s, "train_multihop_conv_stats")) return 1;
+            for (int q = 0; q < 8; ++q) {
+                const std::string c = std::string("decoder.") + (q < 4 ? "K" : "V") + ".0.conv." + std::to_string(q % 4);
+                BnLayer L = dec_bn_layer(m, c + ".1", c + ".0.bias", tp.bn + q * 1024, 512);
+                if (bn_stats_finalize(tp.stats + q * tp.stats_group, (BT + 63) / 64, 1024, BT, L, m->bn_momentum, s)) return 1;
+                gb.p[q].scale = L.scale; gb.p[q].shift = L.shift;
+            }
+        }
         if (launch_gemm(gb, s, "train_multihop_conv_gemm")) return 1;
         GemmBatch bb{};
         for (int kv = 0; kv < 2; ++kv) {
@@ -1047,6 +1088,18 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
         for (int j = 0; j < 4; ++j)
             gb.p[j] = tconv(tp.cat, 4608, B, T, 512, w.ct_branch[j], 512, CT_KS[j], CT_KS[j], 0, tp.cmap[j], 512, ACT_SILU, tp.zagg[j]);
         gb.count = 4;
+        if (m->bn_batch) {
+            GemmBatch sbt = gb;
+            for (int j = 0; j < 4; ++j) { sbt.p[j].stats = tp.stats + j * tp.stats_group; sbt.p[j].scale = nullptr; sbt.p[j].shift = nullptr; }
+            if (launch_gemm(sbt, s, "train_content_agg_stats")) return 1;
+            for (int j = 0; j < 4; ++j) {
+                const std::string c = "decoder.content.agg." + std::to_string(j);
+                const int rows = B * tp.L[j];
+                BnLayer L = dec_bn_layer(m, c + ".1", c + ".0.bias", tp.bn + (8 + j) * 1024, 512);
+                if (bn_stats_finalize(tp.stats + j * tp.stats_group, (rows + 63) / 64, 1024, rows, L, m->bn_momentum, s)) return 1;
+                gb.p[j].scale = L.scale; gb.p[j].shift = L.shift;
+            }
+        }
         if (launch_gemm(gb, s, "train_content_agg_gemm")) return 1;
         PoolCatP pc{};
         pc.x[0] = tp.cat; pc.L[0] = T; pc.ld[0] = 4608;
@@ -1190,6 +1243,18 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
         a.scale = scale; a.gamma = gamma; a.beta = beta; a.partials = partials;
         return act_bwd(a, g_shift, g_gamma, g_aw, g_cb, false, s);
     };
+    // conv + BatchNorm + SiLU branch: with batch statistics the epilogue backward is followed by the coupling term, the conv bias gets a zero gradient
+    const bool bnb = m->bn_batch;
+    auto act_bn = [&](const float* dy, int ldy, const float* z, int ldz, float* dconv, int64_t rows, const float* eval_scale, int slot, const std::string& c) -> int {
+        ActBwdP a{}; a.dy = dy; a.ld_dy = ldy; a.z = z; a.ld_z = ldz; a.dconv = dconv; a.ld_dconv = 512; a.rows = rows; a.C = 512; a.act = ACT_SILU;
+        a.scale = bnb ? tp.bn + slot * 1024 : eval_scale; a.gamma = Cn(c + ".1.weight"); a.beta = Cn(c + ".1.bias"); a.partials = partials;
+        if (act_bwd(a, G(c + ".1.bias"), G(c + ".1.weight"), nullptr, bnb ? nullptr : G(c + ".0.bias"), false, s, bnb ? small : nullptr)) return 1;
+        if (bnb) {
+            if (bn_train_fix(dconv, 512, z, ldz, 1, 0, a.gamma, a.beta, a.scale, small, rows, 512, s)) return 1;
+            if (float* gb = G(c + ".0.bias")) { if (launch_fill(gb, 512, 0.f, s)) return 1; }
+        }
+        return 0;
+    };
 
     // ---- A. K / V bottlenecks: k = PSine(bott([x | branches])) + pos
     for (int kv = 0; kv < 2; ++kv) {
@@ -1211,8 +1276,7 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
     for (int q = 0; q < 8; ++q) {
         const int kv = q / 4, j = q % 4, k = MH_KS[j];
         const std::string c = std::string(kv == 0 ? "K" : "V") + ".0.conv." + std::to_string(j);
-        if (act(dcat + 512 + q * 512, 4608, tp.zcat + 512 + q * 512, 4608, gconv, 512, BT, 512, ACT_SILU, nullptr, w.mh_branch[kv][j].scale, Cn(c + ".1.weight"),
-                Cn(c + ".1.bias"), G(c + ".1.bias"), G(c + ".1.weight"), nullptr, G(c + ".0.bias"))) return 1;
+        if (act_bn(dcat + 512 + q * 512, 4608, tp.zcat + 512 + q * 512, 4608, gconv, BT, w.mh_branch[kv][j].scale, q, c)) return 1;
         if (float* gw = G(c + ".0.weight")) {
             if (launch_gemm_bwd(bwd_dw(gconv, 512, tp.cat, 4608, dwp, B, T, T, 512, 512, k, 1, k / 2, false), s, "train_bwd_multihop_dw")) return 1;
             if (conv1d_grad_to_canonical(dwp, 512, 512, k, gw, false, s)) return 1;
@@ -1266,8 +1330,7 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
         for (int j = 0; j < 4; ++j) {
             const int k = CT_KS[j], Lj = tp.L[j];
             const std::string c = "content.agg." + std::to_string(j);
-            if (act(dmap[j], 512, tp.zagg[j], 512, gconv, 512, (int64_t)B * Lj, 512, ACT_SILU, nullptr, w.ct_branch[j].scale, Cn(c + ".1.weight"), Cn(c + ".1.bias"),
-                    G(c + ".1.bias"), G(c + ".1.weight"), nullptr, G(c + ".0.bias"))) return 1;
+            if (act_bn(dmap[j], 512, tp.zagg[j], 512, gconv, (int64_t)B * Lj, w.ct_branch[j].scale, 8 + j, c)) return 1;
             if (float* gw = G(c + ".0.weight")) {
                 if (launch_gemm_bwd(bwd_dw(gconv, 512, tp.cat, 4608, dwp, B, Lj, T, 512, 512, k, k, 0, false), s, "train_bwd_content_agg_dw")) return 1;
                 if (conv1d_grad_to_canonical(dwp, 512, 512, k, gw, false, s)) return 1;
@@ -1390,7 +1453,7 @@ int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int
 
 int64_t l2s_train_postnet_tape_floats(int B, int S) { return post_tape_floats(B, S); }
 int64_t l2s_train_postnet_ws_bytes(int B, int S) {
-    return ((int64_t)B * S * 512 * 3 + (int64_t)512 * 5 * 512 + (int64_t)AB_RS * 3 * 512 + 64 * 8) * (int64_t)sizeof(float);
+    return ((int64_t)B * S * 512 * 3 + (int64_t)512 * 5 * 512 + (int64_t)AB_RS * 3 * 512 + 1024 + 64 * 10) * (int64_t)sizeof(float);
 }
 
 int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, void* stream) {

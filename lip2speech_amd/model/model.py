@@ -31,6 +31,8 @@ class _HipTrainStep(torch.autograd.Function):
         B, _, T, _, _ = video.shape
         S = mels.shape[2]
         drop = drop or {}
+        ctx.bn_batch = bool(model.training)                 # nn.Module.train(): batch statistics + running-statistics update (in the bound buffers)
+        nm.train_set_bn(ctx.bn_batch)
         pdrop = native.postnet_drop_pack(drop["post"]) if drop.get("post") is not None else None
         vis, _, etape = nm.train_encoder_fwd(video, emb)
         if drop.get("feat") is not None:
@@ -44,12 +46,15 @@ class _HipTrainStep(torch.autograd.Function):
         mel_post, post_tape = nm.train_postnet_fwd(mel, pdrop)
         ctx.model, ctx.tapes = model, (video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, drop.get("feat"))
         ctx.mark_non_differentiable(logits)
+        if ctx.bn_batch:
+            model._count_batch()
         return mel.permute(0, 2, 1).contiguous(), mel_post, stop.unsqueeze(2), logits, dis
 
     @staticmethod
     def backward(ctx, dmel_cf, dmel_post, dstop, _dlogits, ddis):
         model = ctx.model
         nm = model.native_model()
+        nm.train_set_bn(ctx.bn_batch)
         video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, fdrop = ctx.tapes
         B, S = mel.shape[0], mel.shape[1]
         flat = model._flat
@@ -117,6 +122,14 @@ class Lip2Speech(NativeBacked):
             self.__dict__["_refresh_on_device"] = True
         return self._flat
 
+    def _count_batch(self):
+        """num_batches_tracked += 1 on every BatchNorm (what nn.BatchNorm does in train mode; the running statistics themselves are updated
+        by the kernels)."""
+        if self.__dict__.get("_nbt") is None:
+            self.__dict__["_nbt"] = [b for n, b in self.named_buffers() if n.endswith("num_batches_tracked") and n.startswith(("encoder.", "decoder."))]
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+
     def _grads_live(self) -> bool:
         return any(p.grad is not None for p in self._flat.params)
 
@@ -144,8 +157,8 @@ class Lip2Speech(NativeBacked):
         """The differentiable route (train.py:167-184): same outputs as `forward`, attached to autograd through `_HipTrainStep`.
         In `train()` mode the five dropout sites of the reference are active (multipliers drawn on the device by `training.draw_dropout`
         and handed to the kernels as inputs, or supplied through `dropout_masks=`); in `eval()` mode they are off (the configuration the
-        reference gradient goldens pin).  Normalisation layers use their running statistics in both modes in this build; batch-statistics
-        BatchNorm is the next increment."""
+        reference gradient goldens pin).  BatchNorm follows the module mode too: batch statistics with running-statistics updates in
+        `train()`, running statistics in `eval()` (per process: no cross-rank synchronisation, like the single-device reference)."""
         self._train_state()
         with torch.no_grad():
             emb = self._speaker(face_frames, speaker_embedding).to(torch.float32).contiguous()

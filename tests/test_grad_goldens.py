@@ -150,3 +150,85 @@ def test_hip_full_training_step_matches_reference_gradients(case):
     total = float(np.sqrt(sum(float(g.double().pow(2).sum()) for g in grads.values())))
     ref_total = float(np.sqrt((z["grad_norm"] ** 2).sum()))
     assert abs(total - ref_total) < 1e-3 * ref_total           # what clip_grad_norm_ sees (train.py:191)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# train() mode BatchNorm (batch statistics + running-statistics update) with the dropout sites off: golden `lrw_b2_s77_bntrain`.
+# Encoder gradients: with statistics over 58 frames, every ReLU / MaxPool decision that rounding flips shifts the batch statistics of
+# everything downstream, so two correct implementations agree to ~1 % per tensor (fp32 vs fp64 oracle: 0.5 %); they are compared at
+# that level.  The decoder's BatchNorm layers are followed by smooth activations and are compared like the eval-mode goldens.
+def check_bntrain(z, index, grads, loss_terms, buffers):
+    assert np.abs(np.asarray(loss_terms) - z["loss_terms"]).max() < 1e-4 * np.abs(z["loss_terms"]).max(), (loss_terms, z["loss_terms"])
+    for name in z.files:
+        if name.startswith("buf:"):
+            got = buffers[name[4:]].detach().double().cpu().numpy()
+            assert np.abs(got - z[name]).max() < 2e-4 * max(1.0, np.abs(z[name]).max()), name      # downstream of the 77-step fp32 recurrence
+    dec_keys = [k for k in index if k.startswith("decoder.")]
+    # biases of convs in front of a batch-statistics BatchNorm: exactly zero gradient, the reference holds rounding residue there
+    zero = [k for k in dec_keys if k.endswith((".0.bias", ".0.conv.bias")) and (".conv." in k or ".agg." in k or "postnet.convolutions" in k)]
+    check_grads(z, index, grads, [k for k in dec_keys if k not in zero], rel_norm=4e-3, rel_proj=8e-3, rel_full=8e-3)
+    total = float(np.sqrt((z["grad_norm"] ** 2).sum()))
+    for k in zero:
+        assert float(grads[k].detach().double().norm()) < 1e-6 * total and float(z["grad_norm"][index[k]]) < 1e-5 * total, k
+    bad = []
+    for k in index:
+        if not k.startswith("encoder."):
+            continue
+        g = grads[k].detach().double().cpu().numpy().ravel()
+        n_ref = float(z["grad_norm"][index[k]])
+        if n_ref < 1e-7 * total:
+            continue
+        n = float(np.sqrt((g * g).sum()))
+        if abs(n - n_ref) > 4e-2 * n_ref:
+            bad.append(f"{k}: norm {n:.5e} vs {n_ref:.5e}")
+        if "grad:" + k in z.files:
+            full = z["grad:" + k].astype(np.float64).ravel()
+            e = float(np.sqrt(((g - full) ** 2).sum())) / max(n_ref, 1e-30)
+            if e > 5e-2:
+                bad.append(f"{k}: L2-relative error {e:.2e}")
+    assert not bad, "\n".join(bad)
+
+
+def test_oracle_batch_statistics_match_reference_train_mode():
+    """CPU: the oracle inside `batch_statistics()` against the reference's own train() forward + backward."""
+    z, index = load("lrw_b2_s77_bntrain")
+    sd = synth.synth_state_dict()
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked", "pos_table"))      # noqa: E731
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not is_buf(k) and not k.startswith(("speaker_encoder.", "vgg_face.")) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    video = synth.synth_video(B, T, tag="video-lrw2").double()
+    emb = synth.synth_speaker_embedding(B, tag="spk-lrw2").double()
+    gum = synth.synth_gumbel(B * 4, tag="gumbel-lrw2").double()
+    mels = synth.synth_mels(B, S, tag="mel-lrw2").double()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with orc.batch_statistics() as bs:
+        outs = orc.forward_eval(sd64, video, emb, mels, gum)
+    terms = orc.loss_terms(outs, mels, gate_targets().double())
+    terms[-1].backward()
+    buffers = {}
+    for prefix, (rm, rv) in bs.updates.items():
+        buffers[prefix + ".running_mean"], buffers[prefix + ".running_var"] = rm, rv
+    assert len(bs.updates) == 73
+    check_bntrain(z, index, {k: sd64[k].grad for k in index}, [t.item() for t in terms], buffers)
+
+
+@pytest.mark.gpu
+def test_hip_train_mode_batchnorm_matches_reference():
+    """GPU: the HIP training step with batch-statistics BatchNorm (all 73 layers) against the reference's own train() forward + backward."""
+    from lip2speech_amd.training import model_forward_backward
+    z, index = load("lrw_b2_s77_bntrain")
+    sd = synth.synth_state_dict()
+    video = synth.synth_video(B, T, tag="video-lrw2").cuda()
+    emb = synth.synth_speaker_embedding(B, tag="spk-lrw2").cuda()
+    gum = synth.synth_gumbel(B * 4, tag="gumbel-lrw2").cuda()
+    mels = synth.synth_mels(B, S, tag="mel-lrw2").cuda()
+    nm = pc.native_model(sd)
+    bound = {k: v.clone().cuda() for k, v in sd.items() if k.startswith(("encoder.", "decoder.")) and v.is_floating_point()}
+    grads = {k: torch.zeros_like(bound[k]) for k in index}
+    nm.train_bind(bound, grads)
+    nm.train_set_bn(True, 0.1)
+    try:
+        out = model_forward_backward(nm, video, emb, gum, mels, gate_targets().cuda())
+    finally:
+        nm.train_set_bn(False)
+    check_bntrain(z, index, grads, out["loss"].cpu().double().numpy(), bound)

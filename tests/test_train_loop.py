@@ -139,7 +139,12 @@ def test_train_mode_applies_dropout():
     video, emb, gum, mels, gate = (t.cuda() for t in inputs())
     lens = torch.full((B,), T, device="cuda")
     torch.manual_seed(0)
+    rm0 = net.decoder.postnet.convolutions[0][1].running_mean.clone() if False else dict(net.named_buffers())["decoder.postnet.convolutions.0.1.running_mean"].clone()
+    nbt0 = int(dict(net.named_buffers())["encoder.frontend3D.1.num_batches_tracked"])
     o1 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
+    bufs = dict(net.named_buffers())
+    assert pc.maxdiff(bufs["decoder.postnet.convolutions.0.1.running_mean"], rm0) > 1e-4           # BatchNorm ran on batch statistics
+    assert int(bufs["encoder.frontend3D.1.num_batches_tracked"]) == nbt0 + 1
     o2 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
     frac = float((o1[4] == 0).float().mean())
     assert 0.05 < frac < 0.16, frac

@@ -445,3 +445,63 @@ def test_encoder_batchnorm_train_mode(synth_sd):
         vals.append(float((f2.double() * cotc.double()).sum()))
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - ana) < 2e-2 * abs(ana), (fd, ana, worst)
+
+
+@pytest.mark.gpu
+def test_decoder_batchnorm_train_mode_matches_autograd(synth_sd):
+    """nn.Module.train() semantics of the decoder's 17 BatchNorm1d layers (8 MultiHop branches, 4 Content.agg branches, 5 post-net
+    layers; all followed by smooth activations): the HIP decoder step with batch statistics against autograd through the oracle inside
+    `batch_statistics()` - outputs, loss, running-statistics updates, every decoder parameter gradient, d(visual features)."""
+    import parity_common as pc
+    from lip2speech_amd import synth
+    from lip2speech_amd.training import decoder_forward_backward
+    from oracle import l2s_oracle as orc
+    B, T, S = 2, 29, 20
+    gen = torch.Generator().manual_seed(78)
+    feat = torch.nn.functional.normalize(torch.randn(B, T, 768, generator=gen), dim=-1)
+    emb = synth.synth_speaker_embedding(B, tag="bn-dec")
+    gum = synth.synth_gumbel(B * 4, tag="bn-dec")
+    mels = synth.synth_mels(B, S, tag="bn-dec")
+    gate = torch.zeros(B, S)
+    gate[:, -1] = 1.0
+    is_stat = lambda k: k.endswith(("running_mean", "running_var"))      # noqa: E731
+    dec = [k for k in synth_sd if k.startswith("decoder.") and synth_sd[k].is_floating_point()]
+    par = [k for k in dec if not is_stat(k) and not k.endswith("pos_table")]
+    sd64 = {k: synth_sd[k].detach().clone().double().requires_grad_(k in par) for k in dec}
+    vis64 = orc.build_visual(feat, emb).double().requires_grad_(True)
+    with orc.batch_statistics() as bs:
+        st = orc.decoder_prologue(sd64, vis64, emb.double(), gum.double())
+        mel_o, stop_o, logit_o = orc.decode_loop(sd64, st, S, return_logits=True)
+        mel_cf = mel_o.permute(0, 2, 1)
+        post_o = orc.postnet(sd64, mel_cf) + mel_cf
+    terms = orc.loss_terms([mel_cf, post_o, stop_o.unsqueeze(2), None, logit_o, st["content_dis"]], mels.double(), gate.double())
+    terms[-1].backward()
+    assert len(bs.updates) == 17
+
+    nm = pc.native_model(synth_sd)
+    params = {k: synth_sd[k].clone().cuda() for k in dec}
+    grads = {k: torch.zeros_like(params[k]) for k in par}
+    nm.train_bind(params, grads)
+    nm.train_set_bn(True, 0.1)
+    try:
+        out = decoder_forward_backward(nm, orc.build_visual(feat, emb).cuda(), emb.cuda(), gum.cuda(), mels.cuda(), gate.cuda())
+    finally:
+        nm.train_set_bn(False)
+    assert pc.maxdiff(out["mel"], mel_cf) < 2e-4 and pc.maxdiff(out["mel_post"], post_o) < 5e-4
+    want = torch.stack([t.detach() for t in terms])
+    assert (out["loss"].cpu().double() - want).abs().max() < 2e-5 * want.abs().max()
+    for prefix, (rm, rv) in bs.updates.items():
+        assert pc.maxdiff(params[prefix + ".running_mean"], rm) < 1e-5 * max(1.0, rm.abs().max().item()), prefix
+        assert pc.maxdiff(params[prefix + ".running_var"], rv) < 1e-5 * max(1.0, rv.abs().max().item()), prefix
+
+    def rel(got, ref):
+        ref = ref.reshape(got.shape)
+        return pc.maxdiff(got, ref) / max(1e-6, ref.abs().max().item())
+    assert rel(out["dvis"], vis64.grad) < 3e-3
+    bad = [f"{k}: {rel(grads[k], sd64[k].grad):.2e}" for k in par if not k.startswith(("decoder.K.", "decoder.temperature", "decoder.Q."))
+           and rel(grads[k], sd64[k].grad) > 3e-3]
+    assert not bad, "\n".join(bad)
+    # under batch statistics the bias of a conv in front of a BatchNorm has an exactly zero gradient
+    for k in par:
+        if k.endswith((".0.bias", ".0.conv.bias")) and (".conv." in k or ".agg." in k or "postnet.convolutions" in k):
+            assert float(grads[k].abs().max()) == 0.0, k
