@@ -97,9 +97,10 @@ def cpu_baseline(seconds_budget=12.0):
 def train_main(args):
     """Secondary bench line: training throughput.  One step = `Lip2Speech.forward` (encoder + decoder, S=77 targets) + 4-term loss +
     backward through everything + bucketed gradient all-reduce (RCCL, N>1) + global-norm clip + fused AdamW(amsgrad) + device-side
-    re-pack of the weight blob, on B=8 clips per GPU, fp32, eval-mode normalisation statistics."""
+    re-pack of the weight blob, on B=8 clips per GPU, fp32, train() semantics: BatchNorm on batch statistics
+    with running-statistics updates, the five dropout sites live (masks drawn on the device every step), half the steps teacher-forced."""
     from model.model import get_network
-    from lip2speech_amd.training import AdamWAmsgrad, GradAllReducer, model_forward_backward
+    from lip2speech_amd.training import AdamWAmsgrad, GradAllReducer, draw_dropout, model_forward_backward
     Bt, St = 8, 77
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,8 +128,11 @@ def train_main(args):
     mask = torch.zeros(St, dtype=torch.bool)
     mask[1::2] = True                                   # half of the steps teacher-forced (tf_ratio 0.5 regime)
 
+    nm.train_set_bn(True, 0.1)
+
     def step():
-        out = model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bos.detach())
+        drop = draw_dropout(Bt, T, St, video.device)
+        out = model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bos.detach(), drop=drop)
         reducer.start()
         mul = reducer.wait()
         opt.step(max_norm=1.0, grad_mul=mul)
@@ -162,7 +166,7 @@ def train_main(args):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "LRW training step, batch=8 per GPU, 29x96x96 clips, S=77 mel targets, half of the steps teacher-forced, "
-                                   "38.4 M parameters, eval-mode BatchNorm statistics / no dropout", "batch_per_gpu": Bt, "frames": T,
+                                   "38.4 M parameters, train() semantics (batch-statistics BatchNorm, dropout)", "batch_per_gpu": Bt, "frames": T,
                        "decode_steps": St, "parallelism": f"dp{world} (one bucketed gradient all-reduce of 153.7 MB per step)"},
             "final_loss": float(loss[4])}), flush=True)
     if dist:
