@@ -242,6 +242,10 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
 /* launch-floor probe: n dependent launches of an empty kernel (kind 0) or of a kernel in which each of `blocks` 512-thread
  * blocks streams n_per_block x 8 KiB from `in` (kind 1) - the cost model of a latency-bound decode phase (tools/launch_floor.py) */
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream);
+/* measurement: with ts_dev != NULL every batch-row ("skinny") launch runs a stamped build of the same kernel - thread 0 of each block
+ * writes 8 x 64-bit 100 MHz wall-clock stamps (entry, parameters in SGPRs, loads issued, first operands landed, MFMAs done, after the
+ * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
+int l2s_op_skinny_timeline(void* ts_dev);
 /* the same chain issued alternately on two streams (two independent dependency chains): does a second chain hide the launch floor? */
 int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b);
 /* run-time options (A/B switches kept for measurement; defaults are the fastest measured):

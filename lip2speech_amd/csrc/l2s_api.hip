@@ -1457,6 +1457,9 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
     return 0;
 }
 
+/* measurement: ts_dev != NULL routes every skinny launch to the stamped build (8 wall-clock stamps per block into ts_dev); NULL restores */
+int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
+
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream) {
     for (int i = 0; i < n_launches; ++i)
         if (launch_probe(kind, blocks, n_per_block, in, out, (hipStream_t)stream)) return 1;

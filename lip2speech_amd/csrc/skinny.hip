@@ -20,6 +20,16 @@ __global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
     skinny_block(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
 
+// measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
+__global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch batch, unsigned long long* ts) {
+    __shared__ float red[SK_RED_FLOATS];
+    const int g = blockIdx.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    skinny_block<false, SK_MAXC, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
+}
+static unsigned long long* g_skinny_ts = nullptr;
+void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
+
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
     L2S_REQUIRE(b.count >= 1 && b.count <= SKINNY_MAX_GROUP, "skinny group size");
     int maxt = 0, mts = 0;
@@ -35,7 +45,8 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
         mts = m;
     }
     ProfScope ps(name, s);
-    hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, b);
+    if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, b, g_skinny_ts);
+    else hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, b);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -48,20 +48,22 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 a
 // dependent scalar-cache round trips (the kernarg was just written by the host, so they miss) in front of the first operand load.
 #define L2S_PIN_S(...) asm volatile("" ::__VA_ARGS__)
 
-template <bool TRAIN = false, int MAXC = SK_MAXC>
+// TIMED: a measurement build of the same block that drops 100 MHz wall-clock stamps of its phases into ts[0..7] (tools/skinny_timeline.py)
+#define L2S_STAMP(i) do { if (TIMED) { if (threadIdx.x == 0) ts[i] = wall_clock64(); } } while (0)
+template <bool TRAIN = false, int MAXC = SK_MAXC, bool TIMED = false>
 __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/, int ntiles = 1 << 30,
-                                             const SkinnyTrain* tr = nullptr) {
-    // ---- every parameter the block needs, fetched in one batch of scalar loads
+                                             const SkinnyTrain* tr = nullptr, unsigned long long* ts = nullptr) {
+    L2S_STAMP(0);
+    // ---- the parameters the operand loads need first; the rest is fetched while those loads are in flight (a single-group kernel with these
+    // arguments preloaded into SGPRs by the command processor, -amdgpu-kernarg-preload-count, moved the first load 0.2 us earlier and the
+    // kernel end not at all: the block is bound by its 128-192 KB of operand traffic through one CU's vector-memory path)
     const float* const W = p.W;
     const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
     const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
-    const int K = p.K, epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
-    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
-    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
-    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(K), "s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act));
-    L2S_PIN_S("s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow), "s"(ntiles));
+    const int K = p.K;
+    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(K), "s"(ntiles));
     if (tile >= ntiles) return;                      // block-uniform: grid x is sized for the widest group of the launch
-
+    L2S_STAMP(1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NC = K >> 4;
@@ -82,6 +84,11 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
         }
     }
+    // ---- everything else the block needs, fetched in one batch of scalar loads that overlaps the operand loads already in flight
+    const int epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
+    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
+    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
+    L2S_PIN_S("s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act), "s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow));
     // ---- epilogue operands have launch-time addresses too: fetch them under the same round trip
     const int e_row = tid >> 4, e_col = tid & 15;
     const int e_b = mt * 16 + e_row, e_np = tile * 16 + e_col;
@@ -99,6 +106,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         const int b2 = mt * 16 + (tid >> 2);
         if (b2 < nB) pf_c = c_in[frag16_index(b2, tile * 4 + (tid & 3), H)];
     }
+    L2S_STAMP(2);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
@@ -107,7 +115,10 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             if (j & 1) acc1 = mfma4(a[j], w[j], acc1);
             else acc0 = mfma4(a[j], w[j], acc0);
         }
+        if (TIMED && j == 0) { asm volatile("s_nop 0" :: "v"(acc0[0])); L2S_STAMP(3); }      // first operands have landed
     }
+    if (TIMED) { asm volatile("s_nop 0" :: "v"(acc0[0]), "v"(acc1[0])); }
+    L2S_STAMP(4);
     // D layout: col = lane&15, row = 4*(lane>>4) + r
     {
         const int col = lane & 15, rb = 4 * (lane >> 4);
@@ -115,6 +126,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         for (int r = 0; r < 4; ++r) red[(wave * 16 + rb + r) * 17 + col] = acc0[r] + acc1[r];
     }
     __syncthreads();
+    L2S_STAMP(5);
     float* gt = red + SK_WAVES * 16 * 17;               // reduced tile [16][17]
     const int row = tid >> 4, col = tid & 15;          // valid for tid < 256
     const int b = mt * 16 + row;
@@ -135,6 +147,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             gt[row * 17 + col] = v;
         }
         __syncthreads();
+        L2S_STAMP(6);
         if (tid < 64) {
             const int r2 = tid >> 2, u2 = tid & 3;
             const int b2 = mt * 16 + r2, unit2 = tile * 4 + u2;
@@ -159,6 +172,8 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
                 if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
             }
         }
+        if (TIMED) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        L2S_STAMP(7);
         return;
     }
     if (tid >= 256 || b >= nB) return;
@@ -279,19 +294,38 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
         if (lane == 0) sc[t] = (float)d;
     }
     __syncthreads();
-    // ---- softmax over T (T <= 320 < 512: one element per thread)
-    const bool on = tid < T;
-    float x = on ? sc[tid] : -INFINITY;
-    if constexpr (TRAIN) { if (on && tr->logit_mask) x *= tr->logit_mask[(int64_t)b * tr->ld_lmask + tid]; }
-    const float mx = block_max8(x, scratch);
-    const float ex = on ? expf(x - mx) : 0.f;
-    const float tot = block_sum8(ex, scratch);
-    if (on) {
-        const float aw = ex / tot;
-        if (pattn) pattn[(int64_t)b * ld_attn + tid] = logits ? x : aw;
-        sc[tid] = aw;
+    // ---- softmax over T
+    if (T <= 64) {
+        // one wave, shuffles only (LRW: T = 29): one block barrier instead of five
+        if (wave == 0) {
+            const bool on = lane < T;
+            float x = on ? sc[lane] : -INFINITY;
+            if constexpr (TRAIN) { if (on && tr->logit_mask) x *= tr->logit_mask[(int64_t)b * tr->ld_lmask + lane]; }
+            const float mx = wave_max_f(x);
+            const float ex = on ? expf(x - mx) : 0.f;
+            const float tot = wave_sum_f(ex);
+            if (on) {
+                const float aw = ex / tot;
+                if (pattn) pattn[(int64_t)b * ld_attn + lane] = logits ? x : aw;
+                sc[lane] = aw;
+            }
+        }
+        __syncthreads();
+    } else {
+        // T <= 320 < 512: one element per thread
+        const bool on = tid < T;
+        float x = on ? sc[tid] : -INFINITY;
+        if constexpr (TRAIN) { if (on && tr->logit_mask) x *= tr->logit_mask[(int64_t)b * tr->ld_lmask + tid]; }
+        const float mx = block_max8(x, scratch);
+        const float ex = on ? expf(x - mx) : 0.f;
+        const float tot = block_sum8(ex, scratch);
+        if (on) {
+            const float aw = ex / tot;
+            if (pattn) pattn[(int64_t)b * ld_attn + tid] = logits ? x : aw;
+            sc[tid] = aw;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- av = a @ v : one column per thread, t ascending
     float acc = 0.f;
 #pragma unroll
