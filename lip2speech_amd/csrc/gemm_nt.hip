@@ -73,7 +73,19 @@ __device__ __forceinline__ float4 load_w(const GemmP& p, const float* wrow, bool
 template <int VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const GemmP& p = batch.p[blockIdx.z];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (private L2s), so give each XCD a
+    // contiguous run of tiles with the N index fastest - the column tiles that share an A row panel then meet in ONE L2 instead of
+    // fetching it from the Infinity Cache eight times (post-net layer: 309 -> 295 us)
+    int bx, by;
+    {
+        const int gx = gridDim.x, total = gx * gridDim.y;
+        const int L = blockIdx.y * gx + blockIdx.x;
+        const int xcd = L & 7, local = L >> 3;
+        const int chunk = total >> 3, rem = total & 7;
+        const int tile = xcd * chunk + (xcd < rem ? xcd : rem) + local;
+        bx = tile % gx; by = tile / gx;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     if (m0 >= p.M || n0 >= p.N) return;
 
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
             const int k = tid >> 6, c = tid & 63;
             if (n0 + c < p.N) {
                 const float* q = red + k * 256 + c;
-                p.stats[((int64_t)blockIdx.y * 2 + k) * p.N + n0 + c] = (q[0] + q[64]) + (q[128] + q[192]);
+                p.stats[((int64_t)by * 2 + k) * p.N + n0 + c] = (q[0] + q[64]) + (q[128] + q[192]);
             }
         }
         return;
