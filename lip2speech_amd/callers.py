@@ -41,3 +41,30 @@ def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda") -
             outs.append(out[1])
     net.train(was_training)
     return outs
+
+
+def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", max_iters: int = 256, sampling_rate: int = None) -> float:
+    """Mean ESTOI of the vocoded predictions against the ground-truth audio (reference: evaluate.py:22-51): `net(..., tf_ratio=1)[1]`
+    -> `MelSpec2Audio` (InverseMelScale + Griffin-Lim, `max_iters` each) -> `stoi(gt, pred, fs, extended=True)` per clip.  Vocoder and
+    metric are restatements of third-party algorithms (parity unpinned); the mels come from the HIP path."""
+    from .datasets.spectrograms import MelSpec2Audio
+    from .hparams import create_hparams
+    from .metrics import stoi
+    hp = create_hparams()
+    fs = sampling_rate or hp.sampling_rate
+    vocoder = MelSpec2Audio(hp, max_iters=max_iters).to(device)
+    scores = []
+    was_training = net.training
+    net.eval()
+    with torch.no_grad():
+        for (videos, vlen), (audios, alen), (melspecs, mlen, _gate), face_crops in batches:
+            emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
+            mel = net(videos.to(device), face_crops.to(device) if face_crops is not None else None, audios.to(device), melspecs.to(device), vlen, alen,
+                      mlen, 1, speaker_embedding=emb)[1]
+            pred = vocoder(mel).cpu().numpy()
+            gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
+            for i in range(gt.shape[0]):
+                n = min(gt.shape[1], pred.shape[1])
+                scores.append(stoi(gt[i, :n], pred[i, :n], fs, extended=True))
+    net.train(was_training)
+    return sum(scores) / max(1, len(scores))

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from .spectrograms import MelSpectrogram  # noqa: F401
+from .spectrograms import MelSpec2Audio, MelSpectrogram  # noqa: F401
 from .lrw import LRW  # noqa: F401
 
 MEL_PAD = -11.5129      # ln(1e-5), the floor of the log-mel transform

@@ -55,3 +55,66 @@ class MelSpectrogram(torch.nn.Module):
         if self.log:
             mel = torch.log(torch.clamp(mel, min=1e-5))
         return mel.reshape(*shape[:-1], mel.shape[-2], mel.shape[-1])
+
+
+def spectral_de_normalize(x: torch.Tensor) -> torch.Tensor:
+    """exp(x): inverse of the log compression of the targets (spectograms.py:24-39, C = 1)."""
+    return torch.exp(x)
+
+
+class MelSpec2Audio(torch.nn.Module):
+    """Log-mel -> waveform, the vocoder `evaluate.py` scores with (reference: datasets/spectograms.py:76-95): exp, then
+    torchaudio 0.9.0's ``InverseMelScale`` (non-negative least squares of ``mel = spec @ fb`` by SGD, lr 0.1 / momentum 0.9, random
+    start, `max_iters` iterations with the 1e-5 / 1e-8 stopping rules) and ``GriffinLim`` (`max_iters` iterations, momentum 0.99,
+    random start, power 2).  torchaudio is absent here: both published algorithms are restated on torch ops (torch.stft/istft on the
+    device) - PARITY UNPINNED, and stochastic in the reference as well.  Not part of the mel-frames/s path."""
+
+    def __init__(self, hparams=None, max_iters: int = 256):
+        super().__init__()
+        hp = hparams or create_hparams()
+        self.n_fft, self.hop, self.win, self.sr = hp.filter_length, hp.hop_length, hp.win_length, hp.sampling_rate
+        self.max_iters = max_iters
+        self.register_buffer("window", torch.hann_window(self.win, periodic=True))
+        self.register_buffer("fb", mel_filterbank(self.n_fft // 2 + 1, hp.mel_fmin, hp.mel_fmax, hp.n_mel_channels, self.sr))
+
+    # -- torchaudio.transforms.InverseMelScale.forward (0.9.0)
+    def inverse_mel(self, mel: torch.Tensor, generator=None) -> torch.Tensor:
+        """mel (B, n_mels, L) power-mel -> power spectrogram (B, n_freqs, L) >= 0."""
+        B, _, L = mel.shape
+        target = mel.transpose(1, 2)                                              # (B, L, n_mels)
+        spec = torch.rand(B, L, self.fb.shape[0], device=mel.device, dtype=mel.dtype, generator=generator)
+        vel = torch.zeros_like(spec)
+        loss = float("inf")
+        for _ in range(self.max_iters):
+            diff = target - spec @ self.fb
+            new_loss = float(diff.pow(2).sum(dim=-1).mean())
+            grad = (-2.0 / (B * L)) * (diff @ self.fb.t())                        # d/dspec of mean over (B, L) of the per-frame squared error
+            vel = 0.9 * vel + grad                                                # torch.optim.SGD(lr=0.1, momentum=0.9)
+            spec = (spec - 0.1 * vel).clamp_(min=0)
+            if new_loss < 1e-5 or abs(loss - new_loss) < 1e-8:
+                break
+            loss = new_loss
+        return spec.transpose(1, 2)
+
+    # -- torchaudio.functional.griffinlim (0.9.0): power 2, momentum 0.99, rand_init
+    def griffin_lim(self, power_spec: torch.Tensor, generator=None) -> torch.Tensor:
+        mag = power_spec.clamp(min=0).sqrt()                                      # (B, n_freqs, L)
+        B, _, L = mag.shape
+        length = self.hop * (L - 1)
+        ang = torch.view_as_complex(torch.rand(*mag.shape, 2, device=mag.device, dtype=mag.dtype, generator=generator))
+        momentum = 0.99 / (1 + 0.99)
+        prev = torch.zeros_like(ang)
+        stft = lambda x: torch.stft(x, self.n_fft, self.hop, self.win, self.window, center=True, pad_mode="reflect",      # noqa: E731
+                                    normalized=False, onesided=True, return_complex=True)
+        istft = lambda z: torch.istft(z, self.n_fft, self.hop, self.win, self.window, length=length)                      # noqa: E731
+        for _ in range(self.max_iters):
+            rebuilt = stft(istft(mag * ang))
+            ang = rebuilt - prev * momentum
+            ang = ang / (ang.abs() + 1e-16)
+            prev = rebuilt
+        return istft(mag * ang)
+
+    def forward(self, melspec: torch.Tensor, generator=None) -> torch.Tensor:
+        """(B, n_mels, L) log-mel -> (B, hop*(L-1)) waveform."""
+        mel = spectral_de_normalize(melspec.to(torch.float32))
+        return self.griffin_lim(self.inverse_mel(mel, generator), generator)
