@@ -8,8 +8,13 @@
 One "step" = one pass of the whole path (visual encoder -> decoder prologue -> 300 autoregressive steps ->
 post-net -> stop bookkeeping; `l2s_inference`) over one synthetic batch of B=32 clips of 29 frames
 (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  With N ranks every rank runs its
-own B=32 batch (clips are independent: weak scaling, no data-path collective); the reported value is the whole-job
+own B=32 batches (clips are independent: weak scaling, no data-path collective); the reported value is the whole-job
 aggregate N*K*B*S / max-over-ranks(time).
+
+The K steps of a rank are independent batches, and one pass is a chain of ~1 500 dependent launches that leaves the chip idle in
+every kernel boundary / ramp / drain, so they are issued `--inflight` (default 3) at a time, each on its own HIP stream from its own
+host thread (lip2speech_amd.parallel.InflightPool): every step is still one full pass over one B=32 batch with bit-identical results;
+`one_batch_at_a_time` in the JSON line is the same K steps issued strictly one after the other (inflight 1).
 
 The JSON line also carries
   roofline     for the kernel with the largest share of GPU time, timed live with HIP events on the launch stream
@@ -179,6 +184,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    ap.add_argument("--inflight", type=int, default=3, help="independent batches in flight per GPU (streams + host threads); 1 = strictly sequential")
     ap.add_argument("--mode", choices=["inference", "train"], default="inference",
                     help="inference = the headline metric (default); train = one data-parallel training step per 'step' (SURVEY.md §8 config 3)")
     args = ap.parse_args()
@@ -197,35 +203,44 @@ def main():
         dist.init_process_group(backend="nccl")
 
     # replicated weights, per-rank shard of clips (no exchange step on the inference path)
+    from lip2speech_amd.parallel import InflightPool
     sd = synth.synth_state_dict()
-    nm = native.NativeModel()
-    nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+    tensors = {k: v.cuda() for k, v in sd.items()}
+    pool = InflightPool(tensors, list(sd.keys()), n_inflight=max(1, args.inflight))
+    nm = pool.models[0]
     video = synth.synth_video(B, T, tag=f"bench{rank}" if rank else "bench").cuda()
     emb = synth.synth_speaker_embedding(B, tag=f"bench{rank}" if rank else "bench").cuda()
     gum = synth.synth_gumbel(B * native.min_T(T), tag="bench").cuda()
+    batch = (video, emb, gum)
 
     def step():
         return nm.inference(video, emb, gum, S=S)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out[0]).all(), "non-finite mel output"
+    def timed(run):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, res
+
+    pool.map([batch] * max(args.warmup, pool.n_inflight), S=S)          # W untimed warm-up steps (every worker at least once)
+    elapsed, outs = timed(lambda: pool.map([batch] * args.steps, S=S))   # EXACTLY K steps
+    out = outs[-1]
+    assert all(torch.isfinite(o[0]).all() for o in outs), "non-finite mel output"
+    seq_elapsed = elapsed
+    if pool.n_inflight > 1:                                              # the same K steps strictly one after the other, for reference
+        seq_elapsed, _ = timed(lambda: [step() for _ in range(args.steps)])
 
     if rank == 0:
         # per-kernel HIP-event timing in its own pass (events around every launch perturb the pipeline)
@@ -281,7 +296,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LRW single-word, batch=32 per GPU, 29x96x96 RGB mouth crops, S=300 decode steps, "
                                    "speaker embedding supplied (encoding=voice), random-init weights",
-                       "batch_per_gpu": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)"},
+                       "batch_per_gpu": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)",
+                       "batches_in_flight_per_gpu": pool.n_inflight},
+            "one_batch_at_a_time": {"value": world * B * S * args.steps / seq_elapsed, "ms_per_step": seq_elapsed / args.steps * 1e3},
             "roofline": roof,
         }
         if world == 1 and not args.skip_cpu_baseline:

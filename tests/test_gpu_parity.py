@@ -263,3 +263,22 @@ def test_caller_loops_voice_route(synth_sd):
     with torch.no_grad():
         emb_ref = orc.speaker_encoder_inference(spk_sd, torch.cat([it[1] for it in items], dim=0))
     assert pc.maxdiff(spk.inference(torch.cat([it[1] for it in items], dim=0).cuda()), emb_ref) < 2e-4
+
+
+@pytest.mark.gpu
+def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
+    """Three batches in flight on three streams (parallel.InflightPool) give exactly the one-at-a-time results, in order."""
+    import parity_common as pc
+    from lip2speech_amd import synth
+    from lip2speech_amd.parallel import InflightPool
+    B, T, S = 4, 29, 40
+    batches = [(synth.synth_video(B, T, tag=f"pool{i}").cuda(), synth.synth_speaker_embedding(B, tag=f"pool{i}").cuda(),
+                synth.synth_gumbel(B * 4, tag=f"pool{i}").cuda()) for i in range(7)]
+    nm = pc.native_model(synth_sd)
+    want = [nm.inference(*b, S=S, want_attn=True) for b in batches]
+    want = [tuple(t.clone() for t in w) for w in want]
+    pool = InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=3)
+    got = pool.map(batches, S=S, want_attn=True)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
