@@ -23,14 +23,17 @@ __device__ __forceinline__ float apply_act(float v, int act, const float* actw, 
     return v;
 }
 
+// the fields the operand loaders need, copied once into SGPRs (read through the kernarg reference they are re-fetched by scalar loads
+// inside the K loop, each behind its own s_waitcnt)
+struct LoadP { int K, Cin, taps, Tin, lda, a_split, a_gap; };
+
 template <int VEC>
-__device__ __forceinline__ float4 load_a(const GemmP& p, const float* rowbase, bool rowvalid, int tbase, int k) {
+__device__ __forceinline__ float4 load_a(const LoadP& p, const float* rowbase, bool rowvalid, int tbase, int k, int tap4, int ci4) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!rowvalid) return r;
     if (VEC == 4) {
         if (k >= p.K) return r;
-        int tap = 0, ci = k;
-        if (p.taps > 1) { tap = k / p.Cin; ci = k - tap * p.Cin; }
+        const int tap = tap4, ci = ci4;          // (tap, ci) of k, tracked incrementally by the caller: no division in the K loop
         int tin = tbase + tap;
         if (tin < 0 || tin >= p.Tin) return r;
         int col = ci + (ci >= p.a_split ? p.a_gap : 0);
@@ -56,7 +59,7 @@ __device__ __forceinline__ float4 load_a(const GemmP& p, const float* rowbase, b
 }
 
 template <int VEC>
-__device__ __forceinline__ float4 load_w(const GemmP& p, const float* wrow, bool valid, int k) {
+__device__ __forceinline__ float4 load_w(const LoadP& p, const float* wrow, bool valid, int k) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!valid) return r;
     if (VEC == 4) {
@@ -121,12 +124,47 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    const int nkt = (p.K + BK - 1) / BK;
-    float4 ra[2], rb[2];
+    const LoadP lp{p.K, p.Cin, p.taps, p.Tin, p.lda, p.a_split, p.a_gap};
+    asm volatile("" ::"s"(lp.K), "s"(lp.Cin), "s"(lp.taps), "s"(lp.Tin), "s"(lp.lda), "s"(lp.a_split), "s"(lp.a_gap));
+    const int nkt = (lp.K + BK - 1) / BK;
+    // Operand addressing of the float4 path without per-tile multiplications or divisions: this thread's k = kt*BK + kq maps to
+    // (tap, ci), advanced by BK per tile (Cin >= BK or taps == 1, checked at launch); per staged row a pointer to input frame
+    // tbase + tap, refreshed only when the tap changes; the weight rows advance by BK floats.
+    int tap = 0, ci = kq;
+    if (lp.taps > 1) { tap = kq / lp.Cin; ci = kq - tap * lp.Cin; }
+    const float* arp[2];
+    bool aok[2];
+    const float* wp[2];
+    auto set_tap = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        ra[j] = load_a<VEC>(p, arow[j], avalid[j], atbase[j], kq);
-        rb[j] = load_w<VEC>(p, wrow[j], wvalid[j], kq);
+        for (int j = 0; j < 2; ++j) {
+            const int tin = atbase[j] + tap;
+            aok[j] = avalid[j] && tin >= 0 && tin < lp.Tin;
+            arp[j] = arow[j] + (int64_t)(aok[j] ? tin : 0) * lp.lda;
+        }
+    };
+    set_tap();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wp[j] = wrow[j] + kq;
+    auto fetch4 = [&](int k, float4* ra, float4* rb) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool kin = k < lp.K;
+        const int col = ci + (ci >= lp.a_split ? lp.a_gap : 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = zero; rb[j] = zero;
+            if (kin && aok[j]) ra[j] = *reinterpret_cast<const float4*>(arp[j] + col);
+            if (kin && wvalid[j]) rb[j] = *reinterpret_cast<const float4*>(wp[j]);
+        }
+    };
+    float4 ra[2], rb[2];
+    if (VEC == 4) fetch4(kq, ra, rb);
+    else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = load_a<VEC>(lp, arow[j], avalid[j], atbase[j], kq, 0, 0);
+            rb[j] = load_w<VEC>(lp, wrow[j], wvalid[j], kq);
+        }
     }
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -138,10 +176,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         __syncthreads();
         if (kt + 1 < nkt) {
             const int k = (kt + 1) * BK + kq;
+            if (VEC == 4) {
+                ci += BK;
+                if (lp.taps > 1 && ci >= lp.Cin) { ci -= lp.Cin; ++tap; set_tap(); }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                ra[j] = load_a<VEC>(p, arow[j], avalid[j], atbase[j], k);
-                rb[j] = load_w<VEC>(p, wrow[j], wvalid[j], k);
+                for (int j = 0; j < 2; ++j) wp[j] += BK;
+                fetch4(k, ra, rb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ra[j] = load_a<VEC>(lp, arow[j], avalid[j], atbase[j], k, 0, 0);
+                    rb[j] = load_w<VEC>(lp, wrow[j], wvalid[j], k);
+                }
             }
         }
         const float* ap = &As[(wm * 32 + li) * LDS_LD + 4 * lg];
@@ -229,7 +275,7 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         maxM = p.M > maxM ? p.M : maxM;
         maxN = p.N > maxN ? p.N : maxN;
         bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A) &&
-                   aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0);
+                   aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= BK);
         vec4 = vec4 && ok4;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
