@@ -127,34 +127,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const LoadP lp{p.K, p.Cin, p.taps, p.Tin, p.lda, p.a_split, p.a_gap};
     asm volatile("" ::"s"(lp.K), "s"(lp.Cin), "s"(lp.taps), "s"(lp.Tin), "s"(lp.lda), "s"(lp.a_split), "s"(lp.a_gap));
     const int nkt = (lp.K + BK - 1) / BK;
-    // Operand addressing of the float4 path without per-tile multiplications or divisions: this thread's k = kt*BK + kq maps to
-    // (tap, ci), advanced by BK per tile (Cin >= BK or taps == 1, checked at launch); per staged row a pointer to input frame
-    // tbase + tap, refreshed only when the tap changes; the weight rows advance by BK floats.
+    // Operand addressing of the float4 path: buffer loads through two descriptors (A panel, weight matrix) whose hardware range check
+    // returns zeros - no predication, no zero-fill, no 64-bit address arithmetic in the K loop.  This thread's k = kt*BK + kq maps to
+    // (tap, ci), advanced by BK per tile (Cin >= BK or taps == 1, checked at launch); per staged row the byte offset of input frame
+    // tbase + tap (or an out-of-range offset when that frame is padding), refreshed only when the tap changes.
+    constexpr unsigned OOB = 0x80000000u;               // both extents are < 2 GiB (checked at launch)
     int tap = 0, ci = kq;
     if (lp.taps > 1) { tap = kq / lp.Cin; ci = kq - tap * lp.Cin; }
-    const float* arp[2];
-    bool aok[2];
-    const float* wp[2];
+    const int nseq = (p.M + p.Tout - 1) / p.Tout;
+    const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)nseq * lp.Tin * lp.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * lp.K * 4), 0x00020000);
+    unsigned aoff[2], woff[2];
     auto set_tap = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int tin = atbase[j] + tap;
-            aok[j] = avalid[j] && tin >= 0 && tin < lp.Tin;
-            arp[j] = arow[j] + (int64_t)(aok[j] ? tin : 0) * lp.lda;
+            const bool ok = avalid[j] && tin >= 0 && tin < lp.Tin;
+            aoff[j] = ok ? (unsigned)((arow[j] - p.A) + (int64_t)tin * lp.lda) * 4u : OOB;
         }
     };
     set_tap();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wp[j] = wrow[j] + kq;
+    for (int j = 0; j < 2; ++j) woff[j] = wvalid[j] ? (unsigned)((wrow[j] - p.W) + kq) * 4u : OOB;
     auto fetch4 = [&](int k, float4* ra, float4* rb) {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool kin = k < lp.K;
-        const int col = ci + (ci >= lp.a_split ? lp.a_gap : 0);
+        const unsigned kbad = k < lp.K ? 0u : OOB;                                       // K is a multiple of 4: a quad is all in or all out
+        const unsigned col = (unsigned)(ci + (ci >= lp.a_split ? lp.a_gap : 0)) * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            ra[j] = zero; rb[j] = zero;
-            if (kin && aok[j]) ra[j] = *reinterpret_cast<const float4*>(arp[j] + col);
-            if (kin && wvalid[j]) rb[j] = *reinterpret_cast<const float4*>(wp[j]);
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_rs, (int)((aoff[j] | kbad) + (aoff[j] == OOB ? 0u : col)), 0, 0));
+            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_rs, (int)(woff[j] | kbad), 0, 0));
         }
     };
     float4 ra[2], rb[2];
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
                 ci += BK;
                 if (lp.taps > 1 && ci >= lp.Cin) { ci -= lp.Cin; ++tap; set_tap(); }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) wp[j] += BK;
+                for (int j = 0; j < 2; ++j) woff[j] += wvalid[j] ? BK * 4u : 0u;
                 fetch4(k, ra, rb);
             } else {
 #pragma unroll
@@ -275,7 +276,8 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         maxM = p.M > maxM ? p.M : maxM;
         maxN = p.N > maxN ? p.N : maxN;
         bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A) &&
-                   aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= BK);
+                   aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= BK) &&
+                   (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * p.K * 4 < (1ll << 31);
         vec4 = vec4 && ok4;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
