@@ -114,8 +114,11 @@ class Lip2Speech(NativeBacked):
                 p.grad = None
             self.__dict__["_grad_views"] = grads
             native.set_option("refresh_map", 1)                  # the (re)load below also builds the device-side refresh map
-            self.__dict__["_native_sig"] = None
-            nm = self.native_model()
+            try:
+                self.__dict__["_native_sig"] = None
+                nm = self.native_model()
+            finally:
+                native.set_option("refresh_map", 0)              # process-wide switch: other models keep the cheap load
             bound = {k: p.data for k, p in zip(self._flat_names, flat.params)}
             bound.update({k: v for k, v in self._tensors().items() if k not in bound and v.is_floating_point()})   # buffers: BN statistics, pos_table
             nm.train_bind(bound, grads)
