@@ -68,3 +68,59 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
                 scores.append(stoi(gt[i, :n], pred[i, :n], fs, extended=True))
     net.train(was_training)
     return sum(scores) / max(1, len(scores))
+
+
+def reconstruction_losses(outputs, targets) -> dict:
+    """`Loss.forward` (train_utils/losses.py:35-79) on torch tensors, attached to autograd: KLD of the content distribution against the
+    uniform one, MSE of the pre- and (x10) post-net mels, BCE-with-logits of the stop tokens."""
+    import torch.nn.functional as F
+    mel_target, gate_target = targets
+    mel, mel_post, stop, qy = outputs[0], outputs[1], outputs[2], outputs[5]
+    return {"KLD": torch.sum(qy * torch.log(qy * qy.shape[-1] + 1e-20), dim=-1).mean(),
+            "mel_loss": F.mse_loss(mel, mel_target),
+            "postnet_mel_loss": 10 * F.mse_loss(mel_post, mel_target),
+            "gate_loss": F.binary_cross_entropy_with_logits(stop.reshape(-1, 1), gate_target.reshape(-1, 1))}
+
+
+def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_ratio: float = 0.0, lr: float = 1e-4, weight_decay: float = 1e-6,
+                     grad_clip: float = 1.0, fused_optimizer: bool = True, device="cuda") -> List[dict]:
+    """The model-facing half of `train.py`'s loop (train.py:102-104,150-193): `net.train()`; cycle through the collated batches
+    (`tf_ratio += 0.1` every 10 epochs); forward -> 4-term loss -> `backward()` -> gradient all-reduce when a process group is up
+    (one process per GPU) -> clip at `grad_clip` -> AdamW(amsgrad) on the decoder and encoder groups.  Returns the per-iteration loss
+    log (python floats; the `.item()` calls are this loop's only host synchronisations, like the reference's `loss_log`)."""
+    from .training import AdamWAmsgrad, GradAllReducer
+    net.train()
+    flat = net._train_state()
+    if fused_optimizer:
+        optim = AdamWAmsgrad(flat, lr=lr, weight_decay=weight_decay)
+        reducer = GradAllReducer(flat.grad)
+    else:
+        dec, enc = net.trainable_groups()
+        optim = torch.optim.AdamW([{"params": dec}, {"params": enc}], lr=lr, weight_decay=weight_decay, amsgrad=True)
+        reducer = None
+    log, epoch, pos = [], 0, 0
+    for _ in range(n_iters):
+        if pos == len(batches):
+            pos, epoch = 0, epoch + 1
+            if epoch % 10 == 0:
+                tf_ratio += 0.1
+        (videos, vlen), (audios, alen), (melspecs, mlen, gates), face_crops = batches[pos]
+        pos += 1
+        emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
+        outputs = net(videos.to(device), face_crops.to(device) if face_crops is not None else None, audios.to(device), melspecs.to(device), vlen, alen,
+                      mlen, tf_ratio, speaker_embedding=emb)
+        losses = reconstruction_losses(outputs, (melspecs.to(device), gates.to(device)))
+        loss = sum(losses.values())
+        optim.zero_grad()
+        loss.backward()
+        if fused_optimizer:
+            reducer.start()
+            grad_norm = optim.step(max_norm=grad_clip, grad_mul=reducer.wait())
+            net.mark_weights_changed()
+        else:
+            grad_norm = torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
+            optim.step()
+        rec = {k: float(v.detach()) for k, v in losses.items()}
+        rec.update(loss=float(loss.detach()), grad_norm=float(grad_norm), tf_ratio=tf_ratio, epoch=epoch)
+        log.append(rec)
+    return log

@@ -4,6 +4,7 @@ fused flat-buffer optimizer; both are compared, step by step, with the same loop
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,24 @@ def test_train_mode_applies_dropout():
     e1 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
     e2 = net(video, None, None, mels, lens, None, None, 1, speaker_embedding=emb, gumbel_noise=gum)
     assert torch.equal(e1[0], e2[0]) and float((e1[4] == 0).float().mean()) == 0.0
+
+
+@pytest.mark.gpu
+def test_train_iterations_caller():
+    """`callers.train_iterations` = the model-facing half of train.py's loop, in train() mode (batch-statistics BatchNorm, dropout,
+    scheduled sampling): runs, stays finite, cycles the batches and lowers the loss on a repeated batch."""
+    from model.model import get_network
+    from lip2speech_amd import callers
+    net = get_network("train").cuda()
+    net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
+    video, emb, gum, mels, gate = inputs()
+    audio = torch.zeros(B, 256 * (S - 1))
+    batch = ((video, torch.full((B,), T)), (audio, torch.full((B,), audio.shape[1])), (mels, torch.full((B,), S), gate), None)
+
+    class Spk:
+        def inference(self, a):
+            return emb.to(a.device)
+    torch.manual_seed(1)
+    log = callers.train_iterations(net, [batch, batch], 6, speaker_encoder=Spk(), tf_ratio=0.5)
+    assert len(log) == 6 and all(np.isfinite(r["loss"]) and np.isfinite(r["grad_norm"]) for r in log)
+    assert log[-1]["epoch"] == 2 and log[-1]["loss"] < log[0]["loss"]
