@@ -15,10 +15,10 @@ namespace l2s {
 // Backward of a fused GEMM epilogue  y = act(z) [+ residual],  z = conv * s + shift  (s, shift = eval-mode BatchNorm and/or bias):
 //   dpre = dy * act'(z);  dconv = dpre * s;  per-column sums  r0 = sum dpre,  r1 = sum dpre * (z - beta)/gamma,  r2 = sum dy * sin(z)
 // Two-stage column reduction (row splits -> partials -> final), deterministic.
-__global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p, int nsplit) {
     __shared__ float sh[3][4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
-    const int64_t chunk = (p.rows + AB_RS - 1) / AB_RS;
+    const int64_t chunk = (p.rows + nsplit - 1) / nsplit;
     const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < p.rows ? r_begin + chunk : p.rows;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int64_t ldy = p.ld_dy ? p.ld_dy : p.C, ldz = p.ld_z ? p.ld_z : p.C, ldc = p.ld_dconv ? p.ld_dconv : p.C;
@@ -50,15 +50,24 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p) {
 }
 
 // final stage: out_k[col] (+)= mul_k(col) * sum_rs partial[rs][k][col];   k=0 -> shift-like grad (BN beta or plain bias), conv bias = s * r0
-__global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restrict__ partials, int C, const float* __restrict__ scale,
+// block = 64 columns x 4 lanes striding over the row splits
+__global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restrict__ partials, int nsplit, int C, const float* __restrict__ scale,
                                                             float* __restrict__ d_shift, float* __restrict__ d_gamma, float* __restrict__ d_actw,
                                                             float* __restrict__ d_convbias, int accumulate, float* __restrict__ totals) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= C) return;
+    __shared__ float sh[3][4][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float r[3] = {0.f, 0.f, 0.f};
-    for (int rs = 0; rs < AB_RS; ++rs)
+    if (col < C)
+        for (int rs = lane; rs < nsplit; rs += 4)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) r[k] += partials[((int64_t)rs * 3 + k) * C + col];
+            for (int k = 0; k < 3; ++k) r[k] += partials[((int64_t)rs * 3 + k) * C + col];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh[k][lane][cl] = r[k];
+    __syncthreads();
+    if (lane != 0 || col >= C) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = (sh[k][0][cl] + sh[k][1][cl]) + (sh[k][2][cl] + sh[k][3][cl]);
     auto put = [&](float* dst, float v) { if (dst) dst[col] = accumulate ? dst[col] + v : v; };
     put(d_shift, r[0]);
     put(d_gamma, r[1]);
@@ -69,8 +78,10 @@ __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restr
 
 int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s, float* totals) {
     ProfScope ps("train_act_bn_bwd", s);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((p.C + 63) / 64, AB_RS), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, p.partials, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,
+    // row splits: the long, narrow maps of the encoder (24-116 channels = one or two column blocks) need them to fill the chip
+    const int nsplit = (int)std::min<int64_t>(AB_RS, std::max<int64_t>(32, (p.rows + 255) / 256));
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((p.C + 63) / 64, nsplit), dim3(256), 0, s, p, nsplit);
+    hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, nsplit, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,
                        accumulate ? 1 : 0, totals);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

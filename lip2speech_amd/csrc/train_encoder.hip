@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restr
     }
 }
 
-constexpr int DW_RS = 64;      // row splits of the per-tap reductions
+constexpr int DW_RS = 256;     // row splits of the per-tap reductions (58-232 channels = 1-4 column blocks: the splits fill the chip)
 // partial[rs][k][c] = sum over this split's output pixels of gd[.][c] * x[shifted by tap k][c]
 __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restrict__ gd, const float* __restrict__ x, int N, int Hi, int Wi, int ldx, int xoff,
                                                             int Ho, int Wo, int C, int stride, float* __restrict__ partials) {

@@ -158,14 +158,22 @@ namespace l2s {
 
 // ------------------------------------------------------------------------------------------------ batch-statistics BatchNorm
 // partials[blk*blk_stride + k*C + c], k = 0: sum, 1: sum of squares of the raw conv output over the rows of block blk
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partials, int nblk, int blk_stride, double inv_n, double unbias,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-                                                             float* __restrict__ rvar, const float* __restrict__ conv_bias, float momentum, int C,
-                                                             float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// one block = 64 channels x 16 lanes striding over the partial rows (up to ~8 000 of them for the widest maps), fp64 tree in LDS
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ partials, int nblk, int blk_stride, double inv_n, double unbias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, const float* __restrict__ conv_bias, float momentum, int C,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
+    if (c < C)
+        for (int b = lane; b < nblk; b += 16) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
+    sh[0][lane][cl] = s1; sh[1][lane][cl] = s2;
+    __syncthreads();
+    if (lane != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int l = 0; l < 16; ++l) { s1 += sh[0][l][cl]; s2 += sh[1][l][cl]; }
     const double mean = s1 * inv_n;
     double var = s2 * inv_n - mean * mean;                   // biased (the normaliser); fp64 combination of fp32 tile sums
     var = var > 0.0 ? var : 0.0;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
 int bn_stats_finalize(const float* partials, int nblk, int blk_stride, int64_t count, const BnLayer& L, float momentum, hipStream_t s) {
     L2S_REQUIRE(L.gamma && L.beta && L.scale && L.shift && count > 1, "batch-norm layer not bound (l2s_train_bind incl. running statistics)");
     ProfScope ps("train_bn_stats_finalize", s);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((L.C + 255) / 256), dim3(256), 0, s, partials, nblk, blk_stride, 1.0 / (double)count,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((L.C + 63) / 64), dim3(1024), 0, s, partials, nblk, blk_stride, 1.0 / (double)count,
                        (double)count / (double)(count - 1), L.gamma, L.beta, L.rmean, L.rvar, L.conv_bias, momentum, L.C, L.scale, L.shift);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

@@ -6,6 +6,8 @@ from lip2speech_amd import native, synth
 B, T, S = 32, 29, 300
 sd = synth.synth_state_dict()
 NT = int(os.environ.get("NT", 2))
+for kv in filter(None, os.environ.get("L2S_OPTS", "").split(",")):
+    k, v = kv.split("="); native.set_option(k, int(v))
 models, inputs, streams = [], [], []
 for i in range(NT):
     nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
