@@ -122,6 +122,7 @@ def train_main(args):
     nm = net.native_model()
     opt = AdamWAmsgrad(flat, lr=1e-4, weight_decay=1e-6)
     reducer = GradAllReducer(flat.grad)
+    n_dec = reducer.buckets_covering(sum(p.numel() for p in net.decoder.parameters()))     # the flat buffer holds the decoder group first
     tag = f"train{rank}"
     video = synth.synth_video(Bt, T, tag=tag).cuda()
     emb = synth.synth_speaker_embedding(Bt, tag=tag).cuda()
@@ -137,8 +138,10 @@ def train_main(args):
 
     def step():
         drop = draw_dropout(Bt, T, St, video.device)
-        out = model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bos.detach(), drop=drop)
-        reducer.start()
+        # the decoder's buckets are reduced while the encoder backward still runs; the rest follows
+        out = model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bos.detach(), drop=drop,
+                                     on_decoder_grads=lambda: reducer.start(0, n_dec))
+        reducer.start(n_dec)
         mul = reducer.wait()
         opt.step(max_norm=1.0, grad_mul=mul)
         nm.train_refresh_weights()

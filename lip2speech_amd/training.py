@@ -138,12 +138,15 @@ def decoder_forward_backward(nm: "native.NativeModel", vis, emb, gumbel, mel_tar
     return {"loss": loss, "mel": mel_cf, "mel_post": mel_post, "stop": stop, "attn_logits": logits, "content_dis": dis, "dvis": dvis}
 
 
-def model_forward_backward(nm: "native.NativeModel", video, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None, drop=None):
+def model_forward_backward(nm: "native.NativeModel", video, emb, gumbel, mel_target, gate_target, teacher_mask=None, bos=None, drop=None,
+                           on_decoder_grads=None):
     """`Lip2Speech.forward` + `Loss` + `backward()` (model.py:20-41, train.py:167-184) with the speaker embedding supplied and eval-mode
     statistics: encoder forward with a tape, `decoder_forward_backward`, then the encoder backward fed by the visual-feature gradient.
     All encoder and decoder parameter gradients land in the bound slots."""
     vis, _, etape = nm.train_encoder_fwd(video, emb)
     out = decoder_forward_backward(nm, vis, emb, gumbel, mel_target, gate_target, teacher_mask=teacher_mask, bos=bos, drop=drop)
+    if on_decoder_grads is not None:
+        on_decoder_grads()            # every decoder gradient is final: their all-reduce can travel under the encoder backward
     nm.train_encoder_bwd(video, out["dvis"], etape)
     return out
 
@@ -158,6 +161,16 @@ class GradAllReducer:
         per = max(1, bucket_bytes // flat_grad.element_size())
         self.buckets = [flat_grad[i:i + per] for i in range(0, flat_grad.numel(), per)]
         self._work = []
+
+    def buckets_covering(self, numel: int) -> int:
+        """Number of leading buckets that lie entirely inside the first `numel` elements of the flat buffer."""
+        n, count = 0, 0
+        for b in self.buckets:
+            if n + b.numel() > numel:
+                break
+            n += b.numel()
+            count += 1
+        return count
 
     def start(self, first: int = 0, last: Optional[int] = None):
         """Launch the all-reduce of buckets [first, last) - call as soon as those gradients are final."""

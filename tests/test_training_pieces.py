@@ -15,8 +15,9 @@ def _allreduce_worker(rank, size, port, ret):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     red = GradAllReducer(g, bucket_bytes=1024)          # 256 floats per bucket -> 4 buckets
     assert len(red.buckets) == 4
-    red.start(0, 2)                                     # early buckets first, as a backward pass would release them
-    red.start(2, None)
+    assert red.buckets_covering(600) == 2 and red.buckets_covering(1000) == 4 and red.buckets_covering(100) == 0
+    red.start(0, red.buckets_covering(600))             # the decoder group's buckets first, as soon as its gradients are final
+    red.start(red.buckets_covering(600), None)
     mul = red.wait()
     ret[rank] = (g.tolist(), mul)
     dist.barrier()
