@@ -244,6 +244,11 @@ def main():
     seq_elapsed = elapsed
     if pool.n_inflight > 1:                                              # the same K steps strictly one after the other, for reference
         seq_elapsed, _ = timed(lambda: [step() for _ in range(args.steps)])
+    # secondary figure: the evaluate.py path, forward(tf_ratio=1) with S = 77 target frames per clip
+    S77 = 77
+    fwd = lambda model, b: model.forward_eval(b[0], b[1], b[2], S77)      # noqa: E731
+    pool.map([batch] * pool.n_inflight, fn=fwd)
+    fwd_elapsed, _ = timed(lambda: pool.map([batch] * args.steps, fn=fwd))
 
     if rank == 0:
         # per-kernel HIP-event timing in its own pass (events around every launch perturb the pipeline)
@@ -302,6 +307,8 @@ def main():
                        "batch_per_gpu": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)",
                        "batches_in_flight_per_gpu": pool.n_inflight},
             "one_batch_at_a_time": {"value": world * B * S * args.steps / seq_elapsed, "ms_per_step": seq_elapsed / args.steps * 1e3},
+            "evaluate_forward_S77": {"value": world * B * S77 * args.steps / fwd_elapsed, "unit": "mel-frames/s", "ms_per_step": fwd_elapsed / args.steps * 1e3,
+                                     "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), same batches in flight"},
             "roofline": roof,
         }
         if world == 1 and not args.skip_cpu_baseline:

@@ -236,6 +236,17 @@ class NativeModel:
         check(lib().l2s_postnet(self._h, _ptr(mel), B, S, _ptr(out), _ptr(cf), _ptr(ws), ws.numel(), _stream()))
         return out, cf
 
+    def forward_eval(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int):
+        """`Lip2Speech.forward(..., tf_ratio=1)` in eval mode, what evaluate.py runs (evaluate.py:38): S = mels.shape[2] free-running
+        steps; returns (mel (B,80,S), mel_post (B,80,S), stop (B,S), attention LOGITS (B,S,T), content_dis)."""
+        B, _, T, _, _ = video.shape
+        feat = self.encoder_fwd(video)
+        vis = build_visual(feat, emb)
+        state, dis = self.decoder_prologue(vis, emb, gumbel)
+        mel, stop, attn = self.decode_steps(state, B, T, S, want_attn=True, attn_logits=True)
+        mel_post, mel_cf = self.postnet(mel, want_cf=True)
+        return mel_cf, mel_post, stop, attn, dis
+
     def inference(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int = 300, want_attn: bool = False):
         video, emb, gumbel = _f32(video), _f32(emb), _f32(gumbel)
         B, _, T, H, W = video.shape

@@ -77,8 +77,9 @@ class InflightPool:
     def n_inflight(self) -> int:
         return len(self.models)
 
-    def map(self, batches: Sequence, S: int = 300, want_attn: bool = False) -> List:
-        """Run `inference` on every (video, emb, gumbel) of `batches`; worker i takes the next unclaimed batch (dynamic schedule)."""
+    def map(self, batches: Sequence, S: int = 300, want_attn: bool = False, fn: Callable = None) -> List:
+        """Run `inference` on every (video, emb, gumbel) of `batches`; worker i takes the next unclaimed batch (dynamic schedule).
+        `fn(model, batch)` replaces the default `model.inference(*batch, S=S, want_attn=want_attn)`."""
         todo: "queue.Queue[int]" = queue.Queue()
         for i in range(len(batches)):
             todo.put(i)
@@ -97,8 +98,11 @@ class InflightPool:
                             i = todo.get_nowait()
                         except queue.Empty:
                             break
-                        video, emb, gumbel = batches[i]
-                        out[i] = self.models[w].inference(video, emb, gumbel, S=S, want_attn=want_attn)
+                        if fn is not None:
+                            out[i] = fn(self.models[w], batches[i])
+                        else:
+                            video, emb, gumbel = batches[i]
+                            out[i] = self.models[w].inference(video, emb, gumbel, S=S, want_attn=want_attn)
             except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
                 errors.append(e)
 
