@@ -282,3 +282,22 @@ def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
     torch.cuda.synchronize()
     for g, w in zip(got, want):
         assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+
+
+@pytest.mark.gpu
+def test_model_inference_pool_matches_model_inference():
+    """`model.inference_pool(net)` (batches in flight) returns what `net.inference` returns, batch by batch."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from model.model import get_network
+    from lip2speech_amd.model.model import inference_pool
+    net = get_network("test").cuda()
+    B, T = 3, 29
+    batches = [(synth.synth_video(B, T, tag=f"mp{i}").cuda(), synth.synth_speaker_embedding(B, tag=f"mp{i}").cuda(),
+                synth.synth_gumbel(B * 4, tag=f"mp{i}").cuda()) for i in range(4)]
+    want = [net.inference(v, None, speaker_embedding=e, return_attention_map=True, gumbel_noise=g) for v, e, g in batches]
+    got = inference_pool(net, n_inflight=2).map(batches, want_attn=True)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
