@@ -1,8 +1,9 @@
 // Training path of the decoder (reference: Decoder.forward /root/reference/model/modules/decoder.py:320-379 under
 // loss.backward(), train.py:184): forward with a tape of the intermediates the backward needs, and the backward itself.
-// Stage 1 (this file, so far): the post-net (decoder.py:107-156).  Eval-mode normalisation statistics and no dropout - the
-// configuration SURVEY.md §8(a) a16(iii) pins with gradient goldens; batch-statistics BatchNorm and dropout masks are the
-// next increment.
+// Three stages, each with its own tape and C-ABI pair: the post-net (decoder.py:107-156), the autoregressive loop with back-propagation
+// through time (:353-375) and the prologue (:321-351).  BatchNorm runs on running statistics (eval) or batch statistics (train, see
+// l2s_train_set_bn); the dropout sites take their multipliers as inputs.  Gradient parity: tests/test_grad_goldens.py (reference
+// goldens, both modes), tests/test_training_pieces.py (per stage against autograd through the oracle).
 #include "../../include/l2s.h"
 #include "l2s_common.h"
 #include "l2s_model.h"

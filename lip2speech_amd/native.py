@@ -266,7 +266,7 @@ class NativeModel:
         check(lib().l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
         return emb
 
-    # ------------------------------------------------------------------ training (in progress)
+    # ------------------------------------------------------------------ training (forward with tapes + backward)
     def train_bind(self, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]) -> None:
         """Bind canonical-layout device parameters and their gradient slots by checkpoint key."""
         self._bound = (params, grads)                       # keep the tensors alive
