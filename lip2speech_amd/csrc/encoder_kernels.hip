@@ -260,74 +260,90 @@ __device__ __forceinline__ f32x4 su_mfma4(const float4& a, const float4& w, f32x
     return acc;
 }
 
-// dst[m][n] = relu((A[m][:] . W[n][:]) * scale[n] + shift[n]) for all 16-row tiles of the block.
-// Work item = (column tile, group of G row tiles); the last group is shifted back so every item has exactly G tiles
-// (an overlapped tile is computed twice with identical results) - no data-dependent guards around the MFMAs.
-template <int NC, int G>
-__device__ __forceinline__ void su_gemm(const float* __restrict__ A, int lda, int mtiles, const float* __restrict__ Wf,
-                                        int N, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ dst) {
+// buf[m][n] = relu((buf[m][:] . W[n][:]) * scale[n] + shift[n]) for all 16-row tiles of the block, IN PLACE: every wave
+// keeps the accumulators of its (<= IT) work items in registers across a block barrier, so one LDS buffer serves as both
+// operand and result. Work item = (column tile, group of G row tiles); the last group is shifted back so every item
+// has exactly G tiles (an overlapped tile is computed twice with identical results) - no data-dependent guards around
+// the MFMAs. One buffer instead of two is what lets two blocks share a CU.
+template <int NC, int G, int IT>
+__device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mtiles, const float* __restrict__ Wf,
+                                        int N, const float* __restrict__ scale, const float* __restrict__ shift) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = (N + 15) >> 4;
     const int MG = (mtiles + G - 1) / G;
     const int li = lane & 15, lg = lane >> 4;
-#pragma unroll 1
-    for (int item = wave; item < NT * MG; item += 8) {
-        const int nt = item % NT, mg = item / NT;
-        const int mt0 = min(mg * G, mtiles - G);
-        f32x4 acc[G];
+    f32x4 acc[IT][G];
 #pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = {0.f, 0.f, 0.f, 0.f};
-        const float4* wb = reinterpret_cast<const float4*>(Wf) + (int64_t)nt * NC * 64 + lane;
-        const float* ab = A + (mt0 * 16 + li) * lda + 4 * lg;
-        float4 b4[NC];                                   // the whole K strip of this column tile: one round trip to L2
+    for (int it = 0; it < IT; ++it) {
+        const int item = wave + 8 * it;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) b4[c] = wb[c * 64];
+        for (int j = 0; j < G; ++j) acc[it][j] = {0.f, 0.f, 0.f, 0.f};
+        if (item < NT * MG) {
+            const int nt = item % NT, mg = item / NT;
+            const int mt0 = min(mg * G, mtiles - G);
+            const float4* wb = reinterpret_cast<const float4*>(Wf) + (int64_t)nt * NC * 64 + lane;
+            const float* ab = buf + (mt0 * 16 + li) * lda + 4 * lg;
+            float4 b4[NC];                               // the whole K strip of this column tile: one round trip to L2
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+            for (int c = 0; c < NC; ++c) b4[c] = wb[c * 64];
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const float4 a4 = *reinterpret_cast<const float4*>(ab + j * 16 * lda + 16 * c);
-                acc[j] = su_mfma4(a4, b4[c], acc[j]);
+            for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ab + j * 16 * lda + 16 * c);
+                    acc[it][j] = su_mfma4(a4, b4[c], acc[it][j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the LDS operand reads of later chunks from being hoisted (VGPRs)
             }
-            __builtin_amdgcn_sched_barrier(0);          // keep the LDS operand reads of later chunks from being hoisted (VGPRs)
         }
-        const int n = nt * 16 + li;
-        if (n < N) {
-            const float sc = scale[n], sh = shift[n];
+    }
+    __syncthreads();                                     // every wave has read its operand rows
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
+    for (int it = 0; it < IT; ++it) {
+        const int item = wave + 8 * it;
+        if (item < NT * MG) {
+            const int nt = item % NT, mg = item / NT;
+            const int mt0 = min(mg * G, mtiles - G);
+            const int n = nt * 16 + li;
+            if (n < N) {
+                const float sc = scale[n], sh = shift[n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[j][r] * sc + sh;
-                    dst[((mt0 + j) * 16 + 4 * lg + r) * lda + n] = v > 0.f ? v : 0.f;
+                for (int j = 0; j < G; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[it][j][r] * sc + sh;
+                        buf[((mt0 + j) * 16 + 4 * lg + r) * lda + n] = v > 0.f ? v : 0.f;
+                    }
                 }
             }
         }
     }
+    __syncthreads();
 }
 
-// NC = Kpad/16, G = row tiles per GEMM work item, PPW = pixels per wave (ceil(F*h*h/8)), CIT = ceil(2*half/64).
-template <int NC, int G, int PPW, int CIT>
+// NC = Kpad/16, G = row tiles per GEMM work item, PPW = pixels per wave (ceil(F*h*h/8)), CIT = ceil(2*half/64),
+// H = spatial size of the stage, IT = GEMM work items per wave (ceil(ceil(half/16)*ceil(mtiles/G)/8)).
+template <int NC, int G, int PPW, int CIT, int H, int IT>
 __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) {
     extern __shared__ __attribute__((aligned(16))) float su_smem[];
+    constexpr int HH = H * H, CH = (CIT + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = p.h * p.h, C = 2 * p.half;
+    const int C = 2 * p.half;
     const int f0 = blockIdx.x * p.F;
     const int nf = min(p.F, p.NF - f0);
-    const int Mv = nf * hh;                               // valid pixel rows of this block
-    const int mtiles = (p.F * hh + 15) >> 4;
+    const int Mv = nf * HH;                               // valid pixel rows of this block
+    const int mtiles = (p.F * HH + 15) >> 4;
     const int rows = mtiles * 16, lda = p.Kpad + 4;
-    float* bufA = su_smem;
-    float* bufB = su_smem + rows * lda;
-    const float* xb = p.x + (int64_t)f0 * hh * C;
-    float* ob = p.out + (int64_t)f0 * hh * C;
+    float* buf = su_smem;
+    const float* xb = p.x + (int64_t)f0 * HH * C;
+    float* ob = p.out + (int64_t)f0 * HH * C;
 
     // phase 0: the block's whole input, ONE round of loads: wave -> pixels m = wave + 8*i, lane -> channels c = lane + 64*j.
     // Buffer loads (T8): scalar descriptor + scalar per-pixel offset + one per-lane byte offset per j, so the 36-40 loads in
     // flight cost no address VGPRs, and the descriptor's byte count zero-fills everything past the block's valid pixels.
-    // The second channel half goes to bufA (GEMM operand); the first half (passthrough) stays in registers.
+    // The second channel half goes to LDS (GEMM operand); the first half (passthrough) stays in registers.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, Mv * C * 4, 0x00020000);
     int voff[CIT];
 #pragma unroll
@@ -340,14 +356,14 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
         for (int j = 0; j < CIT; ++j)
             xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
     }
-    // zero the K padding columns and the padded rows of bufA (GEMM reads them; 0 * weight-padding must stay 0)
+    // zero the K padding columns and the padded rows (the GEMMs read them; 0 * weight-padding must stay 0)
     for (int idx = tid; idx < rows * (p.Kpad - p.half); idx += 512) {
         const int m = idx / (p.Kpad - p.half), k = p.half + idx - m * (p.Kpad - p.half);
-        bufA[m * lda + k] = 0.f;
+        buf[m * lda + k] = 0.f;
     }
     for (int idx = tid; idx < (rows - Mv) * p.half; idx += 512) {
         const int m = Mv + idx / p.half, k = idx - (m - Mv) * p.half;
-        bufA[m * lda + k] = 0.f;
+        buf[m * lda + k] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -355,42 +371,57 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
 #pragma unroll
         for (int j = 0; j < CIT; ++j) {
             const int c = lane + 64 * j;
-            if (m < Mv && c >= p.half && c < C) bufA[m * lda + (c - p.half)] = xr[i][j];
+            if (m < Mv && c >= p.half && c < C) buf[m * lda + (c - p.half)] = xr[i][j];
         }
     }
     __syncthreads();
-    // phase 1: pw1 + BN + ReLU -> bufB
-    su_gemm<NC, G>(bufA, lda, mtiles, p.w1f, p.half, p.s1, p.b1, bufB);
-    __syncthreads();
-    // phase 2: depthwise 3x3 (pad 1) + BN -> bufA (pad columns keep their zeros)
-    for (int c = lane; c < p.half; c += 64) {
+    // phase 1: pw1 + BN + ReLU, in place
+    su_gemm<NC, G, IT>(buf, lda, mtiles, p.w1f, p.half, p.s1, p.b1);
+    // phase 2: depthwise 3x3 (pad 1) + BN, in place: results wait in registers until every wave has read its taps
+    float dv[CH][PPW];
+#pragma unroll
+    for (int jc = 0; jc < CH; ++jc) {
+        const int c = min(lane + 64 * jc, p.half - 1);
         float wk[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * p.half + c];
         const float sd = p.sd[c], bd = p.bd[c];
-        for (int m = wave; m < Mv; m += 8) {
-            const int f = m / hh, q = m - f * hh;
-            const int y = q / p.h, x = q - y * p.h;           // wave-uniform
-            const float* rb = bufB + (f * hh) * lda + c;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int m = wave + 8 * i;                   // wave-uniform
             float acc = 0.f;
+            if (m < Mv) {
+                const int f = m / HH, q = m - f * HH;
+                const int y = q / H, x = q - y * H;
+                const float* rb = buf + (f * HH) * lda + c;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                if (yy < 0 || yy >= p.h) continue;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y + ky - 1;
+                    if (yy < 0 || yy >= H) continue;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = x + kx - 1;
-                    if (xx < 0 || xx >= p.h) continue;
-                    acc = fmaf(rb[(yy * p.h + xx) * lda], wk[ky * 3 + kx], acc);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = x + kx - 1;
+                        if (xx < 0 || xx >= H) continue;
+                        acc = fmaf(rb[(yy * H + xx) * lda], wk[ky * 3 + kx], acc);
+                    }
                 }
             }
-            bufA[m * lda + c] = acc * sd + bd;
+            dv[jc][i] = acc * sd + bd;
         }
     }
     __syncthreads();
-    // phase 3: pw2 + BN + ReLU -> bufB
-    su_gemm<NC, G>(bufA, lda, mtiles, p.w2f, p.half, p.s2, p.b2, bufB);
+#pragma unroll
+    for (int jc = 0; jc < CH; ++jc) {
+        const int c = lane + 64 * jc;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int m = wave + 8 * i;
+            if (m < Mv && c < p.half) buf[m * lda + c] = dv[jc][i];
+        }
+    }
     __syncthreads();
+    // phase 3: pw2 + BN + ReLU, in place
+    su_gemm<NC, G, IT>(buf, lda, mtiles, p.w2f, p.half, p.s2, p.b2);
     // phase 4: channel_shuffle store: out[2k] = x1[k] (register), out[2k+1] = branch[k] (LDS) as one 8-byte store
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -401,36 +432,45 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
             if (m < Mv && c < p.half) {
                 float2 o;
                 o.x = xr[i][j];
-                o.y = bufB[m * lda + c];
+                o.y = buf[m * lda + c];
                 *reinterpret_cast<float2*>(ob + (int64_t)m * C + 2 * c) = o;
             }
         }
     }
 }
 
-template <int NC, int G, int PPW, int CIT>
+template <int NC, int G, int PPW, int CIT, int H, int IT>
 static int launch_s1_inst(const ShuffleS1P& p, size_t smem, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<NC, G, PPW, CIT>),
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<NC, G, PPW, CIT, H, IT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((shuffle_s1_kernel<NC, G, PPW, CIT>), dim3((p.NF + p.F - 1) / p.F), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((shuffle_s1_kernel<NC, G, PPW, CIT, H, IT>), dim3((p.NF + p.F - 1) / p.F), dim3(512), smem, s, p);
     return 0;
 }
 
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     const int hh = p.h * p.h;
     const int mtiles = (p.F * hh + 15) / 16;
-    const size_t smem = (size_t)2 * mtiles * 16 * (p.Kpad + 4) * sizeof(float);
+    const size_t smem = (size_t)mtiles * 16 * (p.Kpad + 4) * sizeof(float);
     L2S_REQUIRE(smem <= 150 * 1024 && p.Kpad % 16 == 0 && p.Kpad >= p.half, "shuffle_s1 tile does not fit LDS");
-    const int ppw = (p.F * hh + 7) / 8, cit = (2 * p.half + 63) / 64;
-    ProfScope ps("shuffle_unit_s1_fused", s);
+    const int cit = (2 * p.half + 63) / 64, nt = (p.half + 15) / 16;
+    ProfScope ps(p.h == 12 ? "shuffle_unit_s1_fused_h12" : p.h == 6 ? "shuffle_unit_s1_fused_h6" : "shuffle_unit_s1_fused_h3", s);
     int rc = 1;
-    if (p.Kpad == 64 && ppw <= 18 && cit <= 2 && mtiles >= 5) rc = launch_s1_inst<4, 5, 18, 2>(p, smem, s);
-    else if (p.Kpad == 128 && ppw <= 9 && cit <= 4 && mtiles >= 5) rc = launch_s1_inst<8, 5, 9, 4>(p, smem, s);
-    else if (p.Kpad == 240 && ppw <= 5 && cit <= 8 && mtiles >= 3) rc = launch_s1_inst<15, 3, 5, 8>(p, smem, s);
+    // instance = <Kpad/16, G, pixels per wave, channel strips, h, GEMM items per wave>; every instance is exact for one
+    // (stage, frames per block) pair: ppw, the strip count and ceil(nt * ceil(mtiles / G) / 8) must match its bounds
+    const int F = p.F;
+    const bool s2 = p.h == 12 && p.Kpad == 64 && cit <= 2 && nt <= 4;
+    const bool s3 = p.h == 6 && p.Kpad == 128 && cit <= 4 && nt <= 8;
+    const bool s4 = p.h == 3 && p.Kpad == 240 && cit <= 8 && nt <= 15;
+    if (s2 && F == 1) rc = launch_s1_inst<4, 5, 18, 2, 12, 1>(p, smem, s);
+    else if (s3 && F == 1) rc = launch_s1_inst<8, 3, 5, 4, 6, 1>(p, smem, s);
+    else if (s3 && F == 2) rc = launch_s1_inst<8, 5, 9, 4, 6, 1>(p, smem, s);
+    else if (s4 && F == 2) rc = launch_s1_inst<15, 2, 3, 8, 3, 2>(p, smem, s);
+    else if (s4 && F == 3) rc = launch_s1_inst<15, 2, 4, 8, 3, 2>(p, smem, s);
+    else if (s4 && F == 4) rc = launch_s1_inst<15, 3, 5, 8, 3, 2>(p, smem, s);
     else set_error("shuffle_s1: unsupported unit geometry");
     if (rc) return 1;
     L2S_CHECK_HIP(hipGetLastError());

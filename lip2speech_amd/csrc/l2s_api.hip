@@ -708,6 +708,7 @@ static int64_t decode_ws_floats(int B) {
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
 
 // ------------------------------------------------------------------------------------------------ encoder
+static int g_opt_s1_frames[3] = {0, 0, 0};  // frames per block of the fused units at h = 12 / 6 / 3 (0 = default)
 static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each
 
 static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
@@ -749,7 +750,9 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
-            sp.F = std::max(1, 8352 / (h * h * half));        // ~33 KB of activations per LDS buffer
+            sp.F = std::max(1, 8352 / (h * h * half));        // ~33 KB of activations per block
+            const int fo = g_opt_s1_frames[h == 12 ? 0 : h == 6 ? 1 : 2];
+            if (fo > 0) sp.F = fo;
             if (launch_shuffle_s1(sp, s)) return 1;
         } else {
             const int64_t px = (int64_t)NF * h * h;
@@ -1405,6 +1408,9 @@ int l2s_set_option(const char* name, int value) {
     if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
+    else if (!std::strcmp(name, "s1_frames_h12")) g_opt_s1_frames[0] = value;
+    else if (!std::strcmp(name, "s1_frames_h6")) g_opt_s1_frames[1] = value;
+    else if (!std::strcmp(name, "s1_frames_h3")) g_opt_s1_frames[2] = value;
     else if (!std::strcmp(name, "overlap_postnet")) g_opt_overlap_postnet = value;
     else { set_error(std::string("unknown option ") + name); return 1; }
     return 0;
