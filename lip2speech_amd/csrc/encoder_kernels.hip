@@ -457,7 +457,7 @@ int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     const size_t smem = (size_t)mtiles * 16 * (p.Kpad + 4) * sizeof(float);
     L2S_REQUIRE(smem <= 150 * 1024 && p.Kpad % 16 == 0 && p.Kpad >= p.half, "shuffle_s1 tile does not fit LDS");
     const int cit = (2 * p.half + 63) / 64, nt = (p.half + 15) / 16;
-    ProfScope ps(p.h == 12 ? "shuffle_unit_s1_fused_h12" : p.h == 6 ? "shuffle_unit_s1_fused_h6" : "shuffle_unit_s1_fused_h3", s);
+    ProfScope ps(p.h >= 11 ? "shuffle_unit_s1_fused_h12" : p.h == 6 ? "shuffle_unit_s1_fused_h6" : "shuffle_unit_s1_fused_h3", s);
     int rc = 1;
     // instance = <Kpad/16, G, pixels per wave, channel strips, h, GEMM items per wave>; every instance is exact for one
     // (stage, frames per block) pair: ppw, the strip count and ceil(nt * ceil(mtiles / G) / 8) must match its bounds
@@ -465,7 +465,9 @@ int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     const bool s2 = p.h == 12 && p.Kpad == 64 && cit <= 2 && nt <= 4;
     const bool s3 = p.h == 6 && p.Kpad == 128 && cit <= 4 && nt <= 8;
     const bool s4 = p.h == 3 && p.Kpad == 240 && cit <= 8 && nt <= 15;
+    const bool s2b = p.h == 11 && p.Kpad == 64 && cit <= 2 && nt <= 4;      // 88x88 crops: 11 x 11 at stage 2
     if (s2 && F == 1) rc = launch_s1_inst<4, 5, 18, 2, 12, 1>(p, smem, s);
+    else if (s2b && F == 1) rc = launch_s1_inst<4, 5, 16, 2, 11, 1>(p, smem, s);
     else if (s3 && F == 1) rc = launch_s1_inst<8, 3, 5, 4, 6, 1>(p, smem, s);
     else if (s3 && F == 2) rc = launch_s1_inst<8, 5, 9, 4, 6, 1>(p, smem, s);
     else if (s4 && F == 2) rc = launch_s1_inst<15, 2, 3, 8, 3, 2>(p, smem, s);

@@ -750,8 +750,8 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
-            sp.F = std::max(1, 8352 / (h * h * half));        // ~33 KB of activations per block
-            const int fo = g_opt_s1_frames[h == 12 ? 0 : h == 6 ? 1 : 2];
+            sp.F = h >= 11 ? 1 : 2;                            // measured best (tools/sweep_s1_frames.py): 39 / 42 / 31 KB of LDS, two blocks per CU
+            const int fo = g_opt_s1_frames[h >= 11 ? 0 : h == 6 ? 1 : 2];
             if (fo > 0) sp.F = fo;
             if (launch_shuffle_s1(sp, s)) return 1;
         } else {

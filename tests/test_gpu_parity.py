@@ -61,6 +61,15 @@ def test_encoder_matches_reference_golden(nm):
     assert (norms - 1).abs().max() < 1e-5                       # F.normalize over the 768 channels
 
 
+@pytest.mark.parametrize("hw,B,T", [(88, 1, 3), (96, 1, 5), (88, 2, 2)])
+def test_encoder_other_geometries(nm, synth_sd, hw, B, T):
+    """88x88 crops (11x11 at stage 2) and odd frame counts (a half-filled last block of the fused ShuffleNet units)."""
+    v = synth.synth_video(B, T, hw, hw, tag=f"enc{hw}_{B}_{T}")
+    feat = nm.encoder_fwd(v.cuda())
+    ref = orc.encoder_forward(synth_sd, v)
+    assert pc.maxdiff(feat, ref) < 2e-5
+
+
 def test_prologue_matches_oracle(nm):
     g, _, emb = pc.lrw2_inputs()
     B, T = 2, 29
