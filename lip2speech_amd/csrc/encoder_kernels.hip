@@ -479,6 +479,145 @@ int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ fused stride-2 unit
+// depthwise 3x3 / stride 2 / pad 1 (+BN) from an LDS tile of input rows (tile row 0 = frame row iy0) to an LDS tile of output
+// pixels; lanes = channels, waves = output pixels. Frame borders are skipped, not read: the padding is of THIS map (for banch2
+// that is relu(bn(pw1(x))), whose value on a zero pixel is not zero).
+__device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* __restrict__ dst, int lda, int Cn, int h, int ho,
+                                         int iy0, int outv, const float* __restrict__ w9, const float* __restrict__ sc,
+                                         const float* __restrict__ sh) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c = lane; c < Cn; c += 64) {
+        float wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = w9[t * Cn + c];
+        const float s = sc[c], b = sh[c];
+        for (int m = wave; m < outv; m += 8) {                // wave-uniform
+            const int oyl = m / ho, ox = m - oyl * ho;
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = 2 * oyl + ky, iy = iy0 + r;
+                if (iy < 0 || iy >= h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = 2 * ox + kx - 1;
+                    if (ix < 0 || ix >= h) continue;
+                    acc = fmaf(src[(r * h + ix) * lda + c], wk[ky * 3 + kx], acc);
+                }
+            }
+            dst[m * lda + c] = acc * s + b;
+        }
+    }
+}
+
+// NCI / NCH = Kin/16, Kh/16; (G1, IT1) = row tiles per item / items per wave of the full-resolution pw1 GEMM;
+// (G2, IT2) the same for the two output-resolution GEMMs; CIN4 = cin/4 (compile-time divisor of the tile load).
+template <int NCI, int NCH, int G1, int IT1, int G2, int IT2, int CIN4>
+__global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) {
+    extern __shared__ __attribute__((aligned(16))) float su_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = p.h, ho = p.ho, f = blockIdx.y;
+    const int oy0 = blockIdx.x * p.Ro;
+    const int ro = min(p.Ro, ho - oy0);
+    const int iy0 = 2 * oy0 - 1;                           // frame row of tile row 0
+    const int rin = 2 * p.Ro + 1;
+    const int mt_in = (rin * h + 15) >> 4, mt_out = (p.Ro * ho + 15) >> 4;
+    const int outv = ro * ho;                              // valid output pixels of this block
+    const int lda = max(p.Kin, p.Kh) + 4;
+    float* X = su_smem;
+    float* D1 = X + mt_in * 16 * lda;
+    float* D2 = D1 + mt_out * 16 * lda;
+
+    // the tile's rows inside the frame are one contiguous run of (pixel, channel) floats in HBM: float4 loads, LDS row per pixel.
+    // Tile rows outside the frame are never written and never read by the depthwise taps; the GEMM turns them into garbage
+    // rows that nobody reads (GEMM rows are independent).
+    const int iy_lo = max(iy0, 0), iy_hi = min(iy0 + 2 * ro + 1, h);
+    const int n4 = (iy_hi - iy_lo) * h * CIN4;
+    const float4* src4 = reinterpret_cast<const float4*>(p.x + ((int64_t)f * h + iy_lo) * h * p.cin);
+    float* xt = X + (iy_lo - iy0) * h * lda;
+    for (int idx = tid; idx < n4; idx += 512) {
+        const int px = idx / CIN4, c4 = idx - px * CIN4;
+        *reinterpret_cast<float4*>(xt + px * lda + 4 * c4) = src4[idx];
+    }
+    // zero the K padding columns (0 * weight padding must stay 0, and LDS garbage may be NaN)
+    for (int idx = tid; idx < mt_in * 16 * (p.Kin - p.cin); idx += 512) {
+        const int m = idx / (p.Kin - p.cin), k = p.cin + idx - m * (p.Kin - p.cin);
+        X[m * lda + k] = 0.f;
+    }
+    for (int idx = tid; idx < mt_out * 16 * (p.Kin - p.cin); idx += 512) {
+        const int m = idx / (p.Kin - p.cin), k = p.cin + idx - m * (p.Kin - p.cin);
+        D1[m * lda + k] = 0.f;
+    }
+    for (int idx = tid; idx < mt_out * 16 * (p.Kh - p.half); idx += 512) {
+        const int m = idx / (p.Kh - p.half), k = p.half + idx - m * (p.Kh - p.half);
+        D2[m * lda + k] = 0.f;
+    }
+    __syncthreads();
+    // banch1: depthwise s2 + BN of x -> D1 (must read x before pw1 overwrites it in place)
+    su_dw_s2(X, D1, lda, p.cin, h, ho, iy0, outv, p.wd1, p.sd1, p.bd1);
+    // banch2: pw1 + BN + ReLU at full resolution, in place (its first barrier also orders the D1 reads of x before the overwrite)
+    su_gemm<NCI, G1, IT1>(X, lda, mt_in, p.w1f, p.half, p.s1, p.b1);
+    // banch2: depthwise s2 + BN -> D2
+    su_dw_s2(X, D2, lda, p.half, h, ho, iy0, outv, p.wd, p.sd, p.bd);
+    __syncthreads();
+    // the two output-resolution pointwise convs + BN + ReLU, in place
+    su_gemm<NCI, G2, IT2>(D1, lda, mt_out, p.wb1f, p.half, p.sb1, p.bb1);
+    su_gemm<NCH, G2, IT2>(D2, lda, mt_out, p.w2f, p.half, p.s2, p.b2);
+    // channel_shuffle store: out[2k] = banch1[k], out[2k+1] = banch2[k]
+    float* ob = p.out + ((int64_t)f * ho + oy0) * ho * (2 * p.half);
+    for (int m = wave; m < outv; m += 8) {
+        for (int c = lane; c < p.half; c += 64) {
+            float2 o;
+            o.x = D1[m * lda + c];
+            o.y = D2[m * lda + c];
+            *reinterpret_cast<float2*>(ob + (int64_t)m * (2 * p.half) + 2 * c) = o;
+        }
+    }
+}
+
+template <int NCI, int NCH, int G1, int IT1, int G2, int IT2, int CIN4>
+static int launch_s2_inst(const ShuffleS2P& p, size_t smem, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<NCI, NCH, G1, IT1, G2, IT2, CIN4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((shuffle_s2_kernel<NCI, NCH, G1, IT1, G2, IT2, CIN4>), dim3((p.ho + p.Ro - 1) / p.Ro, p.NF), dim3(512), smem, s, p);
+    return 0;
+}
+
+int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s) {
+    const int mt_in = ((2 * p.Ro + 1) * p.h + 15) / 16, mt_out = (p.Ro * p.ho + 15) / 16;
+    const int lda = std::max(p.Kin, p.Kh) + 4, nt = (p.half + 15) / 16;
+    const size_t smem = (size_t)(mt_in + 2 * mt_out) * 16 * lda * sizeof(float);
+    L2S_REQUIRE(smem <= 150 * 1024 && p.cin % 4 == 0 && p.Kin % 16 == 0 && p.Kh % 16 == 0 && p.Kin >= p.cin && p.Kh >= p.half && p.cin <= p.half,
+                "shuffle_s2 tile does not fit");
+    L2S_REQUIRE((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0, "shuffle_s2 input must be 16-byte aligned");
+    auto fits = [&](int g1, int it1, int g2, int it2) {      // every GEMM work item has a wave slot, every item a full group of tiles
+        return mt_in >= g1 && mt_out >= g2 && nt * ((mt_in + g1 - 1) / g1) <= 8 * it1 && nt * ((mt_out + g2 - 1) / g2) <= 8 * it2;
+    };
+    ProfScope ps(p.cin == 24 ? "shuffle_unit_s2_fused_st2" : p.cin == 116 ? "shuffle_unit_s2_fused_st3" : "shuffle_unit_s2_fused_st4", s);
+    int rc = 1;
+    const bool st2 = p.cin == 24 && p.Kin == 32 && p.Kh == 64;
+    if (st2 && fits(3, 2, 3, 1)) rc = launch_s2_inst<2, 4, 3, 2, 3, 1, 6>(p, smem, s);
+    else if (st2 && fits(4, 1, 2, 1)) rc = launch_s2_inst<2, 4, 4, 1, 2, 1, 6>(p, smem, s);
+    else if (st2 && fits(5, 1, 1, 1)) rc = launch_s2_inst<2, 4, 5, 1, 1, 1, 6>(p, smem, s);
+    else if (st2 && fits(4, 2, 3, 1)) rc = launch_s2_inst<2, 4, 4, 2, 3, 1, 6>(p, smem, s);
+    else if (st2 && fits(5, 2, 5, 1)) rc = launch_s2_inst<2, 4, 5, 2, 5, 1, 6>(p, smem, s);
+    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(4, 1, 1, 1)) rc = launch_s2_inst<8, 8, 4, 1, 1, 1, 29>(p, smem, s);
+    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(3, 1, 1, 1)) rc = launch_s2_inst<8, 8, 3, 1, 1, 1, 29>(p, smem, s);
+    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(3, 2, 2, 1)) rc = launch_s2_inst<8, 8, 3, 2, 2, 1, 29>(p, smem, s);
+    else if (p.cin == 232 && p.Kin == 240 && p.Kh == 240 && fits(3, 2, 1, 2)) rc = launch_s2_inst<15, 15, 3, 2, 1, 2, 58>(p, smem, s);
+    else set_error("shuffle_s2: unsupported unit geometry");
+    if (rc) return 1;
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ column copy
 __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ in, int ldi, int off_i,
                                                         float* __restrict__ out, int ldo, int off_o, int cs_o,

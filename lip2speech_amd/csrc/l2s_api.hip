@@ -219,18 +219,23 @@ static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bo
                 P.bn(p + "banch2.4", half, nullptr, &U.dw.scale, &U.dw.shift);
                 P.copy(p + "banch2.5.weight", (int64_t)half * half, &U.pw2.W);
                 P.bn(p + "banch2.6", half, nullptr, &U.pw2.scale, &U.pw2.shift);
-                if (!U.stride2) {      // fused-unit operands: both pointwise weights in frag16 layout, K zero-padded to 16
-                    U.kpad = (half + 15) & ~15;
-                    const int kpad = U.kpad;
-                    for (int which = 0; which < 2; ++which) {
-                        auto wv = P.get(p + (which == 0 ? "banch2.0.weight" : "banch2.5.weight"), (int64_t)half * half);
+                {   // fused-unit operands: the pointwise weights in frag16 layout, K zero-padded to a multiple of 16
+                    U.kpad = pad16(half);
+                    U.kin = pad16(pw1_in);
+                    struct { const char* key; int K, Kp; const float** slot; } fr[3] = {
+                        {"banch2.0.weight", pw1_in, U.stride2 ? U.kin : U.kpad, &U.pw1_frag},
+                        {"banch2.5.weight", half, U.kpad, &U.pw2_frag},
+                        {"banch1.2.weight", cin, U.kin, &U.b1_frag}};
+                    for (int which = 0; which < (U.stride2 ? 3 : 2); ++which) {
+                        const int K = fr[which].K, Kp = fr[which].Kp;
+                        auto wv = P.get(p + fr[which].key, (int64_t)half * K);
                         if (!wv) continue;
-                        P.frag16(pad16(half), kpad, [&](int n, float* row) {
+                        P.frag16(pad16(half), Kp, [&](int n, float* row) {
                             if (n >= half) return false;
-                            std::memset(row, 0, sizeof(float) * kpad);
-                            std::memcpy(row, wv->data() + (int64_t)n * half, sizeof(float) * half);
+                            std::memset(row, 0, sizeof(float) * Kp);
+                            std::memcpy(row, wv->data() + (int64_t)n * K, sizeof(float) * K);
                             return true;
-                        }, which == 0 ? &U.pw1_frag : &U.pw2_frag);
+                        }, fr[which].slot);
                     }
                 }
                 cin = cout;
@@ -709,6 +714,8 @@ static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4
 
 // ------------------------------------------------------------------------------------------------ encoder
 static int g_opt_s1_frames[3] = {0, 0, 0};  // frames per block of the fused units at h = 12 / 6 / 3 (0 = default)
+static int g_opt_fuse_s2 = 1;     // stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk)
+static int g_opt_s2_rows = 0;     // output rows per block of the fused stride-2 units, r2 + 16*r3 + 256*r4 (0 = default)
 static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each
 
 static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
@@ -732,7 +739,21 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
     for (int u = 0; u < N_UNITS; ++u) {
         const UnitW& U = w.unit[u];
         const int half = U.half, cout = 2 * half;
-        if (U.stride2) {
+        if (U.stride2 && g_opt_fuse_trunk && g_opt_fuse_s2) {
+            ShuffleS2P sp{};
+            sp.x = x; sp.out = y;
+            sp.wd1 = U.b1_dw.w9; sp.sd1 = U.b1_dw.scale; sp.bd1 = U.b1_dw.shift;
+            sp.wb1f = U.b1_frag; sp.sb1 = U.b1_pw.scale; sp.bb1 = U.b1_pw.shift;
+            sp.w1f = U.pw1_frag; sp.s1 = U.pw1.scale; sp.b1 = U.pw1.shift;
+            sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
+            sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
+            sp.NF = NF; sp.h = h; sp.ho = (h + 1) / 2; sp.cin = U.cin; sp.half = half; sp.Kin = U.kin; sp.Kh = U.kpad;
+            sp.Ro = U.cin == 232 ? 3 : 2;                      // measured best (tools/sweep_s2_rows.py): 52 / 51 / 78 KB of LDS
+            const int ro_opt = (g_opt_s2_rows >> (U.cin == 24 ? 0 : U.cin == 116 ? 4 : 8)) & 15;    // per stage: r2 + 16*r3 + 256*r4
+            if (ro_opt > 0) sp.Ro = ro_opt;
+            if (launch_shuffle_s2(sp, s)) return 1;
+            h = sp.ho;
+        } else if (U.stride2) {
             const int cin = U.cin, ho = (h + 1) / 2;
             const int64_t in_px = (int64_t)NF * h * h, out_px = (int64_t)NF * ho * ho;
             // banch1: dw s2 (+BN) -> pw (+BN+ReLU) -> even output channels
@@ -1408,6 +1429,8 @@ int l2s_set_option(const char* name, int value) {
     if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
+    else if (!std::strcmp(name, "fuse_s2")) g_opt_fuse_s2 = value;
+    else if (!std::strcmp(name, "s2_rows")) g_opt_s2_rows = value;
     else if (!std::strcmp(name, "s1_frames_h12")) g_opt_s1_frames[0] = value;
     else if (!std::strcmp(name, "s1_frames_h6")) g_opt_s1_frames[1] = value;
     else if (!std::strcmp(name, "s1_frames_h3")) g_opt_s1_frames[2] = value;

@@ -157,6 +157,18 @@ struct ShuffleS1P {
     int NF, h, half, Kpad, F;
 };
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s);
+// fused stride-2 ShuffleNet unit (encoder_kernels.hip): banch1 (dw s2 -> pw) and banch2 (pw -> dw s2 -> pw) of one strip of Ro
+// output rows per block; the full-resolution pw1 map (124 MB at B=32 in stage 2) never leaves the CU
+struct ShuffleS2P {
+    const float* x; float* out;                              // (NF, h, h, cin) -> (NF, ho, ho, 2*half), channel-last
+    const float* wd1; const float* sd1; const float* bd1;    // banch1 dw: [9][cin], BN scale/shift
+    const float* wb1f; const float* sb1; const float* bb1;   // banch1 pw: frag16 [pad16(half)][Kin]
+    const float* w1f; const float* s1; const float* b1;      // banch2 pw1: frag16 [pad16(half)][Kin]
+    const float* wd; const float* sd; const float* bd;       // banch2 dw: [9][half]
+    const float* w2f; const float* s2; const float* b2;      // banch2 pw2: frag16 [pad16(half)][Kh]
+    int NF, h, ho, cin, half, Kin, Kh, Ro;
+};
+int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s);
 // out[r*ldo + off_o + c*cs_o] = in[r*ldi + off_i + c]
 int launch_copy_cols(const float* in, int ldi, int off_i, float* out, int ldo, int off_o, int cs_o,
                      int64_t rows, int cols, hipStream_t s);

@@ -35,7 +35,8 @@ struct UnitW {
     int cin = 0, half = 0;
     DwW b1_dw; ConvW b1_pw;            // stride-2 units only
     ConvW pw1; DwW dw; ConvW pw2;      // banch2
-    const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // stride-1 units: frag16 [pad16(half)][kpad]
+    const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // fused units: frag16 [pad16(half)][K]; kpad = pad16(half)
+    const float* b1_frag = nullptr; int kin = 0;                                      // stride-2 units: banch1 pw, and pw1, have K = kin = pad16(cin)
 };
 struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; };
 

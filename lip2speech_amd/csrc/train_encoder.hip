@@ -228,21 +228,36 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 9; ++k) a[k] = 0.f;
     if (col < C) {
-        for (int64_t r = r_begin + rl; r < r_end; r += 4) {
-            const int ow = r % Wo; const int64_t q = r / Wo;
-            const int oh = q % Ho, n = q / Ho;
-            const float g = gd[r * C + col];
+        // rows are wave-uniform (lanes = channels): 32-bit pixel arithmetic on the scalar unit, and U rows per trip so that
+        // 10 x U independent loads are in flight instead of one dependent round trip per output pixel
+        constexpr int U = 4;
+        const int cx = xoff + col;
+        for (int r0 = (int)r_begin + rl; r0 < (int)r_end; r0 += 4 * U) {
+            float g[U], xv[U][9];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = oh * stride + kh - 1;
-                if (ih < 0 || ih >= Hi) continue;
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + 4 * u;
+                const bool live = r < (int)r_end;
+                const int rr = live ? r : (int)r_begin;
+                const int ow = rr % Wo, q = rr / Wo;
+                const int oh = q % Ho, n = q / Ho;
+                g[u] = live ? gd[(int64_t)rr * C + col] : 0.f;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow * stride + kw - 1;
-                    if (iw < 0 || iw >= Wi) continue;
-                    a[kh * 3 + kw] = fmaf(g, x[(((int64_t)n * Hi + ih) * Wi + iw) * ldx + xoff + col], a[kh * 3 + kw]);
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = oh * stride + kh - 1;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int iw = ow * stride + kw - 1;
+                        const bool in = live && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+                        xv[u][kh * 3 + kw] = in ? x[(((int64_t)n * Hi + ih) * Wi + iw) * ldx + cx] : 0.f;
+                    }
                 }
             }
+            // same accumulation order as one row per trip: rows ascending within the thread
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a[k] = fmaf(g[u], xv[u][k], a[k]);
         }
     }
 #pragma unroll
@@ -255,15 +270,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restr
     }
 }
 // out[c*so_c + k*so_k] (+)= sum_blk partials[blk*blk_stride + k*C + c]
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int blk_stride, int K, int C, float* __restrict__ out, int so_k,
-                                                              int so_c, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= K * C) return;
-    const int c = idx % C, k = idx / C;
+// 64 (k,c) columns x 16 block-lanes per workgroup: every lane sums nblk/16 partials with all its loads in flight, then the 16
+// lane sums are added in a fixed order (deterministic). One thread per column walking all nblk partials was a 30 us serial chain.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int blk_stride, int K, int C, float* __restrict__ out, int so_k,
+                                                               int so_c, int accumulate) {
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
     float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += partials[(int64_t)b * blk_stride + k * C + c];
-    float* dst = out + (int64_t)c * so_c + (int64_t)k * so_k;
-    *dst = accumulate ? *dst + a : a;
+    if (idx < K * C) {
+#pragma unroll 8
+        for (int b = bl; b < nblk; b += 16) a += partials[(int64_t)b * blk_stride + idx];
+    }
+    sh[bl][lane] = a;
+    __syncthreads();
+    if (bl == 0 && idx < K * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][lane];
+        const int c = idx % C, k = idx / C;
+        float* dst = out + (int64_t)c * so_c + (int64_t)k * so_k;
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 // Front-end backward: MaxPool(1x3x3, s 2, p 1) argmax gather + PReLU + BN(eval) backward over the saved pre-PReLU map z (NF,Hc,Wc,24).
@@ -426,7 +454,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         if (gw) {
             ProfScope ps("train_bwd_dwconv_dw", s);
             hipLaunchKernelGGL(dwconv_bwd_dw_kernel, dim3((C + 63) / 64, DW_RS), dim3(256), 0, s, gdz, x, NF, hi, hi, ldx, xoff, ho, ho, C, stride, dwp);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, s, dwp, DW_RS, 9 * C, 9, C, gw, 1, 9, 0);     // canonical (C,1,3,3)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * C + 63) / 64), dim3(1024), 0, s, dwp, DW_RS, 9 * C, 9, C, gw, 1, 9, 0);     // canonical (C,1,3,3)
         }
         L2S_CHECK_HIP(hipGetLastError());
         return 0;
@@ -490,7 +518,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         float* outs[3] = {G("frontend3D.1.bias"), G("frontend3D.1.weight"), G("frontend3D.2.weight")};
         for (int k = 0; k < 3; ++k) {
             float* dst = k < 2 ? totals + k * 24 : outs[2];                  // r0, r1 are needed by the batch-statistics correction as well
-            if (dst) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, dst, 0, 1, 0);
+            if (dst) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, dst, 0, 1, 0);
             if (k < 2 && outs[k]) L2S_CHECK_HIP(hipMemcpyAsync(outs[k], totals + k * 24, 24 * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
         if (bnb) { if (bn_train_fix(dconv, 24, tp.z0, 24, 1, 0, gamma, beta, fscale, totals, (int64_t)NF * Hc * Hc, 24, s)) return 1; }
