@@ -246,12 +246,16 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
  * writes 8 x 64-bit 100 MHz wall-clock stamps (entry, parameters in SGPRs, loads issued, first operands landed, MFMAs done, after the
  * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
 int l2s_op_skinny_timeline(void* ts_dev);
+/* measurement: the same for the fused stride-1 ShuffleNet units of spatial size h (12, 6 or 3; the last such launch leaves its stamps) - 10 x 64-bit words per block to ts_dev[block*10 ..]: 8 stamps (entry,
+ * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID */
+int l2s_op_fused_unit_timeline(void* ts_dev, int h);
 /* the same chain issued alternately on two streams (two independent dependency chains): does a second chain hide the launch floor? */
 int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b);
 /* run-time options (A/B switches kept for measurement; defaults are the fastest measured):
  *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
  *   "use_graph"         (0)  replay the decode loop from a captured hipGraph
  *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
+ *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
 int l2s_set_option(const char* name, int value);

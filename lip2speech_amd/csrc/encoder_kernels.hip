@@ -260,18 +260,30 @@ __device__ __forceinline__ f32x4 su_mfma4(const float4& a, const float4& w, f32x
     return acc;
 }
 
+// Every extent of the fused units is a template constant (stage geometry is fixed by the architecture): with run-time
+// extents the kernels were bound by the SCALAR unit - 1 200-2 800 s_ instructions per wave of software integer division and
+// index arithmetic against 300-600 VALU/MFMA (rocprofv3 counters, profiles/r01_fused_units_pmc.txt).
+constexpr int su_pad16(int v) { return (v + 15) / 16 * 16; }
+constexpr int su_group(int mt) { return (mt + (mt + 4) / 5 - 1) / ((mt + 4) / 5); }   // row tiles per work item: <= 5, groups as even as possible
+
+// One pointwise conv of a fused unit as a GEMM over an LDS tile: N columns, K = NC*16 (zero padded), MT 16-row tiles.
+template <int N_, int NC_, int MT_>
+struct SuGemm {
+    static constexpr int N = N_, NC = NC_, MT = MT_, G = su_group(MT_);
+    static constexpr int NT = (N + 15) / 16, MG = (MT + G - 1) / G, ITEMS = NT * MG, IT = (ITEMS + 7) / 8;
+};
+
 // buf[m][n] = relu((buf[m][:] . W[n][:]) * scale[n] + shift[n]) for all 16-row tiles of the block, IN PLACE: every wave
 // keeps the accumulators of its (<= IT) work items in registers across a block barrier, so one LDS buffer serves as both
 // operand and result. Work item = (column tile, group of G row tiles); the last group is shifted back so every item
 // has exactly G tiles (an overlapped tile is computed twice with identical results) - no data-dependent guards around
 // the MFMAs. One buffer instead of two is what lets two blocks share a CU.
-template <int NC, int G, int IT>
-__device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mtiles, const float* __restrict__ Wf,
-                                        int N, const float* __restrict__ scale, const float* __restrict__ shift) {
+template <class GM, int LDA>
+__device__ __forceinline__ void su_gemm(float* __restrict__ buf, const float* __restrict__ Wf,
+                                        const float* __restrict__ scale, const float* __restrict__ shift) {
+    constexpr int NC = GM::NC, G = GM::G, IT = GM::IT, NT = GM::NT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NT = (N + 15) >> 4;
-    const int MG = (mtiles + G - 1) / G;
     const int li = lane & 15, lg = lane >> 4;
     f32x4 acc[IT][G];
 #pragma unroll
@@ -279,11 +291,11 @@ __device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mt
         const int item = wave + 8 * it;
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[it][j] = {0.f, 0.f, 0.f, 0.f};
-        if (item < NT * MG) {
+        if (item < GM::ITEMS) {
             const int nt = item % NT, mg = item / NT;
-            const int mt0 = min(mg * G, mtiles - G);
-            const float4* wb = reinterpret_cast<const float4*>(Wf) + (int64_t)nt * NC * 64 + lane;
-            const float* ab = buf + (mt0 * 16 + li) * lda + 4 * lg;
+            const int mt0 = min(mg * G, GM::MT - G);
+            const float4* wb = reinterpret_cast<const float4*>(Wf) + nt * (NC * 64) + lane;
+            const float* ab = buf + (mt0 * 16 + li) * LDA + 4 * lg;
             float4 b4[NC];                               // the whole K strip of this column tile: one round trip to L2
 #pragma unroll
             for (int c = 0; c < NC; ++c) b4[c] = wb[c * 64];
@@ -291,7 +303,7 @@ __device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mt
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int j = 0; j < G; ++j) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ab + j * 16 * lda + 16 * c);
+                    const float4 a4 = *reinterpret_cast<const float4*>(ab + j * 16 * LDA + 16 * c);
                     acc[it][j] = su_mfma4(a4, b4[c], acc[it][j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the LDS operand reads of later chunks from being hoisted (VGPRs)
@@ -302,18 +314,18 @@ __device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mt
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int item = wave + 8 * it;
-        if (item < NT * MG) {
+        if (item < GM::ITEMS) {
             const int nt = item % NT, mg = item / NT;
-            const int mt0 = min(mg * G, mtiles - G);
+            const int mt0 = min(mg * G, GM::MT - G);
             const int n = nt * 16 + li;
-            if (n < N) {
+            if (n < GM::N) {
                 const float sc = scale[n], sh = shift[n];
 #pragma unroll
                 for (int j = 0; j < G; ++j) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[it][j][r] * sc + sh;
-                        buf[((mt0 + j) * 16 + 4 * lg + r) * lda + n] = v > 0.f ? v : 0.f;
+                        buf[((mt0 + j) * 16 + 4 * lg + r) * LDA + n] = v > 0.f ? v : 0.f;
                     }
                 }
             }
@@ -322,20 +334,32 @@ __device__ __forceinline__ void su_gemm(float* __restrict__ buf, int lda, int mt
     __syncthreads();
 }
 
-// NC = Kpad/16, G = row tiles per GEMM work item, PPW = pixels per wave (ceil(F*h*h/8)), CIT = ceil(2*half/64),
-// H = spatial size of the stage, IT = GEMM work items per wave (ceil(ceil(half/16)*ceil(mtiles/G)/8)).
-template <int NC, int G, int PPW, int CIT, int H, int IT>
-__global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) {
+// Fused stride-1 unit: H = spatial size of the stage, HALF = channels per branch, F = frames per block.
+template <int H, int HALF, int F>
+struct S1Geo {
+    static constexpr int HH = H * H, C = 2 * HALF, KP = su_pad16(HALF), LDA = KP + 4, PX = F * HH;
+    static constexpr int MT = (PX + 15) / 16, ROWS = MT * 16, PPW = (PX + 7) / 8, CIT = (C + 63) / 64, CH = (HALF + 63) / 64;
+    using GM = SuGemm<HALF, KP / 16, MT>;
+    static constexpr size_t SMEM = (size_t)ROWS * LDA * sizeof(float);
+};
+
+// measurement hook (tools/fused_unit_timeline.py): non-null -> the stamped build; thread 0 of every block writes 8 x 64-bit stamps
+// of the 100 MHz wall clock plus its XCC / CU id
+static unsigned long long* g_su_ts = nullptr;
+static int g_su_ts_h = 0;                                 // stamp only the units of this spatial size
+void shuffle_set_timeline(unsigned long long* ts, int h) { g_su_ts = ts; g_su_ts_h = h; }
+#define SU_STAMP(k) do { if (TIMED && threadIdx.x == 0) ts[blockIdx.x * 10 + (k)] = wall_clock64(); } while (0)
+
+template <int H, int HALF, int F, bool TIMED>
+__global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, unsigned long long* __restrict__ ts) {
+    using Q = S1Geo<H, HALF, F>;
+    constexpr int HH = Q::HH, C = Q::C, KP = Q::KP, LDA = Q::LDA, ROWS = Q::ROWS, PPW = Q::PPW, CIT = Q::CIT, CH = Q::CH;
     extern __shared__ __attribute__((aligned(16))) float su_smem[];
-    constexpr int HH = H * H, CH = (CIT + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int C = 2 * p.half;
-    const int f0 = blockIdx.x * p.F;
-    const int nf = min(p.F, p.NF - f0);
-    const int Mv = nf * HH;                               // valid pixel rows of this block
-    const int mtiles = (p.F * HH + 15) >> 4;
-    const int rows = mtiles * 16, lda = p.Kpad + 4;
+    SU_STAMP(0);
+    const int f0 = blockIdx.x * F;
+    const int Mv = min(F, p.NF - f0) * HH;                // valid pixel rows of this block
     float* buf = su_smem;
     const float* xb = p.x + (int64_t)f0 * HH * C;
     float* ob = p.out + (int64_t)f0 * HH * C;
@@ -357,13 +381,15 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
             xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
     }
     // zero the K padding columns and the padded rows (the GEMMs read them; 0 * weight-padding must stay 0)
-    for (int idx = tid; idx < rows * (p.Kpad - p.half); idx += 512) {
-        const int m = idx / (p.Kpad - p.half), k = p.half + idx - m * (p.Kpad - p.half);
-        buf[m * lda + k] = 0.f;
+    if (KP > HALF) {
+        for (int idx = tid; idx < ROWS * (KP - HALF); idx += 512) {
+            const int m = idx / (KP - HALF), k = HALF + idx - m * (KP - HALF);
+            buf[m * LDA + k] = 0.f;
+        }
     }
-    for (int idx = tid; idx < (rows - Mv) * p.half; idx += 512) {
-        const int m = Mv + idx / p.half, k = idx - (m - Mv) * p.half;
-        buf[m * lda + k] = 0.f;
+    for (int idx = tid; idx < (ROWS - Mv) * HALF; idx += 512) {
+        const int m = Mv + idx / HALF, k = idx - (m - Mv) * HALF;
+        buf[m * LDA + k] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -371,20 +397,23 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
 #pragma unroll
         for (int j = 0; j < CIT; ++j) {
             const int c = lane + 64 * j;
-            if (m < Mv && c >= p.half && c < C) buf[m * lda + (c - p.half)] = xr[i][j];
+            if (m < Mv && c >= HALF && c < C) buf[m * LDA + (c - HALF)] = xr[i][j];
         }
     }
+    SU_STAMP(1);                                          // input landed, LDS written
     __syncthreads();
+    SU_STAMP(2);
     // phase 1: pw1 + BN + ReLU, in place
-    su_gemm<NC, G, IT>(buf, lda, mtiles, p.w1f, p.half, p.s1, p.b1);
+    su_gemm<typename Q::GM, LDA>(buf, p.w1f, p.s1, p.b1);
+    SU_STAMP(3);
     // phase 2: depthwise 3x3 (pad 1) + BN, in place: results wait in registers until every wave has read its taps
     float dv[CH][PPW];
 #pragma unroll
     for (int jc = 0; jc < CH; ++jc) {
-        const int c = min(lane + 64 * jc, p.half - 1);
+        const int c = min(lane + 64 * jc, HALF - 1);
         float wk[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * p.half + c];
+        for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * HALF + c];
         const float sd = p.sd[c], bd = p.bd[c];
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -393,22 +422,23 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
             if (m < Mv) {
                 const int f = m / HH, q = m - f * HH;
                 const int y = q / H, x = q - y * H;
-                const float* rb = buf + (f * HH) * lda + c;
+                const float* rb = buf + (f * HH) * LDA + c;
+                // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
+                // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = y + ky - 1;
-                    if (yy < 0 || yy >= H) continue;
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = x + kx - 1;
-                        if (xx < 0 || xx >= H) continue;
-                        acc = fmaf(rb[(yy * H + xx) * lda], wk[ky * 3 + kx], acc);
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
+                        acc = fmaf(rb[(in ? yy * H + xx : q) * LDA], in ? wk[ky * 3 + kx] : 0.f, acc);
                     }
                 }
             }
             dv[jc][i] = acc * sd + bd;
         }
     }
+    SU_STAMP(4);                                          // depthwise taps computed
     __syncthreads();
 #pragma unroll
     for (int jc = 0; jc < CH; ++jc) {
@@ -416,12 +446,14 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int m = wave + 8 * i;
-            if (m < Mv && c < p.half) buf[m * lda + c] = dv[jc][i];
+            if (m < Mv && c < HALF) buf[m * LDA + c] = dv[jc][i];
         }
     }
     __syncthreads();
+    SU_STAMP(5);
     // phase 3: pw2 + BN + ReLU, in place
-    su_gemm<NC, G, IT>(buf, lda, mtiles, p.w2f, p.half, p.s2, p.b2);
+    su_gemm<typename Q::GM, LDA>(buf, p.w2f, p.s2, p.b2);
+    SU_STAMP(6);
     // phase 4: channel_shuffle store: out[2k] = x1[k] (register), out[2k+1] = branch[k] (LDS) as one 8-byte store
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -429,50 +461,51 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p) 
 #pragma unroll
         for (int j = 0; j < CIT; ++j) {
             const int c = lane + 64 * j;
-            if (m < Mv && c < p.half) {
+            if (m < Mv && c < HALF) {
                 float2 o;
                 o.x = xr[i][j];
-                o.y = buf[m * lda + c];
+                o.y = buf[m * LDA + c];
                 *reinterpret_cast<float2*>(ob + (int64_t)m * C + 2 * c) = o;
             }
         }
     }
+    if (TIMED) {
+        __builtin_amdgcn_s_waitcnt(0);                    // stores drained
+        SU_STAMP(7);
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (threadIdx.x == 0) { ts[blockIdx.x * 10 + 8] = hw; ts[blockIdx.x * 10 + 9] = xcc; }
+    }
 }
 
-template <int NC, int G, int PPW, int CIT, int H, int IT>
-static int launch_s1_inst(const ShuffleS1P& p, size_t smem, hipStream_t s) {
+template <int H, int HALF, int F>
+static int launch_s1_inst(const ShuffleS1P& p, hipStream_t s) {
+    using Q = S1Geo<H, HALF, F>;
+    static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<NC, G, PPW, CIT, H, IT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<H, HALF, F, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<H, HALF, F, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
         attr_set = true;
     }
-    hipLaunchKernelGGL((shuffle_s1_kernel<NC, G, PPW, CIT, H, IT>), dim3((p.NF + p.F - 1) / p.F), dim3(512), smem, s, p);
+    if (g_su_ts && g_su_ts_h == H) hipLaunchKernelGGL((shuffle_s1_kernel<H, HALF, F, true>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, g_su_ts);
+    else hipLaunchKernelGGL((shuffle_s1_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 
+// frames per block (measured, profiles/r01_fused_units_pmc.txt): 1 at 12x12 / 11x11, 2 at 6x6 and 3x3
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
-    const int hh = p.h * p.h;
-    const int mtiles = (p.F * hh + 15) / 16;
-    const size_t smem = (size_t)mtiles * 16 * (p.Kpad + 4) * sizeof(float);
-    L2S_REQUIRE(smem <= 150 * 1024 && p.Kpad % 16 == 0 && p.Kpad >= p.half, "shuffle_s1 tile does not fit LDS");
-    const int cit = (2 * p.half + 63) / 64, nt = (p.half + 15) / 16;
+    L2S_REQUIRE(p.Kpad == su_pad16(p.half), "shuffle_s1: weight fragments are packed for K = pad16(half)");
     ProfScope ps(p.h >= 11 ? "shuffle_unit_s1_fused_h12" : p.h == 6 ? "shuffle_unit_s1_fused_h6" : "shuffle_unit_s1_fused_h3", s);
     int rc = 1;
-    // instance = <Kpad/16, G, pixels per wave, channel strips, h, GEMM items per wave>; every instance is exact for one
-    // (stage, frames per block) pair: ppw, the strip count and ceil(nt * ceil(mtiles / G) / 8) must match its bounds
-    const int F = p.F;
-    const bool s2 = p.h == 12 && p.Kpad == 64 && cit <= 2 && nt <= 4;
-    const bool s3 = p.h == 6 && p.Kpad == 128 && cit <= 4 && nt <= 8;
-    const bool s4 = p.h == 3 && p.Kpad == 240 && cit <= 8 && nt <= 15;
-    const bool s2b = p.h == 11 && p.Kpad == 64 && cit <= 2 && nt <= 4;      // 88x88 crops: 11 x 11 at stage 2
-    if (s2 && F == 1) rc = launch_s1_inst<4, 5, 18, 2, 12, 1>(p, smem, s);
-    else if (s2b && F == 1) rc = launch_s1_inst<4, 5, 16, 2, 11, 1>(p, smem, s);
-    else if (s3 && F == 1) rc = launch_s1_inst<8, 3, 5, 4, 6, 1>(p, smem, s);
-    else if (s3 && F == 2) rc = launch_s1_inst<8, 5, 9, 4, 6, 1>(p, smem, s);
-    else if (s4 && F == 2) rc = launch_s1_inst<15, 2, 3, 8, 3, 2>(p, smem, s);
-    else if (s4 && F == 3) rc = launch_s1_inst<15, 2, 4, 8, 3, 2>(p, smem, s);
-    else if (s4 && F == 4) rc = launch_s1_inst<15, 3, 5, 8, 3, 2>(p, smem, s);
+    if (p.h == 12 && p.half == 58) rc = launch_s1_inst<12, 58, 1>(p, s);
+    else if (p.h == 11 && p.half == 58) rc = launch_s1_inst<11, 58, 1>(p, s);      // 88x88 crops
+    else if (p.h == 6 && p.half == 116) rc = launch_s1_inst<6, 116, 2>(p, s);
+    else if (p.h == 3 && p.half == 232) rc = launch_s1_inst<3, 232, 2>(p, s);
     else set_error("shuffle_s1: unsupported unit geometry");
     if (rc) return 1;
     L2S_CHECK_HIP(hipGetLastError());
@@ -480,138 +513,145 @@ int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ fused stride-2 unit
+// H = input spatial size, CIN = input channels, HALF = channels per output branch, RO = output rows per block.
+template <int H, int CIN, int HALF, int RO>
+struct S2Geo {
+    static constexpr int HO = (H + 1) / 2, KIN = su_pad16(CIN), KH = su_pad16(HALF), LDA = (KIN > KH ? KIN : KH) + 4;
+    static constexpr int RIN = 2 * RO + 1, MTI = (RIN * H + 15) / 16, MTO = (RO * HO + 15) / 16, STRIPS = (HO + RO - 1) / RO;
+    using G1 = SuGemm<HALF, KIN / 16, MTI>;              // banch2 pw1 at input resolution
+    using G2 = SuGemm<HALF, KIN / 16, MTO>;              // banch1 pw
+    using G3 = SuGemm<HALF, KH / 16, MTO>;               // banch2 pw2
+    static constexpr size_t SMEM = (size_t)(MTI + 2 * MTO) * 16 * LDA * sizeof(float);
+    static_assert(CIN % 4 == 0 && CIN <= HALF, "float4 tile rows; pw1 runs in place over the input tile");
+};
+
 // depthwise 3x3 / stride 2 / pad 1 (+BN) from an LDS tile of input rows (tile row 0 = frame row iy0) to an LDS tile of output
 // pixels; lanes = channels, waves = output pixels. Frame borders are skipped, not read: the padding is of THIS map (for banch2
 // that is relu(bn(pw1(x))), whose value on a zero pixel is not zero).
-__device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* __restrict__ dst, int lda, int Cn, int h, int ho,
-                                         int iy0, int outv, const float* __restrict__ w9, const float* __restrict__ sc,
-                                         const float* __restrict__ sh) {
+template <int H, int HO, int LDA, int CN>
+__device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* __restrict__ dst, int iy0, int outv,
+                                         const float* __restrict__ w9, const float* __restrict__ sc, const float* __restrict__ sh) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int c = lane; c < Cn; c += 64) {
-        float wk[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wk[t] = w9[t * Cn + c];
-        const float s = sc[c], b = sh[c];
-        for (int m = wave; m < outv; m += 8) {                // wave-uniform
-            const int oyl = m / ho, ox = m - oyl * ho;
-            float acc = 0.f;
+    for (int jc = 0; jc < (CN + 63) / 64; ++jc) {
+        const int c = lane + 64 * jc;
+        if (c < CN) {
+            float wk[9];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int r = 2 * oyl + ky, iy = iy0 + r;
-                if (iy < 0 || iy >= h) continue;
+            for (int t = 0; t < 9; ++t) wk[t] = w9[t * CN + c];
+            const float s = sc[c], b = sh[c];
+            for (int m = wave; m < outv; m += 8) {            // wave-uniform
+                const int oyl = m / HO, ox = m - oyl * HO;
+                float acc = 0.f;
+                // border taps are predicated (weight 0, the always-valid centre address), not branched around
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = 2 * ox + kx - 1;
-                    if (ix < 0 || ix >= h) continue;
-                    acc = fmaf(src[(r * h + ix) * lda + c], wk[ky * 3 + kx], acc);
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int r = 2 * oyl + ky, iy = iy0 + r, ix = 2 * ox + kx - 1;
+                        const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+                        acc = fmaf(src[(in ? r * H + ix : (2 * oyl + 1) * H + 2 * ox) * LDA + c], in ? wk[ky * 3 + kx] : 0.f, acc);
+                    }
                 }
+                dst[m * LDA + c] = acc * s + b;
             }
-            dst[m * lda + c] = acc * s + b;
         }
     }
 }
 
-// NCI / NCH = Kin/16, Kh/16; (G1, IT1) = row tiles per item / items per wave of the full-resolution pw1 GEMM;
-// (G2, IT2) the same for the two output-resolution GEMMs; CIN4 = cin/4 (compile-time divisor of the tile load).
-template <int NCI, int NCH, int G1, int IT1, int G2, int IT2, int CIN4>
+template <int H, int CIN, int HALF, int RO>
 __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) {
+    using Q = S2Geo<H, CIN, HALF, RO>;
+    constexpr int HO = Q::HO, KIN = Q::KIN, KH = Q::KH, LDA = Q::LDA, MTI = Q::MTI, MTO = Q::MTO, CIN4 = CIN / 4;
     extern __shared__ __attribute__((aligned(16))) float su_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = p.h, ho = p.ho, f = blockIdx.y;
-    const int oy0 = blockIdx.x * p.Ro;
-    const int ro = min(p.Ro, ho - oy0);
+    const int f = blockIdx.y;
+    const int oy0 = blockIdx.x * RO;
+    const int ro = min(RO, HO - oy0);
     const int iy0 = 2 * oy0 - 1;                           // frame row of tile row 0
-    const int rin = 2 * p.Ro + 1;
-    const int mt_in = (rin * h + 15) >> 4, mt_out = (p.Ro * ho + 15) >> 4;
-    const int outv = ro * ho;                              // valid output pixels of this block
-    const int lda = max(p.Kin, p.Kh) + 4;
+    const int outv = ro * HO;                              // valid output pixels of this block
     float* X = su_smem;
-    float* D1 = X + mt_in * 16 * lda;
-    float* D2 = D1 + mt_out * 16 * lda;
+    float* D1 = X + MTI * 16 * LDA;
+    float* D2 = D1 + MTO * 16 * LDA;
 
     // the tile's rows inside the frame are one contiguous run of (pixel, channel) floats in HBM: float4 loads, LDS row per pixel.
     // Tile rows outside the frame are never written and never read by the depthwise taps; the GEMM turns them into garbage
     // rows that nobody reads (GEMM rows are independent).
-    const int iy_lo = max(iy0, 0), iy_hi = min(iy0 + 2 * ro + 1, h);
-    const int n4 = (iy_hi - iy_lo) * h * CIN4;
-    const float4* src4 = reinterpret_cast<const float4*>(p.x + ((int64_t)f * h + iy_lo) * h * p.cin);
-    float* xt = X + (iy_lo - iy0) * h * lda;
+    const int iy_lo = max(iy0, 0), iy_hi = min(iy0 + 2 * ro + 1, H);
+    const int n4 = (iy_hi - iy_lo) * (H * CIN4);
+    const float4* src4 = reinterpret_cast<const float4*>(p.x + ((int64_t)f * H + iy_lo) * (H * CIN));
+    float* xt = X + (iy_lo - iy0) * (H * LDA);
     for (int idx = tid; idx < n4; idx += 512) {
         const int px = idx / CIN4, c4 = idx - px * CIN4;
-        *reinterpret_cast<float4*>(xt + px * lda + 4 * c4) = src4[idx];
+        *reinterpret_cast<float4*>(xt + px * LDA + 4 * c4) = src4[idx];
     }
     // zero the K padding columns (0 * weight padding must stay 0, and LDS garbage may be NaN)
-    for (int idx = tid; idx < mt_in * 16 * (p.Kin - p.cin); idx += 512) {
-        const int m = idx / (p.Kin - p.cin), k = p.cin + idx - m * (p.Kin - p.cin);
-        X[m * lda + k] = 0.f;
+    if (KIN > CIN) {
+        for (int idx = tid; idx < (MTI + MTO) * 16 * (KIN - CIN); idx += 512) {          // X and D1 are adjacent
+            const int m = idx / (KIN - CIN), k = CIN + idx - m * (KIN - CIN);
+            X[m * LDA + k] = 0.f;
+        }
     }
-    for (int idx = tid; idx < mt_out * 16 * (p.Kin - p.cin); idx += 512) {
-        const int m = idx / (p.Kin - p.cin), k = p.cin + idx - m * (p.Kin - p.cin);
-        D1[m * lda + k] = 0.f;
-    }
-    for (int idx = tid; idx < mt_out * 16 * (p.Kh - p.half); idx += 512) {
-        const int m = idx / (p.Kh - p.half), k = p.half + idx - m * (p.Kh - p.half);
-        D2[m * lda + k] = 0.f;
+    if (KH > HALF) {
+        for (int idx = tid; idx < MTO * 16 * (KH - HALF); idx += 512) {
+            const int m = idx / (KH - HALF), k = HALF + idx - m * (KH - HALF);
+            D2[m * LDA + k] = 0.f;
+        }
     }
     __syncthreads();
     // banch1: depthwise s2 + BN of x -> D1 (must read x before pw1 overwrites it in place)
-    su_dw_s2(X, D1, lda, p.cin, h, ho, iy0, outv, p.wd1, p.sd1, p.bd1);
+    su_dw_s2<H, HO, LDA, CIN>(X, D1, iy0, outv, p.wd1, p.sd1, p.bd1);
     // banch2: pw1 + BN + ReLU at full resolution, in place (its first barrier also orders the D1 reads of x before the overwrite)
-    su_gemm<NCI, G1, IT1>(X, lda, mt_in, p.w1f, p.half, p.s1, p.b1);
+    su_gemm<typename Q::G1, LDA>(X, p.w1f, p.s1, p.b1);
     // banch2: depthwise s2 + BN -> D2
-    su_dw_s2(X, D2, lda, p.half, h, ho, iy0, outv, p.wd, p.sd, p.bd);
+    su_dw_s2<H, HO, LDA, HALF>(X, D2, iy0, outv, p.wd, p.sd, p.bd);
     __syncthreads();
     // the two output-resolution pointwise convs + BN + ReLU, in place
-    su_gemm<NCI, G2, IT2>(D1, lda, mt_out, p.wb1f, p.half, p.sb1, p.bb1);
-    su_gemm<NCH, G2, IT2>(D2, lda, mt_out, p.w2f, p.half, p.s2, p.b2);
+    su_gemm<typename Q::G2, LDA>(D1, p.wb1f, p.sb1, p.bb1);
+    su_gemm<typename Q::G3, LDA>(D2, p.w2f, p.s2, p.b2);
     // channel_shuffle store: out[2k] = banch1[k], out[2k+1] = banch2[k]
-    float* ob = p.out + ((int64_t)f * ho + oy0) * ho * (2 * p.half);
+    float* ob = p.out + ((int64_t)f * HO + oy0) * (HO * 2 * HALF);
     for (int m = wave; m < outv; m += 8) {
-        for (int c = lane; c < p.half; c += 64) {
-            float2 o;
-            o.x = D1[m * lda + c];
-            o.y = D2[m * lda + c];
-            *reinterpret_cast<float2*>(ob + (int64_t)m * (2 * p.half) + 2 * c) = o;
+#pragma unroll
+        for (int jc = 0; jc < (HALF + 63) / 64; ++jc) {
+            const int c = lane + 64 * jc;
+            if (c < HALF) {
+                float2 o;
+                o.x = D1[m * LDA + c];
+                o.y = D2[m * LDA + c];
+                *reinterpret_cast<float2*>(ob + m * (2 * HALF) + 2 * c) = o;
+            }
         }
     }
 }
 
-template <int NCI, int NCH, int G1, int IT1, int G2, int IT2, int CIN4>
-static int launch_s2_inst(const ShuffleS2P& p, size_t smem, hipStream_t s) {
+template <int H, int CIN, int HALF, int RO>
+static int launch_s2_inst(const ShuffleS2P& p, hipStream_t s) {
+    using Q = S2Geo<H, CIN, HALF, RO>;
+    static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<NCI, NCH, G1, IT1, G2, IT2, CIN4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
         attr_set = true;
     }
-    hipLaunchKernelGGL((shuffle_s2_kernel<NCI, NCH, G1, IT1, G2, IT2, CIN4>), dim3((p.ho + p.Ro - 1) / p.Ro, p.NF), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p);
     return 0;
 }
 
+// output rows per block (measured): 2 at stages 2 and 3, the whole 3x3 frame at stage 4
 int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s) {
-    const int mt_in = ((2 * p.Ro + 1) * p.h + 15) / 16, mt_out = (p.Ro * p.ho + 15) / 16;
-    const int lda = std::max(p.Kin, p.Kh) + 4, nt = (p.half + 15) / 16;
-    const size_t smem = (size_t)(mt_in + 2 * mt_out) * 16 * lda * sizeof(float);
-    L2S_REQUIRE(smem <= 150 * 1024 && p.cin % 4 == 0 && p.Kin % 16 == 0 && p.Kh % 16 == 0 && p.Kin >= p.cin && p.Kh >= p.half && p.cin <= p.half,
-                "shuffle_s2 tile does not fit");
+    L2S_REQUIRE(p.Kin == su_pad16(p.cin) && p.Kh == su_pad16(p.half) && p.ho == (p.h + 1) / 2, "shuffle_s2: fragment packing / geometry mismatch");
     L2S_REQUIRE((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0, "shuffle_s2 input must be 16-byte aligned");
-    auto fits = [&](int g1, int it1, int g2, int it2) {      // every GEMM work item has a wave slot, every item a full group of tiles
-        return mt_in >= g1 && mt_out >= g2 && nt * ((mt_in + g1 - 1) / g1) <= 8 * it1 && nt * ((mt_out + g2 - 1) / g2) <= 8 * it2;
-    };
     ProfScope ps(p.cin == 24 ? "shuffle_unit_s2_fused_st2" : p.cin == 116 ? "shuffle_unit_s2_fused_st3" : "shuffle_unit_s2_fused_st4", s);
     int rc = 1;
-    const bool st2 = p.cin == 24 && p.Kin == 32 && p.Kh == 64;
-    if (st2 && fits(3, 2, 3, 1)) rc = launch_s2_inst<2, 4, 3, 2, 3, 1, 6>(p, smem, s);
-    else if (st2 && fits(4, 1, 2, 1)) rc = launch_s2_inst<2, 4, 4, 1, 2, 1, 6>(p, smem, s);
-    else if (st2 && fits(5, 1, 1, 1)) rc = launch_s2_inst<2, 4, 5, 1, 1, 1, 6>(p, smem, s);
-    else if (st2 && fits(4, 2, 3, 1)) rc = launch_s2_inst<2, 4, 4, 2, 3, 1, 6>(p, smem, s);
-    else if (st2 && fits(5, 2, 5, 1)) rc = launch_s2_inst<2, 4, 5, 2, 5, 1, 6>(p, smem, s);
-    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(4, 1, 1, 1)) rc = launch_s2_inst<8, 8, 4, 1, 1, 1, 29>(p, smem, s);
-    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(3, 1, 1, 1)) rc = launch_s2_inst<8, 8, 3, 1, 1, 1, 29>(p, smem, s);
-    else if (p.cin == 116 && p.Kin == 128 && p.Kh == 128 && fits(3, 2, 2, 1)) rc = launch_s2_inst<8, 8, 3, 2, 2, 1, 29>(p, smem, s);
-    else if (p.cin == 232 && p.Kin == 240 && p.Kh == 240 && fits(3, 2, 1, 2)) rc = launch_s2_inst<15, 15, 3, 2, 1, 2, 58>(p, smem, s);
+    if (p.h == 24 && p.cin == 24 && p.half == 58) rc = launch_s2_inst<24, 24, 58, 2>(p, s);
+    else if (p.h == 22 && p.cin == 24 && p.half == 58) rc = launch_s2_inst<22, 24, 58, 2>(p, s);      // 88x88 crops
+    else if (p.h == 12 && p.cin == 116 && p.half == 116) rc = launch_s2_inst<12, 116, 116, 2>(p, s);
+    else if (p.h == 11 && p.cin == 116 && p.half == 116) rc = launch_s2_inst<11, 116, 116, 2>(p, s);
+    else if (p.h == 6 && p.cin == 232 && p.half == 232) rc = launch_s2_inst<6, 232, 232, 3>(p, s);
     else set_error("shuffle_s2: unsupported unit geometry");
     if (rc) return 1;
     L2S_CHECK_HIP(hipGetLastError());

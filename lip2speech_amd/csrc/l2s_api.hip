@@ -713,9 +713,7 @@ static int64_t decode_ws_floats(int B) {
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
 
 // ------------------------------------------------------------------------------------------------ encoder
-static int g_opt_s1_frames[3] = {0, 0, 0};  // frames per block of the fused units at h = 12 / 6 / 3 (0 = default)
 static int g_opt_fuse_s2 = 1;     // stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk)
-static int g_opt_s2_rows = 0;     // output rows per block of the fused stride-2 units, r2 + 16*r3 + 256*r4 (0 = default)
 static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each
 
 static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
@@ -748,9 +746,7 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.ho = (h + 1) / 2; sp.cin = U.cin; sp.half = half; sp.Kin = U.kin; sp.Kh = U.kpad;
-            sp.Ro = U.cin == 232 ? 3 : 2;                      // measured best (tools/sweep_s2_rows.py): 52 / 51 / 78 KB of LDS
-            const int ro_opt = (g_opt_s2_rows >> (U.cin == 24 ? 0 : U.cin == 116 ? 4 : 8)) & 15;    // per stage: r2 + 16*r3 + 256*r4
-            if (ro_opt > 0) sp.Ro = ro_opt;
+            sp.Ro = U.cin == 232 ? 3 : 2;                      // informational: fixed by the kernel instance
             if (launch_shuffle_s2(sp, s)) return 1;
             h = sp.ho;
         } else if (U.stride2) {
@@ -771,9 +767,7 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
-            sp.F = h >= 11 ? 1 : 2;                            // measured best (tools/sweep_s1_frames.py): 39 / 42 / 31 KB of LDS, two blocks per CU
-            const int fo = g_opt_s1_frames[h >= 11 ? 0 : h == 6 ? 1 : 2];
-            if (fo > 0) sp.F = fo;
+            sp.F = h >= 11 ? 1 : 2;                            // informational: fixed by the kernel instance
             if (launch_shuffle_s1(sp, s)) return 1;
         } else {
             const int64_t px = (int64_t)NF * h * h;
@@ -1430,10 +1424,6 @@ int l2s_set_option(const char* name, int value) {
     else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
     else if (!std::strcmp(name, "fuse_s2")) g_opt_fuse_s2 = value;
-    else if (!std::strcmp(name, "s2_rows")) g_opt_s2_rows = value;
-    else if (!std::strcmp(name, "s1_frames_h12")) g_opt_s1_frames[0] = value;
-    else if (!std::strcmp(name, "s1_frames_h6")) g_opt_s1_frames[1] = value;
-    else if (!std::strcmp(name, "s1_frames_h3")) g_opt_s1_frames[2] = value;
     else if (!std::strcmp(name, "overlap_postnet")) g_opt_overlap_postnet = value;
     else { set_error(std::string("unknown option ") + name); return 1; }
     return 0;
@@ -1488,6 +1478,7 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
 
 /* measurement: ts_dev != NULL routes every skinny launch to the stamped build (8 wall-clock stamps per block into ts_dev); NULL restores */
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
+int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
 
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream) {
     for (int i = 0; i < n_launches; ++i)

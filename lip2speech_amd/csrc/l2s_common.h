@@ -157,6 +157,7 @@ struct ShuffleS1P {
     int NF, h, half, Kpad, F;
 };
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s);
+void shuffle_set_timeline(unsigned long long* ts, int h);     // non-null: launch the stamped measurement build (tools/fused_unit_timeline.py)
 // fused stride-2 ShuffleNet unit (encoder_kernels.hip): banch1 (dw s2 -> pw) and banch2 (pw -> dw s2 -> pw) of one strip of Ro
 // output rows per block; the full-resolution pw1 map (124 MB at B=32 in stage 2) never leaves the CU
 struct ShuffleS2P {
