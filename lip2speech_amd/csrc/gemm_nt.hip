@@ -73,6 +73,24 @@ __device__ __forceinline__ float4 load_w(const LoadP& p, const float* wrow, bool
     }
 }
 
+// one output element: scale/shift, activation, masks, addends, and the plain / windowed / strided / channel-first store
+__device__ __forceinline__ void gemm_store(const GemmP& p, int row, int col, float accv, float sc, float sh) {
+    if (p.win_T > 0) { const int wb = row / p.Tout; row = wb * p.win_T + p.win_off + (row - wb * p.Tout); }
+    float v = accv * sc + sh;
+    if (p.Zout) p.Zout[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
+    v = apply_act(v, p.act, p.actw, col);
+    if (p.mask && p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
+    if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];
+    if (p.R2) v += p.R2[(int64_t)(p.r2_div ? row / p.r2_div : (p.r2_mod ? row % p.r2_mod : row)) * p.ldr2 + col];
+    if (p.mask && !p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
+    if (p.c_tr_T > 0) {
+        const int b = row / p.c_tr_T, t = row - b * p.c_tr_T;
+        p.C[((int64_t)b * p.N + col) * p.c_tr_T + t] = v;
+    } else {
+        p.C[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const GemmP& p = batch.p[blockIdx.z];
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         arow[j] = p.A + (int64_t)b * p.Tin * p.lda;
         int n = n0 + lr + 32 * j;
         wvalid[j] = n < p.N;
-        wrow[j] = p.W + (int64_t)(wvalid[j] ? n : 0) * p.K;
+        wrow[j] = p.W + (int64_t)(wvalid[j] ? n : 0) * (p.ldw ? p.ldw : p.K);
     }
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     if (lp.taps > 1) { tap = kq / lp.Cin; ci = kq - tap * lp.Cin; }
     const int nseq = (p.M + p.Tout - 1) / p.Tout;
     const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)nseq * lp.Tin * lp.lda * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * lp.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * (p.ldw ? p.ldw : lp.K) * 4), 0x00020000);
     unsigned aoff[2], woff[2];
     auto set_tap = [&]() {
 #pragma unroll
@@ -232,23 +250,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const float sh = p.shift ? p.shift[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (row >= p.M) continue;
-        if (p.win_T > 0) { const int wb = row / p.Tout; row = wb * p.win_T + p.win_off + (row - wb * p.Tout); }
-        float v = acc[r] * sc + sh;
-        if (p.Zout) p.Zout[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
-        v = apply_act(v, p.act, p.actw, col);
-        if (p.mask && p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
-        if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];
-        if (p.R2) v += p.R2[(int64_t)(p.r2_div ? row / p.r2_div : (p.r2_mod ? row % p.r2_mod : row)) * p.ldr2 + col];
-        if (p.mask && !p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
-        if (p.c_tr_T > 0) {
-            const int b = row / p.c_tr_T, t = row - b * p.c_tr_T;
-            p.C[((int64_t)b * p.N + col) * p.c_tr_T + t] = v;
-        } else {
-            p.C[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
-        }
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < p.M) gemm_store(p, row, col, acc[r], sc, sh);
     }
+}
+
+// split-K finish: add the K slices in order, then the epilogue of the unsplit GEMM
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const GemmP p, const float* __restrict__ part, int ksplit) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * p.N) return;
+    const int row = (int)(idx / p.N), col = (int)(idx - (int64_t)row * p.N);
+    float v = 0.f;
+    for (int i = 0; i < ksplit; ++i) v += part[(int64_t)i * p.M * p.N + idx];
+    gemm_store(p, row, col, v, p.scale ? p.scale[col] : 1.0f, p.shift ? p.shift[col] : 0.0f);
 }
 
 GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K) {
@@ -277,7 +291,7 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         maxN = p.N > maxN ? p.N : maxN;
         bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A) &&
                    aligned16(p.W) && (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= BK) &&
-                   (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * p.K * 4 < (1ll << 31);
+                   (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
         vec4 = vec4 && ok4;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
@@ -286,6 +300,25 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, b);
     else
         hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, b);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, const char* name) {
+    L2S_REQUIRE(ksplit >= 2 && ksplit <= GEMM_MAX_GROUP && p.taps == 1 && p.a_split >= p.K && !p.stats && p.win_T == 0 && p.K % (4 * ksplit) == 0,
+                "split-K: plain GEMMs only, K divisible by 4*ksplit");
+    const int kc = p.K / ksplit;
+    GemmBatch b{};
+    for (int i = 0; i < ksplit; ++i) {
+        GemmP q = gemm_plain(p.A + (int64_t)i * kc, p.lda, p.W + (int64_t)i * kc, part + (int64_t)i * p.M * p.N, p.N, p.M, p.N, kc);
+        q.ldw = p.ldw ? p.ldw : p.K;
+        q.vec = p.vec;
+        b.p[i] = q;
+    }
+    b.count = ksplit;
+    if (launch_gemm(b, s, name)) return 1;
+    const int64_t total = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, part, ksplit);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

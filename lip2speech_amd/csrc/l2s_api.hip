@@ -704,7 +704,8 @@ static int64_t prologue_ws_floats(int B, int T) {
     n += (int64_t)B * m * 2560;
     n += (int64_t)B * m * 256 * 4;
     n += (int64_t)B * m * (VOC + VOCP);
-    return n + 64 * 40;
+    n += 8 * std::max((int64_t)B * m * 256, (int64_t)B * 512);   // split-K partial products
+    return n + 64 * 41;
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
@@ -829,6 +830,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     float* tC = bp.f((int64_t)B * mT * 256);
     float* logits = bp.f((int64_t)B * mT * VOC);
     float* z = bp.f((int64_t)B * mT * VOCP);
+    float* part = bp.f(8 * std::max((int64_t)B * mT * 256, (int64_t)B * 512));
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
     // residual_bottleneck, site embeddings
@@ -883,7 +885,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     {
         GemmP p = gemm_plain(cellcat, 1024, w.e_c.W, state + sl.ecell, 512, B, 512, 1024);
         p.shift = w.e_c.shift;
-        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        if (launch_gemm_splitk(p, 8, part, s, "prologue_gemm")) return 1;      // B rows x 512 columns = 8 tiles: split K = 1024 eight ways
         if (launch_stop_const(state + sl.ecell, w.stop_tail, w.stop_bias, B, state + sl.stopc, s)) return 1;
     }
     // enc = encoder_proj(rnn_out) + s_a (broadcast over T) + residual  -> cat[:, 0:512] and the state
@@ -897,13 +899,13 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     }
     // MultiHopConv branches of K and V (8 convs, one grouped launch), then the two bottlenecks (+PSine +pos)
     {
+        // longest K first: the groups are dispatched in order, and the 11-tap convs (K = 5632) would otherwise start last and run alone
         GemmBatch gb{};
-        for (int kv = 0; kv < 2; ++kv)
-            for (int j = 0; j < 4; ++j) {
-                GemmP p = conv_gemm(cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2,
-                                    cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU);
-                gb.p[kv * 4 + j] = p;
-            }
+        int g = 0;
+        for (int j = 3; j >= 0; --j)
+            for (int kv = 0; kv < 2; ++kv)
+                gb.p[g++] = conv_gemm(cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2,
+                                      cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU);
         gb.count = 8;
         if (launch_gemm(gb, s, "multihop_conv_gemm")) return 1;
         GemmBatch bb{};
@@ -920,7 +922,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     // Content.encode (decoder.py:239-260)
     {
         GemmBatch gb{};
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)      // K = 512 * ks is the same for every branch here; rows shrink with ks - largest map first
             gb.p[j] = conv_gemm(cat, 4608, B, T, 512, w.ct_branch[j], 512, CT_KS[j], CT_KS[j], 0, cmap[j], 512, ACT_SILU);
         gb.count = 4;
         if (launch_gemm(gb, s, "content_agg_gemm")) return 1;
@@ -932,7 +934,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
         const int R = B * mT;
         GemmP p = gemm_plain(pooled, 2560, w.ct_bott.W, wv, 256, R, 256, 2560);
         p.shift = w.ct_bott.shift;
-        if (launch_gemm1(p, s, "content_gemm")) return 1;
+        if (launch_gemm_splitk(p, 8, part, s, "content_gemm")) return 1;       // 4B rows x 256 columns = 8 tiles with K = 2560
         GemmBatch g1{};
         g1.p[0] = gemm_plain(wv, 256, w.ct_k0.W, tA, 256, R, 256, 256); g1.p[0].shift = w.ct_k0.shift; g1.p[0].act = ACT_SILU;
         g1.p[1] = gemm_plain(wv, 256, w.ct_fc0.W, tB, 256, R, 256, 256); g1.p[1].shift = w.ct_fc0.shift; g1.p[1].act = ACT_SILU;

@@ -66,6 +66,7 @@ struct GemmP {
     int vec;              // 4: float4 operand loads (K, Cin, lda, offsets multiples of 4); 1: scalar loads
     const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
     int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
+    int ldw;              // row stride of W in floats (0: K) - a K slice of a wider matrix (split-K)
     float* stats;         // training, batch-statistics BatchNorm: STATS PASS - nothing is stored; per-column sums of the raw product
                           //   (no scale/shift) go to stats[(blockIdx.y*2 + {0: sum, 1: sum of squares})*N + n]
 };
@@ -76,6 +77,10 @@ struct GemmBatch {
     int count;
 };
 GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K);
+// split-K for plain GEMMs whose 64x64 tiles are too few to fill the chip (M <= 128 rows in the content path, the B-row Linears):
+// <= 8 K slices as ONE grouped launch writing raw partial products to part[slice][M][N], then one kernel that adds the slices in
+// order and runs the usual epilogue of `p`. Deterministic. part: ksplit*M*N floats.
+int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, const char* name);
 int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name);
 int launch_gemm1(const GemmP& p, hipStream_t s, const char* name);
 
