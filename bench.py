@@ -298,6 +298,22 @@ def main():
                 roof["l2_hit_rate"] = pmc[name]["l2_hit_rate"]
         except OSError:
             pass
+        # the other kernels with a closed-form cost model, same pass (per-launch HIP-event brackets: us-scale kernels carry ~1.8 us of it)
+        others = []
+        for oname, olaunches, oms in prof[1:]:
+            om = kernel_model(oname)
+            if not om or len(others) >= 4:
+                continue
+            oavg = oms / olaunches * 1e-3
+            oflops, obytes = om
+            if oflops / obytes < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                o = {"bound": "hbm", "achieved": obytes / oavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            else:
+                o = {"bound": "mfma", "achieved": oflops / oavg / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            o.update(kernel=oname, launches_per_step=olaunches // 2, share_of_gpu_time=oms / gpu_ms, avg_us_event_per_launch=oavg * 1e6,
+                     frac=o["achieved"] / o["peak"])
+            others.append(o)
+        roof["other_kernels"] = others
         # whole-path figure against the fp32 matrix peak (36.18 MFLOP per mel frame)
         per_gpu = B * S * args.steps / elapsed
         roof["path_tflops"] = per_gpu * 36.18e6 / 1e12

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Golden vectors of THE REFERENCE at the benchmark's full size (BASELINE.json configs[1]: B=32, T=29, S=300).
+
+Same method as make_goldens.py (the reference's VideoExtractor / Decoder imported by file path in the build container, the repo's
+deterministic synthetic checkpoint loaded into them, Gumbel noise fed explicitly).  The inputs are bench.py's own batch (synth tags
+"bench"), regenerated from integers on every host; stored are the noise and the reference outputs - the full post-net mel of four
+clips, the per-frame mean over the 80 mel bins of ALL 32 clips, output lengths, and the attention argmax with its top-2 margin.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fullsize_golden.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_goldens as mg          # noqa: E402  (load_reference, GumbelFeed, top2, sub, min_T)
+
+from lip2speech_amd import synth   # noqa: E402
+from oracle import l2s_oracle as orc   # noqa: E402
+
+CLIPS = [0, 7, 19, 31]
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(16)
+    vid, dec = mg.load_reference()
+    sd = synth.synth_state_dict()
+    enc_ref = vid.VideoExtractor().eval()
+    dec_ref = dec.Decoder().eval()
+    enc_ref.load_state_dict(mg.sub(sd, "encoder."), strict=True)
+    dec_ref.load_state_dict(mg.sub(sd, "decoder."), strict=True)
+    B, T, S = 32, 29, 300
+    video = synth.synth_video(B, T, tag="bench")
+    emb = synth.synth_speaker_embedding(B, tag="bench")
+    gum = synth.synth_gumbel(B * mg.min_T(T), tag="bench")
+    t0 = time.time()
+    with torch.no_grad(), mg.GumbelFeed(dec, gum):
+        feat = enc_ref(video)
+        face = emb.unsqueeze(1).repeat(1, T, 1)
+        mel_post, lengths, attn = dec_ref.inference(torch.cat([feat, face], dim=2), face, return_attention_map=True)
+    print(f"reference inference at B={B}, T={T}, S={S}: {time.time() - t0:.1f} s; mel_post {tuple(mel_post.shape)}, attn {tuple(attn.shape)}")
+    with torch.no_grad():
+        o_post, o_len, o_attn = orc.inference(sd, video, emb, gum, S=S)
+    print("oracle-vs-reference  mel_post max|d| = %.3e   attention max|d| = %.3e   lengths equal: %s" %
+          ((o_post - mel_post).abs().max().item(), (o_attn - attn).abs().max().item(), bool(torch.equal(o_len, lengths))))
+    amax, margin = mg.top2(attn)
+    o_amax, _ = mg.top2(o_attn)
+    print("attention argmax equal:", bool((amax == o_amax).all()), " min top-2 margin:", margin.min().item())
+    assert (o_post - mel_post).abs().max().item() < 1e-3
+    np.savez_compressed(
+        os.path.join(HERE, "inference_lrw_b32_full.npz"),
+        gumbel=gum.numpy(), clips=np.asarray(CLIPS), mel_post_clips=mel_post[CLIPS].numpy(),
+        mel_post_frame_mean=mel_post.mean(dim=1).numpy() if mel_post.shape[1] == 80 else mel_post.mean(dim=2).numpy(),
+        mel_layout=np.asarray(mel_post.shape), output_lengths=lengths.numpy(),
+        attn_argmax=amax.numpy().astype(np.int8), attn_margin=margin.numpy().astype(np.float32))
+    print("wrote inference_lrw_b32_full.npz", os.path.getsize(os.path.join(HERE, "inference_lrw_b32_full.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

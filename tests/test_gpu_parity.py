@@ -101,6 +101,25 @@ def test_inference_matches_reference_golden(nm):
     assert pc.maxdiff(attn[:, ::50], g["attn_rows"]) < MEL_TOL
 
 
+def test_full_size_matches_reference_golden(nm):
+    """BASELINE.json's own configuration (B=32, T=29, S=300 - bench.py's batch) against the reference run at that size
+    (tests/golden/make_fullsize_golden.py): four clips element by element, all 32 through their per-frame means, lengths, argmax."""
+    g = pc.golden("inference_lrw_b32_full.npz")
+    B, T, S = 32, 29, 300
+    video = synth.synth_video(B, T, tag="bench")
+    emb = synth.synth_speaker_embedding(B, tag="bench")
+    mel_post, lengths, attn = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=S, want_attn=True)
+    assert tuple(mel_post.shape) == tuple(int(x) for x in g["mel_layout"])
+    clips = [int(c) for c in g["clips"]]
+    assert pc.maxdiff(mel_post[clips], g["mel_post_clips"]) < MEL_TOL
+    assert pc.maxdiff(mel_post.mean(dim=1), g["mel_post_frame_mean"]) < MEL_TOL
+    assert torch.equal(lengths.cpu(), g["output_lengths"])
+    amax, _ = pc.top2(attn.cpu())
+    sure = g["attn_margin"] > 1e-4
+    assert sure.float().mean() > 0.99
+    assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][sure].to(torch.int64)), "attention argmax differs from the reference"
+
+
 def test_model_api_inference(synth_sd):
     """Through the boundary the reference's callers use: get_network('test').inference(...) (demo.py:82-86)."""
     from model.model import get_network

@@ -88,3 +88,20 @@ def test_oracle_teacher_forcing_golden(golden_dir, synth_sd):
     assert g["teacher_mask"].sum() > 10
     assert (out[0] - g["mel"]).abs().max() < 1e-4
     assert (out[1] - g["mel_post"]).abs().max() < 1e-3
+
+
+def test_oracle_matches_reference_at_benchmark_size(golden_dir, synth_sd):
+    """B=32, T=29, S=300 (bench.py's batch, BASELINE.json configs[1]) against tests/golden/make_fullsize_golden.py's reference run."""
+    g = _load(golden_dir, "inference_lrw_b32_full.npz")
+    video = synth.synth_video(32, 29, tag="bench")
+    emb = synth.synth_speaker_embedding(32, tag="bench")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        mel_post, lengths, attn = orc.inference(synth_sd, video, emb, g["gumbel"], S=300)
+    clips = [int(c) for c in g["clips"]]
+    assert (mel_post[clips] - g["mel_post_clips"]).abs().max() < 1e-3
+    assert (mel_post.mean(dim=1) - g["mel_post_frame_mean"]).abs().max() < 1e-3
+    assert torch.equal(lengths, g["output_lengths"])
+    amax, _ = _top2(attn)
+    sure = g["attn_margin"] > 1e-4
+    assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][sure].to(torch.int64))
