@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
     const int nkt_all = (p.K + TK - 1) / TK;
     int kt_begin = 0, kt_end = nkt_all;
     float* Cout = p.C;
-    if (p.ksplit > 1) {                                // split-K (DW mode): slice z of the reduction -> its own partial matrix
+    if (p.ksplit > 1) {                                // split-K: slice z of the reduction -> its own partial matrix
         const int per = (nkt_all + p.ksplit - 1) / p.ksplit;
         kt_begin = blockIdx.z * per;
         kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
@@ -151,7 +151,7 @@ int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
     else vec = vec && p.M % 4 == 0 && p.Cin % 4 == 0 && p.N % 4 == 0;
     q.vec = vec ? 1 : 0;
     L2S_REQUIRE(vec || p.taps == 1, "bwd gemm: unaligned operands are supported for 1x1 layers only");
-    L2S_REQUIRE(p.ksplit <= 1 || (p.mode == BWD_DW && !p.accumulate), "split-K is a dW-mode feature (partials are reduced by launch_gemm_bwd_splitk)");
+    L2S_REQUIRE(p.ksplit <= 1 || (!p.accumulate && p.c_T == 0), "split-K writes plain partial matrices (reduced by launch_gemm_bwd_splitk)");
     dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB, p.ksplit > 1 ? p.ksplit : 1);
     ProfScope ps(name, s);
     if (p.mode == BWD_DX) hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DX>, grid, dim3(256), 0, s, q);
@@ -175,9 +175,11 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 
 int64_t gemm_bwd_splitk_floats(const BwdGemmP& p, int splits) { return (int64_t)splits * p.M * p.N; }
 
-// dW-mode GEMM with the (long) reduction split over gridDim.z; partials [splits][M][N] are summed in a fixed order
+// backward GEMM with the (long) reduction split over gridDim.z; partials [splits][M][N] are summed in a fixed order. dW mode: the
+// reduction runs over the rows of the batch; dX mode: over (tap, output channel) - the B*T-row input gradients of the wide
+// Conv1d layers have 32 output tiles and K up to 5632, so without the split they run on an eighth of the chip.
 int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipStream_t s, const char* name) {
-    L2S_REQUIRE(p.mode == BWD_DW && p.c_T == 0, "split-K: dW mode only");
+    L2S_REQUIRE(p.c_T == 0, "split-K: plain row-major output only");
     const int nkt = (p.K + TK - 1) / TK;
     if (splits > nkt) splits = nkt;
     if (splits <= 1) return launch_gemm_bwd(p, s, name);

@@ -497,11 +497,26 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnBwdP p) {
         float dq = 0.f;
         float* dkb = p.dk + (int64_t)b * T * 512 + tid;
         float* dvb = p.dv + (int64_t)b * T * 512 + tid;
-        for (int t = 0; t < T; ++t) {
-            const float dl_t = s_dl[t];
-            dq = fmaf(dl_t, kb[(int64_t)t * 512 + tid], dq);
-            dkb[(int64_t)t * 512] += tau * dl_t * q;
-            dvb[(int64_t)t * 512] += s_a[t] * dav;
+        // dk / dv accumulate over the steps in HBM: a read-modify-write per (t, column). Eight frames per trip with all 24 loads
+        // issued before the first store - one frame at a time was a chain of 29 dependent round trips (23 us per launch)
+        constexpr int TC = 8;
+        for (int t0 = 0; t0 < T; t0 += TC) {
+            float kk[TC], dkv[TC], dvv[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int64_t o = (int64_t)min(t0 + u, T - 1) * 512;
+                kk[u] = kb[o + tid]; dkv[u] = dkb[o]; dvv[u] = dvb[o];
+            }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = t0 + u;
+                if (t < T) {
+                    const float dl_t = s_dl[t];
+                    dq = fmaf(dl_t, kk[u], dq);
+                    dkb[(int64_t)t * 512] = dkv[u] + tau * dl_t * q;
+                    dvb[(int64_t)t * 512] = dvv[u] + s_a[t] * dav;
+                }
+            }
         }
         dq *= tau;
         p.dq_stack[(int64_t)b * 512 + tid] = dq;
@@ -540,10 +555,23 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnBwdP p) {
     __syncthreads();
     if (tid < 256) {
         float dqc = 0.f;
-        for (int j = 0; j < m; ++j) {
-            dqc = fmaf(s_dlc[j], keyb[(int64_t)j * 256 + tid], dqc);
-            p.dckey[((int64_t)b * m + j) * 256 + tid] += tau_c * s_dlc[j] * s_qc[tid];
-            p.dcval[((int64_t)b * m + j) * 256 + tid] += s_al[j] * s_dcc[tid];
+        constexpr int MC = 4;
+        for (int j0 = 0; j0 < m; j0 += MC) {                 // same read-modify-write pattern: loads first
+            float kk[MC], dkv[MC], dvv[MC];
+#pragma unroll
+            for (int u = 0; u < MC; ++u) {
+                const int64_t o = ((int64_t)b * m + min(j0 + u, m - 1)) * 256 + tid;
+                kk[u] = keyb[(int64_t)min(j0 + u, m - 1) * 256 + tid]; dkv[u] = p.dckey[o]; dvv[u] = p.dcval[o];
+            }
+#pragma unroll
+            for (int u = 0; u < MC; ++u) {
+                const int j = j0 + u;
+                if (j < m) {
+                    dqc = fmaf(s_dlc[j], kk[u], dqc);
+                    p.dckey[((int64_t)b * m + j) * 256 + tid] = dkv[u] + tau_c * s_dlc[j] * s_qc[tid];
+                    p.dcval[((int64_t)b * m + j) * 256 + tid] = dvv[u] + s_al[j] * s_dcc[tid];
+                }
+            }
         }
         dqc *= tau_c;
         p.dqc_stack[(int64_t)b * 256 + tid] = dqc;
@@ -1208,8 +1236,8 @@ static int64_t pro_bwd_ws_floats(int B, int T) {
     int L[4]; const int m = content_lens(T, L);
     const int64_t BT = (int64_t)B * T, R = (int64_t)B * m, Bp = pad16(B);
     int64_t n = BT * (4608 + 512 * 4 + 1024 + 2048 * 3) + (int64_t)512 * 11 * 512 + (int64_t)AB_RS * 3 * 4608 + R * (2560 + 504 * 3 + 256 * 6) + 504 * 256 +
-                (int64_t)B * (512 * 8 + 1024 * 2) + Bp * 2048 + 4 * BT * 512 + 8192;
-    return n + 64 * 64;
+                (int64_t)B * (512 * 8 + 1024 * 2) + Bp * 2048 + 4 * BT * 512 + 8192 + 16 * BT * 512;
+    return n + 64 * 65;
 }
 
 // Inputs: gradients of the state the loop consumed.  Outputs: every prologue parameter gradient (bound slots) and dvis (B,T,1024).
@@ -1235,6 +1263,7 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
     float* f_dg = bp.f((int64_t)Bp * 2048);
     float* dmap[4]; for (int j = 0; j < 4; ++j) dmap[j] = bp.f((int64_t)B * tp.L[j] * 512);
     float* small = bp.f(8192);
+    float* skp = bp.f((int64_t)16 * BT * 512);                  // split-K partials of the wide input gradients
     L2S_REQUIRE(!bp.overflow, "training prologue backward workspace too small");
     auto G = [&](const std::string& k) { return m->grad(D + k); };
     auto Cn = [&](const std::string& k) { return m->canon(D + k); };
@@ -1294,7 +1323,7 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
             if (conv1d_grad_to_canonical(dwp, 512, 512, k, gw, false, s)) return 1;
         }
         BwdGemmP px = bwd_dx(gconv, 512, w.mh_branch[kv][j].W, dcat, 4608, B, T, T, 512, 512, k, k / 2, true);
-        if (launch_gemm_bwd(px, s, "train_bwd_multihop_dx")) return 1;
+        if (launch_gemm_bwd_splitk(px, std::min(16, 4 * k), skp, s, "train_bwd_multihop_dx")) return 1;      // 32 output tiles, K = 512 k
     }
     // ---- C. Content.encode
     if (launch_fill(dxc, (int64_t)BT * 512, 0.f, s)) return 1;
