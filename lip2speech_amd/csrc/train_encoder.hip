@@ -353,23 +353,82 @@ __global__ __launch_bounds__(192) void frontend_bwd_kernel(const float* __restri
     }
 }
 
-// explicit im2col of frames [f0, f0+nf) for the Conv3d weight gradient: col[(f-f0)*Hc*Wc + r*Wc + c][j], j = (ci*5 + kt)*49 + kh*7 + kw (735 -> ld 736)
-__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ video, int T, int H, int W, int f0, int nf, float* __restrict__ col) {
-    const int Hc = H / 2, Wc = W / 2;
-    const int64_t total = (int64_t)nf * Hc * Wc * 736;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int j = idx % 736; int64_t q = idx / 736;
-        const int c = q % Wc; q /= Wc;
-        const int r = q % Hc; const int fl = q / Hc;
-        float v = 0.f;
-        if (j < 735) {
-            const int f = f0 + fl, b = f / T, t = f - b * T;
-            const int tap = j % 49, slab = j / 49, ci = slab / 5, kt = slab - ci * 5;
-            const int kh = tap / 7, kw = tap - kh * 7;
-            const int tt = t + kt - 2, y = 2 * r + kh - 3, x = 2 * c + kw - 3;
-            if (tt >= 0 && tt < T && y >= 0 && y < H && x >= 0 && x < W) v = video[(((int64_t)(b * 3 + ci) * T + tt) * H + y) * W + x];
+// Conv3d weight gradient of the front-end as an implicit GEMM, no im2col (the explicit patch matrix was 1.6 GB written and read back
+// per step at B=8): dW[co][slab][tap] = sum over conv pixels of dconv[p][co] * x[input pixel of (p, tap) in slab (ci, kt)].
+// Block = frame x 12 conv rows, wave = 3 of those rows. v_mfma_f32_32x32x2_f32 with M = 24 channels (lanes 24..31 feed zeros),
+// N = 49 taps (two 32-column tiles), K = the wave's 144 pixels: the dconv operand sits in registers for the whole block (72 values per
+// lane), the input operand is read from the LDS slab with compile-time offsets along a row. Per slab the four waves' tiles are added
+// through LDS and written as this block's partial [24][15][49]; reduce_partials_kernel adds the blocks in order.
+constexpr int FD_CR = 12;                        // conv rows per block
+constexpr int FD_XROWS = 2 * (FD_CR - 1) + 7;    // input rows of a slab
+constexpr int FD_XLD = 104;                      // slab row stride (floats); input column x lives at x + 4
+constexpr int FD_PART = 24 * 735;                // floats per block partial
+template <int HW>
+__global__ __launch_bounds__(256, 2) void frontend_dw_kernel(const float* __restrict__ video, const float* __restrict__ dconv, int T, float* __restrict__ partials) {
+    constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, C2 = Wc / 2, XS = FD_XROWS * FD_XLD;
+    __shared__ __attribute__((aligned(16))) float Xs[XS];
+    __shared__ float red[4 * 2 * 1024];
+    const int f = blockIdx.y, b = f / T, t = f - b * T;
+    const int r0 = blockIdx.x * FD_CR;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* part = partials + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * FD_PART;
+    for (int i = tid; i < XS; i += 256) Xs[i] = 0.f;                       // column pads stay zero for every slab
+    // the block's dconv pixels: lane (channel li, parity lg) keeps pixel (row, 2*c2 + lg) of its wave's three rows
+    float areg[3][C2];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int row = r0 + wave * 3 + rr;
+#pragma unroll
+        for (int c2 = 0; c2 < C2; ++c2)
+            areg[rr][c2] = (li < 24 && row < Hc) ? dconv[(((int64_t)f * Hc + row) * Wc + 2 * c2 + lg) * 24 + li] : 0.f;
+    }
+    int off[2];                                                             // tap offset of this lane's column in each 32-tap tile
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const int tap = n * 32 + li; off[n] = tap < 49 ? (tap / 7) * FD_XLD + tap % 7 : 0; }
+    const int gy0 = 2 * r0 - 3;                                             // frame row of slab row 0
+    for (int slab = 0; slab < 15; ++slab) {
+        const int ci = slab / 5, kt = slab - ci * 5, tt = t + kt - 2;
+        if (tt < 0 || tt >= T) {                                            // temporal zero padding: this slab's weights get nothing from this frame
+            for (int idx = tid; idx < 24 * 49; idx += 256) { const int co = idx / 49; part[co * 735 + slab * 49 + idx - co * 49] = 0.f; }
+            continue;
         }
-        col[idx] = v;
+        __syncthreads();                                                    // previous slab (and its reduction) fully consumed
+        const float* src = video + ((int64_t)(b * 3 + ci) * T + tt) * (H * W);
+        for (int i = tid; i < FD_XROWS * (W / 4); i += 256) {
+            const int row = i / (W / 4), q = i - row * (W / 4), gy = gy0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H) v = *reinterpret_cast<const float4*>(src + gy * W + 4 * q);
+            *reinterpret_cast<float4*>(&Xs[row * FD_XLD + 4 + 4 * q]) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            // pixel (local row lr, column 2*c2 + lg): top-left tap at slab row 2*lr, column 2*(2*c2 + lg) - 3 + 4
+            const float* xb0 = Xs + (2 * (wave * 3 + rr)) * FD_XLD + 2 * lg + 1 + off[0];
+            const float* xb1 = Xs + (2 * (wave * 3 + rr)) * FD_XLD + 2 * lg + 1 + off[1];
+#pragma unroll
+            for (int c2 = 0; c2 < C2; ++c2) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[rr][c2], xb0[4 * c2], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[rr][c2], xb1[4 * c2], acc[1], 0, 0, 0);
+            }
+        }
+        // C layout of the 32x32 tile: column (tap) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * 2 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * 32 + li] = acc[n][r];
+        __syncthreads();
+        for (int idx = tid; idx < 24 * 49; idx += 256) {
+            const int co = idx / 49, tap = idx - co * 49, n = tap >> 5, col = tap & 31;
+            const float* q = red + (n * 32 + co) * 32 + col;
+            part[co * 735 + slab * 49 + tap] = (q[0] + q[2048]) + (q[4096] + q[6144]);
+        }
     }
 }
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int ld_src, int so, int cs, float* __restrict__ dst, int ld_dst, int dof, int64_t rows, int cols,
@@ -384,14 +443,13 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward driver
-constexpr int IM2COL_FRAMES = 64;
 static int64_t enc_bwd_ws_floats(int B, int T, int H) {
     const int64_t NF = (int64_t)B * T, Hc = H / 2, Hp = H / 4;
     const int64_t maxact = std::max<int64_t>(NF * Hp * Hp * 24, NF * ((Hp + 1) / 2) * ((Hp + 1) / 2) * 116);   // largest unit map
     const int64_t maxhalf = NF * Hp * Hp * 58;                                                                    // largest t1
     int64_t n = 2 * maxact + 4 * maxhalf + NF * 9 * LAST_CH * 2;      // dy/dx ping-pong; g, dt, gd, db1; dlast, gconv
     n += NF * Hc * Hc * 24;                                            // dconv of the front-end
-    n += (int64_t)std::min<int64_t>(NF, IM2COL_FRAMES) * Hc * Hc * 736; // im2col chunk
+    n += NF * ((Hc + FD_CR - 1) / FD_CR) * FD_PART;                    // per-block partials of the Conv3d weight gradient
     n += (int64_t)64 * LAST_CH * STAGE_CH[3] + (int64_t)24 * 736;      // split-K partials (largest: conv_last with <= 64 splits ... bounded below), dW staging
     n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + (int64_t)FB_BLOCKS * 3 * 24 + 2 * 1024;
     return n + 64 * 32;
@@ -410,10 +468,10 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     float* g = bp.f(maxhalf); float* dt = bp.f(maxhalf); float* gd = bp.f(maxhalf); float* dt1 = bp.f(maxhalf);
     float* dlast = bp.f((int64_t)NF * 9 * LAST_CH); float* gconv = bp.f((int64_t)NF * 9 * LAST_CH);
     float* dconv = bp.f((int64_t)NF * Hc * Hc * 24);
-    const int chunkF = std::min(NF, IM2COL_FRAMES);
-    float* col = bp.f((int64_t)chunkF * Hc * Hc * 736);
+    const int fd_strips = (Hc + FD_CR - 1) / FD_CR;
+    float* fdp = bp.f((int64_t)NF * fd_strips * FD_PART);
     const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];
-    float* skp = bp.f(splitk_cap); float* dw3 = bp.f(24 * 736);
+    float* skp = bp.f(splitk_cap);
     float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)FB_BLOCKS * 3 * 24);
     float* totals = bp.f(2 * 1024);
     L2S_REQUIRE(!bp.overflow, "encoder training backward workspace too small");
@@ -525,17 +583,13 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     }
     L2S_CHECK_HIP(hipGetLastError());
     if (float* gw = G("frontend3D.0.weight")) {
-        const int64_t ppf = (int64_t)Hc * Hc;
-        for (int f0 = 0; f0 < NF; f0 += chunkF) {
-            const int nf = std::min(chunkF, NF - f0);
-            {
-                ProfScope ps("train_bwd_frontend_im2col", s);
-                hipLaunchKernelGGL(im2col3d_kernel, dim3(8192), dim3(256), 0, s, video, T, H, W, f0, nf, col);
-            }
-            BwdGemmP p = bwd_dw(dconv + (int64_t)f0 * ppf * 24, 24, col, 736, dw3, 1, (int)(nf * ppf), (int)(nf * ppf), 24, 736, 1, 1, 0, f0 > 0);
-            if (launch_gemm_bwd_splitk(p, 64, skp, s, "train_bwd_frontend_dw")) return 1;
+        {
+            ProfScope ps("train_bwd_frontend_dw", s);
+            if (H == 96) hipLaunchKernelGGL(frontend_dw_kernel<96>, dim3(fd_strips, NF), dim3(256), 0, s, video, dconv, T, fdp);
+            else hipLaunchKernelGGL(frontend_dw_kernel<88>, dim3(fd_strips, NF), dim3(256), 0, s, video, dconv, T, fdp);
         }
-        hipLaunchKernelGGL(copy2d_kernel, blocks(24 * 735), dim3(256), 0, s, dw3, 736, 0, 1, gw, 735, 0, (int64_t)24, 735, 0);
+        ProfScope ps("train_bwd_frontend_dw_reduce", s);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((FD_PART + 63) / 64), dim3(1024), 0, s, fdp, NF * fd_strips, FD_PART, 1, FD_PART, gw, 0, 1, 0);
     }
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
