@@ -432,6 +432,53 @@ __global__ __launch_bounds__(256) void carry_update_kernel(const float* __restri
     dc1[idx] += dcq[(int64_t)b * 1024 + 512 + u];
 }
 
+// two launches of the backward step in one: d(attention_proj input) = d0x[:,256:512] as a fragment + stack, and through prenet layer 2's
+// PSine (same source column block) as a fragment
+__global__ __launch_bounds__(256) void du_dz2_kernel(const float* __restrict__ d0x, int ld, const float* __restrict__ z2, const float* __restrict__ w2, int B,
+                                                     float* __restrict__ du_frag, float* __restrict__ du_stack, float* __restrict__ dz2_frag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int Bp = (B + 15) & ~15;
+    if (idx >= Bp * 256) return;
+    const int b = idx >> 8, c = idx & 255;
+    float d = 0.f, dz = 0.f;
+    if (b < B) {
+        d = d0x[(int64_t)b * ld + 256 + c];
+        du_stack[idx] = d;
+        dz = d * cosf(z2[idx]) * w2[c];
+    }
+    du_frag[frag16_index(b, c, 256)] = d;
+    dz2_frag[frag16_index(b, c, 256)] = dz;
+}
+// two launches in one: blocks [0, nc) run carry_update (above), the rest prenet layer 1's PSine backward of dp1 (+ its dropout mask)
+__global__ __launch_bounds__(256) void carry_dz1_kernel(const float* __restrict__ d0x, const float* __restrict__ d01, const float* __restrict__ dhq,
+                                                        const float* __restrict__ dcq, int B, float* __restrict__ dh0, float* __restrict__ dh1,
+                                                        float* __restrict__ dc0, float* __restrict__ dc1, int nc, const float* __restrict__ dp1,
+                                                        const float* __restrict__ z1, const float* __restrict__ w1, float* __restrict__ dz1_frag,
+                                                        float* __restrict__ dp1_stack, const float* __restrict__ mask) {
+    if ((int)blockIdx.x < nc) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= B * 512) return;
+        const int b = idx / 512, u = idx - b * 512;
+        dh0[idx] = d0x[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + u];
+        dh1[idx] = d01[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + 512 + u];
+        dc0[idx] += dcq[(int64_t)b * 1024 + u];
+        dc1[idx] += dcq[(int64_t)b * 1024 + 512 + u];
+        return;
+    }
+    const int idx = ((int)blockIdx.x - nc) * 256 + threadIdx.x;
+    const int Bp = (B + 15) & ~15;
+    if (idx >= Bp * 256) return;
+    const int b = idx >> 8, c = idx & 255;
+    float dz = 0.f;
+    if (b < B) {
+        float d = dp1[idx];
+        if (mask) d *= mask[idx];
+        dp1_stack[idx] = d;
+        dz = d * cosf(z1[idx]) * w1[c];
+    }
+    dz1_frag[frag16_index(b, c, 256)] = dz;
+}
+
 // ---- attention + content attention backward, one 512-thread block per batch row (decoder.py:414-419, 262-271)
 struct AttnBwdP {
     const float* dav;                 // [B][512]
@@ -873,9 +920,7 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh0c, 512, d01, 1024, dc0c, tp.g0 + r2048, tp.c0 + r512,
                            tp.c0 + r512 + (int64_t)B * 512, B, 512, f_dg0, st_dg0 + r2048, (float*)nullptr, (int64_t)0, drop.rnn ? drop.rnn + r512 : nullptr);
         if (run1(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), s, "train_bwd_lstm_dx")) return 1;
-        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x + 256, 1024, (const float*)nullptr, (int)ACT_NONE, (const float*)nullptr, B, 256,
-                           f_du, st_du + r256);
-        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x + 256, 1024, tp.z2 + r256, (int)ACT_PSINE, w2, B, 256, f_dz2, (float*)nullptr);
+        hipLaunchKernelGGL(du_dz2_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x, 1024, tp.z2 + r256, w2, B, f_du, st_du + r256, f_dz2);
         if (run1(bsk(tw.ap, 512, 256, B, f_du, dav, 512), s, "train_bwd_attention_proj")) return 1;
         {
             AttnBwdP a{};
@@ -896,9 +941,8 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
             sb.count = 3;
             if (launch_train_skinny(sb, tb, s, "train_bwd_q_cq_prenet2")) return 1;
         }
-        hipLaunchKernelGGL(carry_update_kernel, dim3(ew(B * 512)), dim3(256), 0, s, d0x, d01, dhq, dcq, B, dh0c, dh1c, dc0c, dc1c);
-        hipLaunchKernelGGL(act_bwd_small_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, dp1, 256, tp.z1 + r256, (int)ACT_PSINE, w1, B, 256, f_dz1, st_dp1 + r256,
-                           drop.prenet ? drop.prenet + r256 : nullptr);
+        hipLaunchKernelGGL(carry_dz1_kernel, dim3(ew(B * 512) + ew(Bp * 256)), dim3(256), 0, s, d0x, d01, dhq, dcq, B, dh0c, dh1c, dc0c, dc1c, ew(B * 512),
+                           dp1, tp.z1 + r256, w1, f_dz1, st_dp1 + r256, drop.prenet ? drop.prenet + r256 : nullptr);
         if (run1(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), s, "train_bwd_prenet1")) return 1;
         const bool forced = (i == 0) || (mask && mask[i]);
         use_carry = !forced;
