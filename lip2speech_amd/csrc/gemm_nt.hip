@@ -323,6 +323,44 @@ int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, c
     return 0;
 }
 
+int launch_gemm_tapsplit(const GemmBatch& convs, float* part, hipStream_t s, const char* name) {
+    GemmBatch b{};
+    auto flush = [&]() -> int {
+        if (b.count == 0) return 0;
+        if (launch_gemm(b, s, name)) return 1;
+        b = GemmBatch{};
+        return 0;
+    };
+    float* pj = part;
+    const float* parts[GEMM_MAX_GROUP] = {};
+    for (int j = 0; j < convs.count; ++j) {
+        const GemmP& p = convs.p[j];
+        if (p.taps == 1) {                       // nothing to split: runs with its own epilogue next to the slices
+            b.p[b.count++] = p;
+            if (b.count == GEMM_MAX_GROUP && flush()) return 1;
+            continue;
+        }
+        L2S_REQUIRE(p.a_split >= p.K && !p.stats && p.win_T == 0 && p.Cin % 4 == 0, "tap split: plain Conv1d layers only");
+        parts[j] = pj;
+        for (int i = 0; i < p.taps; ++i) {
+            GemmP q = gemm_plain(p.A, p.lda, p.W + (int64_t)i * p.Cin, pj + (int64_t)i * p.M * p.N, p.N, p.M, p.N, p.Cin);
+            q.ldw = p.K; q.Tout = p.Tout; q.Tin = p.Tin; q.stride = p.stride; q.pad = p.pad - i; q.vec = p.vec;
+            b.p[b.count++] = q;
+            if (b.count == GEMM_MAX_GROUP && flush()) return 1;
+        }
+        pj += (int64_t)p.taps * p.M * p.N;
+    }
+    if (flush()) return 1;
+    for (int j = 0; j < convs.count; ++j) {
+        if (!parts[j]) continue;
+        const GemmP& p = convs.p[j];
+        const int64_t total = (int64_t)p.M * p.N;
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, parts[j], p.taps);
+    }
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm1(const GemmP& p, hipStream_t s, const char* name) {
     GemmBatch b{};
     b.p[0] = p;

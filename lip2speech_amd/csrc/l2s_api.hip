@@ -705,7 +705,8 @@ static int64_t prologue_ws_floats(int B, int T) {
     n += (int64_t)B * m * 256 * 4;
     n += (int64_t)B * m * (VOC + VOCP);
     n += 8 * std::max((int64_t)B * m * 256, (int64_t)B * 512);   // split-K partial products
-    return n + 64 * 41;
+    for (int j = 1; j < 4; ++j) n += (int64_t)CT_KS[j] * B * L[j] * 512;   // per-tap partial products of Content.agg
+    return n + 64 * 42;
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
@@ -831,6 +832,9 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     float* logits = bp.f((int64_t)B * mT * VOC);
     float* z = bp.f((int64_t)B * mT * VOCP);
     float* part = bp.f(8 * std::max((int64_t)B * mT * 256, (int64_t)B * 512));
+    int64_t tap_floats = 0;
+    for (int j = 1; j < 4; ++j) tap_floats += (int64_t)CT_KS[j] * B * L[j] * 512;
+    float* tap_part = bp.f(tap_floats);
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
     // residual_bottleneck, site embeddings
@@ -925,7 +929,8 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
         for (int j = 0; j < 4; ++j)      // K = 512 * ks is the same for every branch here; rows shrink with ks - largest map first
             gb.p[j] = conv_gemm(cat, 4608, B, T, 512, w.ct_branch[j], 512, CT_KS[j], CT_KS[j], 0, cmap[j], 512, ACT_SILU);
         gb.count = 4;
-        if (launch_gemm(gb, s, "content_agg_gemm")) return 1;
+        // (4..29) x B rows by 512 columns: 16-120 tiles per branch with K up to 3584 - one slice per tap instead (16 slices, 472 tiles of K = 512)
+        if (launch_gemm_tapsplit(gb, tap_part, s, "content_agg_gemm")) return 1;
         PoolCatP pc{};
         pc.x[0] = cat; pc.L[0] = T; pc.ld[0] = 4608;
         for (int j = 0; j < 4; ++j) { pc.x[j + 1] = cmap[j]; pc.L[j + 1] = L[j]; pc.ld[j + 1] = 512; }
