@@ -304,23 +304,44 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
     return 0;
 }
 
-int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, const char* name) {
-    L2S_REQUIRE(ksplit >= 2 && ksplit <= GEMM_MAX_GROUP && p.taps == 1 && p.a_split >= p.K && !p.stats && p.win_T == 0 && p.K % (4 * ksplit) == 0,
-                "split-K: plain GEMMs only, K divisible by 4*ksplit");
-    const int kc = p.K / ksplit;
+// K slice i of ksplit of a plain (1-tap) GEMM, raw product to `out` [M][N]; honours the two-segment A rows (a_split / a_gap)
+static GemmP gemm_kslice(const GemmP& p, int i, int ksplit, float* out) {
+    const int kc = p.K / ksplit, k0 = i * kc;
+    const bool past = k0 >= p.a_split;
+    GemmP q = gemm_plain(p.A + k0 + (past ? p.a_gap : 0), p.lda, p.W + k0, out, p.N, p.M, p.N, kc);
+    if (!past && p.a_split < k0 + kc) { q.a_split = p.a_split - k0; q.a_gap = p.a_gap; }
+    q.ldw = p.ldw ? p.ldw : p.K;
+    q.vec = p.vec;
+    return q;
+}
+
+int launch_gemm_splitk_group(const GemmBatch& g, int ksplit, float* part, hipStream_t s, const char* name) {
+    L2S_REQUIRE(ksplit >= 2 && g.count >= 1 && g.count * ksplit <= GEMM_MAX_GROUP, "split-K: at most 8 slices per launch");
     GemmBatch b{};
-    for (int i = 0; i < ksplit; ++i) {
-        GemmP q = gemm_plain(p.A + (int64_t)i * kc, p.lda, p.W + (int64_t)i * kc, part + (int64_t)i * p.M * p.N, p.N, p.M, p.N, kc);
-        q.ldw = p.ldw ? p.ldw : p.K;
-        q.vec = p.vec;
-        b.p[i] = q;
+    float* pj = part;
+    for (int j = 0; j < g.count; ++j) {
+        const GemmP& p = g.p[j];
+        L2S_REQUIRE(p.taps == 1 && !p.stats && p.win_T == 0 && p.K % (4 * ksplit) == 0 && p.a_split % 4 == 0 && p.a_gap % 4 == 0,
+                    "split-K: plain GEMMs only, K divisible by 4*ksplit");
+        for (int i = 0; i < ksplit; ++i) b.p[b.count++] = gemm_kslice(p, i, ksplit, pj + (int64_t)i * p.M * p.N);
+        pj += (int64_t)ksplit * p.M * p.N;
     }
-    b.count = ksplit;
     if (launch_gemm(b, s, name)) return 1;
-    const int64_t total = (int64_t)p.M * p.N;
-    hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, part, ksplit);
+    pj = part;
+    for (int j = 0; j < g.count; ++j) {
+        const GemmP& p = g.p[j];
+        const int64_t total = (int64_t)p.M * p.N;
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, pj, ksplit);
+        pj += (int64_t)ksplit * total;
+    }
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, const char* name) {
+    GemmBatch g{};
+    g.p[0] = p; g.count = 1;
+    return launch_gemm_splitk_group(g, ksplit, part, s, name);
 }
 
 int launch_gemm_tapsplit(const GemmBatch& convs, float* part, hipStream_t s, const char* name) {

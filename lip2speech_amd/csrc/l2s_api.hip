@@ -706,7 +706,8 @@ static int64_t prologue_ws_floats(int B, int T) {
     n += (int64_t)B * m * (VOC + VOCP);
     n += 8 * std::max((int64_t)B * m * 256, (int64_t)B * 512);   // split-K partial products
     for (int j = 1; j < 4; ++j) n += (int64_t)CT_KS[j] * B * L[j] * 512;   // per-tap partial products of Content.agg
-    return n + 64 * 42;
+    n += 8 * BT * 512;                                                      // split-K partial products of the two MultiHop bottlenecks
+    return n + 64 * 43;
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
@@ -835,13 +836,14 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     int64_t tap_floats = 0;
     for (int j = 1; j < 4; ++j) tap_floats += (int64_t)CT_KS[j] * B * L[j] * 512;
     float* tap_part = bp.f(tap_floats);
+    float* bott_part = bp.f((int64_t)8 * BT * 512);
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
     // residual_bottleneck, site embeddings
     {
         GemmP p = gemm_plain(vis, 1024, w.resid.W, resid, 512, BT, 512, 1024);
         p.shift = w.resid.shift;
-        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        if (launch_gemm_splitk(p, 4, bott_part, s, "prologue_gemm")) return 1;          // 120 tiles: four K slices
         GemmBatch gb{};
         gb.p[0] = gemm_plain(emb, 256, w.enc_site.W, s_e, 512, B, 512, 256);
         gb.p[0].shift = w.enc_site.shift; gb.p[0].act = ACT_PSINE; gb.p[0].actw = w.enc_site.actw;
@@ -898,7 +900,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
         p.shift = w.enc_proj.shift;
         p.R1 = resid; p.ldr1 = 512; p.r1_mod = 0;
         p.R2 = s_a; p.ldr2 = 512; p.r2_div = T;     // attention_site embedding, broadcast over the T frames of a clip
-        if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        if (launch_gemm_splitk(p, 4, bott_part, s, "prologue_gemm")) return 1;
         if (launch_copy_cols(cat, 4608, 0, state + sl.enc, 512, 0, 1, BT, 512, s)) return 1;
     }
     // MultiHopConv branches of K and V (8 convs, one grouped launch), then the two bottlenecks (+PSine +pos)
@@ -921,7 +923,8 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
             bb.p[kv] = p;
         }
         bb.count = 2;
-        if (launch_gemm(bb, s, "multihop_bottleneck_gemm")) return 1;
+        // 2 x 120 tiles with K = 2560 is one block per CU and 80 dependent K iterations: four K slices each
+        if (launch_gemm_splitk_group(bb, 4, bott_part, s, "multihop_bottleneck_gemm")) return 1;
     }
     // Content.encode (decoder.py:239-260)
     {

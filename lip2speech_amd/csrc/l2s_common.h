@@ -81,6 +81,7 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 // <= 8 K slices as ONE grouped launch writing raw partial products to part[slice][M][N], then one kernel that adds the slices in
 // order and runs the usual epilogue of `p`. Deterministic. part: ksplit*M*N floats.
 int launch_gemm_splitk(const GemmP& p, int ksplit, float* part, hipStream_t s, const char* name);
+int launch_gemm_splitk_group(const GemmBatch& g, int ksplit, float* part, hipStream_t s, const char* name);   // count*ksplit <= 8; part: count*ksplit*M*N
 // the same for a group of Conv1d layers whose tile counts are small and whose K = taps*Cin is long (Content.agg: 2-15 row tiles,
 // K up to 3584): one K slice per TAP (a 1-tap conv with a shifted pad), all slices of all layers in grouped launches, then one finish
 // kernel per multi-tap layer. part: sum over the multi-tap layers of taps*M*N floats.
