@@ -305,11 +305,15 @@ def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
     nm = pc.native_model(synth_sd)
     want = [nm.inference(*b, S=S, want_attn=True) for b in batches]
     want = [tuple(t.clone() for t in w) for w in want]
-    pool = InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=3)
-    got = pool.map(batches, S=S, want_attn=True)
-    torch.cuda.synchronize()
-    for g, w in zip(got, want):
-        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    for stagger in (False, True):
+        pool = InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=3, stagger=stagger)
+        for _ in range(2):                                   # the second call of a staggering pool starts its workers a third of a cycle apart
+            got = pool.map(batches, S=S, want_attn=True)
+            torch.cuda.synchronize()
+            for g, w in zip(got, want):
+                assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    with pytest.raises(ValueError):
+        InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=5)
 
 
 @pytest.mark.gpu
