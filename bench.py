@@ -114,12 +114,14 @@ def train_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("L2S_BENCH_ONE_DEVICE"):      # test hook: several ranks on ONE GPU (with L2S_BENCH_BACKEND=gloo) to exercise the N>1 code path
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=os.environ.get("L2S_BENCH_BACKEND", "nccl"))
     net = get_network("train").cuda()
     net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
     flat = net._train_state()
@@ -210,12 +212,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if os.environ.get("L2S_BENCH_ONE_DEVICE"):      # test hook: several ranks on ONE GPU (with L2S_BENCH_BACKEND=gloo) to exercise the N>1 code path
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=os.environ.get("L2S_BENCH_BACKEND", "nccl"))
 
     # replicated weights, per-rank shard of clips (no exchange step on the inference path)
     from lip2speech_amd.parallel import InflightPool
