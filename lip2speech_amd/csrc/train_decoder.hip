@@ -230,6 +230,7 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
     float* g = bp.f(R * 512);          // gradient wrt the current layer's output
     float* gconv = bp.f(R * 512);      // gradient wrt the conv output
     float* gprev = bp.f(R * 512);
+    float* skp = bp.f(5 * R * 512);    // split-K partials of the input gradients (one slice per tap)
     float* dwp = bp.f((int64_t)512 * 5 * 512);
     float* partials = bp.f((int64_t)AB_RS * 3 * 512);
     float* totals = bp.f(1024);
@@ -260,7 +261,8 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
         if (float* gw = m->grad(c + ".0.conv.weight")) { if (conv1d_grad_to_canonical(dwp, cout, cin, 5, gw, false, s)) return 1; }
         // input gradient (+ residual path for layers 1..3)
         float* gin = gprev;
-        if (launch_gemm_bwd(bwd_dx(gconv, cout, w.post[l].W, gin, cin, B, S, S, cout, cin, 5, 2, false), s, "train_postnet_dx")) return 1;
+        // B*S rows by <= 512 columns is 80 tiles at B = 8 with K = 5 * 512: five K slices
+        if (launch_gemm_bwd_splitk(bwd_dx(gconv, cout, w.post[l].W, gin, cin, B, S, S, cout, cin, 5, 2, false), 5, skp, s, "train_postnet_dx")) return 1;
         if (l >= 1 && l <= 3) { if (add_into(g, gin, R * 512, s)) return 1; }     // x_l = PSine(..) + x_{l-1}
         if (l == 0) { if (add_into(gin, dmel, R * NM_, s)) return 1; }
         std::swap(g, gprev);
@@ -1555,7 +1557,7 @@ int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int
 
 int64_t l2s_train_postnet_tape_floats(int B, int S) { return post_tape_floats(B, S); }
 int64_t l2s_train_postnet_ws_bytes(int B, int S) {
-    return ((int64_t)B * S * 512 * 3 + (int64_t)512 * 5 * 512 + (int64_t)AB_RS * 3 * 512 + 1024 + 64 * 10) * (int64_t)sizeof(float);
+    return ((int64_t)B * S * 512 * 3 + (int64_t)512 * 5 * 512 + (int64_t)AB_RS * 3 * 512 + 1024 + 64 * 11 + (int64_t)5 * B * S * 512) * (int64_t)sizeof(float);
 }
 
 int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, void* stream) {
