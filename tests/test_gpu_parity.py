@@ -120,6 +120,26 @@ def test_full_size_matches_reference_golden(nm):
     assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][sure].to(torch.int64)), "attention argmax differs from the reference"
 
 
+@pytest.mark.parametrize("B,T,HW,S", [(1, 7, 96, 3), (3, 75, 88, 5), (17, 8, 96, 4), (33, 29, 96, 6), (2, 13, 88, 300), (11, 16, 96, 4),
+                                      (3, 59, 88, 24), (19, 14, 88, 38)])
+def test_shapes_against_oracle(nm, synth_sd, B, T, HW, S):
+    """Shapes off the benchmark's grid (tools/fuzz_parity.py draws more): tile remainders of every kernel, the shortest and the longest
+    clips, both crop sizes, batches that are not multiples of the 16-row tile."""
+    tag = f"fz{B}_{T}_{HW}_{S}"
+    v = synth.synth_video(B, T, HW, HW, tag=tag)
+    e = synth.synth_speaker_embedding(B, tag=tag)
+    g = synth.synth_gumbel(B * native.min_T(T), tag=tag)
+    mel, ln, at = nm.inference(v.cuda(), e.cuda(), g.cuda(), S=S, want_attn=True)
+    with torch.no_grad():
+        omel, oln, oat = orc.inference(synth_sd, v, e, g, S=S)
+    assert pc.maxdiff(mel, omel) < MEL_TOL
+    assert torch.equal(ln.cpu(), oln)
+    amax, _ = pc.top2(at.cpu())
+    oamax, margin = pc.top2(oat)
+    sure = margin > 1e-4
+    assert torch.equal(amax[sure], oamax[sure])
+
+
 def test_model_api_inference(synth_sd):
     """Through the boundary the reference's callers use: get_network('test').inference(...) (demo.py:82-86)."""
     from model.model import get_network
