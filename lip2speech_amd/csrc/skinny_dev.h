@@ -13,6 +13,10 @@ struct SkinnyTrain {               // training-side stores of one skinny group (
     float* out_plain; int ld_out;      // SK_FRAG: plain copy of the output [b*ld_out + n]
     const float* out_mask; int ld_mask; // dropout multiplier (0 or 1/(1-p)) applied to the activated output [b*ld_mask + n]
     float* h_drop; int h_drop_K; const float* h_mask; int ld_hmask;   // SK_LSTM: second frag16 copy of the new hidden state times a dropout mask
+    // SK_PLAIN, backward loop: the LSTM-cell backward fused into the GEMM that produces dh (columns n < lb_H are hidden units). dh = the
+    // epilogue's value, or lb_dha[b][n] + value * lb_mask[b][n] when lb_dha is set; gate gradients go out as frag16 (K = 4*lb_H) + stack
+    const float* lb_gates; const float* lb_cprev; const float* lb_cnew; float* lb_dc; const float* lb_dha; int lb_ld_a; const float* lb_mask;
+    float* lb_frag; float* lb_stack; int lb_H;
 };
 struct AttnTrain {
     const float* logit_mask; int ld_lmask;   // dropout multiplier on the attention logits [b*ld_lmask + t] (decoder.py:363)
@@ -106,6 +110,20 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         const int b2 = mt * 16 + (tid >> 2);
         if (b2 < nB) pf_c = c_in[frag16_index(b2, tile * 4 + (tid & 3), H)];
     }
+    float lb_g[4] = {0.f, 0.f, 0.f, 0.f}, lb_cn = 0.f, lb_cp = 0.f, lb_dcv = 0.f, lb_a = 0.f, lb_m = 1.f;
+    bool lb_on = false;
+    if constexpr (TRAIN) {
+        lb_on = tr->lb_gates != nullptr && tid < 256 && e_b < nB && e_np < tr->lb_H;
+        if (lb_on) {                                   // the cell's tape values, fetched with everything else
+            const int LH = tr->lb_H;
+            const int64_t ei = (int64_t)e_b * LH + e_np;
+            const float* g = tr->lb_gates + (int64_t)e_b * 4 * LH + e_np;
+            lb_g[0] = g[0]; lb_g[1] = g[LH]; lb_g[2] = g[2 * LH]; lb_g[3] = g[3 * LH];
+            lb_cn = tr->lb_cnew[ei]; lb_cp = tr->lb_cprev[ei]; lb_dcv = tr->lb_dc[ei];
+            if (tr->lb_dha) lb_a = tr->lb_dha[(int64_t)e_b * tr->lb_ld_a + e_np];
+            if (tr->lb_mask) lb_m = tr->lb_mask[ei];
+        }
+    }
     L2S_STAMP(2);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -192,6 +210,23 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
     v += pf_extra;
     if constexpr (TRAIN) { if (tr->out_mask) v *= tr->out_mask[(int64_t)b * tr->ld_mask + np]; }
     if constexpr (TRAIN) { if (tr->out_plain) tr->out_plain[(int64_t)b * tr->ld_out + np] = v; }
+    if constexpr (TRAIN) {
+        if (lb_on) {        // LSTM cell backward of unit np (train_decoder.hip lstm_bwd_kernel, same expressions in the same order)
+            const int LH = tr->lb_H;
+            float dh = v;
+            if (tr->lb_dha) dh = lb_a + v * lb_m;
+            const float gi = lb_g[0], gf = lb_g[1], gg = lb_g[2], go = lb_g[3];
+            const float tc = tanhf(lb_cn);
+            const float dc = lb_dcv + dh * go * (1.f - tc * tc);
+            const float vals[4] = {dc * gg * gi * (1.f - gi), dc * lb_cp * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
+            tr->lb_dc[(int64_t)b * LH + np] = dc * gf;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tr->lb_frag[frag16_index(b, k * LH + np, 4 * LH)] = vals[k];
+                tr->lb_stack[(int64_t)b * 4 * LH + k * LH + np] = vals[k];
+            }
+        }
+    }
     if (epi == SK_FRAG)
         p.out[frag16_index(b, np, p.ldo)] = v;
     else

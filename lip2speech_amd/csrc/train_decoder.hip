@@ -848,6 +848,12 @@ static int run1(const SkinnyP& p, hipStream_t s, const char* name) {
     sb.p[0] = p; sb.ntiles[0] = (p.N + 15) / 16; sb.count = 1;
     return launch_train_skinny(sb, tb, s, name);
 }
+static int run1t(const SkinnyP& p, const SkinnyTrain& t, hipStream_t s, const char* name) {
+    SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+    sb.p[0] = p; sb.ntiles[0] = (p.N + 15) / 16; sb.count = 1;
+    tb.t[0] = t;
+    return launch_train_skinny(sb, tb, s, name);
+}
 static int ew(int n) { return (n + 255) / 256; }
 
 __global__ __launch_bounds__(256) void psine_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t rows, int C, float* __restrict__ out) {
@@ -915,12 +921,20 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     for (int i = S - 1; i >= 0; --i) {
         const int64_t r256 = (int64_t)i * B * 256, r512 = (int64_t)i * B * 512, r2048 = (int64_t)i * B * 2048;
         hipLaunchKernelGGL(build_dy_kernel, dim3(ew(Bp * 96)), dim3(256), 0, s, dmel, dstop, dyc, use_carry ? 1 : 0, B, S, i, f_dyt, st_dyt + (int64_t)i * B * 96);
-        if (run1(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 512), s, "train_bwd_fc")) return 1;
-        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh1lin, 512, (const float*)nullptr, 0, dc1c, tp.g1 + r2048,
-                           tp.c1 + r512, tp.c1 + r512 + (int64_t)B * 512, B, 512, f_dg1, st_dg1 + r2048);
-        if (run1(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), s, "train_bwd_lstm_dx")) return 1;
-        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh0c, 512, d01, 1024, dc0c, tp.g0 + r2048, tp.c0 + r512,
-                           tp.c0 + r512 + (int64_t)B * 512, B, 512, f_dg0, st_dg0 + r2048, (float*)nullptr, (int64_t)0, drop.rnn ? drop.rnn + r512 : nullptr);
+        // the two LSTM-cell backwards ride in the epilogues of the GEMMs that produce their dh (were two more launches per step)
+        {
+            SkinnyTrain t{};
+            t.lb_gates = tp.g1 + r2048; t.lb_cprev = tp.c1 + r512; t.lb_cnew = tp.c1 + r512 + (int64_t)B * 512; t.lb_dc = dc1c;
+            t.lb_frag = f_dg1; t.lb_stack = st_dg1 + r2048; t.lb_H = 512;
+            if (run1t(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 512), t, s, "train_bwd_fc")) return 1;
+        }
+        {
+            SkinnyTrain t{};
+            t.lb_gates = tp.g0 + r2048; t.lb_cprev = tp.c0 + r512; t.lb_cnew = tp.c0 + r512 + (int64_t)B * 512; t.lb_dc = dc0c;
+            t.lb_dha = dh0c; t.lb_ld_a = 512; t.lb_mask = drop.rnn ? drop.rnn + r512 : nullptr;
+            t.lb_frag = f_dg0; t.lb_stack = st_dg0 + r2048; t.lb_H = 512;
+            if (run1t(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), t, s, "train_bwd_lstm_dx")) return 1;
+        }
         if (run1(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), s, "train_bwd_lstm_dx")) return 1;
         hipLaunchKernelGGL(du_dz2_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x, 1024, tp.z2 + r256, w2, B, f_du, st_du + r256, f_dz2);
         if (run1(bsk(tw.ap, 512, 256, B, f_du, dav, 512), s, "train_bwd_attention_proj")) return 1;
