@@ -8,4 +8,4 @@ try:
 except Exception as e:
     cols = [r[1] for r in c.execute(f"pragma table_info({t})")]; print(cols); sys.exit()
 for r in rows:
-    if r[6] > 100: print(f"{r[0][:34]:34s} {r[1]}x{r[2]}x{r[3]:<3} {r[4]:30s} avg {r[5]:14.1f} (n={r[6]})")
+    if r[6] >= int(sys.argv[2]) if len(sys.argv) > 2 else r[6] > 100: print(f"{r[0][:34]:34s} {r[1]}x{r[2]}x{r[3]:<3} {r[4]:30s} avg {r[5]:14.1f} (n={r[6]})")
