@@ -255,6 +255,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
  *   "use_graph"         (0)  replay the decode loop from a captured hipGraph
  *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
+ *   "skinny_static"     (0)  compile-time K-segment layouts in the batch-row kernels: the load-issue phase of a block 1.9 -> 1.2 us,
+ *                            23.6 -> 23.1 us per step one batch at a time, but 3 % slower with four batches in flight
  *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */

@@ -206,6 +206,7 @@ struct SkinnySeg { const float* a; int nchunks; };   // one K segment of A in fr
 struct SkinnyP {
     SkinnySeg seg[4];
     int nseg;
+    int layout;            // set by launch_skinny: index of a compile-time segment layout the kernel has an instance for (0 = general path)
     const float* W;        // packed frag16 of the [Npad][K] weight, K = sum of segments
     const float* bias;     // [Npad] (permuted order for SK_LSTM)
     const float* actw;     // [N] psine weights
@@ -238,6 +239,7 @@ struct SkinnyP {
 constexpr int SKINNY_MAX_GROUP = 4;
 struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name);
+void skinny_set_static(int v);
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);

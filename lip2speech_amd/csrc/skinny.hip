@@ -14,10 +14,30 @@
 
 namespace l2s {
 
+// segment layouts with their own instance (chunks of 16 columns per segment): the decode step's and the BiLSTM's operand shapes
+//   1: [32]            K = 512   fc_out+stop, prenet1∘fc_out, BiLSTM / speaker LSTM recurrences
+//   2: [32 | 32]       K = 1024  LSTM1 on [h0' | h1], Q on [h0 | h1], content Q on [c0 | c1]
+//   3: [16|16|32|32]   K = 1536  LSTM0 on [content | prenet | a.v | h0] (attention_proj folded in)
+//   4: [16]            K = 256   prenet layers
+static int skinny_layout_of(const SkinnyP& p) {
+    const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
+    if (n0 == 32 && n1 == 0 && n2 == 0 && n3 == 0) return 1;
+    if (n0 == 32 && n1 == 32 && n2 == 0 && n3 == 0) return 2;
+    if (n0 == 16 && n1 == 16 && n2 == 32 && n3 == 32) return 3;
+    if (n0 == 16 && n1 == 0 && n2 == 0 && n3 == 0) return 4;
+    return 0;
+}
+
 __global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
     __shared__ float red[SK_RED_FLOATS];
     const int g = blockIdx.z;
-    skinny_block(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    const SkinnyP& p = batch.p[g];
+    const int lay = p.layout;                       // block-uniform
+    if (lay == 3) skinny_block<false, 12, false, SegLay<16, 16, 32, 32>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else if (lay == 2) skinny_block<false, 8, false, SegLay<32, 32, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else if (lay == 1) skinny_block<false, 4, false, SegLay<32, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else if (lay == 4) skinny_block<false, 2, false, SegLay<16, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else skinny_block(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
@@ -25,9 +45,15 @@ __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch bat
     __shared__ float red[SK_RED_FLOATS];
     const int g = blockIdx.z;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    skinny_block<false, SK_MAXC, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
+    const SkinnyP& p = batch.p[g];
+    if (p.layout == 3) skinny_block<false, 12, true, SegLay<16, 16, 32, 32>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
+    else if (p.layout == 2) skinny_block<false, 8, true, SegLay<32, 32, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
+    else skinny_block<false, SK_MAXC, true>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
 }
 static unsigned long long* g_skinny_ts = nullptr;
+static int g_opt_skinny_static = 0;     // compile-time segment layouts (option "skinny_static"): +2 % one batch at a time (23.6 -> 23.1 us/step),
+                                        // -3 % with four batches in flight (1.60 -> 1.56 M mel-frames/s) - off by default
+void skinny_set_static(int v) { g_opt_skinny_static = v; }
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
@@ -44,9 +70,14 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
         L2S_REQUIRE(mts == 0 || mts == m, "skinny groups must share B");
         mts = m;
     }
+    SkinnyBatch bl = b;
+    for (int i = 0; i < bl.count; ++i) {
+        for (int j = bl.p[i].nseg; j < 4; ++j) { bl.p[i].seg[j].nchunks = 0; bl.p[i].seg[j].a = bl.p[i].seg[0].a; }
+        bl.p[i].layout = g_opt_skinny_static ? skinny_layout_of(bl.p[i]) : 0;
+    }
     ProfScope ps(name, s);
-    if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, b, g_skinny_ts);
-    else hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, b);
+    if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
+    else hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

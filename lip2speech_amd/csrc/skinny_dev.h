@@ -54,7 +54,18 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 a
 
 // TIMED: a measurement build of the same block that drops 100 MHz wall-clock stamps of its phases into ts[0..7] (tools/skinny_timeline.py)
 #define L2S_STAMP(i) do { if (TIMED) { if (threadIdx.x == 0) ts[i] = wall_clock64(); } } while (0)
-template <bool TRAIN = false, int MAXC = SK_MAXC, bool TIMED = false>
+// K-segment layout known at compile time (chunks per segment, every boundary a multiple of the 8 waves): which segment a wave's j-th
+// chunk belongs to is then a constant, and the block's load-issue phase loses its per-chunk compare / branch / 64-bit address chains
+// (24 loads used to sit behind ~250 scalar instructions and ~50 branches per wave).  SegRuntime keeps the general path.
+struct SegRuntime { static constexpr bool STATIC = false; static constexpr int n0 = 0, n1 = 0, n2 = 0, n3 = 0, NC = 0; };
+template <int A0, int A1, int A2, int A3>
+struct SegLay {
+    static constexpr bool STATIC = true;
+    static constexpr int n0 = A0, n1 = A1, n2 = A2, n3 = A3, NC = A0 + A1 + A2 + A3;
+    static_assert(A0 % SK_WAVES == 0 && A1 % SK_WAVES == 0 && A2 % SK_WAVES == 0 && A3 % SK_WAVES == 0, "segment boundaries on wave multiples");
+};
+
+template <bool TRAIN = false, int MAXC = SK_MAXC, bool TIMED = false, class LAY = SegRuntime>
 __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/, int ntiles = 1 << 30,
                                              const SkinnyTrain* tr = nullptr, unsigned long long* ts = nullptr) {
     L2S_STAMP(0);
@@ -70,22 +81,43 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
     L2S_STAMP(1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NC = K >> 4;
+    const int NC = LAY::STATIC ? LAY::NC : (K >> 4);
     const float4* wbase = reinterpret_cast<const float4*>(W) + (int64_t)tile * NC * 64 + lane;
     const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2;
 
     // ---- main operand loads first: the whole K slice of this wave in one round trip
     float4 a[MAXC], w[MAXC];
+    if (LAY::STATIC) {
+        // one scalar base per segment (row tile mt, this wave's first chunk of it); everything per chunk is a constant after unrolling
+        const float4* sb0 = reinterpret_cast<const float4*>(sa0) + ((int64_t)mt * LAY::n0 + wave) * 64 + lane;
+        const float4* sb1 = reinterpret_cast<const float4*>(sa1) + ((int64_t)mt * LAY::n1 + wave) * 64 + lane;
+        const float4* sb2 = reinterpret_cast<const float4*>(sa2) + ((int64_t)mt * LAY::n2 + wave) * 64 + lane;
+        const float4* sb3 = reinterpret_cast<const float4*>(sa3) + ((int64_t)mt * LAY::n3 + wave) * 64 + lane;
+        const float4* wb = wbase + (int64_t)wave * 64;
+        constexpr int E0 = LAY::n0, E1 = E0 + LAY::n1, E2 = E1 + LAY::n2;
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-        const int c = wave + SK_WAVES * j;          // wave-uniform
-        if (c < NC) {
-            const float* ab = sa0; int lc = c, nn = n0;
-            if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
-            else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
-            else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
-            a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
-            w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
+        for (int j = 0; j < MAXC; ++j) {
+            const int cj = SK_WAVES * j;
+            if (cj < LAY::NC) {
+                if (cj >= E2) a[j] = sb3[(cj - E2) * 64];
+                else if (cj >= E1) a[j] = sb2[(cj - E1) * 64];
+                else if (cj >= E0) a[j] = sb1[(cj - E0) * 64];
+                else a[j] = sb0[cj * 64];
+                w[j] = wb[cj * 64];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            const int c = wave + SK_WAVES * j;          // wave-uniform
+            if (c < NC) {
+                const float* ab = sa0; int lc = c, nn = n0;
+                if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
+                else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
+                else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
+                a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
+                w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
+            }
         }
     }
     // ---- everything else the block needs, fetched in one batch of scalar loads that overlaps the operand loads already in flight
@@ -129,7 +161,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
         const int c = wave + SK_WAVES * j;
-        if (c < NC) {
+        if (LAY::STATIC ? (SK_WAVES * j < LAY::NC) : (c < NC)) {
             if (j & 1) acc1 = mfma4(a[j], w[j], acc1);
             else acc0 = mfma4(a[j], w[j], acc0);
         }
