@@ -204,7 +204,8 @@ def main():
     if args.warmup is None:
         args.warmup = 3 if args.mode == "train" else 8
     if args.inflight <= 0:
-        args.inflight = 4 if args.steps >= 48 else 3
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))          # 8 unless the environment pinned it before this script started
+        args.inflight = 4 if (args.steps >= 48 and queues >= 5) else 3
     if args.mode == "train":
         return train_main(args)
 
