@@ -257,6 +257,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
  *   "skinny_static"     (0)  compile-time K-segment layouts in the batch-row kernels: the load-issue phase of a block 1.9 -> 1.2 us,
  *                            23.6 -> 23.1 us per step one batch at a time, but 3 % slower with four batches in flight
+ *   "skinny_sized"      (1)  batch-row kernel instances sized for the launch's longest K (48 / 80 / 118 VGPRs for K <= 512 / 1024 / 1536:
+ *                            4 / 3 / 2 blocks per CU); 0 = the K <= 1536 instance everywhere
  *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */

@@ -28,16 +28,19 @@ static int skinny_layout_of(const SkinnyP& p) {
     return 0;
 }
 
+// MAXC = chunks per wave the instance is unrolled for (K <= 128 * MAXC): the 24 operand registers per chunk pair are what sets the
+// kernel's VGPR count, so launches whose longest K is 512 / 1024 get their own, smaller instances
+template <int MAXC>
 __global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
     __shared__ float red[SK_RED_FLOATS];
     const int g = blockIdx.z;
     const SkinnyP& p = batch.p[g];
     const int lay = p.layout;                       // block-uniform
-    if (lay == 3) skinny_block<false, 12, false, SegLay<16, 16, 32, 32>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
-    else if (lay == 2) skinny_block<false, 8, false, SegLay<32, 32, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
-    else if (lay == 1) skinny_block<false, 4, false, SegLay<32, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    if (MAXC == 12 && lay == 3) skinny_block<false, 12, false, SegLay<16, 16, 32, 32>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else if (MAXC >= 8 && lay == 2) skinny_block<false, 8, false, SegLay<32, 32, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else if (MAXC >= 4 && lay == 1) skinny_block<false, 4, false, SegLay<32, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
     else if (lay == 4) skinny_block<false, 2, false, SegLay<16, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
-    else skinny_block(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+    else skinny_block<false, MAXC>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
@@ -54,6 +57,8 @@ static unsigned long long* g_skinny_ts = nullptr;
 static int g_opt_skinny_static = 0;     // compile-time segment layouts (option "skinny_static"): +2 % one batch at a time (23.6 -> 23.1 us/step),
                                         // -3 % with four batches in flight (1.60 -> 1.56 M mel-frames/s) - off by default
 void skinny_set_static(int v) { g_opt_skinny_static = v; }
+static int g_opt_skinny_sized = 1;      // instances sized for the launch's longest K (option "skinny_sized")
+void skinny_set_sized(int v) { g_opt_skinny_sized = v; }
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
@@ -76,8 +81,13 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
         bl.p[i].layout = g_opt_skinny_static ? skinny_layout_of(bl.p[i]) : 0;
     }
     ProfScope ps(name, s);
+    int maxk = 0;
+    for (int i = 0; i < bl.count; ++i) maxk = bl.p[i].K > maxk ? bl.p[i].K : maxk;
+    const int cls = !g_opt_skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
     if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
-    else hipLaunchKernelGGL(skinny_kernel, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else hipLaunchKernelGGL(skinny_kernel<12>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
