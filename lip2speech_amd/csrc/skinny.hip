@@ -105,6 +105,7 @@ struct StepB {
     int mts;
 };
 
+constexpr int ATT_PRE2_MAXC = 2;      // prenet layer 2: K = 256 = 16 * 8 waves * 2 chunks
 __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
     __shared__ __attribute__((aligned(16))) float sm[ATT_SM_FLOATS > SK_RED_FLOATS ? ATT_SM_FLOATS : SK_RED_FLOATS];
     const int nb = sb.at.B, ptiles = sb.pre2_tiles;
@@ -117,12 +118,13 @@ __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
     } else {
         const int j = bid - 2 * nb;
         const int tile = j % ptiles, mt = j / ptiles;
-        skinny_block(sb.pre2, tile, mt, sm);
+        skinny_block<false, ATT_PRE2_MAXC>(sb.pre2, tile, mt, sm);       // K = 256: the 12-chunk instance would set this kernel's VGPR count
     }
 }
 
 int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s) {
     L2S_REQUIRE(at.T <= ATT_MAXT && at.m <= 16, "attention sizes");
+    L2S_REQUIRE(pre2.K <= 16 * SK_WAVES * ATT_PRE2_MAXC, "prenet layer 2 is a 256-wide layer");
     StepB sb;
     sb.at = at;
     sb.pre2 = pre2;
