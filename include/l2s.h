@@ -259,6 +259,9 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            23.6 -> 23.1 us per step one batch at a time, but 3 % slower with four batches in flight
  *   "skinny_sized"      (1)  batch-row kernel instances sized for the launch's longest K (48 / 80 / 118 VGPRs for K <= 512 / 1024 / 1536:
  *                            4 / 3 / 2 blocks per CU); 0 = the K <= 1536 instance everywhere
+ *   "skinny_split"      (2)  K <= 1536 batch-row launches (LSTM layer 0) fetch their operands in this many batches: 2 = half the operand
+ *                            registers, 66 VGPRs, three blocks per CU instead of two: +2 % with four batches in flight, -0.4 % one at a time;
+ *                            1 = one round trip; 3 = no further gain.  "skinny_split8" (1): the same for the K <= 1024 instance (no gain)
  *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */

@@ -1435,6 +1435,8 @@ int l2s_set_option(const char* name, int value) {
     else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
     else if (!std::strcmp(name, "skinny_static")) skinny_set_static(value);
     else if (!std::strcmp(name, "skinny_sized")) skinny_set_sized(value);
+    else if (!std::strcmp(name, "skinny_split")) skinny_set_split(value);
+    else if (!std::strcmp(name, "skinny_split8")) skinny_set_split8(value);
     else if (!std::strcmp(name, "fuse_s2")) g_opt_fuse_s2 = value;
     else if (!std::strcmp(name, "overlap_postnet")) g_opt_overlap_postnet = value;
     else { set_error(std::string("unknown option ") + name); return 1; }

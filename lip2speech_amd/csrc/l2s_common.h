@@ -241,6 +241,8 @@ struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name);
 void skinny_set_static(int v);
 void skinny_set_sized(int v);
+void skinny_set_split(int v);
+void skinny_set_split8(int v);
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);

@@ -42,6 +42,13 @@ __global__ __launch_bounds__(512) void skinny_kernel(const SkinnyBatch batch) {
     else if (lay == 4) skinny_block<false, 2, false, SegLay<16, 0, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
     else skinny_block<false, MAXC>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
+// instances with their operand loads in NB batches (options "skinny_split" = NB for K <= 1536, "skinny_split8" = NB for K <= 1024)
+template <int MAXC, int NB, int WPS>
+__global__ __launch_bounds__(512, WPS) void skinny_kernel_split(const SkinnyBatch batch) {
+    __shared__ float red[SK_RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block<false, MAXC, false, SegRuntime, NB>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
+}
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
 __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch batch, unsigned long long* ts) {
@@ -59,6 +66,10 @@ static int g_opt_skinny_static = 0;     // compile-time segment layouts (option 
 void skinny_set_static(int v) { g_opt_skinny_static = v; }
 static int g_opt_skinny_sized = 1;      // instances sized for the launch's longest K (option "skinny_sized")
 void skinny_set_sized(int v) { g_opt_skinny_sized = v; }
+static int g_opt_skinny_split = 2;      // K <= 1536 launches: operand loads in this many batches (1 = all at once; option "skinny_split")
+static int g_opt_skinny_split8 = 1;     // the same for the K <= 1024 instance (option "skinny_split8")
+void skinny_set_split(int v) { g_opt_skinny_split = v; }
+void skinny_set_split8(int v) { g_opt_skinny_split8 = v; }
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
@@ -86,7 +97,10 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
     const int cls = !g_opt_skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
     if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
     else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 8 && g_opt_skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 12 && g_opt_skinny_split == 2) hipLaunchKernelGGL((skinny_kernel_split<12, 2, 6>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 12 && g_opt_skinny_split == 3) hipLaunchKernelGGL((skinny_kernel_split<12, 3, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else hipLaunchKernelGGL(skinny_kernel<12>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

@@ -65,7 +65,7 @@ struct SegLay {
     static_assert(A0 % SK_WAVES == 0 && A1 % SK_WAVES == 0 && A2 % SK_WAVES == 0 && A3 % SK_WAVES == 0, "segment boundaries on wave multiples");
 };
 
-template <bool TRAIN = false, int MAXC = SK_MAXC, bool TIMED = false, class LAY = SegRuntime>
+template <bool TRAIN = false, int MAXC = SK_MAXC, bool TIMED = false, class LAY = SegRuntime, int SPLIT = 1>
 __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt, float* red /*[8][16][17] + [16][17]*/, int ntiles = 1 << 30,
                                              const SkinnyTrain* tr = nullptr, unsigned long long* ts = nullptr) {
     L2S_STAMP(0);
@@ -87,6 +87,17 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
 
     // ---- main operand loads first: the whole K slice of this wave in one round trip
     float4 a[MAXC], w[MAXC];
+    auto load_chunk = [&](int j) {
+        const int c = wave + SK_WAVES * j;          // wave-uniform
+        if (c < NC) {
+            const float* ab = sa0; int lc = c, nn = n0;
+            if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
+            else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
+            else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
+            a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
+            w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
+        }
+    };
     if (LAY::STATIC) {
         // one scalar base per segment (row tile mt, this wave's first chunk of it); everything per chunk is a constant after unrolling
         const float4* sb0 = reinterpret_cast<const float4*>(sa0) + ((int64_t)mt * LAY::n0 + wave) * 64 + lane;
@@ -107,18 +118,10 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             }
         }
     } else {
+        // SPLIT > 1: only the first 1/SPLIT of the wave's chunks now, the next batch after this batch's MFMAs (SPLIT round trips, 1/SPLIT of the
+        // operand registers: an instance that fits three or four blocks per CU instead of two - for batches in flight)
 #pragma unroll
-        for (int j = 0; j < MAXC; ++j) {
-            const int c = wave + SK_WAVES * j;          // wave-uniform
-            if (c < NC) {
-                const float* ab = sa0; int lc = c, nn = n0;
-                if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
-                else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
-                else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
-                a[j] = reinterpret_cast<const float4*>(ab)[((int64_t)mt * nn + lc) * 64 + lane];
-                w[j] = wbase[(int64_t)c * 64];      // default cache policy: the tile is read by both row-tile blocks of its XCD (nt: +8 % per step)
-            }
-        }
+        for (int j = 0; j < MAXC / SPLIT; ++j) load_chunk(j);
     }
     // ---- everything else the block needs, fetched in one batch of scalar loads that overlaps the operand loads already in flight
     const int epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
@@ -160,6 +163,12 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
+        if (SPLIT > 1 && !LAY::STATIC && j > 0 && j % (MAXC / SPLIT) == 0) {     // next batch of loads: the previous batch's registers are free again
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j2 = j; j2 < j + MAXC / SPLIT; ++j2) load_chunk(j2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int c = wave + SK_WAVES * j;
         if (LAY::STATIC ? (SK_WAVES * j < LAY::NC) : (c < NC)) {
             if (j & 1) acc1 = mfma4(a[j], w[j], acc1);
