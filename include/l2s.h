@@ -133,6 +133,21 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
                   float* mel_post, int64_t* lengths, float* attn,
                   void* ws, int64_t ws_bytes, void* stream);
 
+/* Grouped inference ("advance G independent batches per launch"): G batches of B clips each - separate tensors, wherever the caller's
+ * loader put them - run as rows g*B .. g*B+B-1 of ONE launch chain on ONE weight blob: the 300 x 4 step launches, the BiLSTM recurrence and
+ * every GEMM are issued once per G batches instead of once per batch, and from M = 64 rows on the batch-row kernels use register-blocked
+ * 2x1 / 2x2 / 4x2 tiles (half the operand traffic per row; at M = 128 the LSTM launches are MFMA-bound).  Replaces G passes through the
+ * reference's loop (model/modules/decoder.py:412-435) over G DataLoader batches (demo.py:60-90 / evaluate.py:22-51 iterate them one by one).
+ * Every kernel of the path is row-independent, so each batch's mel / lengths / attention are bit-identical to l2s_inference on that batch.
+ * video[g] dev (B,3,T,H,W), emb[g] dev (B,256), gumbel[g] dev (B*l2s_min_T(T),501) - host arrays of G device pointers;
+ * mel_post dev (G*B,80,S), lengths dev (G*B) int64, attn dev (G*B,S,T) or NULL - batch g is the g-th slice of B rows. */
+#define L2S_MAX_GROUP 8
+int64_t l2s_workspace_bytes_multi(int G, int B, int T, int H, int W, int S);
+int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const float* const* emb, const float* const* gumbel,
+                        int B, int T, int H, int W, int S,
+                        float* mel_post, int64_t* lengths, float* attn,
+                        void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- training-side primitives of the data-parallel step (train.py:102-104,172-193; train_utils/losses.py:69-77) ----------
  * scratch: l2s_train_scratch_bytes() of device memory.  Reductions are two-stage fp64 (deterministic). */
 int64_t l2s_train_scratch_bytes(void);
@@ -265,7 +280,13 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
+/* l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.
+ * Launch sequences only ever read their own model's copy, so a thread that flips a switch cannot disturb batches other threads have in
+ * flight on other models (lip2speech_amd.parallel keeps several in flight).
+ *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
+ *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
 int l2s_set_option(const char* name, int value);
+int l2s_model_set_option(l2s_model* m, const char* name, int value);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */
 int l2s_profile_enable(int on);

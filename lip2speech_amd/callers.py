@@ -88,16 +88,17 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
     (`tf_ratio += 0.1` every 10 epochs); forward -> 4-term loss -> `backward()` -> gradient all-reduce when a process group is up
     (one process per GPU) -> clip at `grad_clip` -> AdamW(amsgrad) on the decoder and encoder groups.  Returns the per-iteration loss
     log (python floats; the `.item()` calls are this loop's only host synchronisations, like the reference's `loss_log`)."""
+    from .losses import Loss
     from .training import AdamWAmsgrad, GradAllReducer
     net.train()
     flat = net._train_state()
+    reducer = GradAllReducer(flat.grad)          # no-op without a process group; both optimizer routes reduce (ranks must not diverge)
+    reconstruction_criterion = Loss()
     if fused_optimizer:
         optim = AdamWAmsgrad(flat, lr=lr, weight_decay=weight_decay)
-        reducer = GradAllReducer(flat.grad)
     else:
         dec, enc = net.trainable_groups()
         optim = torch.optim.AdamW([{"params": dec}, {"params": enc}], lr=lr, weight_decay=weight_decay, amsgrad=True)
-        reducer = None
     log, epoch, pos = [], 0, 0
     for _ in range(n_iters):
         if pos == len(batches):
@@ -109,7 +110,7 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
         emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
         outputs = net(videos.to(device), face_crops.to(device) if face_crops is not None else None, audios.to(device), melspecs.to(device), vlen, alen,
                       mlen, tf_ratio, speaker_embedding=emb)
-        losses = reconstruction_losses(outputs, (melspecs.to(device), gates.to(device)))
+        losses = reconstruction_criterion(outputs, (melspecs.to(device), gates.to(device)), dict())
         loss = sum(losses.values())
         optim.zero_grad()
         loss.backward()
@@ -118,6 +119,10 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
             grad_norm = optim.step(max_norm=grad_clip, grad_mul=reducer.wait())
             net.mark_weights_changed()
         else:
+            reducer.start()
+            mul = reducer.wait()
+            if mul != 1.0:
+                flat.grad.mul_(mul)                  # average over ranks before the clip (train.py:191 clips the reduced gradient)
             grad_norm = torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
             optim.step()
         rec = {k: float(v.detach()) for k, v in losses.items()}

@@ -24,7 +24,7 @@ constexpr int FE_CO = 24;
 // MODE 0: inference; 1: also save the pre-PReLU map (training tape); 2: batch-statistics pass (training): nothing is stored but the
 // per-channel sum / sum of squares of the RAW conv output over this block's own conv rows -> zout[(block*2 + k)*24 + ch]
 template <int HW, int MODE>
-__global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, const float* __restrict__ video,
+__global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, const FrameSrc vsrc,
                                                             int T, float* __restrict__ out, float* __restrict__ zout) {
     constexpr bool SAVE_Z = MODE == 1;
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     float* Ws = smem + XS;
 
     const int f = blockIdx.y;                        // frame index b*T + t
-    const int b = f / T, t = f - b * T;
+    const int bg = f / T, t = f - bg * T;
+    const int grp = bg / vsrc.per, b = bg - grp * vsrc.per;     // clip b of the grp-th batch tensor (block-uniform)
+    const float* __restrict__ video = vsrc.p[grp];
     const int p0 = blockIdx.x * FE_PR;               // first pooled row of this strip
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, lg = lane >> 5;
@@ -173,9 +175,11 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     }
 }
 
-int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
+int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
-    L2S_REQUIRE((reinterpret_cast<uintptr_t>(video) & 15u) == 0, "video must be 16-byte aligned");
+    L2S_REQUIRE(video.per >= 1 && (B + video.per - 1) / video.per <= MAX_GROUP, "too many frame tensors in one launch");
+    for (int g = 0; g < (B + video.per - 1) / video.per; ++g)
+        L2S_REQUIRE(video.p[g] && (reinterpret_cast<uintptr_t>(video.p[g]) & 15u) == 0, "video must be non-null and 16-byte aligned");
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     ProfScope ps("frontend3d_conv_bn_prelu_pool", s);
@@ -190,8 +194,9 @@ int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H,
     return 0;
 }
 
-int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials, int* nblocks, hipStream_t s) {
+int launch_frontend_stats(const FrontendW& w, const float* video1, int B, int T, int H, int W, float* partials, int* nblocks, hipStream_t s) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
+    FrameSrc video{}; video.p[0] = video1; video.per = B;
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     *nblocks = (int)(grid.x * grid.y);

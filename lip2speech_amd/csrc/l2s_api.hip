@@ -21,6 +21,19 @@ namespace l2s {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
+// ------------------------------------------------------------------------------------------------ options
+static Options g_default_opt;          // process defaults: what l2s_model_create copies into a new model (l2s_set_option)
+int set_option_field(Options& o, const char* name, int value) {
+    struct { const char* name; int Options::*field; } table[] = {
+        {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
+        {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
+        {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}};
+    for (auto& t : table)
+        if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
+    return 1;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 struct ProfEntry { std::string name; int64_t launches = 0; double total_ms = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 bool g_prof_on = false;
@@ -163,7 +176,6 @@ static int lstm_perm_row(int np, int H) {      // packed row (unit-major: 4*unit
     return gate * H + unit;
 }
 
-static int g_opt_refresh_map = 0;     // build the device-side refresh map at finalize (training)
 
 static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bool& want_spk) {
     m->w = Weights{};
@@ -505,7 +517,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     Packer P{m};
     bool want_enc = false, want_dec = false, want_spk = false;
     if (pack_host(m, P, want_enc, want_dec, want_spk)) return 1;
-    if (g_opt_refresh_map && build_refresh_map(m, P, stream)) return 1;
+    if (m->opt.refresh_map && build_refresh_map(m, P, stream)) return 1;
     m->folded_valid = true;
 
     // upload and patch pointers
@@ -716,8 +728,6 @@ static int64_t decode_ws_floats(int B) {
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
 
 // ------------------------------------------------------------------------------------------------ encoder
-static int g_opt_fuse_s2 = 1;     // stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk)
-static int g_opt_fuse_trunk = 1;  // stride-1 ShuffleNet units as one fused kernel each
 
 static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* C, int ldc, int c_off, int cstride,
                      int64_t M, int N, int K, int act) {
@@ -726,7 +736,9 @@ static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* 
     return p;
 }
 
-static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, int W, const float* emb, float* vis,
+static FrameSrc frame_src(const float* video, int B) { FrameSrc f{}; f.p[0] = video; f.per = B; return f; }
+
+static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H, int W, const float* emb, float* vis,
                        float* feat, void* ws, int64_t ws_bytes, hipStream_t s) {
     const Weights& w = m->w;
     EncPlan pl = enc_plan(B, T, H);
@@ -740,7 +752,7 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
     for (int u = 0; u < N_UNITS; ++u) {
         const UnitW& U = w.unit[u];
         const int half = U.half, cout = 2 * half;
-        if (U.stride2 && g_opt_fuse_trunk && g_opt_fuse_s2) {
+        if (U.stride2 && m->opt.fuse_trunk && m->opt.fuse_s2) {
             ShuffleS2P sp{};
             sp.x = x; sp.out = y;
             sp.wd1 = U.b1_dw.w9; sp.sd1 = U.b1_dw.scale; sp.bd1 = U.b1_dw.shift;
@@ -763,7 +775,7 @@ static int encoder_run(l2s_model* m, const float* video, int B, int T, int H, in
             if (launch_dwconv(t1, NF, h, h, half, 0, half, 2, U.dw.w9, U.dw.scale, U.dw.shift, t2, half, 0, s)) return 1;
             if (launch_gemm1(pw_gemm(t2, half, 0, U.pw2, y, cout, 1, 2, out_px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
             h = ho;
-        } else if (g_opt_fuse_trunk) {
+        } else if (m->opt.fuse_trunk) {
             ShuffleS1P sp{};
             sp.x = x; sp.out = y;
             sp.w1f = U.pw1_frag; sp.s1 = U.pw1.scale; sp.b1 = U.pw1.shift;
@@ -879,7 +891,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
             sb.p[d] = p; sb.ntiles[d] = w.whh[d].tiles;
         }
         sb.count = 2;
-        if (launch_skinny(sb, s, "bilstm_step")) return 1;
+        if (launch_skinny(sb, s, "bilstm_step", m->opt)) return 1;
     }
     const int fin = T & 1;     // buffer holding the final hidden states
     // decoder initial hidden = BiLSTM finals (fwd -> layer 0, bwd -> layer 1); kept in the state buffer as frag16
@@ -966,9 +978,10 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
 }
 
 // ------------------------------------------------------------------------------------------------ decode loop
-static int g_opt_fold = 1;       // phase-merged step (4 launches) vs the literal 6-phase step
-static int g_opt_overlap_postnet = 0;   // l2s_inference: post-net in time windows on a second stream under the decode loop (bit-identical; measured SLOWER on MI355X, 13.1 vs 12.0 ms: the GEMM blocks delay the latency-critical step launches)
-static int g_opt_graph = 0;      // replay the loop from a captured hipGraph (measured slower than stream launches on MI355X: 15.0 vs 13.7 ms)
+// options (l2s_common.h Options, per model): "fold_step_weights" - phase-merged step (4 launches) vs the literal 6-phase step; "overlap_postnet" -
+// l2s_inference runs the post-net in time windows on a second stream under the decode loop (bit-identical; measured SLOWER on MI355X, 13.1 vs
+// 12.0 ms: the GEMM blocks delay the latency-critical step launches); "use_graph" - replay the loop from a captured hipGraph (measured slower
+// than stream launches on MI355X: 15.0 vs 13.7 ms)
 
 struct DecodeBufs {
     float *h0[2], *h1[2], *c0, *c1, *av, *p1, *cc, *uu, *yf, *p2f, *q, *qc, *p2;
@@ -1030,7 +1043,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             sb.p[2] = c; sb.ntiles[2] = w.cq.tiles;
             sb.count = 3;
             if (fold && i > 0) { sb.p[3] = fc_group(i - 1, d.h1[cur], false); sb.ntiles[3] = w.fc.tiles; sb.count = 4; }
-            if (launch_skinny(sb, s, fold ? "step_prenet1_q_cq_fc" : "step_prenet1_q_cq")) return 1;
+            if (launch_skinny(sb, s, fold ? "step_prenet1_q_cq_fc" : "step_prenet1_q_cq", m->opt)) return 1;
             if (fold && i > 0 && on_frames && (*on_frames)(i)) return 1;
         }
         {   // phase B: attention + content attention per batch row; prenet layer 2
@@ -1050,7 +1063,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             SkinnyP a = sk_base(w.aproj, B);
             a.seg[0] = {d.av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = d.uu; a.ldo = 256; a.add = d.p2; a.ld_add = 256;
             sb.p[0] = a; sb.ntiles[0] = w.aproj.tiles; sb.count = 1;
-            if (launch_skinny(sb, s, "step_attention_proj")) return 1;
+            if (launch_skinny(sb, s, "step_attention_proj", m->opt)) return 1;
         }
         {   // phase D: LSTM layer 0 on cat(content, u), h0  (folded: cat(content, prenet, a@v) against [W_ih | W_ih_u W_ap | W_hh])
             SkinnyBatch sb{};
@@ -1059,7 +1072,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             else { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.uu, 16}; a.seg[2] = {d.h0[cur], 32}; a.nseg = 3; }
             a.epi = SK_LSTM; a.H = 512; a.c_in = d.c0; a.c_out = d.c0; a.h_out = d.h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
-            if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
+            if (launch_skinny(sb, s, "step_lstm_cell", m->opt)) return 1;
         }
         {   // phase E: LSTM layer 1 on the new h0
             SkinnyBatch sb{};
@@ -1067,12 +1080,12 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             a.seg[0] = {d.h0[nxt], 32}; a.seg[1] = {d.h1[cur], 32}; a.nseg = 2;
             a.epi = SK_LSTM; a.H = 512; a.c_in = d.c1; a.c_out = d.c1; a.h_out = d.h1[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = w.lstm1.tiles; sb.count = 1;
-            if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
+            if (launch_skinny(sb, s, "step_lstm_cell", m->opt)) return 1;
         }
         if (!fold || i == S - 1) {   // phase F: mel frame + stop logit (folded mode: only the last step needs its own launch)
             SkinnyBatch sb{};
             sb.p[0] = fc_group(i, d.h1[nxt], !fold); sb.ntiles[0] = w.fc.tiles; sb.count = 1;
-            if (launch_skinny(sb, s, "step_fc_out_stop")) return 1;
+            if (launch_skinny(sb, s, "step_fc_out_stop", m->opt)) return 1;
             if (on_frames && (*on_frames)(i + 1)) return 1;
         }
     }
@@ -1082,8 +1095,8 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
 static int decode_run(l2s_model* m, float* state, int B, int T, int S, const float* teacher, const uint8_t* teacher_mask,
                       float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
-    const bool fold = g_opt_fold != 0 && m->folded_valid;
-    const bool use_graph = g_opt_graph && !teacher && !g_prof_on;
+    const bool fold = m->opt.fold != 0 && m->folded_valid;
+    const bool use_graph = m->opt.graph && !teacher && !g_prof_on;
     if (!use_graph) return decode_launches(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, s, fold);
 
     if (!m->side) {
@@ -1196,7 +1209,7 @@ static int speaker_run(l2s_model* m, const float* audio, int B, int N, float* em
             p.h_out = hf[(t & 1) ^ 1]; p.h_out_K = 256; p.h_out_off = 0;
             p.h_seq = out + (int64_t)t * 256; p.ld_hseq = (int64_t)L * 256;
             sb.p[0] = p; sb.ntiles[0] = 64; sb.count = 1;
-            if (launch_skinny(sb, s, "spk_lstm_step")) return 1;
+            if (launch_skinny(sb, s, "spk_lstm_step", m->opt)) return 1;
         }
         x = out;
         xin = 256;
@@ -1221,6 +1234,7 @@ const char* l2s_last_error(void) { return g_err.c_str(); }
 int l2s_model_create(l2s_model** out) {
     L2S_REQUIRE(out != nullptr, "null out pointer");
     *out = new l2s_model();
+    (*out)->opt = g_default_opt;
     return 0;
 }
 int l2s_model_set_tensor(l2s_model* m, const char* key, const float* host_data, int64_t numel) {
@@ -1281,7 +1295,7 @@ int64_t l2s_state_offset(int B, int T, int field) {
 int l2s_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W, float* feat, void* ws, int64_t ws_bytes, void* stream) {
     L2S_ENC_READY(m);
     L2S_REQUIRE(video && feat && ws && B > 0 && T > 0, "bad arguments");
-    return encoder_run(m, video, B, T, H, W, nullptr, nullptr, feat, ws, ws_bytes, (hipStream_t)stream);
+    return encoder_run(m, frame_src(video, B), B, T, H, W, nullptr, nullptr, feat, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int l2s_build_visual(const float* feat, const float* emb, int B, int T, float* vis, void* stream) {
@@ -1325,12 +1339,8 @@ int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* 
     return launch_output_lengths(stop, B, S, lengths, (hipStream_t)stream);
 }
 
-int l2s_inference(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
-                  float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, void* stream) {
-    L2S_ENC_READY(m);
-    L2S_DEC_READY(m);
-    L2S_REQUIRE(video && emb && gumbel && mel_post && lengths && ws, "bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                         float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, hipStream_t s) {
     Bump bp(ws, ws_bytes);
     float* vis = bp.f((int64_t)B * T * 1024);
     float* state = bp.f(l2s_state_floats(B, T));
@@ -1341,7 +1351,7 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
     const int64_t rest_bytes = ws_bytes - bp.off;
     if (encoder_run(m, video, B, T, H, W, emb, vis, nullptr, rest, rest_bytes, s)) return 1;
     if (prologue_run(m, vis, emb, gumbel, B, T, state, nullptr, rest, rest_bytes, s)) return 1;
-    if (!g_opt_overlap_postnet || g_prof_on || g_opt_graph) {
+    if (!m->opt.overlap_postnet || g_prof_on || m->opt.graph) {
         if (decode_run(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s)) return 1;
         if (postnet_run(m, mel, B, S, mel_post, nullptr, rest, rest_bytes, s)) return 1;
     } else {
@@ -1379,11 +1389,50 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
         // the side stream must not start before earlier work on `s` (previous users of these buffers) is done
         L2S_CHECK_HIP(hipEventRecord(m->ev_in, s));
         L2S_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_in, 0));
-        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, g_opt_fold != 0 && m->folded_valid, &on_frames)) return 1;
+        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, m->opt.fold != 0 && m->folded_valid, &on_frames)) return 1;
         L2S_CHECK_HIP(hipEventRecord(m->ev_out, m->side));
         L2S_CHECK_HIP(hipStreamWaitEvent(s, m->ev_out, 0));
     }
     return launch_output_lengths(stop, B, S, lengths, s);
+}
+
+int l2s_inference(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                  float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(video && emb && gumbel && mel_post && lengths && ws && B > 0, "bad arguments");
+    return inference_run(m, frame_src(video, B), emb, gumbel, B, T, H, W, S, mel_post, lengths, attn, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Grouped inference: the G batches are rows g*B .. g*B+B-1 of ONE launch chain on ONE weight blob.  Every kernel of the path is row-independent
+// (a row's arithmetic does not depend on how many rows share the launch), so each batch's results are bit-identical to l2s_inference on it.
+int64_t l2s_workspace_bytes_multi(int G, int B, int T, int H, int W, int S) {
+    int L[4];
+    const int64_t rows = (int64_t)G * B;
+    return l2s_workspace_bytes((int)rows, T, H, W, S) + align_up(rows * L2S_D_EMB * 4, 256) + align_up(rows * content_lens(T, L) * VOC * 4, 256);
+}
+int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const float* const* emb, const float* const* gumbel, int B, int T, int H,
+                        int W, int S, float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(G >= 1 && G <= L2S_MAX_GROUP && video && emb && gumbel && mel_post && lengths && ws && B > 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int L[4];
+    const int mT = content_lens(T, L);
+    Bump bp(ws, ws_bytes);
+    float* emb_all = bp.f((int64_t)G * B * L2S_D_EMB);
+    float* gum_all = bp.f((int64_t)G * B * mT * VOC);
+    L2S_REQUIRE(!bp.overflow, "workspace too small (l2s_workspace_bytes_multi)");
+    FrameSrc src{};
+    src.per = B;
+    for (int g = 0; g < G; ++g) {
+        L2S_REQUIRE(video[g] && emb[g] && gumbel[g], "null batch pointer");
+        src.p[g] = video[g];
+        // the small per-batch operands are gathered (G x 32 KB + G x 256 KB at B = 32); the frames (102.6 MB per batch) are read in place
+        L2S_CHECK_HIP(hipMemcpyAsync(emb_all + (int64_t)g * B * L2S_D_EMB, emb[g], sizeof(float) * B * L2S_D_EMB, hipMemcpyDeviceToDevice, s));
+        L2S_CHECK_HIP(hipMemcpyAsync(gum_all + (int64_t)g * B * mT * VOC, gumbel[g], sizeof(float) * B * mT * VOC, hipMemcpyDeviceToDevice, s));
+    }
+    return inference_run(m, src, emb_all, gum_all, G * B, T, H, W, S, mel_post, lengths, attn, (char*)ws + bp.off, ws_bytes - bp.off, s);
 }
 
 // ---- operator-level entry points
@@ -1412,7 +1461,7 @@ int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* d
 }
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
     L2S_ENC_READY(m);
-    return launch_frontend(m->w.fe, video, B, T, H, W, out, (hipStream_t)stream);
+    return launch_frontend(m->w.fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }
 
 int l2s_train_set_bn(l2s_model* m, int batch_stats, float momentum) {
@@ -1429,17 +1478,12 @@ int l2s_train_refresh_weights(l2s_model* m, void* stream) {
 
 int l2s_set_option(const char* name, int value) {
     L2S_REQUIRE(name != nullptr, "null option name");
-    if (!std::strcmp(name, "refresh_map")) { g_opt_refresh_map = value; return 0; }
-    if (!std::strcmp(name, "fold_step_weights")) g_opt_fold = value;
-    else if (!std::strcmp(name, "use_graph")) g_opt_graph = value;
-    else if (!std::strcmp(name, "fuse_trunk")) g_opt_fuse_trunk = value;
-    else if (!std::strcmp(name, "skinny_static")) skinny_set_static(value);
-    else if (!std::strcmp(name, "skinny_sized")) skinny_set_sized(value);
-    else if (!std::strcmp(name, "skinny_split")) skinny_set_split(value);
-    else if (!std::strcmp(name, "skinny_split8")) skinny_set_split8(value);
-    else if (!std::strcmp(name, "fuse_s2")) g_opt_fuse_s2 = value;
-    else if (!std::strcmp(name, "overlap_postnet")) g_opt_overlap_postnet = value;
-    else { set_error(std::string("unknown option ") + name); return 1; }
+    if (set_option_field(g_default_opt, name, value)) { set_error(std::string("unknown option ") + name); return 1; }
+    return 0;
+}
+int l2s_model_set_option(l2s_model* m, const char* name, int value) {
+    L2S_REQUIRE(m != nullptr && name != nullptr, "bad arguments");
+    if (set_option_field(m->opt, name, value)) { set_error(std::string("unknown option ") + name); return 1; }
     return 0;
 }
 
@@ -1470,13 +1514,13 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
         a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.seg[2] = {av, 32}; a.seg[3] = {h0[cur], 32}; a.nseg = 4;
         a.epi = SK_LSTM; a.H = 512; a.c_in = c0; a.c_out = c0; a.h_out = h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
         sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
-        if (launch_skinny(sb, s, "step_lstm_cell")) return 1;
+        if (launch_skinny(sb, s, "step_lstm_cell", m->opt)) return 1;
         SkinnyBatch sc{};
         SkinnyP b = sk_base(w.lstm1, B);
         b.seg[0] = {h0[nxt], 32}; b.seg[1] = {h1[cur], 32}; b.nseg = 2;
         b.epi = SK_LSTM; b.H = 512; b.c_in = c1; b.c_out = c1; b.h_out = h1[nxt]; b.h_out_K = 512; b.h_out_off = 0;
         sc.p[0] = b; sc.ntiles[0] = 128; sc.count = 1;
-        return launch_skinny(sc, s, "step_lstm_cell");
+        return launch_skinny(sc, s, "step_lstm_cell", m->opt);
     };
     for (int i = 0; i < 8; ++i) if (pair(i & 1)) return 1;                   // warm-up
     L2S_CHECK_HIP(hipEventRecord(e0, s));

@@ -38,6 +38,25 @@ struct ProfScope {
     ~ProfScope() { prof_end(s); }
 };
 
+// ---------------------------------------------------------------- run-time options (include/l2s.h "run-time options")
+// Every model carries its own copy (l2s_model::opt, copied from the process defaults at l2s_model_create), so host threads that drive
+// different models - or one model - never read a switch another thread is flipping.
+struct Options {
+    int fold = 1;               // "fold_step_weights": phase-merged 4-launch step vs the literal 6-phase step
+    int graph = 0;              // "use_graph": replay the decode loop from a captured hipGraph
+    int overlap_postnet = 0;    // "overlap_postnet": windowed post-net on a second stream under the decode loop
+    int fuse_trunk = 1;         // "fuse_trunk": stride-1 ShuffleNet units as one fused kernel each
+    int fuse_s2 = 1;            // "fuse_s2": stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk)
+    int refresh_map = 0;        // "refresh_map": l2s_model_finalize also builds the device-side refresh map (training)
+    int skinny_static = 0;      // "skinny_static": compile-time K-segment layouts in the batch-row kernels
+    int skinny_sized = 1;       // "skinny_sized": batch-row instances sized for the launch's longest K
+    int skinny_split = 2;       // "skinny_split": operand-load batches of the K <= 1536 instance
+    int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
+    int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
+    int rc_jb = 2;              // "skinny_rc_jb": chunks per operand batch of the 2x1 / 2x2 blocks (2 or 4)
+};
+int set_option_field(Options& o, const char* name, int value);    // 0 = ok, 1 = unknown name
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_PSINE = 3, ACT_PRELU = 4 /* backward only */ };
 
 // ---------------------------------------------------------------- tiled fp32 MFMA GEMM (gemm_nt.hip)
@@ -150,7 +169,15 @@ struct FrontendW {          // device pointers into the weight blob
     const float* shift;     // [24]
     const float* slope;     // [24] PReLU
 };
-int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout = nullptr);
+// where the clips of a launch live: clip b is clip (b % per) of the (per,3,T,H,W) tensor p[b / per] - the G batches of a grouped pass
+// (l2s_inference_multi) stay where their caller put them
+constexpr int MAX_GROUP = 8;       // = L2S_MAX_GROUP (include/l2s.h)
+struct FrameSrc { const float* p[MAX_GROUP]; int per; };
+int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout = nullptr);
+inline int launch_frontend(const FrontendW& w, const float* video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout = nullptr) {
+    FrameSrc f{}; f.p[0] = video; f.per = B;
+    return launch_frontend(w, f, B, T, H, W, out, s, zout);
+}
 // batch-statistics pass of the front-end conv (training): partials[(block*2 + k)*24 + ch], *nblocks blocks
 int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials /*[blocks][2][24]*/, int* nblocks, hipStream_t s);
 
@@ -238,11 +265,7 @@ struct SkinnyP {
 };
 constexpr int SKINNY_MAX_GROUP = 4;
 struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
-int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name);
-void skinny_set_static(int v);
-void skinny_set_sized(int v);
-void skinny_set_split(int v);
-void skinny_set_split8(int v);
+int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o = Options());
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);

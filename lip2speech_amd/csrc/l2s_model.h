@@ -74,6 +74,7 @@ struct l2s_model {
     bool finalized = false;
     bool has_enc = false, has_dec = false, has_spk = false;
     l2s::Weights w;
+    l2s::Options opt;            // this model's run-time options (l2s_model_set_option; defaults from l2s_set_option at creation)
     // captured decode loops (hipGraph), replayed on a private non-blocking stream fenced against the caller's stream
     struct GraphEntry { int B, T, S, attn_logits, fold; const void *state, *mel, *stop, *attn, *ws; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;

@@ -50,6 +50,28 @@ __global__ __launch_bounds__(512, WPS) void skinny_kernel_split(const SkinnyBatc
     skinny_block<false, MAXC, false, SegRuntime, NB>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g]);
 }
 
+// register-blocked instances for many batch rows (grouped decode, skinny_dev.h skinny_block_rc): RT x CT tiles of 16x16 per block
+template <int RT, int CT, int MAXC, int JB, int WPS>
+__global__ __launch_bounds__(512, WPS) void skinny_rc_kernel(const SkinnyBatch batch, int mts) {
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rc<RT, CT, MAXC, JB>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
+template <int RT, int CT>
+static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb) {
+    const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(512);
+    constexpr int JBW = RT * CT >= 8 ? 2 : 4;            // the 4x2 form holds 6 fragments per chunk: batches of two chunks
+    if (RT * CT < 8 && rc_jb == 2) {
+        if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 2, 2>), grid, blk, 0, s, bl, mts);
+        else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 2, 2>), grid, blk, 0, s, bl, mts);
+        else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 2, 2>), grid, blk, 0, s, bl, mts);
+        return;
+    }
+    if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, JBW, 2>), grid, blk, 0, s, bl, mts);
+    else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, JBW, 2>), grid, blk, 0, s, bl, mts);
+    else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, JBW, 2>), grid, blk, 0, s, bl, mts);
+}
+
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
 __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch batch, unsigned long long* ts) {
     __shared__ float red[SK_RED_FLOATS];
@@ -61,18 +83,12 @@ __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch bat
     else skinny_block<false, SK_MAXC, true>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
 }
 static unsigned long long* g_skinny_ts = nullptr;
-static int g_opt_skinny_static = 0;     // compile-time segment layouts (option "skinny_static"): +2 % one batch at a time (23.6 -> 23.1 us/step),
-                                        // -3 % with four batches in flight (1.60 -> 1.56 M mel-frames/s) - off by default
-void skinny_set_static(int v) { g_opt_skinny_static = v; }
-static int g_opt_skinny_sized = 1;      // instances sized for the launch's longest K (option "skinny_sized")
-void skinny_set_sized(int v) { g_opt_skinny_sized = v; }
-static int g_opt_skinny_split = 2;      // K <= 1536 launches: operand loads in this many batches (1 = all at once; option "skinny_split")
-static int g_opt_skinny_split8 = 1;     // the same for the K <= 1024 instance (option "skinny_split8")
-void skinny_set_split(int v) { g_opt_skinny_split = v; }
-void skinny_set_split8(int v) { g_opt_skinny_split8 = v; }
+// options (l2s_common.h Options): "skinny_static" = compile-time segment layouts: +2 % one batch at a time (23.6 -> 23.1 us/step), -3 % with four
+// batches in flight (1.60 -> 1.56 M mel-frames/s), off by default; "skinny_sized" = instances sized for the launch's longest K;
+// "skinny_split" / "skinny_split8" = operand loads of the K <= 1536 / K <= 1024 instance in this many batches
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
-int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
+int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o) {
     L2S_REQUIRE(b.count >= 1 && b.count <= SKINNY_MAX_GROUP, "skinny group size");
     int maxt = 0, mts = 0;
     for (int i = 0; i < b.count; ++i) {
@@ -89,18 +105,32 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name) {
     SkinnyBatch bl = b;
     for (int i = 0; i < bl.count; ++i) {
         for (int j = bl.p[i].nseg; j < 4; ++j) { bl.p[i].seg[j].nchunks = 0; bl.p[i].seg[j].a = bl.p[i].seg[0].a; }
-        bl.p[i].layout = g_opt_skinny_static ? skinny_layout_of(bl.p[i]) : 0;
+        bl.p[i].layout = o.skinny_static ? skinny_layout_of(bl.p[i]) : 0;
     }
     ProfScope ps(name, s);
     int maxk = 0;
     for (int i = 0; i < bl.count; ++i) maxk = bl.p[i].K > maxk ? bl.p[i].K : maxk;
-    const int cls = !g_opt_skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
+    const int cls = !o.skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
+    // many batch rows: register-blocked blocks, the largest shape that still gives the chip one block per CU
+    int shape = o.rc_shape;
+    if (shape == 0) {
+        shape = 11;
+        if (mts >= 4) {
+            auto blocks = [&](int rt, int ct) { int n = 0; for (int i = 0; i < bl.count; ++i) n += (bl.ntiles[i] + ct - 1) / ct; return n * ((mts + rt - 1) / rt); };
+            if (blocks(4, 2) >= 224) shape = 42;
+            else if (blocks(2, 2) >= 224) shape = 22;
+            else if (blocks(2, 1) >= 224) shape = 21;
+        }
+    }
     if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
+    else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb);
+    else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb);
+    else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb);
     else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
-    else if (cls == 8 && g_opt_skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 8 && o.skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
-    else if (cls == 12 && g_opt_skinny_split == 2) hipLaunchKernelGGL((skinny_kernel_split<12, 2, 6>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
-    else if (cls == 12 && g_opt_skinny_split == 3) hipLaunchKernelGGL((skinny_kernel_split<12, 3, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 12 && o.skinny_split == 2) hipLaunchKernelGGL((skinny_kernel_split<12, 2, 6>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
+    else if (cls == 12 && o.skinny_split == 3) hipLaunchKernelGGL((skinny_kernel_split<12, 3, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else hipLaunchKernelGGL(skinny_kernel<12>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

@@ -276,6 +276,171 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
 
 constexpr int SK_RED_FLOATS = (SK_WAVES + 1) * 16 * 17;
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Register-blocked form for many batch rows (grouped decode: G independent B=32 batches advance in ONE launch chain, M = 32*G rows).
+// One block (8 waves) owns RT row tiles x CT column tiles of 16x16; the waves split K exactly as in skinny_block (wave w owns chunks
+// w, w+8, ...) and every operand fragment a wave fetches feeds CT (activations) or RT (weights) MFMA groups, so a 2x2 block moves
+// (32+32)*K*4 bytes for four tiles where four 1x1 blocks move 4*(16+16)*K*4 - half the traffic through the CU's vector-memory path, which
+// is what bounds the 1x1 form - and at M = 128 the launch becomes MFMA-bound (805 MFLOP per LSTM0 launch = 5.1 us at the fp32
+// matrix peak).  Operands arrive in batches of JB chunks, two batches in flight, the next one requested right after a batch's MFMAs.
+// Per output element the arithmetic is the 1x1 kernel's, operation for operation (even chunks into one accumulator, odd chunks into a
+// second one, x,y,z,w in order; acc0+acc1; waves 0..7 in order; then bias, pre-gates), so a row's result does not depend on how many
+// rows share the launch: a grouped pass is bit-identical to the same batches run one by one.
+template <int RT, int CT>
+struct SkRc { static constexpr int NT = RT * CT, RED_FLOATS = (SK_WAVES + 1) * NT * 16 * 17; };
+
+template <int RT, int CT, int MAXC, int JB>
+__device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts) {
+    static_assert(MAXC % JB == 0, "chunk batches");
+    constexpr int NT = RT * CT, NBATCH = MAXC / JB, NQ = (NT + 1) / 2;
+    const float* const W = p.W;
+    const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
+    const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
+    const int K = p.K;
+    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(K), "s"(ntiles), "s"(mts));
+    if (tp * CT >= ntiles) return;                   // block-uniform: grid x is sized for the widest group of the launch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NC = K >> 4;
+    const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2;
+    // tiles past the end of the group / batch are computed on the last valid tile's operands and dropped in the epilogue
+    int ct_[CT], rt_[RT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) ct_[i] = min(tp * CT + i, ntiles - 1);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) rt_[r] = min(mg * RT + r, mts - 1);
+    const float4* wb[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wb[i] = reinterpret_cast<const float4*>(W) + (int64_t)ct_[i] * NC * 64 + lane;
+
+    float4 a[MAXC][RT], w[MAXC][CT];
+    auto load_chunk = [&](int j) {
+        const int c = wave + SK_WAVES * j;          // wave-uniform
+        if (c < NC) {
+            const float* ab = sa0; int lc = c, nn = n0;
+            if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }
+            else if (c >= e1) { ab = sa2; lc = c - e1; nn = n2; }
+            else if (c >= e0) { ab = sa1; lc = c - e0; nn = n1; }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[j][r] = reinterpret_cast<const float4*>(ab)[((int64_t)rt_[r] * nn + lc) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) w[j][i] = wb[i][(int64_t)c * 64];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < (NBATCH > 1 ? 2 * JB : JB); ++j) load_chunk(j);
+    // ---- everything else the block needs: one batch of scalar loads under the operand loads already in flight
+    const int epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
+    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
+    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
+    L2S_PIN_S("s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act), "s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow));
+    // epilogue roles: thread (half, l) finishes element (l>>4, l&15) of tiles q = half, half+2, ...; thread (q2, t64) runs the LSTM cell of
+    // (row t64>>2, unit t64&3) of tile q2
+    const int half = tid >> 8, l256 = tid & 255, e_row = l256 >> 4, e_col = l256 & 15;
+    float pf_bias[NQ], pf_extra[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q = half + 2 * n;
+        pf_bias[n] = 0.f; pf_extra[n] = 0.f;
+        if (q < NT) {
+            const int t = tp * CT + q % CT, rt = mg * RT + q / CT;
+            const int e_b = rt * 16 + e_row, e_np = t * 16 + e_col;
+            if (t < ntiles && rt < mts) {
+                if (bias) pf_bias[n] = bias[e_np];
+                if (epi == SK_LSTM) {
+                    if (pre && e_b < nB) pf_extra[n] = pre[(int64_t)e_b * ld_pre + (e_col & 3) * H + t * 4 + (e_col >> 2)];
+                } else if (epi != SK_MEL && e_b < nB && e_np < N) {
+                    if (add) pf_extra[n] = add[(int64_t)e_b * ld_add + e_np];
+                    if (addrow) pf_extra[n] += addrow[e_np];
+                }
+            }
+        }
+    }
+    float pf_c = 0.f;
+    const int q2 = tid >> 6, t64 = tid & 63;
+    const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
+    const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
+    const bool cell_on = epi == SK_LSTM && q2 < NT && t2 < ntiles && rt2 < mts && b2 < nB;
+    if (cell_on) pf_c = c_in[frag16_index(b2, unit2, H)];
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int bt = 0; bt < NBATCH; ++bt) {
+#pragma unroll
+        for (int j = bt * JB; j < (bt + 1) * JB; ++j) {
+            if (wave + SK_WAVES * j < NC) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) acc[r * CT + i][j & 1] = mfma4(a[j][r], w[j][i], acc[r * CT + i][j & 1]);
+            }
+        }
+        if (bt + 2 < NBATCH) {                    // the registers of this batch are free again: request the batch after the next
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = (bt + 2) * JB; j < (bt + 3) * JB; ++j) load_chunk(j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D layout: col = lane&15, row = 4*(lane>>4) + r
+    {
+        const int col = lane & 15, rb = 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * NT + q) * 16 + rb + r) * 17 + col] = acc[q][0][r] + acc[q][1][r];
+    }
+    __syncthreads();
+    float* gt = red + SK_WAVES * NT * 16 * 17;          // reduced tiles [NT][16][17]
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q = half + 2 * n;
+        if (q >= NT) continue;
+        const int t = tp * CT + q % CT, rt = mg * RT + q / CT;
+        if (t >= ntiles || rt >= mts) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q) * 16 + e_row) * 17 + e_col];
+        v += pf_bias[n];
+        const int b = rt * 16 + e_row, np = t * 16 + e_col;
+        if (epi == SK_LSTM) {
+            v += pf_extra[n];
+            gt[(q * 16 + e_row) * 17 + e_col] = v;
+            continue;
+        }
+        if (b >= nB) continue;
+        if (epi == SK_MEL) {
+            if (np < 80) {
+                p.mel[(int64_t)b * p.ld_mel_b + np] = v;
+                if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
+            } else if (np == 80) {
+                p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
+            }
+            continue;
+        }
+        if (np >= N) continue;
+        v = act_apply(v, act, p.actw, np);
+        v += pf_extra[n];
+        if (epi == SK_FRAG) p.out[frag16_index(b, np, p.ldo)] = v;
+        else p.out[(int64_t)b * p.ldo + np] = v;
+    }
+    if (epi != SK_LSTM) return;
+    __syncthreads();
+    if (cell_on) {
+        const int r2 = t64 >> 2, u2 = t64 & 3;
+        const float* g4 = gt + (q2 * 16 + r2) * 17 + 4 * u2;
+        const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
+        const float cn = sigmoidf_(gf) * pf_c + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        p.c_out[frag16_index(b2, unit2, H)] = cn;
+        p.h_out[frag16_index(b2, p.h_out_off + unit2, p.h_out_K)] = hn;
+        if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
+        if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
+    }
+}
+
 __device__ __forceinline__ double wave_sum_d(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);

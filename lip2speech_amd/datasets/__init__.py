@@ -11,6 +11,8 @@ import torch
 
 from .spectrograms import MelSpec2Audio, MelSpectrogram  # noqa: F401
 from .lrw import LRW  # noqa: F401
+from .augmentation import FaceAugmentation  # noqa: F401
+from .unported import GRID, AVSpeech, WILD  # noqa: F401
 
 MEL_PAD = -11.5129      # ln(1e-5), the floor of the log-mel transform
 

@@ -42,10 +42,13 @@ def normalise_mouth(frames_u8: np.ndarray) -> torch.Tensor:
 
 
 class LRW(Dataset):
-    def __init__(self, rootpth, face_size=(96, 96), mode="train", demo=False, duration=1, face_augmentation=None):
+    def __init__(self, rootpth, face_size=(96, 96), mode="train", demo=False, duration=1, face_augmentation=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
         assert mode in ("train", "test", "val")
         self.rootpth, self.mode, self.demo = rootpth, mode, demo
-        self.face_augmentation = face_augmentation
+        self.face_size, self.duration = face_size, duration
+        # kept but never applied - exactly like the reference's LRW.__getitem__ (dataset.py:86-89 stores it, :123-146 does not call it)
+        self.face_augmentation = face_augmentation if face_augmentation is not None else torch.nn.Identity()
         self.melspec_g = MelSpectrogram()
         index = os.path.join(rootpth, "lrw500_detected_face.csv")
         if os.path.exists(index):
@@ -63,8 +66,6 @@ class LRW(Dataset):
     def __getitem__(self, idx):
         face_path, mouth_path, audio_path = self.items[idx]
         frames = load_frames(mouth_path)
-        if self.face_augmentation is not None:
-            frames = self.face_augmentation(frames)
         mouth = normalise_mouth(frames)
         speech = torch.from_numpy(np.load(audio_path)["data"][np.newaxis])
         melspec = self.melspec_g(speech).squeeze(0)

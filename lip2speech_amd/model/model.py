@@ -113,12 +113,12 @@ class Lip2Speech(NativeBacked):
                 grads[key] = flat.grad[off:off + p.numel()].view_as(p)
                 p.grad = None
             self.__dict__["_grad_views"] = grads
-            native.set_option("refresh_map", 1)                  # the (re)load below also builds the device-side refresh map
-            try:
-                self.__dict__["_native_sig"] = None
-                nm = self.native_model()
-            finally:
-                native.set_option("refresh_map", 0)              # process-wide switch: other models keep the cheap load
+            # the (re)load below also builds the device-side refresh map (a per-model option: other models keep the cheap load)
+            nm = self.__dict__.get("_native") or native.NativeModel()
+            nm.set_option("refresh_map", 1)
+            self.__dict__["_native"] = nm
+            self.__dict__["_native_sig"] = None
+            nm = self.native_model()
             bound = {k: p.data for k, p in zip(self._flat_names, flat.params)}
             bound.update({k: v for k, v in self._tensors().items() if k not in bound and v.is_floating_point()})   # buffers: BN statistics, pos_table
             nm.train_bind(bound, grads)

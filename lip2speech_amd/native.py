@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Dict, Iterable, Optional
 
 import numpy as np
@@ -24,7 +25,7 @@ ABI_SYMBOLS = (
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
-    "l2s_output_lengths", "l2s_inference", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
+    "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
@@ -75,6 +76,10 @@ def lib() -> ctypes.CDLL:
     L.l2s_speaker_workspace_bytes.restype = _i64
     L.l2s_speaker_encoder_fwd.argtypes = [_vp, _fp, _i, _i, _fp, _vp, _i64, _vp]
     L.l2s_inference.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
+    L.l2s_workspace_bytes_multi.argtypes = [_i] * 6
+    L.l2s_workspace_bytes_multi.restype = _i64
+    L.l2s_inference_multi.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
+    L.l2s_model_set_option.argtypes = [_vp, ctypes.c_char_p, _i]
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]
@@ -157,7 +162,11 @@ class NativeModel:
     def __init__(self):
         self._h = _vp()
         check(lib().l2s_model_create(ctypes.byref(self._h)))
-        self._ws: Optional[torch.Tensor] = None
+        self._tls = threading.local()      # the workspace is per host thread: several threads may run batches on ONE model (one weight blob)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Run-time option of THIS model (include/l2s.h "run-time options"); `native.set_option` changes the defaults of models created later."""
+        check(lib().l2s_model_set_option(self._h, name.encode(), int(value)))
 
     def __del__(self):
         try:
@@ -178,11 +187,12 @@ class NativeModel:
         check(L.l2s_model_finalize(self._h, _stream()))
 
     # ------------------------------------------------------------------ workspace (caller-owned, cached)
-    def workspace(self, B: int, T: int, H: int, W: int, S: int, device) -> torch.Tensor:
-        need = int(lib().l2s_workspace_bytes(B, T, H, W, S))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+    def workspace(self, B: int, T: int, H: int, W: int, S: int, device, G: int = 0) -> torch.Tensor:
+        need = int(lib().l2s_workspace_bytes_multi(G, B, T, H, W, S)) if G else int(lib().l2s_workspace_bytes(B, T, H, W, S))
+        ws = getattr(self._tls, "ws", None)
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = self._tls.ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     # ------------------------------------------------------------------ stages
     def encoder_fwd(self, video: torch.Tensor) -> torch.Tensor:
@@ -259,6 +269,27 @@ class NativeModel:
                                   _ptr(lengths), _ptr(attn), _ptr(ws), ws.numel(), _stream()))
         return mel_post, lengths, attn
 
+    def inference_multi(self, batches, S: int = 300, want_attn: bool = False):
+        """Grouped inference (`l2s_inference_multi`): `batches` = up to 8 (video, emb, gumbel) tuples of the same shape, advanced through ONE
+        launch chain.  Returns [(mel_post (B,80,S), lengths (B,), attn (B,S,T) or None)] - views of one allocation, each bit-identical to
+        `inference` on that batch."""
+        G = len(batches)
+        assert 1 <= G <= 8, "1..8 batches per group"
+        vids = [_f32(b[0]) for b in batches]
+        embs = [_f32(b[1]) for b in batches]
+        gums = [_f32(b[2]) for b in batches]
+        B, _, T, H, W = vids[0].shape
+        assert all(v.shape == vids[0].shape for v in vids) and all(e.shape == (B, 256) for e in embs), "the batches of a group share one shape"
+        dev = vids[0].device
+        mel_post = torch.empty(G * B, 80, S, dtype=torch.float32, device=dev)
+        lengths = torch.empty(G * B, dtype=torch.int64, device=dev)
+        attn = torch.empty(G * B, S, T, dtype=torch.float32, device=dev) if want_attn else None
+        ws = self.workspace(B, T, H, W, S, dev, G=G)
+        arr = lambda ts: (_vp * G)(*[t.data_ptr() for t in ts])      # noqa: E731
+        check(lib().l2s_inference_multi(self._h, G, arr(vids), arr(embs), arr(gums), B, T, H, W, S, _ptr(mel_post), _ptr(lengths), _ptr(attn),
+                                        _ptr(ws), ws.numel(), _stream()))
+        return [(mel_post[g * B:(g + 1) * B], lengths[g * B:(g + 1) * B], attn[g * B:(g + 1) * B] if want_attn else None) for g in range(G)]
+
     def speaker_encoder_fwd(self, audio: torch.Tensor) -> torch.Tensor:
         audio = _f32(audio)
         B, N = audio.shape
@@ -282,7 +313,7 @@ class NativeModel:
         check(lib().l2s_train_set_bn(self._h, 1 if batch_stats else 0, float(momentum)))
 
     def train_refresh_weights(self) -> None:
-        """Device-side re-pack of the weight blob from the bound tensors (needs set_option('refresh_map', 1) before load())."""
+        """Device-side re-pack of the weight blob from the bound tensors (needs self.set_option('refresh_map', 1) before load())."""
         check(lib().l2s_train_refresh_weights(self._h, _stream()))
 
     def train_postnet_fwd(self, mel: torch.Tensor, drop: Optional[torch.Tensor] = None):
@@ -484,6 +515,7 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
 
 
 def set_option(name: str, value: int) -> None:
+    """Process DEFAULT of a run-time option: copied into models created afterwards (`NativeModel.set_option` changes one model)."""
     check(lib().l2s_set_option(name.encode(), int(value)))
 
 

@@ -36,6 +36,16 @@ def native_model(sd=None):
     return _models["m"]
 
 
+def fresh_native_model(sd=None, **options):
+    """A NativeModel of its own (not the cached one) with run-time options set BEFORE the weights are packed - options are per model."""
+    sd = synth.synth_state_dict() if sd is None else sd
+    nm = native.NativeModel()
+    for k, v in options.items():
+        nm.set_option(k, v)
+    nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+    return nm
+
+
 def lrw2_inputs():
     g = golden("inference_lrw_b2.npz")
     video = synth.synth_video(2, 29, tag="video-lrw2")

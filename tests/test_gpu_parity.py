@@ -315,25 +315,57 @@ def test_caller_loops_voice_route(synth_sd):
 
 @pytest.mark.gpu
 def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
-    """Three batches in flight on three streams (parallel.InflightPool) give exactly the one-at-a-time results, in order."""
+    """Chains in flight on several streams and G batches per chain (parallel.InflightPool: ONE shared weight blob, `l2s_inference_multi`)
+    give exactly the one-at-a-time results, in order - including a ragged last group and a shape change inside the list."""
     import parity_common as pc
     from lip2speech_amd import synth
     from lip2speech_amd.parallel import InflightPool
     B, T, S = 4, 29, 40
     batches = [(synth.synth_video(B, T, tag=f"pool{i}").cuda(), synth.synth_speaker_embedding(B, tag=f"pool{i}").cuda(),
                 synth.synth_gumbel(B * 4, tag=f"pool{i}").cuda()) for i in range(7)]
+    batches.append((synth.synth_video(B, 31, tag="pool7").cuda(), synth.synth_speaker_embedding(B, tag="pool7").cuda(),
+                    synth.synth_gumbel(B * 4, tag="pool7").cuda()))                 # another T: closes the running group
     nm = pc.native_model(synth_sd)
     want = [nm.inference(*b, S=S, want_attn=True) for b in batches]
     want = [tuple(t.clone() for t in w) for w in want]
-    for stagger in (False, True):
-        pool = InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=3, stagger=stagger)
-        for _ in range(2):                                   # the second call of a staggering pool starts its workers a third of a cycle apart
+    for n_inflight, group in ((3, 1), (2, 3), (1, 8)):
+        pool = InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=n_inflight, group=group)
+        assert len({id(m) for m in pool.models}) == 1                             # one packed blob for every chain
+        for _ in range(2):
             got = pool.map(batches, S=S, want_attn=True)
             torch.cuda.synchronize()
             for g, w in zip(got, want):
                 assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
     with pytest.raises(ValueError):
         InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,B", [(2, 32), (4, 32), (8, 32), (3, 17)])
+def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
+    """`l2s_inference_multi`: G batches as rows of ONE launch chain (register-blocked 2x1 / 2x2 / 4x2 step kernels from 64 rows on) return,
+    batch by batch, exactly what `l2s_inference` returns - mel, lengths and attention, bit for bit (B=32 is BASELINE.json's batch;
+    17 exercises row tiles that straddle two batches)."""
+    import parity_common as pc
+    from lip2speech_amd import synth
+    T, S = 29, 48
+    batches = [(synth.synth_video(B, T, tag=f"grp{g}").cuda(), synth.synth_speaker_embedding(B, tag=f"grp{g}").cuda(),
+                synth.synth_gumbel(B * 4, tag=f"grp{g}").cuda()) for g in range(G)]
+    nm = pc.native_model(synth_sd)
+    want = [tuple(t.clone() for t in nm.inference(*b, S=S, want_attn=True)) for b in batches]
+    got = nm.inference_multi(batches, S=S, want_attn=True)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    # and the forced block shapes agree with each other (options are per model: this handle only)
+    own = pc.fresh_native_model(synth_sd)
+    for shape in (11, 21, 22, 42):
+        own.set_option("skinny_rc", shape)
+        for jb in (2, 4):
+            own.set_option("skinny_rc_jb", jb)
+            alt = own.inference_multi(batches, S=S, want_attn=True)
+            for a, w in zip(alt, want):
+                assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[2], w[2]), (shape, jb)
 
 
 @pytest.mark.gpu
