@@ -1,22 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark of the hot path: mel-frames/s of Lip2Speech.inference on LRW-shaped clips.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole path (visual encoder -> decoder prologue -> 300 autoregressive steps ->
-post-net -> stop bookkeeping; `l2s_inference`) over one synthetic batch of B=32 clips of 29 frames
-(BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  With N ranks every rank runs its
-own B=32 batches (clips are independent: weak scaling, no data-path collective); the reported value is the whole-job
-aggregate N*K*B*S / max-over-ranks(time).
+post-net -> stop bookkeeping) over one synthetic batch of B=32 clips of 29 frames (BASELINE.json configs[1]).
+Inputs are resident in HBM before the timed region.  With N ranks every rank runs its own B=32 batches (clips are
+independent: weak scaling, no data-path collective); the reported value is the whole-job aggregate
+N*K*B*S / max-over-ranks(time).
 
-The K steps of a rank are independent batches, and one pass is a chain of ~1 500 dependent launches that leaves the chip idle in
-every kernel boundary / ramp / drain, so they are issued `--inflight` (default 4; 3 for runs shorter than 48 steps) at a time, each on its own HIP stream from its own
-host thread (lip2speech_amd.parallel.InflightPool): every step is still one full pass over one B=32 batch with bit-identical results;
-`one_batch_at_a_time` in the JSON line is the same K steps issued strictly one after the other (inflight 1).  Four streams need four
-hardware queues of their own: the ROCm runtime's default of 4 includes the null stream's, so GPU_MAX_HW_QUEUES is raised to 8 below,
-before the HIP runtime starts (4 in flight: 1.27 M mel-frames/s with the default, 1.61 M with it; 5 active queues collapse to 0.8 M).
+The K steps of a rank are independent batches.  One pass is a chain of ~1 500 dependent launches whose 1 200 step kernels are
+latency-bound at 32 rows, so the steps are advanced `--group` (default 8) batches per launch chain (`l2s_inference_multi`: the G batches
+are rows of the same launches, on one weight blob) with `--inflight` (default 2) chains in flight, each on its own HIP stream from its
+own host thread (lip2speech_amd.parallel.InflightPool).  Every step is still one full pass over one B=32 batch and every batch's
+results are bit-identical to `l2s_inference` on it alone (tests/test_gpu_parity.py); `one_batch_at_a_time` in the JSON line is the same K
+steps as K sequential `l2s_inference` calls, `one_chain_at_a_time` the same with one chain, `latency` what one group takes alone.
+Each stream needs a hardware queue: GPU_MAX_HW_QUEUES is raised to 8 below, before the HIP runtime starts (the secondary figures
+use four chains).
 
 The JSON line also carries
   roofline     for the kernel with the largest share of GPU time, timed live with HIP events on the launch stream
@@ -45,24 +47,25 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_m
 HBM_PEAK_GBS = 8000.0
 
 
-def kernel_model(name):
-    """Algorithmic (FLOPs, bytes) of ONE launch of a kernel of the path at B=32, T=29."""
+def kernel_model(name, rows=B):
+    """Algorithmic (FLOPs, bytes) of ONE launch of a kernel of the path over `rows` clips (G batches of B=32 per launch chain), T=29:
+    SURVEY.md §8(d)'s per-clip figures x the clips one launch processes; weights counted once per launch."""
     m = native.min_T(T)
     w4 = 4
+    R = rows
     table = {
         # both decoder LSTM layers run the same kernel (600 launches per pass): layer 0 has K=1536 (attention_proj folded in),
         # layer 1 K=1024; figures are the per-launch mean of the two
-        "step_lstm_cell": (2 * B * 2048 * (1536 + 1024) / 2,
-                           ((2048 * (1536 + 1024) / 2 + 2048) * w4 + B * ((1536 + 1024) / 2 + 3 * 512) * w4)),
-        "step_prenet1_q_cq_fc": (2 * B * (256 * 512 + 512 * 1024 + 256 * 1024 + 81 * 512),
-                                 (256 * 512 + 512 * 1024 + 256 * 1024 + 96 * 512 + 1024) * w4 + B * (2048 + 256 + 512 + 256 + 81) * w4),
-        "step_attention_prenet2": (2 * B * (2 * T * 512 + 2 * m * 256 + 256 * 256),
-                                   B * (2 * T * 512 + 2 * m * 256 + 512 + 256 + 512 + 256 + T) * w4 + (256 * 256) * w4),
-        "step_attention_proj": (2 * B * 256 * 512, 256 * 512 * w4 + B * (512 + 512) * w4),
-        "step_fc_out_stop": (2 * B * 81 * 512, 96 * 512 * w4 + B * (512 + 160) * w4),
-        "frontend3d_conv_bn_prelu_pool": (2 * 1178.6e6 * B, (B * 3 * T * HW * HW + B * T * 24 * 24 * 24 + 17640) * w4),
-        "postnet_conv_gemm": (2 * 4.34e6 * S * B / 5, (B * S * (80 + 512 * 4 * 2 + 80) + 4.35e6) * w4 / 5),
-        "decode_persistent": (2 * B * 5.27e6 * S, 21.0e6 + B * (2 * T * 512 + S * (80 + 1 + T)) * w4),
+        "step_lstm_cell": (2 * R * 2048 * (1536 + 1024) / 2,
+                           ((2048 * (1536 + 1024) / 2 + 2048) * w4 + R * ((1536 + 1024) / 2 + 3 * 512) * w4)),
+        "step_prenet1_q_cq_fc": (2 * R * (256 * 512 + 512 * 1024 + 256 * 1024 + 81 * 512),
+                                 (256 * 512 + 512 * 1024 + 256 * 1024 + 96 * 512 + 1024) * w4 + R * (2048 + 256 + 512 + 256 + 81) * w4),
+        "step_attention_prenet2": (2 * R * (2 * T * 512 + 2 * m * 256 + 256 * 256),
+                                   R * (2 * T * 512 + 2 * m * 256 + 512 + 256 + 512 + 256 + T) * w4 + (256 * 256) * w4),
+        "step_attention_proj": (2 * R * 256 * 512, 256 * 512 * w4 + R * (512 + 512) * w4),
+        "step_fc_out_stop": (2 * R * 81 * 512, 96 * 512 * w4 + R * (512 + 160) * w4),
+        "frontend3d_conv_bn_prelu_pool": (2 * 1178.6e6 * R, (R * 3 * T * HW * HW + R * T * 24 * 24 * 24 + 17640) * w4),
+        "postnet_conv_gemm": (2 * 4.34e6 * S * R / 5, (R * S * (80 + 512 * 4 * 2 + 80) + 4.35e6) * w4 / 5),
     }
     return table.get(name)
 
@@ -187,54 +190,77 @@ def train_main(args):
         dist.destroy_process_group()
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run and let rank 0 print
+    the line.  Fails loudly when fewer than N devices are visible instead of quietly measuring one."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible to this process; refusing to report an {args.gpus}-GPU figure")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 200 inference passes (1.3 s) / 20 training steps")
-    ap.add_argument("--warmup", type=int, default=None, help="default: 8 / 3")
+    ap.add_argument("--steps", type=int, default=None, help="default: 192 inference passes (0.9 s) / 20 training steps")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 16 / 3")
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
-    ap.add_argument("--inflight", type=int, default=0, help="independent batches in flight per GPU (streams + host threads); 1 = strictly "
-                    "sequential; 0 (default) = 4 for runs of 48 steps or more, else 3 (a short run is mostly the start-up transient in which "
-                    "the workers still move in lockstep: 20 steps give 1.46 M mel-frames/s with three and 1.38 M with four, 200 steps 1.50 M / 1.58 M)")
+    ap.add_argument("--group", type=int, default=8, help="independent B=32 batches advanced per launch chain (l2s_inference_multi, 1..8); 1 = one batch per chain")
+    ap.add_argument("--inflight", type=int, default=2, help="launch chains in flight per GPU (HIP streams + host threads); 1 = strictly sequential chains")
     ap.add_argument("--mode", choices=["inference", "train"], default="inference",
                     help="inference = the headline metric (default); train = one data-parallel training step per 'step' (SURVEY.md §8 config 3)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.mode == "train" else 200
+        args.steps = 20 if args.mode == "train" else 192
     if args.warmup is None:
-        args.warmup = 3 if args.mode == "train" else 8
-    if args.inflight <= 0:
-        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))          # 8 unless the environment pinned it before this script started
-        args.inflight = 4 if (args.steps >= 48 and queues >= 5) else 3
+        args.warmup = 3 if args.mode == "train" else 16
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args)
     if args.mode == "train":
         return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if os.environ.get("L2S_BENCH_ONE_DEVICE"):      # test hook: several ranks on ONE GPU (with L2S_BENCH_BACKEND=gloo) to exercise the N>1 code path
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("L2S_BENCH_BACKEND", "nccl"))
+        backend = os.environ.get("L2S_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend=backend)
 
     # replicated weights, per-rank shard of clips (SURVEY.md §8(e): no exchange step on the inference path)
     from lip2speech_amd.parallel import InflightPool
     sd = synth.synth_state_dict()
     tensors = {k: v.cuda() for k, v in sd.items()}
-    pool = InflightPool(tensors, list(sd.keys()), n_inflight=max(1, args.inflight))
-    nm = pool.models[0]
-    video = synth.synth_video(B, T, tag=f"bench{rank}" if rank else "bench").cuda()
-    emb = synth.synth_speaker_embedding(B, tag=f"bench{rank}" if rank else "bench").cuda()
-    gum = synth.synth_gumbel(B * native.min_T(T), tag="bench").cuda()
-    batch = (video, emb, gum)
-
-    def step():
-        return nm.inference(video, emb, gum, S=S)
+    G, NI = max(1, min(8, args.group)), max(1, args.inflight)
+    pool = InflightPool(tensors, list(sd.keys()), n_inflight=NI, group=G)
+    nm = pool.model
+    # every slot of every chain gets its own batch (different clips, embeddings and noise): concurrent passes share nothing but the weights
+    n_distinct = G * NI
+    batches = []
+    for i in range(n_distinct):
+        tag = f"bench{rank}.{i}" if (rank or i) else "bench"
+        batches.append((synth.synth_video(B, T, tag=tag).cuda(), synth.synth_speaker_embedding(B, tag=tag).cuda(),
+                        synth.synth_gumbel(B * native.min_T(T), tag=tag).cuda()))
+    video, emb, gum = batches[0]
+    work = lambda n: [batches[i % n_distinct] for i in range(n)]      # noqa: E731
 
     def timed(run):
         torch.cuda.synchronize()
@@ -254,46 +280,68 @@ def main():
             dt = float(tt.item())
         return dt, res
 
-    pool.map([batch] * max(args.warmup, pool.n_inflight), S=S)          # W untimed warm-up steps (every worker at least once)
-    elapsed, outs = timed(lambda: pool.map([batch] * args.steps, S=S))   # EXACTLY K steps
-    out = outs[-1]
+    # W untimed warm-up steps (at least one group per chain), then - still untimed - windows of one round of groups until two consecutive
+    # windows agree within 2 % (clocks, allocator and the chains' relative phase have settled), at most 8 windows
+    pool.map(work(max(args.warmup, n_distinct)), S=S)
+    extra, prev_w = 0, None
+    for _ in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pool.map(work(n_distinct), S=S)
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        extra += n_distinct
+        if prev_w is not None and abs(w - prev_w) <= 0.02 * max(w, prev_w):
+            break
+        prev_w = w
+    elapsed, outs = timed(lambda: pool.map(work(args.steps), S=S))   # EXACTLY K steps
     assert all(torch.isfinite(o[0]).all() for o in outs), "non-finite mel output"
-    seq_elapsed = elapsed
-    if pool.n_inflight > 1:                                              # the same K steps strictly one after the other, for reference
-        seq_elapsed, _ = timed(lambda: [step() for _ in range(args.steps)])
-    # secondary figure: the evaluate.py path, forward(tf_ratio=1) with S = 77 target frames per clip
+    # reference figures, same K steps: strictly one batch at a time on one stream; and one chain of G batches at a time
+    seq_elapsed, _ = timed(lambda: [nm.inference(*batches[i % n_distinct], S=S) for i in range(args.steps)])
+    one_chain = InflightPool(model=nm, n_inflight=1, group=G)
+    chain_elapsed, _ = timed(lambda: one_chain.map(work(args.steps), S=S))
+    # latency of ONE group through the path with the chip otherwise idle (what a caller waits for G batches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nm.inference_multi(batches[:G], S=S) if G > 1 else nm.inference(*batches[0], S=S)
+    torch.cuda.synchronize()
+    group_latency = time.perf_counter() - t0
+
+    # secondary figures on a pool of four single-batch chains (the entry points below are per batch)
+    pool4 = pool if (G == 1 and NI == 4) else InflightPool(model=nm, n_inflight=4, group=1)
+    # the evaluate.py path: forward(tf_ratio=1) with S = 77 target frames per clip
     S77 = 77
     fwd = lambda model, b: model.forward_eval(b[0], b[1], b[2], S77)      # noqa: E731
-    pool.map([batch] * pool.n_inflight, fn=fwd)
-    fwd_elapsed, _ = timed(lambda: pool.map([batch] * args.steps, fn=fwd))
-
-    # secondary figure: the boundary handed HOST buffers (pinned): every step first copies its 102.6 MB of frames, the speaker embedding
-    # and the Gumbel noise to the GPU on its own stream, overlapping the other batches' compute. Never `value` (inputs resident there).
-    host_batch = tuple(t.cpu().pin_memory() for t in batch)
+    pool4.map(work(4), fn=fwd)
+    fwd_elapsed, _ = timed(lambda: pool4.map(work(args.steps), fn=fwd))
+    # the boundary handed HOST buffers (pinned): every step first copies its 102.6 MB of frames, the speaker embedding and the Gumbel
+    # noise to the GPU on its own stream, overlapping the other chains' compute.  Never `value` (inputs resident there).
+    host_batches = [tuple(t.cpu().pin_memory() for t in b) for b in batches[:4]]
     h2d = lambda model, b: model.inference(*(t.cuda(non_blocking=True) for t in b), S=S)      # noqa: E731
-    pool.map([host_batch] * pool.n_inflight, fn=h2d)
-    h2d_elapsed, _ = timed(lambda: pool.map([host_batch] * args.steps, fn=h2d))
+    pool4.map(host_batches, fn=h2d)
+    h2d_elapsed, _ = timed(lambda: pool4.map([host_batches[i % 4] for i in range(args.steps)], fn=h2d))
 
     if rank == 0:
-        # per-kernel HIP-event timing in its own pass (events around every launch perturb the pipeline)
+        # per-kernel HIP-event timing in its own pass over ONE group (events around every launch perturb the pipeline)
         native.profile_enable(True)
         native.profile_reset()
         for _ in range(2):
-            step()
+            nm.inference_multi(batches[:G], S=S) if G > 1 else nm.inference(*batches[0], S=S)
         torch.cuda.synchronize()
         prof = sorted(native.profile_read(), key=lambda r: -r[2])
         native.profile_enable(False)
         gpu_ms = sum(r[2] for r in prof)
         name, launches, total_ms = prof[0]
         avg_s = total_ms / launches * 1e-3
-        roof = {"kernel": name, "launches_per_step": launches // 2, "share_of_gpu_time": total_ms / gpu_ms,
+        rows = G * B
+        roof = {"kernel": name, "rows_per_launch": rows, "launches_per_group_pass": launches // 2, "share_of_gpu_time": total_ms / gpu_ms,
                 "avg_us_event_per_launch": avg_s * 1e6}
         if name == "step_lstm_cell":
-            # per-launch event brackets inflate a 6 us kernel by ~1.8 us; time the same launches as one chain between ONE event pair
-            avg_s = nm.lstm_cell_chain_us(B, 300) * 1e-6
+            # per-launch event brackets inflate a us-scale kernel by ~1.8 us; time the same launches as one chain between ONE event pair
+            avg_s = nm.lstm_cell_chain_us(rows, 300) * 1e-6
             roof["timing"] = "one HIP-event pair around a chain of 600 launches (300 x {layer 0, layer 1}) on the launch stream"
         roof["avg_us"] = avg_s * 1e6
-        model = kernel_model(name)
+        model = kernel_model(name, rows)
         if model:
             flops, nbytes = model
             ai = flops / nbytes
@@ -305,21 +353,27 @@ def main():
                 roof.update(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TFLOPS)
             roof["algorithmic_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
-        # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
-        # offline with tools/prof_decode.py and committed as profiles/r01_pmc_decode.json
+            roof["arithmetic_intensity"] = ai
+        # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
+        # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_decode.json")))["kernels"]
-            if name in pmc:
-                roof["traffic"] = pmc[name]["traffic_bytes_per_launch"]
-                roof["l2_hit_rate"] = pmc[name]["l2_hit_rate"]
-        except OSError:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_decode.json")))
+            k = pmc["kernels"].get(name)
+            if k and pmc.get("rows_per_launch") == rows:
+                roof["traffic"] = k["traffic_bytes_per_launch"]
+                roof["traffic_source"] = "offline: profiles/r02_pmc_decode.json (rocprofv3 --pmc, same kernel and rows per launch), not measured in this run"
+                roof["l2_hit_rate_offline"] = k.get("l2_hit_rate")
+                if k.get("avg_us_rocprofv3"):
+                    roof["avg_us_rocprofv3_offline"] = k["avg_us_rocprofv3"]
+                    roof["frac_at_rocprofv3_duration"] = roof["frac"] * roof["avg_us"] / k["avg_us_rocprofv3"]
+        except (OSError, KeyError, ValueError):
             pass
         # the other kernels with a closed-form cost model, same pass (per-launch HIP-event brackets: us-scale kernels carry ~1.8 us of it)
         others = []
         for oname, olaunches, oms in prof[1:]:
-            om = kernel_model(oname)
-            if not om or len(others) >= 4:
+            om = kernel_model(oname, rows)
+            if not om or len(others) >= 5:
                 continue
             oavg = oms / olaunches * 1e-3
             oflops, obytes = om
@@ -327,7 +381,7 @@ def main():
                 o = {"bound": "hbm", "achieved": obytes / oavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             else:
                 o = {"bound": "mfma", "achieved": oflops / oavg / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
-            o.update(kernel=oname, launches_per_step=olaunches // 2, share_of_gpu_time=oms / gpu_ms, avg_us_event_per_launch=oavg * 1e6,
+            o.update(kernel=oname, launches_per_group_pass=olaunches // 2, share_of_gpu_time=oms / gpu_ms, avg_us_event_per_launch=oavg * 1e6,
                      frac=o["achieved"] / o["peak"])
             others.append(o)
         roof["other_kernels"] = others
@@ -342,15 +396,23 @@ def main():
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LRW single-word, batch=32 per GPU, 29x96x96 RGB mouth crops, S=300 decode steps, "
-                                   "speaker embedding supplied (encoding=voice), random-init weights",
-                       "batch_per_gpu": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)",
-                       "batches_in_flight_per_gpu": pool.n_inflight},
-            "one_batch_at_a_time": {"value": world * B * S * args.steps / seq_elapsed, "ms_per_step": seq_elapsed / args.steps * 1e3},
+            "config": {"workload": "LRW single-word, batch=32 per step, 29x96x96 RGB mouth crops, S=300 decode steps, speaker embedding "
+                                   "supplied (encoding=voice), random-init weights; every step is one full pass over one B=32 batch",
+                       "batch_per_step": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)",
+                       "batches_per_launch_chain": G, "launch_chains_in_flight_per_gpu": NI, "distinct_batches_per_gpu": n_distinct,
+                       "collective_backend": backend, "ranks": world},
+            "warmup_extra_steps_until_steady": extra,
+            "latency": {"ms_one_group_alone": group_latency * 1e3, "batches_in_group": G,
+                        "note": "wall time of ONE launch chain over G batches on an otherwise idle GPU: what a caller waits for its G results; "
+                                "ms_per_step above is elapsed / steps with all chains busy, a throughput figure, not a latency"},
+            "one_chain_at_a_time": {"value": world * B * S * args.steps / chain_elapsed, "ms_per_step": chain_elapsed / args.steps * 1e3,
+                                    "note": f"the same K steps, groups of {G} issued one after the other on one stream"},
+            "one_batch_at_a_time": {"value": world * B * S * args.steps / seq_elapsed, "ms_per_step": seq_elapsed / args.steps * 1e3,
+                                    "note": "the same K steps as K calls of l2s_inference, strictly sequential (one B=32 batch per launch chain)"},
             "evaluate_forward_S77": {"value": world * B * S77 * args.steps / fwd_elapsed, "unit": "mel-frames/s", "ms_per_step": fwd_elapsed / args.steps * 1e3,
-                                     "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), same batches in flight"},
+                                     "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), four single-batch chains in flight"},
             "host_resident_inputs": {"value": world * B * S * args.steps / h2d_elapsed, "unit": "mel-frames/s", "ms_per_step": h2d_elapsed / args.steps * 1e3,
-                                     "note": "PCIe-inclusive: each step copies its batch from pinned host memory on its own stream first"},
+                                     "note": "PCIe-inclusive: each step copies its batch from pinned host memory on its own stream first; four single-batch chains in flight"},
             "roofline": roof,
         }
         if world == 1 and not args.skip_cpu_baseline:

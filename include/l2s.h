@@ -244,6 +244,12 @@ int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float
 int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw,
                   float* out, int B, int Tin, int Cin, int Cout, int taps, int stride, int pad, int act,
                   void* stream);
+/* the same two operators with flags: bit 0 = run on the split-bf16 kernel (fp32 operands split into 3 bf16 planes, six bf16 MFMAs per
+ * K step; eligible shapes only - otherwise the f32 kernel runs) */
+int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
+                   int K, int act, int flags, void* stream);
+int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
+                     int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream);
 /* backward of l2s_op_conv1d (no scale/shift/activation): dZ (B,Tout,Cout), X (B,Tin,Cin), Wp (Cout, taps*Cin) ->
  * dX (B,Tin,Cin) (stride 1 only; may be NULL) and dWp (Cout, taps*Cin) (may be NULL) */
 int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
@@ -283,6 +289,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
 /* l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.
  * Launch sequences only ever read their own model's copy, so a thread that flips a switch cannot disturb batches other threads have in
  * flight on other models (lip2speech_amd.parallel keeps several in flight).
+ *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
+ *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
  *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
 int l2s_set_option(const char* name, int value);

@@ -11,17 +11,11 @@
 // k = 8c + 4g + e (e = 0..3) and MFMA e consumes element e of both operands.
 // Global loads of tile t+1 are issued before the MFMAs of tile t (register prefetch).
 #include "l2s_common.h"
+#include "gemm_dev.h"
 
 namespace l2s {
 
 constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4;
-
-__device__ __forceinline__ float apply_act(float v, int act, const float* actw, int col) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
-    if (act == ACT_PSINE) return sinf(v) * actw[col];
-    return v;
-}
 
 // the fields the operand loaders need, copied once into SGPRs (read through the kernarg reference they are re-fetched by scalar loads
 // inside the K loop, each behind its own s_waitcnt)
@@ -70,24 +64,6 @@ __device__ __forceinline__ float4 load_w(const LoadP& p, const float* wrow, bool
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? wrow[k + e] : 0.f;
         return make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
-// one output element: scale/shift, activation, masks, addends, and the plain / windowed / strided / channel-first store
-__device__ __forceinline__ void gemm_store(const GemmP& p, int row, int col, float accv, float sc, float sh) {
-    if (p.win_T > 0) { const int wb = row / p.Tout; row = wb * p.win_T + p.win_off + (row - wb * p.Tout); }
-    float v = accv * sc + sh;
-    if (p.Zout) p.Zout[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
-    v = apply_act(v, p.act, p.actw, col);
-    if (p.mask && p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
-    if (p.R1) v += p.R1[(int64_t)(p.r1_mod ? row % p.r1_mod : row) * p.ldr1 + col];
-    if (p.R2) v += p.R2[(int64_t)(p.r2_div ? row / p.r2_div : (p.r2_mod ? row % p.r2_mod : row)) * p.ldr2 + col];
-    if (p.mask && !p.mask_pre) v *= p.mask[(int64_t)row * p.ldmask + col];
-    if (p.c_tr_T > 0) {
-        const int b = row / p.c_tr_T, t = row - b * p.c_tr_T;
-        p.C[((int64_t)b * p.N + col) * p.c_tr_T + t] = v;
-    } else {
-        p.C[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride] = v;
     }
 }
 
@@ -274,8 +250,13 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
     p.act = ACT_NONE;
     p.ldc = ldc; p.c_cstride = 1; p.c_tr_T = 0;
     p.vec = 4;
+    p.x3 = gemm_x3_mode();
+    p.x3_group = gemm_x3_group();
     return p;
 }
+
+int& gemm_x3_mode() { static thread_local int mode = 0; return mode; }
+int& gemm_x3_group() { static thread_local int group = 1; return group; }
 
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
@@ -294,6 +275,9 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
                    (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
         vec4 = vec4 && ok4;
     }
+    bool x3 = vec4;
+    for (int i = 0; i < b.count; ++i) x3 = x3 && b.p[i].x3 != 0;
+    if (x3 && gemm_x3_eligible(b)) return launch_gemm_x3(b, s, name);
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
     ProfScope ps(name, s);
     if (vec4)
@@ -311,7 +295,7 @@ static GemmP gemm_kslice(const GemmP& p, int i, int ksplit, float* out) {
     GemmP q = gemm_plain(p.A + k0 + (past ? p.a_gap : 0), p.lda, p.W + k0, out, p.N, p.M, p.N, kc);
     if (!past && p.a_split < k0 + kc) { q.a_split = p.a_split - k0; q.a_gap = p.a_gap; }
     q.ldw = p.ldw ? p.ldw : p.K;
-    q.vec = p.vec;
+    q.vec = p.vec; q.x3 = p.x3; q.x3_group = p.x3_group;
     return q;
 }
 
@@ -365,7 +349,7 @@ int launch_gemm_tapsplit(const GemmBatch& convs, float* part, hipStream_t s, con
         parts[j] = pj;
         for (int i = 0; i < p.taps; ++i) {
             GemmP q = gemm_plain(p.A, p.lda, p.W + (int64_t)i * p.Cin, pj + (int64_t)i * p.M * p.N, p.N, p.M, p.N, p.Cin);
-            q.ldw = p.K; q.Tout = p.Tout; q.Tin = p.Tin; q.stride = p.stride; q.pad = p.pad - i; q.vec = p.vec;
+            q.ldw = p.K; q.Tout = p.Tout; q.Tin = p.Tin; q.stride = p.stride; q.pad = p.pad - i; q.vec = p.vec; q.x3 = p.x3; q.x3_group = p.x3_group;
             b.p[b.count++] = q;
             if (b.count == GEMM_MAX_GROUP && flush()) return 1;
         }

@@ -1,0 +1,286 @@
+// Tiled GEMM with fp32 operands on the bf16 matrix cores ("split-bf16", 3 x bf16 = 24 significand bits).
+//
+// gfx950 has no reduced-precision f32 MFMA (no xf32): v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate, 1/16 of the bf16 rate, so the
+// dense kernels of this path top out at 157 TFLOP/s (gemm_nt.hip reaches 119).  Every fp32 value is EXACTLY the sum of three bf16 values,
+//      x = hi + mid + lo,   hi = x with the low 16 significand bits cleared,  mid = (x - hi) likewise,  lo = x - hi - mid
+// (each difference is exact in fp32, and the last remainder has <= 8 significant bits), and a product of two bf16 values is exact in the
+// fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Of the nine partial products of x*y the six with weight >= 2^-16 are kept,
+//      x*y ~= hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi          (dropped: mid*lo + lo*mid + lo*lo <= 2^-22 |x*y|),
+// six bf16 MFMAs for one K step of 16 where the f32 form needs eight MFMAs of K = 2 at 16x the cost each: 6/16 of the f32 matrix time.
+// Accumulation is fp32 inside the MFMA as before; results differ from the f32-MFMA kernel by rounding-level amounts (tests/: measured
+// against an fp64 product next to the f32 kernel's own error).
+//
+// Block = 512 threads = 4 MFMA waves (2x2, each 64x64 = 2x2 tiles of 32x32, 64 accumulator registers) + 4 staging waves, block tile
+// 128(M) x 128(N) x 32(K).  Operands are fetched as fp32 float4 by range-checked buffer loads (the implicit-Conv1d addressing of
+// gemm_nt.hip), split while they are staged into LDS - three bf16 planes per operand, rows of 80 bytes (64 + 16 pad: conflict-free
+// ds_read_b128 for the 32x32x16 operand layout: lane l reads the 8 consecutive k of row l&31 at k offset 8*(l>>5)) - so a value is split once
+// per block that uses it and every ds_read_b128 is one MFMA operand.  Two LDS stages (120 KB, one block per CU).
+#include "l2s_common.h"
+#include "gemm_dev.h"
+
+namespace l2s {
+
+constexpr int XM = 128, XN = 128, XK = 32;
+constexpr int XLDB = 80;                         // bytes per LDS row (32 bf16 + pad)
+constexpr int XPLANE = XM * XLDB;                // bytes per plane (128 rows)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct X3Split { uint2 hi, mid, lo; };           // 4 consecutive k as bf16 pairs
+
+__device__ __forceinline__ X3Split x3_split(const float4& v) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned xb = __float_as_uint(f[e]);
+        const unsigned hb = xb & 0xFFFF0000u;
+        const float r1 = f[e] - __uint_as_float(hb);            // exact
+        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(mb);              // exact, <= 8 significant bits
+        h[e] = xb; m[e] = __float_as_uint(r1); l[e] = __float_as_uint(r2);
+    }
+    X3Split s;
+    // pack the upper halves of two words: {lo16 = even k, hi16 = odd k}
+    s.hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    s.mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    s.lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+    return s;
+}
+
+struct X3LoadP { int K, Cin, taps, Tin, lda, a_split, a_gap; };
+
+// Wave-specialised: waves 0-3 (one per SIMD) only read operands from LDS and issue MFMAs, waves 4-7 only fetch, split and stage the next
+// K tile into the other LDS stage - the split's VALU work and the global-load latency run beside the matrix pipe instead of in front of
+// it, and there is ONE barrier per K tile (stage kt+1 written / stage kt read).
+__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch) {
+    const GemmP& p = batch.p[blockIdx.z];
+    // XCD-aware tile order (see gemm_nt.hip): each XCD gets a contiguous run of tiles, N index fastest
+    int bx, by;
+    {
+        const int gx = gridDim.x, total = gx * gridDim.y;
+        const int L = blockIdx.y * gx + blockIdx.x;
+        const int xcd = L & 7, local = L >> 3;
+        const int chunk = total >> 3, rem = total & 7;
+        const int tile = xcd * chunk + (xcd < rem ? xcd : rem) + local;
+        bx = tile % gx; by = tile / gx;
+    }
+    const int m0 = by * XM, n0 = bx * XN;
+    if (m0 >= p.M || n0 >= p.N) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x {A planes, B planes}
+    constexpr int STAGE = 6 * XPLANE;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nkt = (p.K + XK - 1) / XK;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int li = lane & 31, lg = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        // staging role: 8 lanes per row (32 k); the two rows of a 16-lane ds_write group are 4 apart - with 80-byte rows their 16-dword
+        // spans then fall on disjoint halves of the 32 banks a ds_write_b64 sees (consecutive rows overlap in 4 banks)
+        const int oct = pt >> 3;
+        const int lr = (oct & ~7) + ((oct & 1) << 2) + ((oct & 7) >> 1), kq = (pt & 7) * 4;
+        bool avalid[4], wvalid[4];
+        int atbase[4];
+        unsigned arow_off[4];                                // float offset of the row's sequence inside A
+        const X3LoadP lp{p.K, p.Cin, p.taps, p.Tin, p.lda, p.a_split, p.a_gap};
+        asm volatile("" ::"s"(lp.K), "s"(lp.Cin), "s"(lp.taps), "s"(lp.Tin), "s"(lp.lda), "s"(lp.a_split), "s"(lp.a_gap));
+        const int ldw = p.ldw ? p.ldw : lp.K;
+        constexpr unsigned OOB = 0x80000000u;                // both extents are < 2 GiB (checked at launch)
+        unsigned woff[4], aoff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + lr + 32 * j;
+            avalid[j] = m < p.M;
+            const int mm = avalid[j] ? m : 0;
+            const int b = mm / p.Tout, t = mm - b * p.Tout + p.win_off;
+            atbase[j] = t * p.stride - p.pad;
+            arow_off[j] = (unsigned)((int64_t)b * lp.Tin * lp.lda);
+            const int n = n0 + lr + 32 * j;
+            wvalid[j] = n < p.N;
+            woff[j] = wvalid[j] ? (unsigned)((int64_t)n * ldw + kq) * 4u : OOB;
+        }
+        int tap = 0, ci = kq;
+        if (lp.taps > 1) { tap = kq / lp.Cin; ci = kq - tap * lp.Cin; }
+        const int nseq = (p.M + p.Tout - 1) / p.Tout;
+        const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)nseq * lp.Tin * lp.lda * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * ldw * 4), 0x00020000);
+        auto set_tap = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tin = atbase[j] + tap;
+                const bool ok = avalid[j] && tin >= 0 && tin < lp.Tin;
+                aoff[j] = ok ? (arow_off[j] + (unsigned)(tin * lp.lda)) * 4u : OOB;
+            }
+        };
+        set_tap();
+        auto fetch = [&](int k, float4* ra, float4* rb) {
+            const unsigned kbad = k < lp.K ? 0u : OOB;                                       // K is a multiple of 4: a quad is all in or all out
+            const unsigned col = (unsigned)(ci + (ci >= lp.a_split ? lp.a_gap : 0)) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_rs, (int)((aoff[j] | kbad) + (aoff[j] == OOB ? 0u : col)), 0, 0));
+                rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_rs, (int)(woff[j] | kbad), 0, 0));
+            }
+        };
+        auto advance = [&]() {
+            ci += XK;
+            if (lp.taps > 1 && ci >= lp.Cin) { ci -= lp.Cin; ++tap; set_tap(); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) woff[j] += wvalid[j] ? XK * 4u : 0u;
+        };
+        const int st_off = lr * XLDB + kq * 2;                              // byte offset of this thread's first staged row inside a plane
+        auto stage = [&](const float4* ra, const float4* rb, int st) {
+            unsigned char* base = smem + st * STAGE + st_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const X3Split sa = x3_split(ra[j]), sb = x3_split(rb[j]);
+                unsigned char* ad = base + 32 * j * XLDB;
+                unsigned char* bd = ad + 3 * XPLANE;
+                *reinterpret_cast<uint2*>(ad) = sa.hi; *reinterpret_cast<uint2*>(ad + XPLANE) = sa.mid; *reinterpret_cast<uint2*>(ad + 2 * XPLANE) = sa.lo;
+                *reinterpret_cast<uint2*>(bd) = sb.hi; *reinterpret_cast<uint2*>(bd + XPLANE) = sb.mid; *reinterpret_cast<uint2*>(bd + 2 * XPLANE) = sb.lo;
+            }
+        };
+        // two register sets: tile kt+2 is requested before tile kt+1 is split, so a fetch has a whole K tile of MFMA time to land
+        float4 ra0[4], rb0[4], ra1[4], rb1[4];
+        fetch(kq, ra0, rb0);
+        if (nkt > 1) { advance(); fetch(XK + kq, ra1, rb1); }
+        stage(ra0, rb0, 0);
+        __syncthreads();                                     // stage 0 = tile 0
+        for (int kt = 0; kt < nkt; kt += 2) {
+            // iteration kt: consumers read stage 0; stage 1 <- tile kt+1 (registers set 1), request tile kt+2 into set 0
+            if (kt + 2 < nkt) { advance(); fetch((kt + 2) * XK + kq, ra0, rb0); }
+            if (kt + 1 < nkt) stage(ra1, rb1, 1);
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            // iteration kt+1: consumers read stage 1; stage 0 <- tile kt+2 (set 0), request tile kt+3 into set 1
+            if (kt + 3 < nkt) { advance(); fetch((kt + 3) * XK + kq, ra1, rb1); }
+            if (kt + 2 < nkt) stage(ra0, rb0, 0);
+            __syncthreads();
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ consumers
+        // Operand fragments are double-buffered in registers: the ds_read_b128s of the next K step (or of the next tile's first step, right
+        // after the barrier) are in flight while the 24 MFMAs of the current one issue, so the matrix pipe never waits for LDS.
+        const unsigned char* a_rd = smem + (wm * 64 + li) * XLDB + lg * 16;               // this lane's operand rows: + i*32 rows, + s*32 bytes, + plane
+        const unsigned char* b_rd = smem + 3 * XPLANE + (wn * 64 + li) * XLDB + lg * 16;
+        struct Frags { bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2]; };
+        auto read_frags = [&](Frags& f, int so, int st) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned char* ap = a_rd + so + i * 32 * XLDB + st * 32;
+                const unsigned char* bp = b_rd + so + i * 32 * XLDB + st * 32;
+                f.ah[i] = *reinterpret_cast<const bf16x8*>(ap); f.am[i] = *reinterpret_cast<const bf16x8*>(ap + XPLANE); f.al[i] = *reinterpret_cast<const bf16x8*>(ap + 2 * XPLANE);
+                f.bh[i] = *reinterpret_cast<const bf16x8*>(bp); f.bm[i] = *reinterpret_cast<const bf16x8*>(bp + XPLANE); f.bl[i] = *reinterpret_cast<const bf16x8*>(bp + 2 * XPLANE);
+            }
+        };
+        // smallest partial products first; the four accumulators interleave so that no MFMA waits on its predecessor
+#define L2S_X3_TERM(A_, B_)                                                                           \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[0], acc[0][0], 0, 0, 0);     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[1], acc[0][1], 0, 0, 0);     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[0], acc[1][0], 0, 0, 0);     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[1], acc[1][1], 0, 0, 0);
+#define L2S_X3_MMA(F_) { L2S_X3_TERM(F_.al, F_.bh) L2S_X3_TERM(F_.ah, F_.bl) L2S_X3_TERM(F_.am, F_.bm) L2S_X3_TERM(F_.am, F_.bh) L2S_X3_TERM(F_.ah, F_.bm) L2S_X3_TERM(F_.ah, F_.bh) }
+        Frags f0, f1;
+        __syncthreads();                                     // stage 0 ready
+        read_frags(f0, 0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int so = (kt & 1) * STAGE;
+            read_frags(f1, so, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            L2S_X3_MMA(f0)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // this stage is read (f1 has landed: the barrier waits for it); the other one is written
+            if (kt + 1 < nkt) read_frags(f0, STAGE - so, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            L2S_X3_MMA(f1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef L2S_X3_MMA
+#undef L2S_X3_TERM
+    }
+
+    // epilogue.  The accumulators leave through LDS, half a tile (the 32-row sub-tiles i of both wave rows = 64 rows x 128 columns, 32 KB)
+    // at a time: every accumulator element is addressed with compile-time indices (a rolled loop over them would put all 64 in scratch
+    // memory), the rolled store loop that follows - all eight waves - reads LDS, runs the fused epilogue once per element and writes rows
+    // of 128 consecutive columns.  C/D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* const ct = reinterpret_cast<float*>(smem);          // [64][128]; the operand stages are dead (barrier at the loop end)
+    const GemmP pl = p;                                        // epilogue parameters in SGPRs: through the kernarg reference the rolled loop
+                                                               // below re-fetches them with scalar loads on every iteration
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * XN + wn * 64 + j * 32 + li] = acc[i][j][r];
+        }
+        __syncthreads();
+        const int cl = tid & 127, col = n0 + cl;
+        if (col < pl.N) {
+            const float sc = pl.scale ? pl.scale[col] : 1.0f;
+            const float sh = pl.shift ? pl.shift[col] : 0.0f;
+#pragma unroll 4
+            for (int q = tid >> 7; q < 64; q += 4) {              // local row q: wave-row q >> 5, row q & 31 of sub-tile i
+                const int row = m0 + (q >> 5) * 64 + i * 32 + (q & 31);
+                if (row < pl.M) gemm_store(pl, row, col, ct[q * XN + cl], sc, sh);
+            }
+        }
+    }
+}
+
+static bool x3_aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+// true when every GEMM of the group can run on the split-bf16 kernel (float4-addressable operands, no batch-statistics pass) AND the
+// launch is large enough to win: the kernel keeps one 128x128 tile per CU and is bound by the operand bytes a CU can pull per MFMA cycle
+// (~10 B/clk/CU under load, measured), so it only pays with at least one full round of tiles and long K; measured on MI355X
+// (tools/time_gemm_x3.py, f32 kernel -> this one): 38400x512x2560 846 -> 602 us (167 TFLOP/s, above the 157 TFLOP/s f32 matrix peak),
+// 9600x512x2560 267 -> 216 us, 3712x4096x1024 278 -> 210 us; 3712x512x5632 (116 tiles) 218 -> 200 us; 928x512x5632 (32 tiles) and K = 400 lose.
+bool gemm_x3_eligible(const GemmBatch& b) {
+    int64_t tiles = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const GemmP& p = b.p[i];
+        const bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && x3_aligned16(p.A) && x3_aligned16(p.W) &&
+                         (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= XK) &&
+                         (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
+        if (!ok4 || p.stats) return false;
+        if (p.x3 != 2 && (p.N < 96 || p.K < 1024)) return false;          // x3 == 2: forced (operator tests run every eligible shape)
+        const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);                    // rows of ONE batch of a grouped launch
+        tiles += (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
+    }
+    return tiles >= (b.count > 1 ? 256 : 100) || b.p[0].x3 == 2;
+}
+
+int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
+    L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP && gemm_x3_eligible(b), "split-bf16 gemm: group not eligible");
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < b.count; ++i) {
+        L2S_REQUIRE(b.p[i].taps * b.p[i].Cin == b.p[i].K, "gemm K = taps*Cin");
+        maxM = b.p[i].M > maxM ? b.p[i].M : maxM;
+        maxN = b.p[i].N > maxN ? b.p[i].N : maxN;
+    }
+    dim3 grid((maxN + XN - 1) / XN, (maxM + XM - 1) / XM, b.count);
+    constexpr int LDS_BYTES = 2 * 6 * XPLANE;              // 122 880: two operand stages (one block per CU)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    L2S_CHECK_HIP(attr);
+    ProfScope ps(name, s);
+    hipLaunchKernelGGL(gemm_x3_kernel, grid, dim3(512), LDS_BYTES, s, b);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace l2s

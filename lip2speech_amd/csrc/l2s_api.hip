@@ -28,7 +28,8 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}};
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb},
+        {"gemm_x3", &Options::gemm_x3}};
     for (auto& t : table)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
     return 1;
@@ -740,6 +741,7 @@ static FrameSrc frame_src(const float* video, int B) { FrameSrc f{}; f.p[0] = vi
 
 static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H, int W, const float* emb, float* vis,
                        float* feat, void* ws, int64_t ws_bytes, hipStream_t s) {
+    X3Scope x3scope(m->opt.gemm_x3);
     const Weights& w = m->w;
     EncPlan pl = enc_plan(B, T, H);
     Bump bp(ws, ws_bytes);
@@ -819,6 +821,7 @@ static SkinnyP sk_base(const SkW& sw, int B) {
 
 static int prologue_run(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T,
                         float* state, float* content_dis, void* ws, int64_t ws_bytes, hipStream_t s) {
+    X3Scope x3scope(m->opt.gemm_x3);
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     int L[4];
@@ -1157,6 +1160,7 @@ static int postnet_layer(const Weights& w, int layer, const float* mel, const Po
 }
 
 static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf, void* ws, int64_t ws_bytes, hipStream_t s) {
+    X3Scope x3scope(m->opt.gemm_x3);
     const Weights& w = m->w;
     Bump bp(ws, ws_bytes);
     PostBufs pb;
@@ -1175,6 +1179,7 @@ static int64_t spk_ws_floats(int B, int N) {
 
 // SpeakerEncoder.inference (audio.py:131-150): mel40 -> 3 x LSTM(256), zero initial state -> Linear(h_last) -> ReLU -> L2 norm
 static int speaker_run(l2s_model* m, const float* audio, int B, int N, float* emb, void* ws, int64_t ws_bytes, hipStream_t s) {
+    X3Scope x3scope(m->opt.gemm_x3);
     const Weights& w = m->w;
     L2S_REQUIRE(N > 200, "audio shorter than the reflect padding (200 samples)");
     const int L = N / 160 + 1, Bp = pad16(B);
@@ -1341,6 +1346,7 @@ int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* 
 
 static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
                          float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, hipStream_t s) {
+    X3Scope x3scope(m->opt.gemm_x3);
     Bump bp(ws, ws_bytes);
     float* vis = bp.f((int64_t)B * T * 1024);
     float* state = bp.f(l2s_state_floats(B, T));
@@ -1432,6 +1438,7 @@ int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const fl
         L2S_CHECK_HIP(hipMemcpyAsync(emb_all + (int64_t)g * B * L2S_D_EMB, emb[g], sizeof(float) * B * L2S_D_EMB, hipMemcpyDeviceToDevice, s));
         L2S_CHECK_HIP(hipMemcpyAsync(gum_all + (int64_t)g * B * mT * VOC, gumbel[g], sizeof(float) * B * mT * VOC, hipMemcpyDeviceToDevice, s));
     }
+    X3Group x3group(G);
     return inference_run(m, src, emb_all, gum_all, G * B, T, H, W, S, mel_post, lengths, attn, (char*)ws + bp.off, ws_bytes - bp.off, s);
 }
 
@@ -1447,6 +1454,16 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
     ConvW c; c.W = Wp; c.scale = scale; c.shift = shift; c.actw = actw;
     GemmP p = conv_gemm(X, Cin, B, Tin, Cin, c, Cout, taps, stride, pad, out, Cout, act);
     return launch_gemm1(p, (hipStream_t)stream, "op_conv1d");
+}
+int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
+                   int K, int act, int flags, void* stream) {
+    X3Scope x3scope((flags & 1) ? 2 : 0);
+    return l2s_op_gemm(A, Wt, scale, shift, actw, C, M, N, K, act, stream);
+}
+int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
+                     int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream) {
+    X3Scope x3scope((flags & 1) ? 2 : 0);
+    return l2s_op_conv1d(X, Wp, scale, shift, actw, out, B, Tin, Cin, Cout, taps, stride, pad, act, stream);
 }
 int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
                       int stride, int pad, void* stream) {

@@ -54,6 +54,7 @@ struct Options {
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 2;              // "skinny_rc_jb": chunks per operand batch of the 2x1 / 2x2 blocks (2 or 4)
+    int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
 };
 int set_option_field(Options& o, const char* name, int value);    // 0 = ok, 1 = unknown name
 
@@ -86,6 +87,9 @@ struct GemmP {
     const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
     int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
     int ldw;              // row stride of W in floats (0: K) - a K slice of a wider matrix (split-K)
+    int x3;               // 1: run on the split-bf16 kernel (gemm_x3.hip) when the whole launch group is eligible; set from gemm_x3_mode()
+    int x3_group;         // batches sharing this launch (grouped inference): the size thresholds of the kernel choice look at M / x3_group,
+                          //   so a batch meets the same kernels alone and in a group (results stay bit-identical)
     float* stats;         // training, batch-statistics BatchNorm: STATS PASS - nothing is stored; per-column sums of the raw product
                           //   (no scale/shift) go to stats[(blockIdx.y*2 + {0: sum, 1: sum of squares})*N + n]
 };
@@ -96,6 +100,15 @@ struct GemmBatch {
     int count;
 };
 GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K);
+// split-bf16 GEMM (gemm_x3.hip): fp32 operands split into 3 bf16 planes on their way into LDS, six bf16 MFMAs per K step instead of the
+// f32 MFMA chain.  gemm_plain() stamps new descriptors with the calling thread's current mode; the inference launch sequences open an
+// X3Scope with their model's "gemm_x3" option, everything else (training, operator tests) stays on the f32 kernel unless it asks.
+int& gemm_x3_mode();                     // thread-local
+int& gemm_x3_group();                    // thread-local: batches per launch chain (1 outside l2s_inference_multi)
+struct X3Scope { int prev; explicit X3Scope(int on) : prev(gemm_x3_mode()) { gemm_x3_mode() = on; } ~X3Scope() { gemm_x3_mode() = prev; } };
+struct X3Group { int prev; explicit X3Group(int g) : prev(gemm_x3_group()) { gemm_x3_group() = g; } ~X3Group() { gemm_x3_group() = prev; } };
+bool gemm_x3_eligible(const GemmBatch& b);
+int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name);
 // split-K for plain GEMMs whose 64x64 tiles are too few to fill the chip (M <= 128 rows in the content path, the B-row Linears):
 // <= 8 K slices as ONE grouped launch writing raw partial products to part[slice][M][N], then one kernel that adds the slices in
 // order and runs the usual epilogue of `p`. Deterministic. part: ksplit*M*N floats.

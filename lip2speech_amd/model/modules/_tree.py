@@ -14,16 +14,20 @@ from typing import Iterable, List, Optional
 import torch
 from torch import nn
 
-from ... import native, statespec, synth
+from ... import native, statespec
+from ...init import reference_init
 
 
 class ParamTree(nn.Module):
-    def __init__(self, spec: Optional[Iterable] = None, seed: int = 1234, key_prefix: str = ""):
+    """`spec` = (key, shape, kind) rows of `statespec`; values start from the reference's own initialisers (`init.reference_init`, drawn
+    from torch's global RNG).  Tests, goldens and bench.py load `synth.synth_state_dict()` on top, explicitly."""
+
+    def __init__(self, spec: Optional[Iterable] = None, key_prefix: str = ""):
         super().__init__()
         if spec is None:
             return
         for key, shape, kind in spec:
-            value = synth._draw(key_prefix + key, tuple(shape), kind, seed)
+            value = reference_init(tuple(shape), kind)
             node = self
             parts = key.split(".")
             for name in parts[:-1]:

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
@@ -82,6 +82,8 @@ def lib() -> ctypes.CDLL:
     L.l2s_model_set_option.argtypes = [_vp, ctypes.c_char_p, _i]
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_gemm_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]
     L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
@@ -493,24 +495,24 @@ def state_field(state: torch.Tensor, B: int, T: int, field: int, shape) -> torch
     return state[off:off + n].view(*shape)
 
 
-def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0) -> torch.Tensor:
+def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0, x3: bool = False) -> torch.Tensor:
     A, Wt = _f32(A), _f32(Wt)
     M, K = A.shape
     N = Wt.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    check(lib().l2s_op_gemm(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, _stream()))
+    check(lib().l2s_op_gemm_ex(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, 1 if x3 else 0, _stream()))
     return C
 
 
-def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0, act: int = 0) -> torch.Tensor:
+def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0, act: int = 0, x3: bool = False) -> torch.Tensor:
     """X (B,Tin,Cin) channel-last, Wp (Cout, taps*Cin) tap-major."""
     X, Wp = _f32(X), _f32(Wp)
     B, Tin, Cin = X.shape
     Cout = Wp.shape[0]
     Tout = (Tin + 2 * pad - taps) // stride + 1
     out = torch.empty(B, Tout, Cout, dtype=torch.float32, device=X.device)
-    check(lib().l2s_op_conv1d(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
-                              taps, stride, pad, act, _stream()))
+    check(lib().l2s_op_conv1d_ex(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
+                                 taps, stride, pad, act, 1 if x3 else 0, _stream()))
     return out
 
 

@@ -74,10 +74,11 @@ class InflightPool:
     `tensors` / `keys`: the checkpoint tensors as for `NativeModel.load`.  `map(batches)` takes a list of (video, emb, gumbel) and returns
     the (mel_post, lengths, attn) tuples in order."""
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], keys=None, n_inflight: int = 2, device=None, group: int = 1):
+    def __init__(self, tensors: Dict[str, torch.Tensor] = None, keys=None, n_inflight: int = 2, device=None, group: int = 1, model=None):
+        """`model`: an already packed `NativeModel` to share (then `tensors` is not needed) - e.g. a second pool with another shape of
+        concurrency over the same weight blob."""
         from . import native
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        keys = list(tensors.keys()) if keys is None else list(keys)
         if n_inflight > 4:
             raise ValueError("more than four chains in flight oversubscribe the GPU's compute pipes (measured 0.9x of ONE at a time)")
         if not 1 <= group <= 8:
@@ -86,8 +87,10 @@ class InflightPool:
             warnings.warn("InflightPool(n_inflight=4) needs GPU_MAX_HW_QUEUES >= 5 set before the first HIP call; with the default the "
                           "four streams share hardware queues and run slower than three in flight", RuntimeWarning)
         self.group = group
-        self.model = native.NativeModel()             # ONE packed blob for every chain
-        self.model.load(tensors, keys)
+        if model is None:
+            model = native.NativeModel()              # ONE packed blob for every chain
+            model.load(tensors, list(tensors.keys()) if keys is None else list(keys))
+        self.model = model
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_inflight))]
 
     @property

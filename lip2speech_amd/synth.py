@@ -166,3 +166,27 @@ def synth_mels(B: int, S: int, seed: int = 1234, tag: str = "mel") -> torch.Tens
     reference/datasets/__init__.py:17)."""
     m = pseudo_normal(f"{tag}:{B}x{S}", (B, statespec.N_MELS, S), 2.0, seed) - np.float32(5.0)
     return torch.from_numpy(np.maximum(m, np.float32(-11.5129)).astype(np.float32))
+
+
+def synth_clip_lengths(B: int, lo: int, hi: int, tag: str) -> np.ndarray:
+    """Deterministic per-clip frame counts in [lo, hi] (variable-length corpora: GRID up to 75 frames, AVSpeech 25-50); the clip with the
+    largest draw is forced to `hi` so the padded batch has T = hi."""
+    u = uniform01(f"lens:{tag}", B)
+    t = (lo + np.floor(u.astype(np.float64) * (hi - lo + 1))).astype(np.int64).clip(lo, hi)
+    t[int(np.argmax(u))] = hi
+    return t
+
+
+def synth_padded_video(B: int, lens, tag: str) -> torch.Tensor:
+    """What the collate hands the model for clips of different lengths: every clip zero-padded to the batch maximum
+    (reference/datasets/__init__.py:17,29-31).  The model ignores lengths, so the padding is part of the semantics."""
+    T = int(np.max(lens))
+    video = synth_video(B, T, tag=tag)
+    for b, t in enumerate(lens):
+        video[b, :, int(t):] = 0
+    return video
+
+
+def synth_audio(B: int, n_samples: int, tag: str, sigma: float = 0.1) -> torch.Tensor:
+    """(B, n_samples) noise-like 16 kHz audio in about +-0.35 (the range of the LRW sample clips)."""
+    return torch.from_numpy(pseudo_normal(f"audio:{tag}", (B, n_samples), sigma))

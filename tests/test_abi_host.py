@@ -71,6 +71,57 @@ def test_boundary_interface_matches_reference():
     assert torch.equal(net.state_dict()["encoder.trunk.0.4.banch2.3.weight"], sd["encoder.trunk.0.4.banch2.3.weight"])
 
 
+def test_fresh_model_starts_from_the_reference_initialisers():
+    """A new model is initialised like the reference's (video.py:27-43, decoder.py:43-49,78-80,99-100,206,237,289,302; torch defaults) from
+    torch's RNG - not from the randomised test fixture - so `torch.manual_seed` decides it."""
+    import math
+
+    from model.model import get_network
+    torch.manual_seed(1)
+    sd = get_network("train").state_dict()
+    for k, v in sd.items():
+        if k.endswith(("running_mean",)) or (".1.bias" in k and k.startswith("encoder.")):
+            assert float(v.abs().max()) == 0.0, k
+        if k.endswith("running_var"):
+            assert torch.equal(v, torch.ones_like(v)), k
+    assert torch.equal(sd["encoder.frontend3D.1.weight"], torch.ones(24)) and torch.equal(sd["encoder.frontend3D.2.weight"], torch.full((24,), 0.25))
+    assert torch.equal(sd["decoder.postnet.sin_activation.0.w"], torch.ones(512))
+    assert abs(float(sd["decoder.temperature"]) - 512 ** 0.5) < 1e-5 and float(sd["decoder.content.temperature"]) == 16.0
+    w = sd["encoder.frontend3D.0.weight"]
+    assert abs(float(w.std()) / math.sqrt(2.0 / (5 * 7 * 7 * 24)) - 1) < 0.03
+    q = sd["decoder.Q.0.linear_layer.weight"]                      # xavier_uniform, gain 1: bound sqrt(6 / (fan_in + fan_out))
+    assert float(q.abs().max()) <= math.sqrt(6.0 / (1024 + 512)) and float(q.abs().max()) > 0.99 * math.sqrt(6.0 / (1024 + 512))
+    assert float(sd["decoder.decoder_rnn.weight_hh_l1"].abs().max()) <= 1 / math.sqrt(512)
+    assert 0.0 <= float(sd["decoder.content.word_embeddings"].min()) and float(sd["decoder.content.word_embeddings"].max()) < 1.0
+    torch.manual_seed(1)
+    again = get_network("train").state_dict()
+    torch.manual_seed(2)
+    other = get_network("train").state_dict()
+    assert torch.equal(again["decoder.BOS"], sd["decoder.BOS"]) and not torch.equal(other["decoder.BOS"], sd["decoder.BOS"])
+
+
+def test_reference_checkpoint_with_face_tower_keys_round_trips_strictly():
+    """demo.py:30-38: the checkpoint carries `vgg_face.resnet.*` / `vgg_face.projection_layer.*` (third-party tower) and is loaded with
+    strict=True after the `speaker_encoder.*` keys are popped; the keys come back from state_dict() unchanged."""
+    from lip2speech_amd import synth
+    from model.model import get_network
+    ck = dict(synth.synth_state_dict(seed=3))
+    ck["vgg_face.resnet.conv2d_1a.conv.weight"] = torch.randn(32, 3, 3, 3)
+    ck["vgg_face.resnet.conv2d_1a.bn.num_batches_tracked"] = torch.tensor(7)
+    ck["vgg_face.resnet.last_linear.weight"] = torch.randn(512, 1792)
+    ck["vgg_face.projection_layer.0.weight"] = torch.randn(512, 512)
+    ck["vgg_face.projection_layer.2.bias"] = torch.randn(256)
+    net = get_network("test")
+    res = net.load_state_dict(ck, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = net.state_dict()
+    assert set(out) == set(ck) and all(torch.equal(out[k], ck[k]) for k in ck)
+    net2 = get_network("test")                                       # and what this model saves loads strictly again
+    net2.load_state_dict(out, strict=True)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({**ck, "decoder.not_a_key": torch.zeros(1)}, strict=True)
+
+
 def test_product_path_has_no_cpu_fallback():
     """CPU tensors must raise, not silently compute elsewhere; and the product never imports the oracle."""
     from model.model import get_network

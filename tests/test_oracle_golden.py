@@ -100,8 +100,29 @@ def test_oracle_matches_reference_at_benchmark_size(golden_dir, synth_sd):
         mel_post, lengths, attn = orc.inference(synth_sd, video, emb, g["gumbel"], S=300)
     clips = [int(c) for c in g["clips"]]
     assert (mel_post[clips] - g["mel_post_clips"]).abs().max() < 1e-3
+    assert (mel_post - _load(golden_dir, "inference_lrw_b32_full_mel.npz")["mel_post"]).abs().max() < 1e-3      # every clip, every value
     assert (mel_post.mean(dim=1) - g["mel_post_frame_mean"]).abs().max() < 1e-3
     assert torch.equal(lengths, g["output_lengths"])
     amax, _ = _top2(attn)
     sure = g["attn_margin"] > 1e-4
     assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][sure].to(torch.int64))
+
+
+@pytest.mark.parametrize("name,B,lo,hi,tag", [("inference_grid_b16_full.npz", 16, 25, 75, "grid16"), ("inference_avspeech_b32_full.npz", 32, 25, 50, "avs32")])
+def test_oracle_matches_reference_on_variable_length_batches(golden_dir, synth_sd, name, B, lo, hi, tag):
+    """BASELINE.json configs[3] / [4] shapes (clips of different lengths zero-padded by the collate) against the reference run at full size.
+    The oracle runs the first 48 decode steps only (CPU minutes): pre-post-net frames do not depend on later steps, and post-net frame t
+    sees frames t-10..t+10, so the first 38 post-net frames are complete."""
+    g = _load(golden_dir, name)
+    lens = synth.synth_clip_lengths(B, lo, hi, tag)
+    assert list(lens) == list(g["clip_frames"].numpy())
+    video = synth.synth_padded_video(B, lens, tag)
+    emb = g["speaker_embedding"] if "speaker_embedding" in g else synth.synth_speaker_embedding(B, tag=tag)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    S = 48
+    with torch.no_grad():
+        mel_post, _, attn = orc.inference(synth_sd, video, emb, g["gumbel"], S=S)
+    assert (mel_post[:, :, :S - 10] - g["mel_post"][:, :, :S - 10]).abs().max() < 1e-3
+    amax, _ = _top2(attn)
+    sure = g["attn_margin"][:, :S] > 1e-4
+    assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][:, :S][sure].to(torch.int64))
