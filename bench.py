@@ -320,6 +320,14 @@ def main():
     h2d = lambda model, b: model.inference(*(t.cuda(non_blocking=True) for t in b), S=S)      # noqa: E731
     pool4.map(host_batches, fn=h2d)
     h2d_elapsed, _ = timed(lambda: pool4.map([host_batches[i % 4] for i in range(args.steps)], fn=h2d))
+    # the same with the data boundary on the device: the decoded uint8 frames (25.7 MB per batch) cross PCIe packed and
+    # l2s_normalise_pad_frames builds the fp32 batch (datasets.device.PackedFrames; bit-identical to the host collate)
+    from lip2speech_amd.datasets import PackedFrames
+    gen = torch.Generator().manual_seed(1234)
+    u8_batches = [(PackedFrames([torch.randint(0, 256, (T, HW, HW, 3), dtype=torch.uint8, generator=gen) for _ in range(B)]), hb[1], hb[2]) for hb in host_batches]
+    u8 = lambda model, b: model.inference(b[0].to_device(), b[1].cuda(non_blocking=True), b[2].cuda(non_blocking=True), S=S)      # noqa: E731
+    pool4.map(u8_batches, fn=u8)
+    u8_elapsed, _ = timed(lambda: pool4.map([u8_batches[i % 4] for i in range(args.steps)], fn=u8))
 
     if rank == 0:
         # per-kernel HIP-event timing in its own pass over ONE group (events around every launch perturb the pipeline)
@@ -413,6 +421,9 @@ def main():
                                      "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), four single-batch chains in flight"},
             "host_resident_inputs": {"value": world * B * S * args.steps / h2d_elapsed, "unit": "mel-frames/s", "ms_per_step": h2d_elapsed / args.steps * 1e3,
                                      "note": "PCIe-inclusive: each step copies its batch from pinned host memory on its own stream first; four single-batch chains in flight"},
+            "host_resident_uint8_frames": {"value": world * B * S * args.steps / u8_elapsed, "unit": "mel-frames/s", "ms_per_step": u8_elapsed / args.steps * 1e3,
+                                           "note": "PCIe-inclusive with the data boundary on the device: packed uint8 frames (25.7 MB per batch) copied from pinned host "
+                                                   "memory, normalised + padded by l2s_normalise_pad_frames; four single-batch chains in flight"},
             "roofline": roof,
         }
         if world == 1 and not args.skip_cpu_baseline:

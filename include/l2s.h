@@ -82,6 +82,14 @@ enum { L2S_ST_K = 0, L2S_ST_V = 1, L2S_ST_CKEY = 2, L2S_ST_CVAL = 3, L2S_ST_ECEL
 int64_t l2s_state_offset(int B, int T, int field);
 
 /* ---- stages ---------------------------------------------------------------------------------------- */
+/* Data boundary on the device (datasets/lrw/dataset.py:83-86,123-146 + datasets/__init__.py:7-46, the model-facing half): the decoded
+ * uint8 RGB frames of B clips, packed back to back in ONE device buffer (clip i = frames[i] x H x W x 3 bytes at packed_u8 + offsets[i],
+ * offsets multiples of 4; both tables are HOST arrays of B entries), become the model's input video dev (B,3,T,H,W) fp32:
+ * x/255, then (x - mean_c)/std_c with the ImageNet constants, clips shorter than T zero-padded.  Same fp32 operations in the same order
+ * as the reference's host transforms: bit-identical, at a quarter of the PCIe bytes. */
+int l2s_normalise_pad_frames(const uint8_t* packed_u8, const int64_t* offsets, const int32_t* frames, int B, int T, int H, int W,
+                             float* video, void* stream);
+
 /* VideoExtractor.forward (video.py:76-87): video dev (B,3,T,H,W) -> feat dev (B,T,768), L2-normalised.
  * H = W in {88, 96}. */
 int l2s_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W,

@@ -207,6 +207,55 @@ int launch_frontend_stats(const FrontendW& w, const float* video1, int B, int T,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ data boundary: normalise + pad
+// The host side of the reference turns every decoded clip into fp32 before it reaches the model: `im.float() / 255.0`, then
+// `Normalize(mean, std)` per channel (datasets/lrw/dataset.py:83-86), then the collate zero-pads every clip to the batch's longest and
+// permutes to (B,3,T,H,W) (datasets/__init__.py:7-46) - 102.6 MB of fp32 per B=32 batch built by the CPU and pushed over PCIe.  Here the
+// decoded uint8 frames (25.7 MB) cross the bus and ONE kernel does the rest, with the same three fp32 operations in the same order
+// (IEEE division, no fma contraction), so the batch is bit-identical to the host collate's.
+struct ClipTab { int64_t off[MAX_COLLATE_CLIPS]; int frames[MAX_COLLATE_CLIPS]; };
+
+__global__ __launch_bounds__(256) void normalise_pad_kernel(const uint8_t* __restrict__ packed, const ClipTab tab, int b0, int T, int HW4,
+                                                            float* __restrict__ video) {
+    // block (x: chunks of 256 pixel quads of one frame, y: frame t, z: clip); thread = 4 consecutive pixels = 12 bytes in, 3 x float4 out
+    const int q = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, bl = blockIdx.z;
+    if (q >= HW4) return;
+    const int b = b0 + bl;
+    const int64_t plane = (int64_t)HW4 * 4;
+    float* out = video + (((int64_t)b * 3) * T + t) * plane + (int64_t)q * 4;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), g = r, bl4 = r;
+    if (t < tab.frames[bl]) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(packed + tab.off[bl] + ((int64_t)t * plane + (int64_t)q * 4) * 3);
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];                 // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        auto nrm = [&](uint32_t byte, int c) { return __fdiv_rn(__fsub_rn(__fdiv_rn((float)byte, 255.0f), mean[c]), stdv[c]); };
+        r = make_float4(nrm(w0 & 255u, 0), nrm(w0 >> 24, 0), nrm((w1 >> 16) & 255u, 0), nrm((w2 >> 8) & 255u, 0));
+        g = make_float4(nrm((w0 >> 8) & 255u, 1), nrm(w1 & 255u, 1), nrm(w1 >> 24, 1), nrm((w2 >> 16) & 255u, 1));
+        bl4 = make_float4(nrm((w0 >> 16) & 255u, 2), nrm((w1 >> 8) & 255u, 2), nrm(w2 & 255u, 2), nrm(w2 >> 24, 2));
+    }
+    *reinterpret_cast<float4*>(out) = r;
+    *reinterpret_cast<float4*>(out + (int64_t)T * plane) = g;
+    *reinterpret_cast<float4*>(out + 2 * (int64_t)T * plane) = bl4;
+}
+
+int launch_normalise_pad(const uint8_t* packed, const int64_t* offsets, const int* frames, int B, int T, int H, int W, float* video, hipStream_t s) {
+    L2S_REQUIRE((H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && (reinterpret_cast<uintptr_t>(video) & 15u) == 0,
+                "frames: H*W must be a multiple of 4, buffers aligned");
+    const int HW4 = H * W / 4;
+    ProfScope ps("normalise_pad_frames", s);
+    for (int b0 = 0; b0 < B; b0 += MAX_COLLATE_CLIPS) {
+        const int nb = B - b0 < MAX_COLLATE_CLIPS ? B - b0 : MAX_COLLATE_CLIPS;
+        ClipTab tab{};
+        for (int i = 0; i < nb; ++i) {
+            L2S_REQUIRE(frames[b0 + i] >= 0 && frames[b0 + i] <= T && offsets[b0 + i] % 4 == 0, "clip table: 0 <= frames <= T, 4-byte aligned offsets");
+            tab.off[i] = offsets[b0 + i]; tab.frames[i] = frames[b0 + i];
+        }
+        hipLaunchKernelGGL(normalise_pad_kernel, dim3((HW4 + 255) / 256, T, nb), dim3(256), 0, s, packed, tab, b0, T, HW4, video);
+    }
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, int N, int Hi, int Wi, int ldi,
                                                         int ci_off, int C, int stride, const float* __restrict__ w9,

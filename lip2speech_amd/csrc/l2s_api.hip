@@ -1303,6 +1303,12 @@ int l2s_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H, int W
     return encoder_run(m, frame_src(video, B), B, T, H, W, nullptr, nullptr, feat, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int l2s_normalise_pad_frames(const uint8_t* packed_u8, const int64_t* offsets, const int32_t* frames, int B, int T, int H, int W, float* video,
+                             void* stream) {
+    L2S_REQUIRE(packed_u8 && offsets && frames && video && B > 0 && T > 0, "bad arguments");
+    return launch_normalise_pad(packed_u8, offsets, frames, B, T, H, W, video, (hipStream_t)stream);
+}
+
 int l2s_build_visual(const float* feat, const float* emb, int B, int T, float* vis, void* stream) {
     L2S_REQUIRE(feat && emb && vis && B > 0 && T > 0, "bad arguments");
     hipStream_t s = (hipStream_t)stream;

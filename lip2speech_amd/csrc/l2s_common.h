@@ -194,6 +194,10 @@ inline int launch_frontend(const FrontendW& w, const float* video, int B, int T,
 // batch-statistics pass of the front-end conv (training): partials[(block*2 + k)*24 + ch], *nblocks blocks
 int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials /*[blocks][2][24]*/, int* nblocks, hipStream_t s);
 
+// data boundary: packed uint8 RGB clips (clip i = frames[i] x H x W x 3 bytes at packed + offsets[i]) -> video (B,3,T,H,W) fp32,
+// /255 then ImageNet mean/std, clips shorter than T zero-padded; offsets / frames are HOST arrays
+constexpr int MAX_COLLATE_CLIPS = 64;        // per launch (the clip table travels in the kernel arguments)
+int launch_normalise_pad(const uint8_t* packed, const int64_t* offsets, const int* frames, int B, int T, int H, int W, float* video, hipStream_t s);
 // depthwise 3x3, pad 1, channel-last: in (N,Hi,Wi,ldi) channels [ci_off, ci_off+C) -> out (N,Ho,Wo,ldo) at co_off
 int launch_dwconv(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,
                   const float* w9 /*[9][C]*/, const float* scale, const float* shift,

@@ -13,8 +13,26 @@ from .spectrograms import MelSpec2Audio, MelSpectrogram  # noqa: F401
 from .lrw import LRW  # noqa: F401
 from .augmentation import FaceAugmentation  # noqa: F401
 from .unported import GRID, AVSpeech, WILD  # noqa: F401
+from .device import PackedFrames, device_collate_fn_pad  # noqa: F401
 
 MEL_PAD = -11.5129      # ln(1e-5), the floor of the log-mel transform
+
+
+def _pad_audio_mels(speeches, melspecs):
+    """((audio (n,a_max), lengths), (mels (n,80,m_max) padded with ln(1e-5), lengths, gate = 1 from the last real frame on))."""
+    n = len(speeches)
+    a_max = max(s.shape[1] for s in speeches)
+    m_max = max(m.shape[1] for m in melspecs)
+    audio = torch.zeros(n, a_max)
+    mels = torch.full((n, melspecs[0].shape[0], m_max), MEL_PAD)
+    gate = torch.zeros(n, m_max)
+    a_len, m_len = [], []
+    for i, (speech, mel) in enumerate(zip(speeches, melspecs)):
+        audio[i, :speech.shape[-1]] = speech.reshape(-1)
+        mels[i, :, :mel.shape[-1]] = mel
+        gate[i, mel.shape[-1] - 1:] = 1.0
+        a_len.append(speech.shape[-1]); m_len.append(mel.shape[-1])
+    return (audio, torch.tensor(a_len)), (mels, torch.tensor(m_len), gate)
 
 
 def _collate(batch, with_paths: bool):
@@ -25,21 +43,11 @@ def _collate(batch, with_paths: bool):
         paths = None
     n = len(mouths)
     t_max = max(m.shape[0] for m in mouths)
-    a_max = max(s.shape[1] for s in speeches)
-    m_max = max(m.shape[1] for m in melspecs)
     video = torch.zeros(n, t_max, *mouths[0].shape[1:])
-    audio = torch.zeros(n, a_max)
-    mels = torch.full((n, melspecs[0].shape[0], m_max), MEL_PAD)
-    gate = torch.zeros(n, m_max)
-    v_len, a_len, m_len = [], [], []
-    for i, (mouth, speech, mel) in enumerate(zip(mouths, speeches, melspecs)):
+    for i, mouth in enumerate(mouths):
         video[i, :mouth.shape[0]] = mouth
-        audio[i, :speech.shape[-1]] = speech.reshape(-1)
-        mels[i, :, :mel.shape[-1]] = mel
-        gate[i, mel.shape[-1] - 1:] = 1.0
-        v_len.append(mouth.shape[0]); a_len.append(speech.shape[-1]); m_len.append(mel.shape[-1])
-    out = ((video.permute(0, 2, 1, 3, 4), torch.tensor(v_len)), (audio, torch.tensor(a_len)),
-           (mels, torch.tensor(m_len), gate), torch.stack(list(faces), dim=0))
+    out = (((video.permute(0, 2, 1, 3, 4), torch.tensor([m.shape[0] for m in mouths])),) + _pad_audio_mels(speeches, melspecs) +
+           (torch.stack(list(faces), dim=0),))
     return out + (paths,) if with_paths else out
 
 

@@ -42,8 +42,11 @@ def normalise_mouth(frames_u8: np.ndarray) -> torch.Tensor:
 
 
 class LRW(Dataset):
-    def __init__(self, rootpth, face_size=(96, 96), mode="train", demo=False, duration=1, face_augmentation=None, *args, **kwargs):
+    def __init__(self, rootpth, face_size=(96, 96), mode="train", demo=False, duration=1, face_augmentation=None, *args, raw_frames=False, **kwargs):
+        """`raw_frames=True` (an extension): items carry the decoded uint8 clip `(T,H,W,3)` instead of the normalised fp32 one - the
+        normalisation then runs on the device (`datasets.device.device_collate_fn_pad` + `PackedFrames.to_device`)."""
         super().__init__(*args, **kwargs)
+        self.raw_frames = raw_frames
         assert mode in ("train", "test", "val")
         self.rootpth, self.mode, self.demo = rootpth, mode, demo
         self.face_size, self.duration = face_size, duration
@@ -66,7 +69,7 @@ class LRW(Dataset):
     def __getitem__(self, idx):
         face_path, mouth_path, audio_path = self.items[idx]
         frames = load_frames(mouth_path)
-        mouth = normalise_mouth(frames)
+        mouth = torch.from_numpy(np.ascontiguousarray(frames)) if self.raw_frames else normalise_mouth(frames)
         speech = torch.from_numpy(np.load(audio_path)["data"][np.newaxis])
         melspec = self.melspec_g(speech).squeeze(0)
         # two random face frames resized to 160x160 feed the third-party face tower (outside this path); a zero

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "l2s_abi_version", "l2s_last_error",
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
-    "l2s_encoder_fwd", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
+    "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
@@ -67,6 +67,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_state_offset.argtypes = [_i, _i, _i]
     L.l2s_state_offset.restype = _i64
     L.l2s_encoder_fwd.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp, _i64, _vp]
+    L.l2s_normalise_pad_frames.argtypes = [_vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), _i, _i, _i, _i, _fp, _vp]
     L.l2s_build_visual.argtypes = [_fp, _fp, _i, _i, _fp, _vp]
     L.l2s_decoder_prologue.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _i64, _vp]
     L.l2s_decode_steps.argtypes = [_vp, _fp, _i, _i, _i, _fp, _vp, _fp, _fp, _fp, _i, _vp, _i64, _vp]
@@ -471,6 +472,19 @@ def postnet_drop_pack(masks) -> torch.Tensor:
         assert tuple(mk.shape) == (B, C, S)
         out[l * B * S * 512: l * B * S * 512 + B * S * C] = mk.to(torch.float32).permute(0, 2, 1).reshape(-1)
     return out
+
+
+def normalise_pad_frames(packed_u8: torch.Tensor, offsets, frames, H: int = 96, W: int = 96, T: Optional[int] = None) -> torch.Tensor:
+    """Packed uint8 RGB clips on the device -> the model's (B,3,T,H,W) fp32 input (`l2s_normalise_pad_frames`): /255, ImageNet mean/std,
+    zero padding to T (default: the longest clip).  `offsets` / `frames`: per-clip byte offsets into `packed_u8` and frame counts."""
+    assert packed_u8.is_cuda and packed_u8.dtype == torch.uint8 and packed_u8.is_contiguous()
+    B = len(frames)
+    T = int(max(frames)) if T is None else int(T)
+    video = torch.empty(B, 3, T, H, W, dtype=torch.float32, device=packed_u8.device)
+    off = (_i64 * B)(*[int(o) for o in offsets])
+    fr = (ctypes.c_int32 * B)(*[int(f) for f in frames])
+    check(lib().l2s_normalise_pad_frames(packed_u8.data_ptr(), off, fr, B, T, H, W, _ptr(video), _stream()))
+    return video
 
 
 def build_visual(feat: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:

@@ -72,3 +72,28 @@ def test_lrw_dataset_index_rebuild(tmp_path):
     assert len(ds) == 2
     (video, vlen), (audio, alen), (mels, mlen, gate), faces = train_collate_fn_pad([ds[0], ds[1]])
     assert video.shape == (2, 3, 29, 96, 96) and mels.shape == (2, 80, 77) and vlen.tolist() == [29, 29]
+
+
+def test_device_collate_packs_raw_clips(tmp_path):
+    """`LRW(raw_frames=True)` + `device_collate_fn_pad`: the uint8 clips travel packed (a quarter of the bytes of the fp32 batch); audio,
+    mels, gate and lengths are exactly what `train_collate_fn_pad` builds.  (The kernel that finishes the job is GPU-tested.)"""
+    import shutil
+    from lip2speech_amd.datasets import PackedFrames, device_collate_fn_pad
+    d = tmp_path / "LRW_Faces" / "ABOUT" / "test"
+    a = tmp_path / "lipread_audio" / "ABOUT" / "test"
+    d.mkdir(parents=True); a.mkdir(parents=True)
+    for i in (1, 2):
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}_mouth.npz"), d / f"ABOUT_0000{i}_mouth.npz")
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}.npz"), a / f"ABOUT_0000{i}.npz")
+    raw, ref = LRW(str(tmp_path), mode="test", raw_frames=True), LRW(str(tmp_path), mode="test")
+    assert raw[0][0].dtype == torch.uint8 and raw[0][0].shape == (29, 96, 96, 3)
+    (packed, vlen), (audio, alen), (mels, mlen, gate), faces = device_collate_fn_pad([raw[0], raw[1]])
+    (video, vlen2), (audio2, alen2), (mels2, mlen2, gate2), faces2 = train_collate_fn_pad([ref[0], ref[1]])
+    assert isinstance(packed, PackedFrames) and packed.frames == [29, 29] and packed.offsets == [0, 29 * 96 * 96 * 3]
+    assert packed.data.numel() == video.numel() and packed.data.element_size() * 4 == video.element_size()      # 1 byte per value instead of 4
+    assert torch.equal(vlen, vlen2) and torch.equal(audio, audio2) and torch.equal(mels, mels2) and torch.equal(gate, gate2) and torch.equal(mlen, mlen2)
+    # the packed bytes are the decoded frames, clip after clip
+    assert torch.equal(packed.data[:29 * 96 * 96 * 3].view(29, 96, 96, 3), raw[0][0])
+    # ragged clips: offsets stay 4-byte aligned
+    p2 = PackedFrames([torch.zeros(3, 6, 6, 3, dtype=torch.uint8), torch.ones(5, 6, 6, 3, dtype=torch.uint8)], pin=False)
+    assert p2.frames == [3, 5] and p2.offsets == [0, 324] and p2.lengths.tolist() == [3, 5]

@@ -127,6 +127,30 @@ def test_inference_matches_reference_golden(nm):
     assert pc.maxdiff(attn[:, ::50], g["attn_rows"]) < MEL_TOL
 
 
+def test_device_normalise_pad_is_bit_identical_to_host_collate():
+    """Data boundary on the device (l2s_normalise_pad_frames): the SAMPLE_LRW clips and a ragged synthetic batch of every byte value give
+    exactly the fp32 batch the host transforms + collate build (dataset.py:83-86, datasets/__init__.py:7-46)."""
+    import os
+    from lip2speech_amd.datasets import PackedFrames, train_collate_fn_pad
+    from lip2speech_amd.datasets.lrw import load_frames, normalise_mouth
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_lrw")
+    clips = [torch.from_numpy(load_frames(os.path.join(sample, f"ABOUT_0000{i}_mouth.npz"))) for i in (1, 2)]
+    g = torch.Generator().manual_seed(3)
+    clips += [torch.randint(0, 256, (t, 96, 96, 3), dtype=torch.uint8, generator=g) for t in (7, 25, 29, 12)]
+    clips.append(torch.arange(256, dtype=torch.uint8).repeat(96 * 96 * 3 * 2 // 256).view(2, 96, 96, 3))      # every byte value
+    items = [(normalise_mouth(c.numpy()), torch.zeros(1, 8), torch.zeros(80, 2), torch.zeros(2, 3, 4, 4)) for c in clips]
+    want = train_collate_fn_pad(items)[0][0]
+    got = PackedFrames(clips).to_device()
+    assert got.shape == want.shape == (len(clips), 3, 29, 96, 96)
+    assert torch.equal(got.cpu(), want)
+    longer = PackedFrames(clips[:2]).to_device(T=31)                      # explicit T: two more zero frames
+    assert torch.equal(longer[:, :, :29].cpu(), want[:2]) and float(longer[:, :, 29:].abs().max()) == 0.0
+    big = PackedFrames([clips[0]] * 70).to_device()                       # more clips than one launch's table holds
+    assert torch.equal(big[69].cpu(), want[0]) and torch.equal(big[64].cpu(), want[0])
+    small = PackedFrames([torch.randint(0, 256, (5, 88, 88, 3), dtype=torch.uint8, generator=g)])
+    assert torch.equal(small.to_device().cpu(), normalise_mouth(small.data.view(5, 88, 88, 3).numpy()).permute(1, 0, 2, 3).unsqueeze(0))
+
+
 def test_full_size_lrw_every_clip(nm):
     """BASELINE.json configs[1] in full: all 32 x 80 x 300 post-net mel values of the reference run at the benchmark's own size."""
     g = pc.golden("inference_lrw_b32_full_mel.npz")
