@@ -418,29 +418,39 @@ def test_smoke_entry():
     ge.smoke()
 
 
-def test_sample_lrw_clips_plumbing(nm, synth_sd):
-    """BASELINE config[0] shape: two real SAMPLE_LRW mouth clips (JPEG -> PIL -> ImageNet normalisation -> collate) through
-    the HIP path vs the oracle on the same frames (plumbing with real data; synthetic weights, supplied embedding)."""
+def test_sample_lrw_clips_plumbing(nm, synth_sd, tmp_path):
+    """BASELINE.json configs[0]: all 10 SAMPLE_LRW clips in batches of 2, the way demo.py / evaluate.py feed them - `LRW` loader
+    (bz2 pickle of JPEGs -> PIL), `DataLoader`, collate - with the data boundary on the device (uint8 clips -> l2s_normalise_pad_frames) and
+    the five batches advanced as ONE launch chain; every batch against the oracle on the host-collated frames (plumbing with real data:
+    synthetic weights, supplied embedding; cv2 and PIL may decode a JPEG 1 LSB apart, so this is not a parity gate against the reference)."""
     import os
-    from lip2speech_amd.datasets import train_collate_fn_pad
-    from lip2speech_amd.datasets.lrw import load_frames, normalise_mouth
-    from lip2speech_amd.datasets.spectrograms import MelSpectrogram
+    import shutil
+    from torch.utils.data import DataLoader
+    from lip2speech_amd.datasets import LRW, device_collate_fn_pad, train_collate_fn_pad
     root = os.path.join(pc.GOLDEN, "sample_lrw")
-    mel_t = MelSpectrogram()
-    items = []
-    for i in (1, 2):
-        mouth = normalise_mouth(load_frames(os.path.join(root, f"ABOUT_0000{i}_mouth.npz")))
-        speech = torch.from_numpy(np.load(os.path.join(root, f"ABOUT_0000{i}.npz"))["data"][None])
-        items.append((mouth, speech, mel_t(speech).squeeze(0), torch.zeros(2, 3, 160, 160)))
-    (video, vlen), _, (mels, mlen, gate), _ = train_collate_fn_pad(items)
-    assert video.shape == (2, 3, 29, 96, 96) and mels.shape == (2, 80, 77)
-    emb = synth.synth_speaker_embedding(2, tag="sample")
-    gum = synth.synth_gumbel(2 * 4, tag="sample")
-    mel_post, lengths, _ = nm.inference(video.cuda(), emb.cuda(), gum.cuda(), S=300)
-    with torch.no_grad():
-        ref_post, ref_len, _ = orc.inference(synth_sd, video, emb, gum, S=300)
-    assert pc.maxdiff(mel_post, ref_post) < MEL_TOL
-    assert torch.equal(lengths.cpu(), ref_len)
+    d = tmp_path / "LRW_Faces" / "ABOUT" / "test"
+    a = tmp_path / "lipread_audio" / "ABOUT" / "test"
+    d.mkdir(parents=True); a.mkdir(parents=True)
+    for i in range(1, 11):
+        shutil.copy(os.path.join(root, f"ABOUT_{i:05d}_mouth.npz"), d)
+        shutil.copy(os.path.join(root, f"ABOUT_{i:05d}.npz"), a)
+    raw, ref = LRW(str(tmp_path), mode="test", raw_frames=True), LRW(str(tmp_path), mode="test")
+    assert len(raw) == 10
+    dev_batches = list(DataLoader(raw, batch_size=2, shuffle=False, collate_fn=device_collate_fn_pad))
+    host_batches = list(DataLoader(ref, batch_size=2, shuffle=False, collate_fn=train_collate_fn_pad))
+    assert len(dev_batches) == 5
+    group = []
+    for i, ((packed, vlen), _, (mels, mlen, gate), _) in enumerate(dev_batches):
+        video = packed.to_device()
+        assert video.shape == (2, 3, 29, 96, 96) and mels.shape == (2, 80, 77) and vlen.tolist() == [29, 29]
+        assert torch.equal(video.cpu(), host_batches[i][0][0])                  # device collate == host collate, bit for bit
+        group.append((video, synth.synth_speaker_embedding(2, tag=f"sample{i}").cuda(), synth.synth_gumbel(2 * 4, tag=f"sample{i}").cuda()))
+    outs = nm.inference_multi(group, S=300)
+    for i, (mel_post, lengths, _) in enumerate(outs):
+        with torch.no_grad():
+            ref_post, ref_len, _ = orc.inference(synth_sd, host_batches[i][0][0], group[i][1].cpu(), group[i][2].cpu(), S=300)
+        assert pc.maxdiff(mel_post, ref_post) < MEL_TOL
+        assert torch.equal(lengths.cpu(), ref_len)
 
 
 def test_caller_loops_voice_route(synth_sd):
