@@ -299,6 +299,7 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  * flight on other models (lip2speech_amd.parallel keeps several in flight).
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
+ *   "frontend_x3"       (1)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path; 0 = f32 MFMA kernel
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
  *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
 int l2s_set_option(const char* name, int value);

@@ -175,6 +175,208 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ frontend, split-bf16 matrix path
+// The same fused Conv3d + BN + PReLU + MaxPool block (one frame x strip of 6 pooled rows) on the bf16 matrix cores: every fp32 input
+// value and weight is split EXACTLY into three bf16 planes (x = hi + mid + lo, see gemm_x3.hip) and a conv product is the six partial
+// products of weight >= 2^-16 - six v_mfma_f32_32x32x16_bf16 per 16 taps instead of eight v_mfma_f32_32x32x2_f32 per 16 taps at 2x the
+// cost each.  K order per (ci,kt) slab: 4 steps of 16 = two kernel rows (kh = 2s + lane>>5) x 8 columns: a ZERO tap in front of the 7 real
+// ones (the operand of a conv pixel is then the 8 consecutive bf16 starting at LDS column 2c, a 4-byte aligned address), and kernel row 7 is
+// a zero row.  The input slab is split by the threads that stage it (once per slab per block), the weights arrive pre-split from the packer
+// in operand order ([slab][step][plane][32 channels][16 taps, 48-byte rows: conflict-free ds_read_b128]).
+// bf16 per LDS row: data column x at x + 4, zero columns in front and behind.  The row length in dwords is = Wc/2... chosen so that TWICE the
+// row (one conv row down) shifts the banks by exactly Wc mod 32: a 32-pixel tile that straddles two conv rows then still touches 32
+// different banks (96x96: 48 columns, 56 dwords per row; 88x88: 44 columns, 54 dwords) - with 52-dword rows 21 % of the LDS cycles were conflicts
+template <int HW> struct FxGeom { static constexpr int XLD = HW == 96 ? 112 : 108, PLANE = FE_XROWS * XLD * 2; };
+constexpr int FX_WROW = 48;                          // bytes per weight row (16 bf16 + pad)
+constexpr int FX_WSLAB = 4 * 3 * 32 * FX_WROW;       // 18 432 bytes per slab
+
+typedef __bf16 fx_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void fx_split4(const float4& v, uint2& hi, uint2& mid, uint2& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned xb = __float_as_uint(f[e]);
+        const float r1 = f[e] - __uint_as_float(xb & 0xFFFF0000u);                          // exact
+        const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);           // exact, <= 8 significant bits
+        h[e] = xb; m[e] = __float_as_uint(r1); l[e] = __float_as_uint(r2);
+    }
+    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+
+template <int HW>
+__global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
+    constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
+    constexpr int P = FE_CR * Wc;                    // conv pixels per strip
+    constexpr int NT = (P + 31) / 32;                // 32-pixel MFMA row tiles
+    constexpr int TPW = (NT + 3) / 4;                // tiles per wave
+    constexpr int XLD = FxGeom<HW>::XLD, PLANE = FxGeom<HW>::PLANE;
+    static_assert((2 * (XLD / 2)) % 32 == Wc % 32 && XLD >= W + 8, "row pitch: conflict-free straddling tiles");
+    constexpr int XS = 3 * PLANE;                    // bytes: input planes
+    constexpr int CS = P * FE_CO * 4;                // bytes: conv tile (aliases the operand area)
+    constexpr int SMEM = (XS + FX_WSLAB) > CS ? (XS + FX_WSLAB) : CS;
+    constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
+    constexpr int NWL = (FX_WSLAB / 16 + 255) / 256;                 // weight uint4 per thread per slab
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Xs = smem;
+    unsigned char* const Ws = smem + XS;
+
+    const int f = blockIdx.y;                        // frame index b*T + t
+    const int bg = f / T, t = f - bg * T;
+    const int grp = bg / vsrc.per, b = bg - grp * vsrc.per;     // clip b of the grp-th batch tensor (block-uniform)
+    const float* __restrict__ video = vsrc.p[grp];
+    const int p0 = blockIdx.x * FE_PR;               // first pooled row of this strip
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lg = lane >> 5;
+
+    // zero the planes once: the column pads, the rows outside the image and the spare row stay zero for every slab
+    for (int i = tid; i < XS / 16; i += 256) reinterpret_cast<uint4*>(Xs)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // byte offset of this lane's operand inside a plane, per tile: row 2*lr + (lane>>5), column 2*c
+    int base[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        int p = (wave + 4 * j) * 32 + li;
+        p = p < P ? p : P - 1;
+        const int lr = p / Wc, c = p - lr * Wc;
+        base[j] = ((2 * lr + lg) * XLD + 2 * c) * 2;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int gy0 = 4 * p0 - 5;                      // global input row of slab row 0
+    // the (ci,kt) slabs whose frame t+kt-2 exists (temporal zero padding contributes nothing), in order
+    auto valid = [&](int slab) { const int tt = t + (slab % 5) - 2; return tt >= 0 && tt < T; };
+    auto next_valid = [&](int slab) { while (slab < 15 && !valid(slab)) ++slab; return slab; };
+
+    float4 rin[NLD];
+    uint4 rw[NWL];
+    auto fetch = [&](int slab) {
+        const int ci = slab / 5, kt = slab - ci * 5;
+        const float* src = video + ((int64_t)(b * 3 + ci) * T + (t + kt - 2)) * (H * W);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            const int row = i / (W / 4), x4 = i - row * (W / 4);
+            const int gy = gy0 + row;
+            rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
+        }
+        const uint4* wsrc = reinterpret_cast<const uint4*>(w.w3) + (int64_t)slab * (FX_WSLAB / 16);
+#pragma unroll
+        for (int q = 0; q < NWL; ++q) {
+            const int i = tid + 256 * q;
+            rw[q] = i < FX_WSLAB / 16 ? wsrc[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            if (i < (FE_XROWS - 1) * (W / 4)) {
+                const int row = i / (W / 4), x4 = i - row * (W / 4);
+                uint2 hi, mid, lo;
+                fx_split4(rin[q], hi, mid, lo);
+                unsigned char* d = Xs + (row * XLD + 4 + 4 * x4) * 2;
+                *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + PLANE) = mid; *reinterpret_cast<uint2*>(d + 2 * PLANE) = lo;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NWL; ++q) {
+            const int i = tid + 256 * q;
+            if (i < FX_WSLAB / 16) reinterpret_cast<uint4*>(Ws)[i] = rw[q];
+        }
+    };
+
+    int slab = next_valid(0);
+    if (slab < 15) fetch(slab);
+    while (slab < 15) {
+        __syncthreads();                             // previous slab fully consumed (first pass: the zero fill is complete)
+        stage();
+        const int nxt = next_valid(slab + 1);
+        if (nxt < 15) fetch(nxt);                    // lands under this slab's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // weights of this step: lane (channel li, tap half lg) reads 8 bf16 of each plane
+            const unsigned char* wp = Ws + ((s * 3) * 32 + li) * FX_WROW + lg * 16;
+            const fx_bf16x8 bh = *reinterpret_cast<const fx_bf16x8*>(wp);
+            const fx_bf16x8 bm = *reinterpret_cast<const fx_bf16x8*>(wp + 32 * FX_WROW);
+            const fx_bf16x8 bl = *reinterpret_cast<const fx_bf16x8*>(wp + 64 * FX_WROW);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (wave + 4 * j < NT) {             // wave-uniform
+                    const unsigned* ap = reinterpret_cast<const unsigned*>(Xs + base[j] + s * (2 * XLD * 2));
+                    const unsigned* am_ = reinterpret_cast<const unsigned*>(Xs + base[j] + s * (2 * XLD * 2) + PLANE);
+                    const unsigned* al_ = reinterpret_cast<const unsigned*>(Xs + base[j] + s * (2 * XLD * 2) + 2 * PLANE);
+                    const fx_bf16x8 ah = __builtin_bit_cast(fx_bf16x8, make_uint4(ap[0], ap[1], ap[2], ap[3]));
+                    const fx_bf16x8 am = __builtin_bit_cast(fx_bf16x8, make_uint4(am_[0], am_[1], am_[2], am_[3]));
+                    const fx_bf16x8 al = __builtin_bit_cast(fx_bf16x8, make_uint4(al_[0], al_[1], al_[2], al_[3]));
+                    // smallest partial products first (interleaving the terms across tiles measured 5 % slower: more operand registers live)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        slab = nxt;
+    }
+    __syncthreads();                                 // operands dead; reuse LDS as the conv tile
+
+    // BN + PReLU, conv tile Cs[pixel][24]
+    float* Cs = reinterpret_cast<float*>(smem);
+    if (li < FE_CO) {
+        const float sc = w.scale[li], sh = w.shift[li], sl = w.slope[li];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            if (wave + 4 * j < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    if (p < P) {
+                        float v = acc[j][r] * sc + sh;
+                        v = v >= 0.f ? v : sl * v;
+                        Cs[p * FE_CO + li] = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3x3 / stride 2 / pad 1 max pool (padding never wins: -inf) -> channel-last output
+    for (int i = tid; i < FE_PR * Wp * FE_CO; i += 256) {
+        const int ch = i % FE_CO;
+        const int pw = (i / FE_CO) % Wp;
+        const int prl = i / (FE_CO * Wp);
+        const int pr = p0 + prl;
+        if (pr >= Hp) continue;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+            const int crow = 2 * pr - 1 + dr;        // global conv row
+            if (crow < 0 || crow >= Hc) continue;
+            const int lrow = 2 * prl + dr;           // local conv row (local row 0 = conv row 2*p0-1)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int cc = 2 * pw + dc;
+                if (cc < 0 || cc >= Wc) continue;
+                m = fmaxf(m, Cs[(lrow * Wc + cc) * FE_CO + ch]);
+            }
+        }
+        out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + ch] = m;
+    }
+}
+
 int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
     L2S_REQUIRE(video.per >= 1 && (B + video.per - 1) / video.per <= MAX_GROUP, "too many frame tensors in one launch");
@@ -183,7 +385,10 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     ProfScope ps("frontend3d_conv_bn_prelu_pool", s);
-    if (zout) {
+    if (!zout && w.w3) {                       // inference on the split-bf16 matrix path (option "frontend_x3")
+        if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96>), grid, dim3(256), 0, s, w, video, T, out);
+        else hipLaunchKernelGGL((frontend3d_x3_kernel<88>), grid, dim3(256), 0, s, w, video, T, out);
+    } else if (zout) {
         if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);
         else hipLaunchKernelGGL((frontend3d_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);
     } else {

@@ -29,7 +29,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb},
-        {"gemm_x3", &Options::gemm_x3}};
+        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}};
     for (auto& t : table)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
     return 1;
@@ -204,6 +204,26 @@ static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bo
                         for (int tap = 0; tap < 49; ++tap)
                             P.blob.data[o + ((int64_t)(ci * 5 + kt) * 50 + tap) * 32 + co] = (*v)[(((int64_t)co * 3 + ci) * 5 + kt) * 49 + tap];
             P.bind(&w.fe.w, o);
+            // the same weights as split-bf16 operand planes (frontend3d_x3_kernel): per slab, step s = kernel rows 2s, 2s+1 (row 7: zeros),
+            // 8 taps per row = one zero tap + the 7 real ones; every value split exactly into hi + mid + lo by truncation
+            const int64_t o3 = P.blob.alloc(15 * 18432 / 4);
+            unsigned char* base3 = reinterpret_cast<unsigned char*>(&P.blob.data[o3]);
+            for (int slab = 0; slab < 15; ++slab)
+                for (int st = 0; st < 4; ++st)
+                    for (int n = 0; n < 32; ++n)
+                        for (int k = 0; k < 16; ++k) {
+                            const int kh = 2 * st + (k >> 3), kw = (k & 7) - 1, ci = slab / 5, kt = slab % 5;
+                            float x = 0.f;
+                            if (n < 24 && kh < 7 && kw >= 0) x = (*v)[(((int64_t)n * 3 + ci) * 5 + kt) * 49 + kh * 7 + kw];
+                            uint32_t xb, hb, mb, lb; float r1, r2, tmp;
+                            std::memcpy(&xb, &x, 4); hb = xb & 0xFFFF0000u; std::memcpy(&tmp, &hb, 4); r1 = x - tmp;
+                            std::memcpy(&mb, &r1, 4); mb &= 0xFFFF0000u; std::memcpy(&tmp, &mb, 4); r2 = r1 - tmp;
+                            std::memcpy(&lb, &r2, 4);
+                            const uint16_t planes[3] = {(uint16_t)(hb >> 16), (uint16_t)(mb >> 16), (uint16_t)(lb >> 16)};
+                            for (int pl = 0; pl < 3; ++pl)
+                                std::memcpy(base3 + (int64_t)slab * 18432 + ((st * 3 + pl) * 32 + n) * 48 + k * 2, &planes[pl], 2);
+                        }
+            P.bind(&w.fe.w3, o3);
         }
         P.bn(E + "frontend3D.1", 24, nullptr, &w.fe.scale, &w.fe.shift);
         P.copy(E + "frontend3D.2.weight", 24, &w.fe.slope);
@@ -747,7 +767,9 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
     Bump bp(ws, ws_bytes);
     float* a = bp.f(pl.act_a); float* b = bp.f(pl.act_b); float* t1 = bp.f(pl.t1); float* t2 = bp.f(pl.t2); float* last = bp.f(pl.last);
     L2S_REQUIRE(!bp.overflow, "encoder workspace too small");
-    if (launch_frontend(w.fe, video, B, T, H, W, a, s)) return 1;
+    FrontendW fe = w.fe;
+    if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale (like the merged step weights)
+    if (launch_frontend(fe, video, B, T, H, W, a, s)) return 1;
     float* x = a; float* y = b;
     int h = pl.Hp;
     const int NF = pl.NF;
@@ -1484,7 +1506,9 @@ int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* d
 }
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
     L2S_ENC_READY(m);
-    return launch_frontend(m->w.fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
+    FrontendW fe = m->w.fe;
+    if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;
+    return launch_frontend(fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }
 
 int l2s_train_set_bn(l2s_model* m, int batch_stats, float momentum) {

@@ -55,6 +55,7 @@ struct Options {
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 2;              // "skinny_rc_jb": chunks per operand batch of the 2x1 / 2x2 blocks (2 or 4)
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
+    int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)
 };
 int set_option_field(Options& o, const char* name, int value);    // 0 = ok, 1 = unknown name
 
@@ -181,6 +182,8 @@ struct FrontendW {          // device pointers into the weight blob
     const float* scale;     // [24] BN scale
     const float* shift;     // [24]
     const float* slope;     // [24] PReLU
+    const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows]
+                            //   (null: f32 MFMA kernel)
 };
 // where the clips of a launch live: clip b is clip (b % per) of the (per,3,T,H,W) tensor p[b / per] - the G batches of a grouped pass
 // (l2s_inference_multi) stay where their caller put them

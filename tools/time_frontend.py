@@ -1,0 +1,19 @@
+"""Front-end conv kernel: split-bf16 path vs f32 MFMA path, time per batch and difference."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from lip2speech_amd import native, synth
+sd = synth.synth_state_dict()
+tens = {k: v.cuda() for k, v in sd.items()}
+def mk(x3):
+    nm = native.NativeModel(); nm.set_option("frontend_x3", x3); nm.load(tens, list(sd.keys())); return nm
+a, b = mk(1), mk(0)
+for B in (32, 128):
+    v = synth.synth_video(32, 29, tag="bench").cuda().repeat(B // 32, 1, 1, 1, 1)
+    oa, ob = a.op_frontend(v), b.op_frontend(v)
+    print(f"B={B}: max|x3 - f32| = {(oa-ob).abs().max().item():.3e}  (|out| max {ob.abs().max().item():.2f})")
+    for name, nm in (("x3 ", a), ("f32", b)):
+        for _ in range(3): nm.op_frontend(v)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): nm.op_frontend(v)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        print(f"  {name}: {dt*1e3:.3f} ms  ({2*1178.6e6*B/dt/1e12:.1f} TFLOP/s useful)")
