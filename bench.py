@@ -106,6 +106,52 @@ def cpu_baseline(seconds_budget=12.0):
                       f"thread-count probe (S=20 pass, seconds): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
 
 
+def cpu_baseline_train(Bt, St, seconds_budget=25.0):
+    """One training step of the same shape on this host's cores: forward (batch-statistics BatchNorm) -> 4-term loss -> autograd backward
+    through the CPU oracle -> clip -> torch AdamW(amsgrad); `cores` from the inference probe's best setting."""
+    from oracle import l2s_oracle as orc
+    sd = synth.synth_state_dict()
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked", "pos_table"))      # noqa: E731
+    keys = [k for k in sd if k.startswith(("encoder.", "decoder."))]
+    work = {k: (sd[k].clone().requires_grad_(sd[k].is_floating_point() and not is_buf(k))) for k in keys}
+    params = [work[k] for k in keys if work[k].requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-6, amsgrad=True)
+    video = synth.synth_video(Bt, T, tag="train0")
+    emb = synth.synth_speaker_embedding(Bt, tag="train0")
+    gum = synth.synth_gumbel(Bt * native.min_T(T), tag="train0")
+    mels = synth.synth_mels(Bt, St, tag="train0")
+    gate = torch.zeros(Bt, St)
+    gate[:, -1] = 1.0
+    hw = os.cpu_count() or 1
+    cores = min(32, hw)
+    torch.set_num_threads(cores)
+    times = []
+    while (sum(times) < seconds_budget and len(times) < 4) or len(times) < 2:
+        t0 = time.time()
+        with orc.batch_statistics():
+            outs = orc.forward_eval(work, video, emb, mels, gum)
+        terms = orc.loss_terms(outs, mels, gate)
+        opt.zero_grad()
+        terms[-1].backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        times.append(time.time() - t0)
+    best = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": Bt / best, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times) - 1} training steps after 1 warm-up of the B={Bt}, T={T}, S={St} batch on the CPU oracle with torch autograd "
+                      f"(batch-statistics BatchNorm, no dropout, no teacher forcing); median {best:.2f} s per step"}
+
+
+def train_kernel_model(name, Bt, St):
+    """Algorithmic (FLOPs, bytes) of ONE launch of the training step's kernels that have a closed form (literal 6-phase step)."""
+    w4 = 4
+    table = {
+        "train_step_lstm_cell": (2 * Bt * 2048 * 1024, (2048 * 1024 + 2048) * w4 + Bt * (1024 + 3 * 512 + 4 * 2048) * w4),
+        "train_bwd_lstm_dx": (2 * Bt * 1024 * 2048, (1024 * 2048) * w4 + Bt * (2048 + 1024) * w4),       # d[x|h] = dgates (B,2048) x [W_ih | W_hh]
+    }
+    return table.get(name)
+
+
 def train_main(args):
     """Secondary bench line: training throughput.  One step = `Lip2Speech.forward` (encoder + decoder, S=77 targets) + 4-term loss +
     backward through everything + bucketed gradient all-reduce (RCCL, N>1) + global-norm clip + fused AdamW(amsgrad) + device-side
@@ -177,6 +223,27 @@ def train_main(args):
     loss = out["loss"].cpu()
     assert torch.isfinite(loss).all(), "non-finite loss"
     if rank == 0:
+        # per-kernel HIP-event timing of ONE more step (events around every launch perturb the pipeline: separate pass)
+        native.profile_enable(True)
+        native.profile_reset()
+        step()
+        torch.cuda.synchronize()
+        prof = sorted(native.profile_read(), key=lambda r: -r[2])
+        native.profile_enable(False)
+        gpu_ms = sum(r[2] for r in prof)
+        roof = {"kernels_by_gpu_time": [{"kernel": n, "launches": l, "total_ms": ms, "avg_us_event_per_launch": ms / l * 1e3, "share": ms / gpu_ms}
+                                        for n, l, ms in prof[:8]], "gpu_ms_event_sum": gpu_ms}
+        for n, l, ms in prof:
+            km = train_kernel_model(n, Bt, St)
+            if km:
+                flops, nbytes = km
+                avg_s = ms / l * 1e-3
+                roof.update(kernel=n, launches_per_step=l, avg_us=avg_s * 1e6, bound="hbm", achieved=nbytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=nbytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_flops=flops, algorithmic_bytes=nbytes, traffic=None,
+                            note="largest kernel with a closed-form cost: at 8 rows per launch the step kernels stream their weights once per "
+                                 "launch (AI = 4 FLOP/B): per-launch HIP-event brackets add ~1.8 us to these us-scale kernels")
+                break
+        cpu = cpu_baseline_train(Bt, St) if (world == 1 and not args.skip_cpu_baseline) else None
         print(json.dumps({
             "metric": "training clips/sec (forward + loss + backward + all-reduce + clip + AdamW-amsgrad + weight re-pack)",
             "value": world * Bt * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,6 +252,8 @@ def train_main(args):
             "config": {"workload": "LRW training step, batch=8 per GPU, 29x96x96 clips, S=77 mel targets, half of the steps teacher-forced, "
                                    "38.4 M parameters, train() semantics (batch-statistics BatchNorm, dropout)", "batch_per_gpu": Bt, "frames": T,
                        "decode_steps": St, "parallelism": f"dp{world} (one bucketed gradient all-reduce of 153.7 MB per step)"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "speedup_vs_cpu_baseline": (world * Bt * args.steps / elapsed) / cpu["value"] if cpu else None,
             "final_loss": float(loss[4])}), flush=True)
     if dist:
         dist.destroy_process_group()
