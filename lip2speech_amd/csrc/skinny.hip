@@ -112,7 +112,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     for (int i = 0; i < bl.count; ++i) maxk = bl.p[i].K > maxk ? bl.p[i].K : maxk;
     const int cls = !o.skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
     // many batch rows: register-blocked blocks, the largest shape that still gives the chip one block per CU
-    int shape = o.rc_shape;
+    int shape = (bl.count > 1 && o.rc_shape_multi) ? o.rc_shape_multi : o.rc_shape;
     if (shape == 0) {
         shape = 11;
         if (mts >= 4) {

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 passes of tools/prof_decode.py (kernel trace + three --pmc passes: TCC_HIT_sum TCC_MISS_sum / FETCH_SIZE / WRITE_SIZE)
+into profiles/r02_pmc_decode.json: per decode-step kernel role, HBM-side bytes per launch (FETCH_SIZE x 2 - the gfx950 correction of
+MI355X_MICROARCH.md - + WRITE_SIZE, both KiB), L2 hit rate and the kernel-trace average duration.
+usage: pmc_decode_json.py <trace.db> <hitmiss.db> <fetch.db> <write.db> <rows> > out.json"""
+import json, sqlite3, sys
+trace, hm, fe, wr, rows = sys.argv[1:6]
+ROLE = [("step_lstm_cell", lambda n, g: "skinny" in n and g[2] == 1 and g[0] * g[1] >= 128 * 512 // 1),      # refined below by grid
+        ]
+def table(db):
+    c = sqlite3.connect(db)
+    t = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')") if r[0].startswith("counters_collection")][0]
+    return list(c.execute(f"select kernel_name, grid_size_x, grid_size_y, grid_size_z, counter_name, avg(value), count(*) from {t} group by 1,2,3,4,5"))
+def role_of(name, gz, n_launch):
+    if "step_attn_kernel" in name: return "step_attention_prenet2"
+    if "skinny" in name and gz == 4: return "step_prenet1_q_cq_fc"
+    if "skinny" in name and gz == 1 and n_launch >= 250: return "step_lstm_cell"
+    return None
+out = {}
+for db in (hm, fe, wr):
+    for name, gx, gy, gz, cname, avg, n in table(db):
+        r = role_of(name, gz, n)
+        if r is None: continue
+        d = out.setdefault(r, {"_w": {}})
+        # several instances may serve one role (LSTM layer 0 / layer 1): launch-weighted mean
+        acc = d["_w"].setdefault(cname, [0.0, 0])
+        acc[0] += avg * n; acc[1] += n
+        d.setdefault("kernel_symbols", set()).add(f"{name[:60]} grid {gx}x{gy}x{gz}")
+c = sqlite3.connect(trace)
+dur = {}
+for name, gx, gy, gz, n, avg in c.execute("select name, grid_x, grid_y, grid_z, count(*), avg(duration) from kernels group by 1,2,3,4"):
+    r = role_of(name, gz // 1 if gz else 1, n) if "skinny" in name or "step_attn" in name else None
+    if r:
+        a = dur.setdefault(r, [0.0, 0]); a[0] += avg * n; a[1] += n
+res = {"note": "rocprofv3 passes over tools/prof_decode.py (3 x 300 decode steps, ROWS clips per launch = 8 batches of 32 per chain) on MI355X: one kernel-trace pass and one "
+               "--pmc pass per counter set (TCC_HIT_sum+TCC_MISS_sum / FETCH_SIZE / WRITE_SIZE). FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md gfx950 "
+               "FETCH_SIZE counts wide coalesced reads at half their bytes, so read bytes = 2*FETCH_SIZE*1024. The counters sit at the L2's memory side: they include "
+               "Infinity-Cache hits (the step weights never leave the Infinity Cache), so this is fabric traffic, not DRAM traffic.",
+       "rows_per_launch": int(rows), "kernels": {}}
+for r, d in out.items():
+    w = {k: v[0] / v[1] for k, v in d["_w"].items()}
+    k = {"kernel_symbols": sorted(d["kernel_symbols"]), **w}
+    if "FETCH_SIZE" in w and "WRITE_SIZE" in w:
+        k["read_bytes"] = 2 * w["FETCH_SIZE"] * 1024; k["write_bytes"] = w["WRITE_SIZE"] * 1024
+        k["traffic_bytes_per_launch"] = k["read_bytes"] + k["write_bytes"]
+    if "TCC_HIT_sum" in w: k["l2_hit_rate"] = w["TCC_HIT_sum"] / (w["TCC_HIT_sum"] + w["TCC_MISS_sum"])
+    if r in dur: k["avg_us_rocprofv3"] = dur[r][0] / dur[r][1] / 1e3
+    res["kernels"][r] = k
+print(json.dumps(res, indent=1))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Run only the decode loop (prologue once, then 3 x 300 steps at B=32) - for rocprofv3 counter passes."""
+"""Run only the decode loop (prologue once, then REPS x 300 steps over ROWS clips; ROWS = 32 x batches per launch chain, default 256) - for
+rocprofv3 counter passes."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,10 +8,11 @@ from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
 nm = native.NativeModel()
 nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
-B, T, S = 32, 29, 300
-v = synth.synth_video(B, T, tag="bench").cuda()
-emb = synth.synth_speaker_embedding(B, tag="bench").cuda()
-gum = synth.synth_gumbel(B * 4, tag="bench").cuda()
+B, T, S = int(os.environ.get("ROWS", "256")), 29, 300
+G = B // 32
+v = synth.synth_video(32, T, tag="bench").cuda().repeat(G, 1, 1, 1, 1)
+emb = synth.synth_speaker_embedding(32, tag="bench").cuda().repeat(G, 1)
+gum = synth.synth_gumbel(32 * 4, tag="bench").cuda().repeat(G, 1)
 feat = nm.encoder_fwd(v)
 state, _ = nm.decoder_prologue(native.build_visual(feat, emb), emb, gum)
 for _ in range(int(os.environ.get("REPS", "3"))):

@@ -15,7 +15,13 @@ g = torch.full((38_436_836,), float(rank + 1), device="cuda")
 red = GradAllReducer(g)
 for _ in range(3):
     g.fill_(float(rank + 1)); torch.cuda.synchronize(); t0 = time.perf_counter()
-    red.start(); mul = red.wait(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if world > 1:
+        red.start(); mul = red.wait()
+    else:                                   # GradAllReducer skips the collective on one rank; call RCCL on its buckets directly
+        work = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in red.buckets]
+        for w in work: w.wait()
+        mul = 1.0
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
 want = sum(range(1, world + 1))
 print(f"rank {rank}: RCCL all-reduce of 153.7 MB in {len(red.buckets)} buckets over {world} rank(s): {dt*1e3:.2f} ms, sum ok = {bool((g == want).all())}, 1/world = {mul}", flush=True)
 dist.destroy_process_group()
