@@ -190,6 +190,7 @@ def train_main(args):
     mask[1::2] = True                                   # half of the steps teacher-forced (tf_ratio 0.5 regime)
 
     nm.train_set_bn(True, 0.1)
+    nm.set_option("train_bf16", 1 if args.bf16 else 0)
 
     def step():
         drop = draw_dropout(Bt, T, St, video.device)
@@ -247,7 +248,8 @@ def train_main(args):
         print(json.dumps({
             "metric": "training clips/sec (forward + loss + backward + all-reduce + clip + AdamW-amsgrad + weight re-pack)",
             "value": world * Bt * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 operands / f32 accumulate in encoder, prologue and post-net GEMMs; f32 loop, statistics, master weights" if args.bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": "LRW training step, batch=8 per GPU, 29x96x96 clips, S=77 mel targets, half of the steps teacher-forced, "
                                    "38.4 M parameters, train() semantics (batch-statistics BatchNorm, dropout)", "batch_per_gpu": Bt, "frames": T,
@@ -284,6 +286,8 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
     ap.add_argument("--group", type=int, default=8, help="independent B=32 batches advanced per launch chain (l2s_inference_multi, 1..8); 1 = one batch per chain")
     ap.add_argument("--inflight", type=int, default=2, help="launch chains in flight per GPU (HIP streams + host threads); 1 = strictly sequential chains")
+    ap.add_argument("--bf16", action="store_true", help="--mode train: bf16 operands in the GEMMs / Conv1d stacks of encoder, prologue and post-net "
+                    "(option train_bf16; BASELINE.json configs[2] names bf16), fp32 accumulation / master weights / recurrent loop")
     ap.add_argument("--mode", choices=["inference", "train"], default="inference",
                     help="inference = the headline metric (default); train = one data-parallel training step per 'step' (SURVEY.md §8 config 3)")
     args = ap.parse_args()

@@ -300,6 +300,9 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
  *   "frontend_x3"       (1)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path; 0 = f32 MFMA kernel
+ *   "train_bf16"        (0)  TRAINING entry points (encoder, prologue, post-net; forward and backward): GEMMs / Conv1d stacks round their operands to
+ *                            bf16 (RNE) on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 results; the
+ *                            recurrent loop, the Conv3d front-end, BatchNorm statistics, master weights and optimizer stay fp32
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
  *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
 int l2s_set_option(const char* name, int value);

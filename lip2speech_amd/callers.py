@@ -83,15 +83,19 @@ def reconstruction_losses(outputs, targets) -> dict:
 
 
 def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_ratio: float = 0.0, lr: float = 1e-4, weight_decay: float = 1e-6,
-                     grad_clip: float = 1.0, fused_optimizer: bool = True, device="cuda") -> List[dict]:
+                     grad_clip: float = 1.0, fused_optimizer: bool = True, device="cuda", bf16: bool = False) -> List[dict]:
     """The model-facing half of `train.py`'s loop (train.py:102-104,150-193): `net.train()`; cycle through the collated batches
     (`tf_ratio += 0.1` every 10 epochs); forward -> 4-term loss -> `backward()` -> gradient all-reduce when a process group is up
     (one process per GPU) -> clip at `grad_clip` -> AdamW(amsgrad) on the decoder and encoder groups.  Returns the per-iteration loss
-    log (python floats; the `.item()` calls are this loop's only host synchronisations, like the reference's `loss_log`)."""
+    log (python floats; the `.item()` calls are this loop's only host synchronisations, like the reference's `loss_log`).
+    `bf16=True`: the training entry points run their GEMMs with bf16 operands (option "train_bf16", include/l2s.h)."""
     from .losses import Loss
     from .training import AdamWAmsgrad, GradAllReducer
     net.train()
     flat = net._train_state()
+    # reduced-precision training (the reference's switch is hparams.fp16_run = apex O2, train.py:106-107,180-191): here bf16 OPERANDS in the
+    # GEMMs / Conv1d stacks of encoder, prologue and post-net on the bf16 matrix cores, fp32 accumulation, fp32 master weights, fp32 loop
+    net.native_model().set_option("train_bf16", 1 if bf16 else 0)
     reducer = GradAllReducer(flat.grad)          # no-op without a process group; both optimizer routes reduce (ranks must not diverge)
     reconstruction_criterion = Loss()
     if fused_optimizer:

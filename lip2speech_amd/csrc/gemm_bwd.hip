@@ -8,6 +8,7 @@
 //
 // Reference semantics: autograd of nn.Linear / nn.Conv1d in /root/reference/model/modules/decoder.py (train.py:184 loss.backward()).
 #include "l2s_common.h"
+#include "gemm_dev.h"
 
 #include <algorithm>
 
@@ -21,7 +22,17 @@ __device__ __forceinline__ void stage_transposed(float* S, int r0, int c4, const
     S[(c4 + 0) * TLD + r0 + 16] = v1.x; S[(c4 + 1) * TLD + r0 + 16] = v1.y; S[(c4 + 2) * TLD + r0 + 16] = v1.z; S[(c4 + 3) * TLD + r0 + 16] = v1.w;
 }
 
-template <int MODE>
+// bf16 form of the transposed staging: S[col][row] as bf16, rows of GD_BROW bytes
+__device__ __forceinline__ void stage_transposed_bf16(unsigned char* S, int r0, int c4, const float4& v0, const float4& v1) {
+    const float a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<unsigned short*>(S + (c4 + e) * GD_BROW + r0 * 2) = gd_bf16(a[e]);
+        *reinterpret_cast<unsigned short*>(S + (c4 + e) * GD_BROW + (r0 + 16) * 2) = gd_bf16(b[e]);
+    }
+}
+
+template <int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
     const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
     __shared__ __attribute__((aligned(16))) float As[TB * TLD];
@@ -98,13 +109,24 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
         else { ra[j] = load_dw_a(j, kt_begin * TK); rb[j] = load_dw_b(j, kt_begin * TK); }
     }
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (MODE == BWD_DX) {
+        if (BF16) {
+            unsigned char* Ab = reinterpret_cast<unsigned char*>(As);
+            if (MODE == BWD_DX) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(lr + 32 * j) * TLD + kq]) = ra[j];
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<uint2*>(Ab + (lr + 32 * j) * GD_BROW + kq * 2) = gd_pack4(ra[j]);
+            } else {
+                stage_transposed_bf16(Ab, r0, c4, ra[0], ra[1]);
+            }
+            stage_transposed_bf16(reinterpret_cast<unsigned char*>(Bs), r0, c4, rb[0], rb[1]);
         } else {
-            stage_transposed(As, r0, c4, ra[0], ra[1]);
+            if (MODE == BWD_DX) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(lr + 32 * j) * TLD + kq]) = ra[j];
+            } else {
+                stage_transposed(As, r0, c4, ra[0], ra[1]);
+            }
+            stage_transposed(Bs, r0, c4, rb[0], rb[1]);
         }
-        stage_transposed(Bs, r0, c4, rb[0], rb[1]);
         __syncthreads();
         if (kt + 1 < kt_end) {
             const int k0 = (kt + 1) * TK;
@@ -114,16 +136,20 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
                 else { ra[j] = load_dw_a(j, k0); rb[j] = load_dw_b(j, k0); }
             }
         }
-        const float* ap = &As[(wm * 32 + li) * TLD + 4 * lg];
-        const float* bp = &Bs[(wn * 32 + li) * TLD + 4 * lg];
+        if (BF16) {
+            acc = gd_mma_tile_bf16(reinterpret_cast<const unsigned char*>(As), reinterpret_cast<const unsigned char*>(Bs), wm, wn, li, lg, acc);
+        } else {
+            const float* ap = &As[(wm * 32 + li) * TLD + 4 * lg];
+            const float* bp = &Bs[(wn * 32 + li) * TLD + 4 * lg];
 #pragma unroll
-        for (int c = 0; c < TK / 8; ++c) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
-            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            for (int c = 0; c < TK / 8; ++c) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -154,8 +180,11 @@ int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
     L2S_REQUIRE(p.ksplit <= 1 || (!p.accumulate && p.c_T == 0), "split-K writes plain partial matrices (reduced by launch_gemm_bwd_splitk)");
     dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB, p.ksplit > 1 ? p.ksplit : 1);
     ProfScope ps(name, s);
-    if (p.mode == BWD_DX) hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DX>, grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(gemm_bwd_kernel<BWD_DW>, grid, dim3(256), 0, s, q);
+    const bool bf16 = gemm_bf16_mode() != 0;                 // option "train_bf16"
+    if (p.mode == BWD_DX && bf16) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DX, true>), grid, dim3(256), 0, s, q);
+    else if (p.mode == BWD_DX) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DX, false>), grid, dim3(256), 0, s, q);
+    else if (bf16) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DW, true>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DW, false>), grid, dim3(256), 0, s, q);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -29,4 +29,26 @@ __device__ __forceinline__ void gemm_store(const GemmP& p, int row, int col, flo
     }
 }
 
+// ---- bf16-operand mode of the training GEMMs (option "train_bf16"): operands rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on
+// their way into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  LDS tile = [64 rows][32 k] bf16, rows of 80 bytes (64 + 16 pad:
+// conflict-free ds_read_b128 for the 32x32x16 operand layout: lane l reads the 8 consecutive k of row l&31 at k offset 8*(l>>5)).
+typedef __bf16 gd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gd_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GD_BROW = 80;            // bytes per bf16 LDS row
+__device__ __forceinline__ unsigned gd_pack2(float a, float b) { gd_bf16x2 v = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ uint2 gd_pack4(const float4& v) { return make_uint2(gd_pack2(v.x, v.y), gd_pack2(v.z, v.w)); }
+__device__ __forceinline__ unsigned short gd_bf16(float a) { return __builtin_bit_cast(unsigned short, (__bf16)a); }
+// the two K steps of a 64x64x32 tile for this wave's 32x32 sub-tile
+__device__ __forceinline__ f32x16 gd_mma_tile_bf16(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int li, int lg, f32x16 acc) {
+    const unsigned char* ap = As + (wm * 32 + li) * GD_BROW + lg * 16;
+    const unsigned char* bp = Bs + (wn * 32 + li) * GD_BROW + lg * 16;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const gd_bf16x8 a = *reinterpret_cast<const gd_bf16x8*>(ap + st * 32);
+        const gd_bf16x8 b = *reinterpret_cast<const gd_bf16x8*>(bp + st * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 }  // namespace l2s

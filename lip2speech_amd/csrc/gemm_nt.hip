@@ -67,7 +67,7 @@ __device__ __forceinline__ float4 load_w(const LoadP& p, const float* wrow, bool
     }
 }
 
-template <int VEC>
+template <int VEC, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const GemmP& p = batch.p[blockIdx.z];
     // XCD-aware tile order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (private L2s), so give each XCD a
@@ -165,8 +165,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(&As[(lr + 32 * j) * LDS_LD + kq]) = ra[j];
-            *reinterpret_cast<float4*>(&Bs[(lr + 32 * j) * LDS_LD + kq]) = rb[j];
+            if (BF16) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(As) + (lr + 32 * j) * GD_BROW + kq * 2) = gd_pack4(ra[j]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(Bs) + (lr + 32 * j) * GD_BROW + kq * 2) = gd_pack4(rb[j]);
+            } else {
+                *reinterpret_cast<float4*>(&As[(lr + 32 * j) * LDS_LD + kq]) = ra[j];
+                *reinterpret_cast<float4*>(&Bs[(lr + 32 * j) * LDS_LD + kq]) = rb[j];
+            }
         }
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -185,16 +190,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
                 }
             }
         }
-        const float* ap = &As[(wm * 32 + li) * LDS_LD + 4 * lg];
-        const float* bp = &Bs[(wn * 32 + li) * LDS_LD + 4 * lg];
+        if (BF16) {
+            acc = gd_mma_tile_bf16(reinterpret_cast<const unsigned char*>(As), reinterpret_cast<const unsigned char*>(Bs), wm, wn, li, lg, acc);
+        } else {
+            const float* ap = &As[(wm * 32 + li) * LDS_LD + 4 * lg];
+            const float* bp = &Bs[(wn * 32 + li) * LDS_LD + 4 * lg];
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
-            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            for (int c = 0; c < BK / 8; ++c) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -257,6 +266,7 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 
 int& gemm_x3_mode() { static thread_local int mode = 0; return mode; }
 int& gemm_x3_group() { static thread_local int group = 1; return group; }
+int& gemm_bf16_mode() { static thread_local int mode = 0; return mode; }
 
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
@@ -280,10 +290,11 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
     if (x3 && gemm_x3_eligible(b)) return launch_gemm_x3(b, s, name);
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
     ProfScope ps(name, s);
-    if (vec4)
-        hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, b);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), 0, s, b);
+    const bool bf16 = gemm_bf16_mode() != 0;                 // training, option "train_bf16": bf16 operands, fp32 accumulation
+    if (vec4 && bf16) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), grid, dim3(256), 0, s, b);
+    else if (vec4) hipLaunchKernelGGL((gemm_nt_kernel<4, false>), grid, dim3(256), 0, s, b);
+    else if (bf16) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, dim3(256), 0, s, b);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -29,7 +29,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
-        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}};
+        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16}};
     for (auto& t : table)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
     return 1;

@@ -57,6 +57,7 @@ struct Options {
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
     int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)
+    int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
 };
 int set_option_field(Options& o, const char* name, int value);    // 0 = ok, 1 = unknown name
 
@@ -109,6 +110,11 @@ int& gemm_x3_mode();                     // thread-local
 int& gemm_x3_group();                    // thread-local: batches per launch chain (1 outside l2s_inference_multi)
 struct X3Scope { int prev; explicit X3Scope(int on) : prev(gemm_x3_mode()) { gemm_x3_mode() = on; } ~X3Scope() { gemm_x3_mode() = prev; } };
 struct X3Group { int prev; explicit X3Group(int g) : prev(gemm_x3_group()) { gemm_x3_group() = g; } ~X3Group() { gemm_x3_group() = prev; } };
+// bf16-operand mode of the TRAINING GEMMs (forward gemm_nt.hip and backward gemm_bwd.hip; option "train_bf16"): operands rounded to bf16
+// (RNE) while they are staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results.  Thread-local, opened by the l2s_train_*
+// entry points; the recurrent loop, the front-end conv, BatchNorm statistics and every elementwise kernel stay fp32.
+int& gemm_bf16_mode();
+struct Bf16Scope { int prev; explicit Bf16Scope(int on) : prev(gemm_bf16_mode()) { gemm_bf16_mode() = on; } ~Bf16Scope() { gemm_bf16_mode() = prev; } };
 bool gemm_x3_eligible(const GemmBatch& b);
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name);
 // split-K for plain GEMMs whose 64x64 tiles are too few to fill the chip (M <= 128 rows in the content path, the B-row Linears):

@@ -1557,6 +1557,7 @@ int l2s_train_prologue_fwd(l2s_model* m, const float* vis, const float* emb, con
                            float* tape, void* ws, int64_t ws_bytes, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && vis && emb && gumbel && state && tape && ws, "bad arguments");
     L2S_REQUIRE(B >= 1 && B <= 96, "sizes");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return prologue_train_fwd(m, vis, emb, gumbel, B, T, state, content_dis, tape, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1566,6 +1567,7 @@ int l2s_train_prologue_bwd(l2s_model* m, const float* vis, const float* emb, int
     L2S_REQUIRE(m && m->finalized && m->has_dec && vis && emb && state && tape && wbuf && dk && dv && dckey && dcval && dh_init && de_c && dvis && ws, "bad arguments");
     L2S_REQUIRE(B >= 1 && B <= 96 && T >= 7 && T <= L2S_MAX_STEPS, "sizes");
     L2S_REQUIRE(m->canon("decoder.encoder_rnn.weight_hh_l0") != nullptr, "parameters not bound (l2s_train_bind)");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return prologue_train_bwd(m, vis, emb, B, T, state, tape, wbuf, dk, dv, dckey, dcval, dh_init, de_c, dcontent_dis, dvis, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1576,6 +1578,7 @@ int64_t l2s_train_postnet_ws_bytes(int B, int S) {
 
 int l2s_train_postnet_fwd(l2s_model* m, const float* mel, int B, int S, float* tape, float* mel_post, const float* drop, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && mel && tape && mel_post, "bad arguments");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return postnet_train_fwd(m, mel, B, S, tape, mel_post, drop, (hipStream_t)stream);
 }
 
@@ -1583,6 +1586,7 @@ int l2s_train_postnet_bwd(l2s_model* m, const float* mel, const float* dmel_post
                           int64_t ws_bytes, void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_dec && mel && dmel_post && tape && dmel && ws, "bad arguments");
     L2S_REQUIRE(m->canon("decoder.postnet.convolutions.0.1.weight") != nullptr, "parameters not bound (l2s_train_bind)");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return postnet_train_bwd(m, mel, dmel_post, B, S, tape, dmel, drop, ws, ws_bytes, (hipStream_t)stream);
 }
 

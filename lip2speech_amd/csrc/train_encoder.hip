@@ -610,6 +610,7 @@ int l2s_train_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H,
     L2S_REQUIRE(m && m->finalized && m->has_enc && video && tape && (vis || feat), "bad arguments");
     L2S_REQUIRE(B >= 1 && T >= 1 && H == W && (H == 96 || H == 88), "sizes");
     L2S_REQUIRE(!vis || emb, "the visual sequence needs the speaker embedding");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return encoder_train_fwd(m, video, B, T, H, W, emb, vis, feat, tape, (hipStream_t)stream);
 }
 
@@ -617,6 +618,7 @@ int l2s_train_encoder_bwd(l2s_model* m, const float* video, int B, int T, int H,
                           void* stream) {
     L2S_REQUIRE(m && m->finalized && m->has_enc && video && dfeat && tape && ws, "bad arguments");
     L2S_REQUIRE(B >= 1 && T >= 1 && H == W && (H == 96 || H == 88) && ld_dfeat >= LAST_CH, "sizes");
+    Bf16Scope bf16scope(m->opt.train_bf16);      // GEMMs / Conv1d stacks with bf16 operands when the model asks for it (fp32 accumulation)
     return encoder_train_bwd(m, video, B, T, H, W, dfeat, ld_dfeat, tape, ws, ws_bytes, (hipStream_t)stream);
 }
 
