@@ -315,7 +315,9 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
 
     float4 a[MAXC][RT], w[MAXC][CT];
     auto load_chunk = [&](int j) {
-        const int c = wave + SK_WAVES * j;          // wave-uniform
+        const int c = wave + SK_WAVES * j;          // wave-uniform (starting the K walk at a different chunk per block - so that the blocks of an
+                                                    // XCD do not ask its L2 for the same lines at the same time - measured no gain: 10.7 vs 10.9 us at
+                                                    // 128 rows, 18.7 vs 17.8 at 256)
         if (c < NC) {
             const float* ab = sa0; int lc = c, nn = n0;
             if (c >= e2) { ab = sa3; lc = c - e2; nn = n3; }

@@ -11,14 +11,14 @@ nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd
 G = int(os.environ.get("G", 4))
 parts = [(synth.synth_video(32, T, tag=f"g{g}").cuda(), synth.synth_speaker_embedding(32, tag=f"g{g}").cuda(), synth.synth_gumbel(128, tag=f"g{g}").cuda()) for g in range(G)]
 big = tuple(torch.cat([p[i] for p in parts]) for i in range(3))
-native.set_option("skinny_rc", 11)
+nm.set_option("skinny_rc", 11)
 ref = [nm.inference(*p, S=S, want_attn=True) for p in parts]
 ref = tuple(torch.cat([r[i] for r in ref]) for i in range(3))
 one = nm.inference(*big, S=S, want_attn=True)
 print("B=%d 1x1 blocks vs %d x B=32: mel equal %s lengths equal %s attn equal %s" % (32 * G, G, torch.equal(one[0], ref[0]), torch.equal(one[1], ref[1]), torch.equal(one[2], ref[2])))
 for shape in (0, 21, 22, 42):
     for jb in (4, 2):
-        native.set_option("skinny_rc", shape); native.set_option("skinny_rc_jb", jb)
+        nm.set_option("skinny_rc", shape); nm.set_option("skinny_rc_jb", jb)
         out = nm.inference(*big, S=S, want_attn=True)
         ok = all(torch.equal(out[i], ref[i]) for i in range(3))
         torch.cuda.synchronize(); t0 = time.perf_counter()

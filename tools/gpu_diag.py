@@ -68,7 +68,7 @@ def encoder_stages():
     frames = g["frames"].tolist()
     line("frontend3d vs golden taps", pc.maxdiff(full[frames], g["oracle_frontend"].permute(0, 2, 3, 1)), 2e-5)
     for fuse in (0, 1):
-        native.set_option("fuse_trunk", fuse)
+        nm.set_option("fuse_trunk", fuse)
         feat = nm.encoder_fwd(video.cuda())
         line(f"fuse_trunk={fuse} encoder feat vs reference golden", pc.maxdiff(feat, g["feat"]), 1e-5)
         v32 = synth.synth_video(32, 29, tag="bench").cuda()
@@ -99,7 +99,7 @@ def decoder_stages():
     fg = pc.golden("forward_lrw_b2_s77.npz")
     line("prologue content_dis", pc.maxdiff(dis, fg["content_dis"]), 1e-6)
     for fold, graph in ((0, 0), (1, 0), (0, 1), (1, 1)):
-        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph)
+        nm.set_option("fold_step_weights", fold); nm.set_option("use_graph", graph)
         for Sx in (3, 77, 300):
             mel, stop, attn = nm.decode_steps(state, B, T, Sx, want_attn=True)
             line(f"fold{fold} graph{graph} decode S={Sx} mel_pre", pc.maxdiff(mel.permute(0, 2, 1), g["oracle_mel_pre"][:, :, :Sx]), 1e-3)
@@ -119,18 +119,18 @@ def decoder_stages():
     line("postnet alone (oracle mel in)", pc.maxdiff(post_only, g["mel_post"]), 1e-4)
     lens = native.output_lengths(stop)
     print("   output_lengths", lens.tolist(), "golden", g["output_lengths"].tolist())
-    native.set_option("fold_step_weights", 1); native.set_option("use_graph", 0)
+    nm.set_option("fold_step_weights", 1); nm.set_option("use_graph", 0)
     for ov in (0, 1, 1):
-        native.set_option("overlap_postnet", ov)
+        nm.set_option("overlap_postnet", ov)
         t0 = time.time()
         mp, ln, at = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=300, want_attn=True)
         torch.cuda.synchronize()
         line(f"overlap_postnet={ov} l2s_inference mel_post", pc.maxdiff(mp, g["mel_post"]), 1e-3)
         print(f"   l2s_inference B=2 wall {time.time() - t0:.3f}s lengths {ln.tolist()}")
     for Sx in (5, 13, 70, 130):
-        native.set_option("overlap_postnet", 0)
+        nm.set_option("overlap_postnet", 0)
         a, _, _ = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=Sx)
-        native.set_option("overlap_postnet", 1)
+        nm.set_option("overlap_postnet", 1)
         b, _, _ = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=Sx)
         line(f"overlap vs sequential post-net, S={Sx}", pc.maxdiff(a, b), 1e-12)
 
@@ -142,7 +142,7 @@ def timing():
     emb = synth.synth_speaker_embedding(B, tag="bench").cuda()
     gum = synth.synth_gumbel(B * 4, tag="bench").cuda()
     for fold, graph, ov in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 1)):
-        native.set_option("fold_step_weights", fold); native.set_option("use_graph", graph); native.set_option("overlap_postnet", ov)
+        nm.set_option("fold_step_weights", fold); nm.set_option("use_graph", graph); nm.set_option("overlap_postnet", ov)
         for it in range(4):
             torch.cuda.synchronize(); t0 = time.time()
             nm.inference(video, emb, gum, S=S)

@@ -11,7 +11,7 @@ for B in (32, 64, 128, 256):
     row = []
     for shape in (11, 21, 22, 42):
         for jb in (4, 2):
-            native.set_option("skinny_rc", shape); native.set_option("skinny_rc_jb", jb)
+            nm.set_option("skinny_rc", shape); nm.set_option("skinny_rc_jb", jb)
             us = min(nm.lstm_cell_chain_us(B, 300) for _ in range(3))
             fl = 2 * B * 2048 * (1536 + 1024) / 2
             row.append(f"{shape}/jb{jb}: {us:6.2f} us ({fl/us/1e6:5.1f} TF)")

@@ -9,7 +9,7 @@ nm = native.NativeModel()
 nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
 B, T, S = 32, 29, 300
 for kv in filter(None, os.environ.get("L2S_OPTS", "").split(",")):
-    k, v = kv.split("="); native.set_option(k, int(v))
+    k, v = kv.split("="); nm.set_option(k, int(v))
 v = synth.synth_video(B, T, tag="bench").cuda()
 emb = synth.synth_speaker_embedding(B, tag="bench").cuda()
 gum = synth.synth_gumbel(B * 4, tag="bench").cuda()
