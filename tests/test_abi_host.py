@@ -133,3 +133,17 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"
+
+
+def test_bench_refuses_to_report_more_gpus_than_it_sees():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself - and must fail loudly when fewer than N devices are visible
+    (this container has none) instead of measuring one GPU and printing `n_gpus: 1`."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing to report" in (r.stdout + r.stderr), r.stdout + r.stderr
+    # a launcher / --gpus mismatch is an error too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
