@@ -358,12 +358,19 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
             }
         }
     }
-    float pf_c = 0.f;
-    const int q2 = tid >> 6, t64 = tid & 63;
-    const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
-    const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
-    const bool cell_on = epi == SK_LSTM && q2 < NT && t2 < ntiles && rt2 < mts && b2 < nB;
-    if (cell_on) pf_c = c_in[frag16_index(b2, unit2, H)];
+    // LSTM cells: thread (q2 = tid>>6 (+8 per round), t64) owns (row t64>>2, unit t64&3) of tile q2; NT <= 8 tiles need one round, 16 two
+    constexpr int NCR = (NT + 7) / 8;
+    const int t64 = tid & 63;
+    float pf_c[NCR];
+    bool cell_on[NCR];
+#pragma unroll
+    for (int cr = 0; cr < NCR; ++cr) {
+        const int q2 = (tid >> 6) + 8 * cr;
+        const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
+        const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
+        cell_on[cr] = epi == SK_LSTM && q2 < NT && t2 < ntiles && rt2 < mts && b2 < nB;
+        pf_c[cr] = cell_on[cr] ? c_in[frag16_index(b2, unit2, H)] : 0.f;
+    }
 
     f32x4 acc[NT][2];
 #pragma unroll
@@ -430,11 +437,16 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
     }
     if (epi != SK_LSTM) return;
     __syncthreads();
-    if (cell_on) {
+#pragma unroll
+    for (int cr = 0; cr < NCR; ++cr) {
+        if (!cell_on[cr]) continue;
+        const int q2 = (tid >> 6) + 8 * cr;
+        const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
+        const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
         const int r2 = t64 >> 2, u2 = t64 & 3;
         const float* g4 = gt + (q2 * 16 + r2) * 17 + 4 * u2;
         const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
-        const float cn = sigmoidf_(gf) * pf_c + sigmoidf_(gi) * tanhf(gg);
+        const float cn = sigmoidf_(gf) * pf_c[cr] + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
         p.c_out[frag16_index(b2, unit2, H)] = cn;
         p.h_out[frag16_index(b2, p.h_out_off + unit2, p.h_out_K)] = hn;

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
 nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
-for B in (32, 64, 128, 256):
+for B in (32, 64, 128, 256, 512):
     nm.workspace(B, 29, 96, 96, 300, torch.device("cuda", 0))
     row = []
     for shape in (11, 21, 22, 42):
