@@ -89,7 +89,7 @@ class Lip2Speech(NativeBacked):
         self.encoder.__dict__["_native_parent"] = self
         self.decoder.__dict__["_native_parent"] = self
 
-    def _tensors(self):
+    def _collect_tensors(self):
         sd = self.state_dict(keep_vars=True)
         return {k: v for k, v in sd.items() if k.startswith(("encoder.", "decoder."))}
 

@@ -54,7 +54,31 @@ class NativeBacked(nn.Module):
         self.__dict__["_native_parent"] = None
 
     def _tensors(self):
+        """The module's tensors by checkpoint key.  The dict is cached (walking ~600 state_dict entries costs ~1 ms per call - more than a
+        tenth of a B=32 pass) and dropped whenever the module tree can have changed its tensor OBJECTS: `.to()/.cuda()/.float()` (`_apply`)
+        and `load_state_dict`.  In-place updates keep the objects and show up in the version part of the signature."""
+        cache = self.__dict__.get("_tensor_cache")
+        if cache is None:
+            cache = self._collect_tensors()
+            self.__dict__["_tensor_cache"] = cache
+        return cache
+
+    def _collect_tensors(self):
         return {self._key_prefix + k: v for k, v in self.state_dict(keep_vars=True).items()}
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_tensor_cache"] = None
+        for mod in self.modules():
+            if isinstance(mod, NativeBacked):
+                mod.__dict__["_tensor_cache"] = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        for mod in self.modules():
+            if isinstance(mod, NativeBacked):
+                mod.__dict__["_tensor_cache"] = None
+        return out
 
     def _signature(self, tensors):
         return tuple((t.data_ptr(), t._version) for t in tensors.values())
@@ -84,7 +108,8 @@ class NativeBacked(nn.Module):
         return self.__dict__["_native"]
 
     def mark_weights_changed(self):
-        """Call after updating parameters behind autograd's back (the fused optimizer writes the flat buffer directly): the packed
+        """Call after updating parameters behind autograd's back - the fused optimizer writes the flat buffer directly, and writes through
+        `p.data` (`p.data.clamp_()`, `p.data.copy_()`) bump no version counter, so `native_model()` cannot see them: the packed
         blob is rebuilt - on the device when the training state is set up (l2s_train_refresh_weights), else from the host on next use."""
         target = self.__dict__.get("_native_parent") or self
         if target.__dict__.get("_refresh_on_device") and target.__dict__.get("_native") is not None:
