@@ -392,7 +392,7 @@ def main():
     fwd_elapsed, _ = timed(lambda: pool4.map(work(args.steps), fn=fwd))
     # the boundary handed HOST buffers (pinned): every step first copies its 102.6 MB of frames, the speaker embedding and the Gumbel
     # noise to the GPU on its own stream, overlapping the other chains' compute.  Never `value` (inputs resident there).
-    host_batches = [tuple(t.cpu().pin_memory() for t in b) for b in batches[:4]]
+    host_batches = [tuple(t.cpu().pin_memory() for t in batches[i % n_distinct]) for i in range(4)]
     h2d = lambda model, b: model.inference(*(t.cuda(non_blocking=True) for t in b), S=S)      # noqa: E731
     pool4.map(host_batches, fn=h2d)
     h2d_elapsed, _ = timed(lambda: pool4.map([host_batches[i % 4] for i in range(args.steps)], fn=h2d))
