@@ -42,5 +42,5 @@ for G in [int(g) for g in os.environ.get("G", "1,2,4").split(",")]:
     native.profile_enable(False)
     tot = sum(r[2] for r in prof)
     print(f"  event-bracketed kernel time {tot:.2f} ms:")
-    for name, launches, ms in prof[:14]:
+    for name, launches, ms in prof[:int(os.environ.get("TOP", 14))]:
         print(f"    {name:40s} {launches:5d} x {ms/launches*1e3:8.1f} us = {ms:7.3f} ms")
