@@ -102,17 +102,21 @@ class InflightPool:
         """The per-worker model handles - all the same object (one weight blob)."""
         return [self.model] * len(self.streams)
 
-    def map(self, batches: Sequence, S: int = 300, want_attn: bool = False, fn: Callable = None) -> List:
+    def map(self, batches: Sequence, S: int = 300, want_attn: bool = False, fn: Callable = None, prepare: Callable = None, shape_of: Callable = None) -> List:
         """Run `inference` on every (video, emb, gumbel) of `batches`.  Consecutive batches form groups of `self.group` (the last one may be
         smaller; batches of a group must share one shape, so a shape change also closes a group); worker i takes the next unclaimed group
-        (dynamic schedule).  `fn(model, batch)` replaces the default call and is applied batch by batch (no grouping)."""
+        (dynamic schedule).  `fn(model, batch)` replaces the default call and is applied batch by batch (no grouping).
+        `prepare(batch) -> (video, emb, gumbel)` runs on the worker's stream right before a batch is used - e.g. the host-to-device copy
+        of packed uint8 frames and their normalisation (`datasets.device.PackedFrames.to_device`), which then overlaps the other chains'
+        compute; with it `shape_of(batch)` must give the (B,3,T,H,W) shape the batch will have (groups are formed before preparation)."""
+        shape = (lambda b: tuple(shape_of(b))) if shape_of is not None else (lambda b: tuple(b[0].shape))
         items: List[List[int]] = []
         if fn is not None or self.group == 1:
             items = [[i] for i in range(len(batches))]
         else:
             cur: List[int] = []
             for i, b in enumerate(batches):
-                if cur and (len(cur) == self.group or tuple(batches[cur[0]][0].shape) != tuple(b[0].shape)):
+                if cur and (len(cur) == self.group or shape(batches[cur[0]]) != shape(b)):
                     items.append(cur)
                     cur = []
                 cur.append(i)
@@ -138,11 +142,12 @@ class InflightPool:
                             break
                         if fn is not None:
                             out[idx[0]] = fn(self.model, batches[idx[0]])
-                        elif len(idx) == 1:
-                            video, emb, gumbel = batches[idx[0]]
-                            out[idx[0]] = self.model.inference(video, emb, gumbel, S=S, want_attn=want_attn)
+                            continue
+                        grp = [prepare(batches[i]) if prepare is not None else batches[i] for i in idx]
+                        if len(idx) == 1:
+                            out[idx[0]] = self.model.inference(*grp[0], S=S, want_attn=want_attn)
                         else:
-                            for i, r in zip(idx, self.model.inference_multi([batches[i] for i in idx], S=S, want_attn=want_attn)):
+                            for i, r in zip(idx, self.model.inference_multi(grp, S=S, want_attn=want_attn)):
                                 out[i] = r
             except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
                 errors.append(e)

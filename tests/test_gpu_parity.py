@@ -513,6 +513,17 @@ def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
                 assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
     with pytest.raises(ValueError):
         InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=5)
+    # host-resident batches prepared on the worker's stream (uint8 clips -> device normalise) and then grouped: same results
+    from lip2speech_amd.datasets import PackedFrames
+    gen = torch.Generator().manual_seed(5)
+    raw = [(PackedFrames([torch.randint(0, 256, (T, 96, 96, 3), dtype=torch.uint8, generator=gen) for _ in range(B)]), b[1].cpu(), b[2].cpu()) for b in batches[:5]]
+    prep = lambda b: (b[0].to_device(), b[1].cuda(), b[2].cuda())      # noqa: E731
+    want_raw = [tuple(t.clone() for t in nm.inference(*prep(b), S=S, want_attn=True)) for b in raw]
+    pool = InflightPool(model=nm, n_inflight=2, group=2)
+    got = pool.map(raw, S=S, want_attn=True, prepare=prep, shape_of=lambda b: (B, 3, T, 96, 96))
+    torch.cuda.synchronize()
+    for g, w in zip(got, want_raw):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
 
 
 @pytest.mark.gpu
