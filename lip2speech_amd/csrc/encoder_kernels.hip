@@ -612,7 +612,7 @@ void shuffle_set_timeline(unsigned long long* ts, int h) { g_su_ts = ts; g_su_ts
 template <int H, int HALF, int F, bool TIMED>
 __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, unsigned long long* __restrict__ ts) {
     using Q = S1Geo<H, HALF, F>;
-    constexpr int HH = Q::HH, C = Q::C, KP = Q::KP, LDA = Q::LDA, ROWS = Q::ROWS, PPW = Q::PPW, CIT = Q::CIT, CH = Q::CH;
+    constexpr int HH = Q::HH, C = Q::C, KP = Q::KP, LDA = Q::LDA, ROWS = Q::ROWS, PPW = Q::PPW, CIT = Q::CIT;
     extern __shared__ __attribute__((aligned(16))) float su_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -665,47 +665,102 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, 
     // phase 1: pw1 + BN + ReLU, in place
     su_gemm<typename Q::GM, LDA>(buf, p.w1f, p.s1, p.b1);
     SU_STAMP(3);
-    // phase 2: depthwise 3x3 (pad 1) + BN, in place: results wait in registers until every wave has read its taps
-    float dv[CH][PPW];
+    // phase 2: depthwise 3x3 (pad 1) + BN, in place.  From 116 channels per branch on, a lane takes TWO channels (8-byte LDS reads, float2
+    // FMAs): one pass over the pixels instead of two, half the reads / address arithmetic / border selects per value (6x6 unit 263 -> 236 us,
+    // 3x3 unit 287 -> 272 us at 256 clips).  With 58 channels one pass already covers them and the pair form only idles half the lanes
+    // (12x12 unit 370 -> 377 us): it keeps one channel per lane.  Per channel the arithmetic (tap order, fma chain) is the same in both forms.
+    constexpr bool PAIRS = HALF > 64;
+    if constexpr (PAIRS) {
+        typedef float su_f2 __attribute__((ext_vector_type(2)));
+        constexpr int CH2 = (HALF + 127) / 128;
+        static_assert(HALF % 2 == 0 && LDA % 2 == 0, "channel pairs");
+        su_f2 dv[CH2][PPW];
 #pragma unroll
-    for (int jc = 0; jc < CH; ++jc) {
-        const int c = min(lane + 64 * jc, HALF - 1);
-        float wk[9];
+        for (int jc = 0; jc < CH2; ++jc) {
+            const int c = min(2 * lane + 128 * jc, HALF - 2);
+            su_f2 wk[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * HALF + c];
-        const float sd = p.sd[c], bd = p.bd[c];
+            for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const su_f2*>(p.wd + t * HALF + c);
+            const su_f2 sd = *reinterpret_cast<const su_f2*>(p.sd + c), bd = *reinterpret_cast<const su_f2*>(p.bd + c);
+            const su_f2 zero2 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int m = wave + 8 * i;                   // wave-uniform
-            float acc = 0.f;
-            if (m < Mv) {
-                const int f = m / HH, q = m - f * HH;
-                const int y = q / H, x = q - y * H;
-                const float* rb = buf + (f * HH) * LDA + c;
-                // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
-                // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
+            for (int i = 0; i < PPW; ++i) {
+                const int m = wave + 8 * i;                   // wave-uniform
+                su_f2 acc = zero2;
+                if (m < Mv) {
+                    const int f = m / HH, q = m - f * HH;
+                    const int y = q / H, x = q - y * H;
+                    const float* rb = buf + (f * HH) * LDA + c;
+                    // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
+                    // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+                    for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int yy = y + ky - 1, xx = x + kx - 1;
-                        const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
-                        acc = fmaf(rb[(in ? yy * H + xx : q) * LDA], in ? wk[ky * 3 + kx] : 0.f, acc);
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y + ky - 1, xx = x + kx - 1;
+                            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
+                            const su_f2 v = *reinterpret_cast<const su_f2*>(rb + (in ? yy * H + xx : q) * LDA);
+                            acc = __builtin_elementwise_fma(v, in ? wk[ky * 3 + kx] : zero2, acc);
+                        }
                     }
                 }
+                dv[jc][i] = acc * sd + bd;
             }
-            dv[jc][i] = acc * sd + bd;
         }
-    }
-    SU_STAMP(4);                                          // depthwise taps computed
-    __syncthreads();
+        SU_STAMP(4);                                          // depthwise taps computed
+        __syncthreads();
 #pragma unroll
-    for (int jc = 0; jc < CH; ++jc) {
-        const int c = lane + 64 * jc;
+        for (int jc = 0; jc < CH2; ++jc) {
+            const int c = 2 * lane + 128 * jc;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int m = wave + 8 * i;
-            if (m < Mv && c < HALF) buf[m * LDA + c] = dv[jc][i];
+            for (int i = 0; i < PPW; ++i) {
+                const int m = wave + 8 * i;
+                if (m < Mv && c < HALF) *reinterpret_cast<su_f2*>(buf + m * LDA + c) = dv[jc][i];
+            }
+        }
+    } else {
+        constexpr int CH = Q::CH;
+        float dv[CH][PPW];
+#pragma unroll
+        for (int jc = 0; jc < CH; ++jc) {
+            const int c = min(lane + 64 * jc, HALF - 1);
+            float wk[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * HALF + c];
+            const float sd = p.sd[c], bd = p.bd[c];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int m = wave + 8 * i;                   // wave-uniform
+                float acc = 0.f;
+                if (m < Mv) {
+                    const int f = m / HH, q = m - f * HH;
+                    const int y = q / H, x = q - y * H;
+                    const float* rb = buf + (f * HH) * LDA + c;
+                    // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
+                    // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y + ky - 1, xx = x + kx - 1;
+                            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
+                            acc = fmaf(rb[(in ? yy * H + xx : q) * LDA], in ? wk[ky * 3 + kx] : 0.f, acc);
+                        }
+                    }
+                }
+                dv[jc][i] = acc * sd + bd;
+            }
+        }
+        SU_STAMP(4);                                          // depthwise taps computed
+        __syncthreads();
+#pragma unroll
+        for (int jc = 0; jc < CH; ++jc) {
+            const int c = lane + 64 * jc;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int m = wave + 8 * i;
+                if (m < Mv && c < HALF) buf[m * LDA + c] = dv[jc][i];
+            }
         }
     }
     __syncthreads();
