@@ -847,6 +847,38 @@ __device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* _
                                          const float* __restrict__ w9, const float* __restrict__ sc, const float* __restrict__ sh) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (CN > 64) {
+        // two channels per lane (8-byte LDS accesses, float2 FMAs): one pass over the pixels per 128 channels - see the stride-1 unit
+        typedef float su_f2 __attribute__((ext_vector_type(2)));
+        static_assert(CN % 2 == 0 && LDA % 2 == 0, "channel pairs");
+#pragma unroll
+        for (int jc = 0; jc < (CN + 127) / 128; ++jc) {
+            const int c = 2 * lane + 128 * jc;
+            if (c < CN) {
+                su_f2 wk[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const su_f2*>(w9 + t * CN + c);
+                const su_f2 s = *reinterpret_cast<const su_f2*>(sc + c), b = *reinterpret_cast<const su_f2*>(sh + c);
+                const su_f2 zero2 = {0.f, 0.f};
+                for (int m = wave; m < outv; m += 8) {            // wave-uniform
+                    const int oyl = m / HO, ox = m - oyl * HO;
+                    su_f2 acc = zero2;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int r = 2 * oyl + ky, iy = iy0 + r, ix = 2 * ox + kx - 1;
+                            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+                            const su_f2 v = *reinterpret_cast<const su_f2*>(src + (in ? r * H + ix : (2 * oyl + 1) * H + 2 * ox) * LDA + c);
+                            acc = __builtin_elementwise_fma(v, in ? wk[ky * 3 + kx] : zero2, acc);
+                        }
+                    }
+                    *reinterpret_cast<su_f2*>(dst + m * LDA + c) = acc * s + b;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int jc = 0; jc < (CN + 63) / 64; ++jc) {
         const int c = lane + 64 * jc;
