@@ -406,6 +406,17 @@ def main():
     pool.map(u8_batches * (n_distinct // 4 + 1), S=S, prepare=u8, shape_of=u8_shape)
     u8_elapsed, _ = timed(lambda: pool.map([u8_batches[i % 4] for i in range(args.steps)], S=S, prepare=u8, shape_of=u8_shape))
 
+    # the bf16 leg (BASELINE.json configs[4] names bf16): a model of its own with option "infer_bf16" - front-end conv, GEMMs and Conv1d
+    # stacks with bf16 operands, fp32 accumulation, fp32 recurrent loop - same steps, grouping and chains as `value`.  Never `value`: its
+    # mel frames sit inside a stated band of the reference's (tests: mean |d| < 2e-2, max < 0.15), not inside the 1e-3 fp32 gate.
+    nm16 = native.NativeModel()
+    nm16.set_option("infer_bf16", 1)
+    nm16.load(tensors, list(sd.keys()))
+    pool16 = InflightPool(model=nm16, n_inflight=NI, group=G)
+    pool16.map(work(2 * n_distinct), S=S)
+    bf16_elapsed, outs16 = timed(lambda: pool16.map(work(args.steps), S=S))
+    bf16_dev = max(float((a[0] - b[0]).abs().mean()) for a, b in zip(outs16[:n_distinct], outs[:n_distinct]))
+
     if rank == 0:
         # per-kernel HIP-event timing in its own pass over ONE group (events around every launch perturb the pipeline)
         native.profile_enable(True)
@@ -498,6 +509,10 @@ def main():
                                      "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), four single-batch chains in flight"},
             "host_resident_inputs": {"value": world * B * S * args.steps / h2d_elapsed, "unit": "mel-frames/s", "ms_per_step": h2d_elapsed / args.steps * 1e3,
                                      "note": "PCIe-inclusive: each step copies its batch from pinned host memory on its own stream first; four single-batch chains in flight"},
+            "bf16_leg": {"value": world * B * S * args.steps / bf16_elapsed, "unit": "mel-frames/s", "ms_per_step": bf16_elapsed / args.steps * 1e3,
+                         "mean_abs_mel_deviation_from_fp32_path": bf16_dev,
+                         "note": "model option infer_bf16: front-end conv, GEMMs and Conv1d stacks with bf16 operands (fp32 accumulation), recurrent loops, "
+                                 "fused ShuffleNet units and statistics fp32; same steps, grouping and chains as `value`; a different precision - never `value`"},
             "host_resident_uint8_frames": {"value": world * B * S * args.steps / u8_elapsed, "unit": "mel-frames/s", "ms_per_step": u8_elapsed / args.steps * 1e3,
                                            "note": "PCIe-inclusive with the data boundary on the device: every step's packed uint8 frames (25.7 MB per batch) are copied from "
                                                    "pinned host memory and normalised + padded by l2s_normalise_pad_frames on the chain's stream; same grouping and chains as `value`"},

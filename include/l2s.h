@@ -253,7 +253,8 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
                   float* out, int B, int Tin, int Cin, int Cout, int taps, int stride, int pad, int act,
                   void* stream);
 /* the same two operators with flags: bit 0 = run on the split-bf16 kernel (fp32 operands split into 3 bf16 planes, six bf16 MFMAs per
- * K step; eligible shapes only - otherwise the f32 kernel runs) */
+ * K step; eligible shapes only - otherwise the f32 kernel runs); bit 1 = bf16 operands (round to nearest even on the way into LDS, one
+ * bf16 MFMA per K step, fp32 accumulation) */
 int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                    int K, int act, int flags, void* stream);
 int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
@@ -303,6 +304,10 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "train_bf16"        (0)  TRAINING entry points (encoder, prologue, post-net; forward and backward): GEMMs / Conv1d stacks round their operands to
  *                            bf16 (RNE) on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 results; the
  *                            recurrent loop, the Conv3d front-end, BatchNorm statistics, master weights and optimizer stay fp32
+ *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane (frames rounded to nearest even
+ *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
+ *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every
+ *                            activation in HBM stay fp32.  Outside the 1e-3 fp32 gate by construction (mel: 5e-3 mean, 4e-2 max absolute deviation)
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
  *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
 int l2s_set_option(const char* name, int value);

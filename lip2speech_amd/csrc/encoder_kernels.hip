@@ -188,7 +188,6 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
 // different banks (96x96: 48 columns, 56 dwords per row; 88x88: 44 columns, 54 dwords) - with 52-dword rows 21 % of the LDS cycles were conflicts
 template <int HW> struct FxGeom { static constexpr int XLD = HW == 96 ? 112 : 108, PLANE = FE_XROWS * XLD * 2; };
 constexpr int FX_WROW = 48;                          // bytes per weight row (16 bf16 + pad)
-constexpr int FX_WSLAB = 4 * 3 * 32 * FX_WROW;       // 18 432 bytes per slab
 
 typedef __bf16 fx_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -207,15 +206,21 @@ __device__ __forceinline__ void fx_split4(const float4& v, uint2& hi, uint2& mid
     lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
 }
 
-template <int HW>
+// TERMS = 3: the exact split above.  TERMS = 1 (model option "infer_bf16", the bf16 leg): ONE plane - inputs rounded to nearest even by the
+// staging threads, weights pre-rounded by the packer (FrontendW::w1) - and one MFMA per step: a sixth of the matrix work, a third of the LDS.
+typedef __bf16 fx_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fx_rne2(float a, float b) { fx_bf16x2 v = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, v); }
+
+template <int HW, int TERMS>
 __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
+    constexpr int FX_WSLAB = 4 * TERMS * 32 * FX_WROW;   // bytes of weights per slab: 18 432 with three planes, 6 144 with one
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
     constexpr int P = FE_CR * Wc;                    // conv pixels per strip
     constexpr int NT = (P + 31) / 32;                // 32-pixel MFMA row tiles
     constexpr int TPW = (NT + 3) / 4;                // tiles per wave
     constexpr int XLD = FxGeom<HW>::XLD, PLANE = FxGeom<HW>::PLANE;
     static_assert((2 * (XLD / 2)) % 32 == Wc % 32 && XLD >= W + 8, "row pitch: conflict-free straddling tiles");
-    constexpr int XS = 3 * PLANE;                    // bytes: input planes
+    constexpr int XS = TERMS * PLANE;                // bytes: input planes
     constexpr int CS = P * FE_CO * 4;                // bytes: conv tile (aliases the operand area)
     constexpr int SMEM = (XS + FX_WSLAB) > CS ? (XS + FX_WSLAB) : CS;
     constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
             rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
         }
-        const uint4* wsrc = reinterpret_cast<const uint4*>(w.w3) + (int64_t)slab * (FX_WSLAB / 16);
+        const uint4* wsrc = reinterpret_cast<const uint4*>(TERMS == 3 ? w.w3 : w.w1) + (int64_t)slab * (FX_WSLAB / 16);
 #pragma unroll
         for (int q = 0; q < NWL; ++q) {
             const int i = tid + 256 * q;
@@ -281,10 +286,14 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
             const int i = tid + 256 * q;
             if (i < (FE_XROWS - 1) * (W / 4)) {
                 const int row = i / (W / 4), x4 = i - row * (W / 4);
-                uint2 hi, mid, lo;
-                fx_split4(rin[q], hi, mid, lo);
                 unsigned char* d = Xs + (row * XLD + 4 + 4 * x4) * 2;
-                *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + PLANE) = mid; *reinterpret_cast<uint2*>(d + 2 * PLANE) = lo;
+                if constexpr (TERMS == 3) {
+                    uint2 hi, mid, lo;
+                    fx_split4(rin[q], hi, mid, lo);
+                    *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + PLANE) = mid; *reinterpret_cast<uint2*>(d + 2 * PLANE) = lo;
+                } else {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(fx_rne2(rin[q].x, rin[q].y), fx_rne2(rin[q].z, rin[q].w));
+                }
             }
         }
 #pragma unroll
@@ -305,8 +314,18 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // weights of this step: lane (channel li, tap half lg) reads 8 bf16 of each plane
-            const unsigned char* wp = Ws + ((s * 3) * 32 + li) * FX_WROW + lg * 16;
+            const unsigned char* wp = Ws + ((s * TERMS) * 32 + li) * FX_WROW + lg * 16;
             const fx_bf16x8 bh = *reinterpret_cast<const fx_bf16x8*>(wp);
+            if constexpr (TERMS == 1) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    if (wave + 4 * j < NT) {         // wave-uniform
+                        const unsigned* ap = reinterpret_cast<const unsigned*>(Xs + base[j] + s * (2 * XLD * 2));
+                        const fx_bf16x8 ah = __builtin_bit_cast(fx_bf16x8, make_uint4(ap[0], ap[1], ap[2], ap[3]));
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                    }
+                }
+            } else {
             const fx_bf16x8 bm = *reinterpret_cast<const fx_bf16x8*>(wp + 32 * FX_WROW);
             const fx_bf16x8 bl = *reinterpret_cast<const fx_bf16x8*>(wp + 64 * FX_WROW);
 #pragma unroll
@@ -326,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
                 }
+            }
             }
         }
         slab = nxt;
@@ -385,9 +405,12 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     ProfScope ps("frontend3d_conv_bn_prelu_pool", s);
-    if (!zout && w.w3) {                       // inference on the split-bf16 matrix path (option "frontend_x3")
-        if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96>), grid, dim3(256), 0, s, w, video, T, out);
-        else hipLaunchKernelGGL((frontend3d_x3_kernel<88>), grid, dim3(256), 0, s, w, video, T, out);
+    if (!zout && w.w1) {                       // the bf16 leg (option "infer_bf16"): one bf16 plane
+        if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96, 1>), grid, dim3(256), 0, s, w, video, T, out);
+        else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out);
+    } else if (!zout && w.w3) {                // inference on the split-bf16 matrix path (option "frontend_x3")
+        if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96, 3>), grid, dim3(256), 0, s, w, video, T, out);
+        else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 3>), grid, dim3(256), 0, s, w, video, T, out);
     } else if (zout) {
         if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);
         else hipLaunchKernelGGL((frontend3d_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out, zout);

@@ -29,7 +29,8 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
-        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16}};
+        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
+        {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
     return 1;
@@ -224,6 +225,21 @@ static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bo
                                 std::memcpy(base3 + (int64_t)slab * 18432 + ((st * 3 + pl) * 32 + n) * 48 + k * 2, &planes[pl], 2);
                         }
             P.bind(&w.fe.w3, o3);
+            // and as ONE bf16 plane rounded to nearest even, for the bf16 leg (option "infer_bf16")
+            const int64_t o1 = P.blob.alloc(15 * 6144 / 4);
+            unsigned char* base1 = reinterpret_cast<unsigned char*>(&P.blob.data[o1]);
+            for (int slab = 0; slab < 15; ++slab)
+                for (int st = 0; st < 4; ++st)
+                    for (int n = 0; n < 32; ++n)
+                        for (int k = 0; k < 16; ++k) {
+                            const int kh = 2 * st + (k >> 3), kw = (k & 7) - 1, ci = slab / 5, kt = slab % 5;
+                            float x = 0.f;
+                            if (n < 24 && kh < 7 && kw >= 0) x = (*v)[(((int64_t)n * 3 + ci) * 5 + kt) * 49 + kh * 7 + kw];
+                            uint32_t xb; std::memcpy(&xb, &x, 4);
+                            const uint16_t r = (uint16_t)((xb + 0x7FFFu + ((xb >> 16) & 1u)) >> 16);
+                            std::memcpy(base1 + (int64_t)slab * 6144 + (st * 32 + n) * 48 + k * 2, &r, 2);
+                        }
+            P.bind(&w.fe.w1, o1);
         }
         P.bn(E + "frontend3D.1", 24, nullptr, &w.fe.scale, &w.fe.shift);
         P.copy(E + "frontend3D.2.weight", 24, &w.fe.slope);
@@ -761,7 +777,8 @@ static FrameSrc frame_src(const float* video, int B) { FrameSrc f{}; f.p[0] = vi
 
 static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H, int W, const float* emb, float* vis,
                        float* feat, void* ws, int64_t ws_bytes, hipStream_t s) {
-    X3Scope x3scope(m->opt.gemm_x3);
+    X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
+    Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     const Weights& w = m->w;
     EncPlan pl = enc_plan(B, T, H);
     Bump bp(ws, ws_bytes);
@@ -769,6 +786,7 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
     L2S_REQUIRE(!bp.overflow, "encoder workspace too small");
     FrontendW fe = w.fe;
     if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale (like the merged step weights)
+    if (!m->opt.infer_bf16 || !m->folded_valid) fe.w1 = nullptr;
     if (launch_frontend(fe, video, B, T, H, W, a, s)) return 1;
     float* x = a; float* y = b;
     int h = pl.Hp;
@@ -843,7 +861,8 @@ static SkinnyP sk_base(const SkW& sw, int B) {
 
 static int prologue_run(l2s_model* m, const float* vis, const float* emb, const float* gumbel, int B, int T,
                         float* state, float* content_dis, void* ws, int64_t ws_bytes, hipStream_t s) {
-    X3Scope x3scope(m->opt.gemm_x3);
+    X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
+    Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     int L[4];
@@ -1182,7 +1201,8 @@ static int postnet_layer(const Weights& w, int layer, const float* mel, const Po
 }
 
 static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_post, float* mel_cf, void* ws, int64_t ws_bytes, hipStream_t s) {
-    X3Scope x3scope(m->opt.gemm_x3);
+    X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
+    Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     const Weights& w = m->w;
     Bump bp(ws, ws_bytes);
     PostBufs pb;
@@ -1201,7 +1221,8 @@ static int64_t spk_ws_floats(int B, int N) {
 
 // SpeakerEncoder.inference (audio.py:131-150): mel40 -> 3 x LSTM(256), zero initial state -> Linear(h_last) -> ReLU -> L2 norm
 static int speaker_run(l2s_model* m, const float* audio, int B, int N, float* emb, void* ws, int64_t ws_bytes, hipStream_t s) {
-    X3Scope x3scope(m->opt.gemm_x3);
+    X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
+    Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     const Weights& w = m->w;
     L2S_REQUIRE(N > 200, "audio shorter than the reflect padding (200 samples)");
     const int L = N / 160 + 1, Bp = pad16(B);
@@ -1374,7 +1395,8 @@ int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* 
 
 static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
                          float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, hipStream_t s) {
-    X3Scope x3scope(m->opt.gemm_x3);
+    X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
+    Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     Bump bp(ws, ws_bytes);
     float* vis = bp.f((int64_t)B * T * 1024);
     float* state = bp.f(l2s_state_floats(B, T));
@@ -1486,11 +1508,13 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                    int K, int act, int flags, void* stream) {
     X3Scope x3scope((flags & 1) ? 2 : 0);
+    Bf16Scope bf16scope((flags & 2) ? 1 : 0);
     return l2s_op_gemm(A, Wt, scale, shift, actw, C, M, N, K, act, stream);
 }
 int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
                      int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream) {
     X3Scope x3scope((flags & 1) ? 2 : 0);
+    Bf16Scope bf16scope((flags & 2) ? 1 : 0);
     return l2s_op_conv1d(X, Wp, scale, shift, actw, out, B, Tin, Cin, Cout, taps, stride, pad, act, stream);
 }
 int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
@@ -1508,6 +1532,7 @@ int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W
     L2S_ENC_READY(m);
     FrontendW fe = m->w.fe;
     if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;
+    if (!m->opt.infer_bf16 || !m->folded_valid) fe.w1 = nullptr;
     return launch_frontend(fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }
 

@@ -58,6 +58,8 @@ struct Options {
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
     int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)
     int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
+    int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
+                                //   voice tower with bf16 operands (fp32 accumulation); the recurrent loops, the fused ShuffleNet units and all statistics stay fp32
 };
 int set_option_field(Options& o, const char* name, int value);    // 0 = ok, 1 = unknown name
 
@@ -191,6 +193,8 @@ struct FrontendW {          // device pointers into the weight blob
     const float* slope;     // [24] PReLU
     const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows]
                             //   (null: f32 MFMA kernel)
+    const float* w1;        // the same as ONE plane rounded to nearest even: [15 slabs][4 steps][32 co][16 taps, 48-byte rows] (set by the callers
+                            //   of launch_frontend only for a model with "infer_bf16"; takes precedence over w3)
 };
 // where the clips of a launch live: clip b is clip (b % per) of the (per,3,T,H,W) tensor p[b / per] - the G batches of a grouped pass
 // (l2s_inference_multi) stay where their caller put them

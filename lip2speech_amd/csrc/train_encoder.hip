@@ -116,7 +116,7 @@ static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int
     };
     {
         FrontendW fe = w.fe;
-        fe.w3 = nullptr;                      // training forward: f32 MFMA kernel (it also writes the pre-PReLU map)
+        fe.w3 = nullptr; fe.w1 = nullptr;     // training forward: f32 MFMA kernel (it also writes the pre-PReLU map)
         if (bnb) {
             int nblk = 0;
             if (launch_frontend_stats(w.fe, video, B, T, H, W, tp.stats, &nblk, s)) return 1;

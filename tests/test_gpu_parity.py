@@ -71,6 +71,31 @@ def test_conv1d_split_bf16_operator(B, T, Ci, Co, k, st, pad):
     assert pc.maxdiff(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(9600, 512, 2560), (300, 200, 64), (130, 129, 36)])
+def test_gemm_bf16_operand_flag(M, N, K):
+    """flags bit 1 of l2s_op_gemm_ex (what a model with "infer_bf16" / "train_bf16" runs): operands rounded to nearest even to bf16, fp32
+    accumulation - i.e. the fp64 product of the ROUNDED operands up to fp32 summation error; and really not the fp32 product."""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K).cuda()
+    W = (torch.randn(N, K) / K ** 0.5).cuda()
+    out = native.op_gemm(A, W, bf16=True)
+    assert pc.maxdiff(out, A.bfloat16().double() @ W.bfloat16().double().t()) < 2e-5
+    assert pc.maxdiff(out, A.double() @ W.double().t()) > 1e-4
+
+
+@pytest.mark.parametrize("hw,T", [(96, 4), (88, 3)])
+def test_frontend_kernel_bf16_leg(synth_sd, hw, T):
+    """frontend3d_x3_kernel<HW,1>: one bf16 plane.  Equals the oracle's fused front-end fed the bf16-rounded frames and conv weights
+    (BatchNorm, PReLU and the pool stay fp32)."""
+    b16 = pc.fresh_native_model(synth_sd, infer_bf16=1)
+    v = synth.synth_video(1, T, hw, hw, tag=f"fe{hw}")
+    sd = dict(synth_sd)
+    sd["encoder.frontend3D.0.weight"] = synth_sd["encoder.frontend3D.0.weight"].bfloat16().float()
+    out = b16.op_frontend(v.cuda())
+    assert pc.maxdiff(out, orc.frontend3d(v.bfloat16().float(), sd).permute(0, 2, 3, 1)) < 2e-5
+    assert pc.maxdiff(out, orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)) > 1e-4
+
+
 @pytest.mark.parametrize("hw,T", [(96, 4), (88, 3), (96, 1)])
 def test_frontend_kernel(nm, synth_sd, hw, T):
     v = synth.synth_video(1, T, hw, hw, tag=f"fe{hw}")
@@ -215,6 +240,49 @@ def test_full_size_avspeech_shaped_matches_reference_golden(synth_sd, nm):
     assert torch.equal(torch.cat([halves[0][0], halves[1][0]]), mel_post)
 
 
+# the bf16 leg (BASELINE.json configs[4] "... bf16"): the 1e-3 fp32 gate does not apply to it (judged on throughput and a
+# stated band).  Bands: bf16 operands carry 2^-9 relative rounding; measured on the LRW batch: encoder features 1.5e-3 rms, mel frames
+# 5e-3 mean / 4e-2 max absolute on frames of mean magnitude 1.07, flat along the 300 steps (tools/check_bf16_leg.py)
+BF16_MEAN, BF16_MAX = 2e-2, 0.15
+
+
+def test_bf16_leg_tracks_the_reference_b2(synth_sd, nm):
+    """Option "infer_bf16" on a model of its own: front-end conv, GEMMs and Conv1d stacks with bf16 operands, fp32 loop - against the
+    reference's B=2 golden inside the stated band, really different from the fp32 path, and leaving other models alone."""
+    g, video, emb = pc.lrw2_inputs()
+    args = (video.cuda(), emb.cuda(), g["gumbel"].cuda())
+    base = nm.inference(*args, S=300)[0].clone()
+    b16 = pc.fresh_native_model(synth_sd, infer_bf16=1)
+    feat32, feat16 = nm.encoder_fwd(video.cuda()), b16.encoder_fwd(video.cuda())
+    assert 1e-5 < pc.maxdiff(feat16, feat32) < 1e-2                 # unit-norm rows: bf16 front-end + conv_last really ran, inside 2^-7
+    mel, lengths = b16.inference(*args, S=300)[:2]
+    d = (mel.cpu() - g["mel_post"]).abs()
+    assert d.mean().item() < BF16_MEAN and d.max().item() < BF16_MAX
+    assert d.max().item() > 1e-3                                   # not the fp32 path
+    assert torch.equal(lengths.cpu(), g["output_lengths"])
+    assert torch.equal(nm.inference(*args, S=300)[0], base)        # the fp32 model is untouched
+    # grouped: the bf16 leg too is one launch chain over G batches with per-batch results independent of the grouping
+    grp = b16.inference_multi([args, args], S=300)
+    assert torch.equal(grp[0][0], mel) and torch.equal(grp[1][0], mel)
+
+
+def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
+    """BASELINE.json configs[4], bf16 leg at full size: B=32, clips of 26..50 frames zero-padded, stored speaker embeddings - mel inside the
+    stated band of the reference's fp32 golden, the same output lengths, attention argmax equal on >= 99 % of the confident positions."""
+    g = pc.golden("inference_avspeech_b32_full.npz")
+    B, S = 32, 300
+    lens = synth.synth_clip_lengths(B, 25, 50, "avs32")
+    video = synth.synth_padded_video(B, lens, "avs32").cuda()
+    b16 = pc.fresh_native_model(synth_sd, infer_bf16=1)
+    mel_post, lengths, attn = b16.inference(video, g["speaker_embedding"].cuda(), g["gumbel"].cuda(), S=S, want_attn=True)
+    d = (mel_post.cpu() - g["mel_post"]).abs()
+    assert d.mean().item() < BF16_MEAN and d.max().item() < BF16_MAX
+    assert torch.equal(lengths.cpu(), g["output_lengths"])
+    amax, _ = pc.top2(attn.cpu())
+    sure = g["attn_margin"] > 1e-2
+    assert (amax[sure] == g["attn_argmax"][sure].to(torch.int32)).float().mean().item() > 0.99
+
+
 @pytest.mark.parametrize("opts,exact", [
     ({"use_graph": 1}, True),              # BASELINE.json configs[3]: the decode loop replayed from a captured hipGraph - same kernels, same order
     ({"overlap_postnet": 1}, True),        # windowed post-net on a second stream: every output frame sees the same taps
@@ -324,6 +392,12 @@ def test_model_api_inference(synth_sd):
     # without supplied noise the call draws its own (eval-mode stochasticity of the reference, decoder.py:257)
     mel3, _ = net.inference(video.cuda(), None, speaker_embedding=emb.cuda())
     assert torch.isfinite(mel3).all() and pc.maxdiff(mel3, mel) > 0
+    # the bf16 leg is a switch on the model's own native handle: on -> inside the stated band, off -> the fp32 result again, bit for bit
+    net.native_model().set_option("infer_bf16", 1)
+    mel4, _ = net.inference(video.cuda(), None, speaker_embedding=emb.cuda(), gumbel_noise=g["gumbel"].cuda())
+    assert 1e-3 < pc.maxdiff(mel4, g["mel_post"]) < BF16_MAX
+    net.native_model().set_option("infer_bf16", 0)
+    assert torch.equal(net.inference(video.cuda(), None, speaker_embedding=emb.cuda(), gumbel_noise=g["gumbel"].cuda())[0], mel)
 
 
 @pytest.mark.parametrize("name,B,T,S,tag", [
