@@ -16,7 +16,17 @@ struct SkinnyTrain {               // training-side stores of one skinny group (
     // SK_PLAIN, backward loop: the LSTM-cell backward fused into the GEMM that produces dh (columns n < lb_H are hidden units). dh = the
     // epilogue's value, or lb_dha[b][n] + value * lb_mask[b][n] when lb_dha is set; gate gradients go out as frag16 (K = 4*lb_H) + stack
     const float* lb_gates; const float* lb_cprev; const float* lb_cnew; float* lb_dc; const float* lb_dha; int lb_ld_a; const float* lb_mask;
-    float* lb_frag; float* lb_stack; int lb_H;
+    float* lb_frag; float* lb_stack; int lb_H; int lb_ld_dc;     // lb_ld_dc: row pitch of lb_dc (0 = lb_H)
+    // SK_PLAIN, backward loop: columns n >= add_hi_from take their addend from add_hi[b*ld_add + n] instead of add
+    const float* add_hi; int add_hi_from;
+    // SK_PLAIN, backward loop: side outputs on the column block [sd_lo, sd_hi), C = sd_hi - sd_lo, c = n - sd_lo: d = value (* sd_mask[b*C + c])
+    // -> sd_stack[b*C + c] and frag16 sd_frag_d (K = C; may be null); through a PSine, d * cos(sd_z[b*C + c]) * sd_w[c] -> frag16 sd_frag_dz
+    // (what du_dz2_kernel and the second half of carry_dz1_kernel did in launches of their own)
+    const float* sd_z; const float* sd_w; const float* sd_mask; float* sd_stack; float* sd_frag_d; float* sd_frag_dz; int sd_lo, sd_hi;
+    // SK_PLAIN, backward loop, the N = 80 product that yields the carry into the previous frame: total gradient of frame s-1 =
+    // dy_dmel[b*dy_ld_mel + n] (+ value when dy_use_carry), column 80 = dy_dstop[b*dy_ld_stop], columns 81..95 zero -> dy_stack[b*96 + n] and
+    // frag16 dy_frag (K = 96) (what build_dy_kernel did in a launch of its own)
+    const float* dy_dmel; int64_t dy_ld_mel; const float* dy_dstop; int64_t dy_ld_stop; int dy_use_carry; float* dy_stack; float* dy_frag;
 };
 struct AttnTrain {
     const float* logit_mask; int ld_lmask;   // dropout multiplier on the attention logits [b*ld_lmask + t] (decoder.py:363)
@@ -137,7 +147,11 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         if (epi == SK_LSTM) {
             if (pre && e_b < nB) pf_extra = pre[(int64_t)e_b * ld_pre + (e_col & 3) * H + tile * 4 + (e_col >> 2)];
         } else if (epi != SK_MEL && e_b < nB && e_np < N) {
-            if (add) pf_extra = add[(int64_t)e_b * ld_add + e_np];
+            if (add) {
+                const float* ad = add;
+                if constexpr (TRAIN) { if (tr->add_hi && e_np >= tr->add_hi_from) ad = tr->add_hi; }
+                pf_extra = ad[(int64_t)e_b * ld_add + e_np];
+            }
             if (addrow) pf_extra += addrow[e_np];
         }
     }
@@ -154,9 +168,26 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             const int64_t ei = (int64_t)e_b * LH + e_np;
             const float* g = tr->lb_gates + (int64_t)e_b * 4 * LH + e_np;
             lb_g[0] = g[0]; lb_g[1] = g[LH]; lb_g[2] = g[2 * LH]; lb_g[3] = g[3 * LH];
-            lb_cn = tr->lb_cnew[ei]; lb_cp = tr->lb_cprev[ei]; lb_dcv = tr->lb_dc[ei];
+            lb_cn = tr->lb_cnew[ei]; lb_cp = tr->lb_cprev[ei]; lb_dcv = tr->lb_dc[(int64_t)e_b * (tr->lb_ld_dc ? tr->lb_ld_dc : LH) + e_np];
             if (tr->lb_dha) lb_a = tr->lb_dha[(int64_t)e_b * tr->lb_ld_a + e_np];
             if (tr->lb_mask) lb_m = tr->lb_mask[ei];
+        }
+    }
+    // side outputs of the backward loop: their tape operands too are fetched under the operand round trip
+    float sd_zv = 0.f, sd_wv = 0.f, sd_mv = 1.f, dy_mv = 0.f, dy_sv = 0.f;
+    bool sd_on = false, dy_on = false;
+    if constexpr (TRAIN) {
+        const bool live = tid < 256 && e_b < nB && e_np < N && epi == SK_PLAIN;
+        sd_on = live && tr->sd_stack != nullptr && e_np >= tr->sd_lo && e_np < tr->sd_hi;
+        if (sd_on) {
+            const int C = tr->sd_hi - tr->sd_lo, c = e_np - tr->sd_lo;
+            sd_zv = tr->sd_z[(int64_t)e_b * C + c]; sd_wv = tr->sd_w[c];
+            if (tr->sd_mask) sd_mv = tr->sd_mask[(int64_t)e_b * C + c];
+        }
+        dy_on = live && tr->dy_frag != nullptr;
+        if (dy_on) {
+            dy_mv = tr->dy_dmel[(int64_t)e_b * tr->dy_ld_mel + e_np];
+            if (e_np == 0) dy_sv = tr->dy_dstop[(int64_t)e_b * tr->dy_ld_stop];
         }
     }
     L2S_STAMP(2);
@@ -260,11 +291,31 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             const float tc = tanhf(lb_cn);
             const float dc = lb_dcv + dh * go * (1.f - tc * tc);
             const float vals[4] = {dc * gg * gi * (1.f - gi), dc * lb_cp * gf * (1.f - gf), dc * gi * (1.f - gg * gg), dh * tc * go * (1.f - go)};
-            tr->lb_dc[(int64_t)b * LH + np] = dc * gf;
+            tr->lb_dc[(int64_t)b * (tr->lb_ld_dc ? tr->lb_ld_dc : LH) + np] = dc * gf;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 tr->lb_frag[frag16_index(b, k * LH + np, 4 * LH)] = vals[k];
                 tr->lb_stack[(int64_t)b * 4 * LH + k * LH + np] = vals[k];
+            }
+        }
+    }
+    if constexpr (TRAIN) {
+        if (sd_on) {
+            const int C = tr->sd_hi - tr->sd_lo, c = np - tr->sd_lo;
+            const float d = tr->sd_mask ? v * sd_mv : v;
+            tr->sd_stack[(int64_t)b * C + c] = d;
+            if (tr->sd_frag_d) tr->sd_frag_d[frag16_index(b, c, C)] = d;
+            tr->sd_frag_dz[frag16_index(b, c, C)] = d * cosf(sd_zv) * sd_wv;
+        }
+        if (dy_on) {
+            float t = dy_mv;
+            if (tr->dy_use_carry) t += v;
+            tr->dy_stack[(int64_t)b * 96 + np] = t;
+            tr->dy_frag[frag16_index(b, np, 96)] = t;
+            if (np < 16) {                               // columns 80..95 of the (B,96) gradient: the stop logit's, then zeros
+                const float s2 = np == 0 ? dy_sv : 0.f;
+                tr->dy_stack[(int64_t)b * 96 + 80 + np] = s2;
+                tr->dy_frag[frag16_index(b, 80 + np, 96)] = s2;
             }
         }
     }

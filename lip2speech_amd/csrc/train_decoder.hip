@@ -401,86 +401,6 @@ __global__ __launch_bounds__(256) void build_dy_kernel(const float* __restrict__
     frag[frag16_index(b, n, 96)] = v;
 }
 
-// generic: dz = dy * f'(z) with f = PSine(w) / SiLU / identity; writes dz as frag16 (K = C) and dy to a stack (for the parameter sums)
-__global__ __launch_bounds__(256) void act_bwd_small_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int act,
-                                                            const float* __restrict__ actw, int B, int C, float* __restrict__ dz_frag,
-                                                            float* __restrict__ dy_stack, const float* __restrict__ mask = nullptr) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int Bp = (B + 15) & ~15;
-    if (idx >= Bp * C) return;
-    const int b = idx / C, c = idx - b * C;
-    float dzv = 0.f;
-    if (b < B) {
-        float d = dy[(int64_t)b * ld_dy + c];
-        if (mask) d *= mask[idx];                         // dropout on the activated output: [b*C + c]
-        if (dy_stack) dy_stack[idx] = d;
-        dzv = d;
-        if (act == ACT_PSINE) dzv = d * cosf(z[idx]) * actw[c];
-        else if (act == ACT_SILU) { const float zz = z[idx], sg = 1.f / (1.f + expf(-zz)); dzv = d * sg * (1.f + zz * (1.f - sg)); }
-    }
-    dz_frag[frag16_index(b, c, C)] = dzv;
-}
-
-// carries for the previous step: dh0 = d0x[:,512:] + dhq[:,:512]; dh1 = d01[:,512:] + dhq[:,512:]; dc0 += dcq[:,:512]; dc1 += dcq[:,512:]
-__global__ __launch_bounds__(256) void carry_update_kernel(const float* __restrict__ d0x, const float* __restrict__ d01, const float* __restrict__ dhq,
-                                                           const float* __restrict__ dcq, int B, float* __restrict__ dh0, float* __restrict__ dh1,
-                                                           float* __restrict__ dc0, float* __restrict__ dc1) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * 512) return;
-    const int b = idx / 512, u = idx - b * 512;
-    dh0[idx] = d0x[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + u];
-    dh1[idx] = d01[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + 512 + u];
-    dc0[idx] += dcq[(int64_t)b * 1024 + u];
-    dc1[idx] += dcq[(int64_t)b * 1024 + 512 + u];
-}
-
-// two launches of the backward step in one: d(attention_proj input) = d0x[:,256:512] as a fragment + stack, and through prenet layer 2's
-// PSine (same source column block) as a fragment
-__global__ __launch_bounds__(256) void du_dz2_kernel(const float* __restrict__ d0x, int ld, const float* __restrict__ z2, const float* __restrict__ w2, int B,
-                                                     float* __restrict__ du_frag, float* __restrict__ du_stack, float* __restrict__ dz2_frag) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int Bp = (B + 15) & ~15;
-    if (idx >= Bp * 256) return;
-    const int b = idx >> 8, c = idx & 255;
-    float d = 0.f, dz = 0.f;
-    if (b < B) {
-        d = d0x[(int64_t)b * ld + 256 + c];
-        du_stack[idx] = d;
-        dz = d * cosf(z2[idx]) * w2[c];
-    }
-    du_frag[frag16_index(b, c, 256)] = d;
-    dz2_frag[frag16_index(b, c, 256)] = dz;
-}
-// two launches in one: blocks [0, nc) run carry_update (above), the rest prenet layer 1's PSine backward of dp1 (+ its dropout mask)
-__global__ __launch_bounds__(256) void carry_dz1_kernel(const float* __restrict__ d0x, const float* __restrict__ d01, const float* __restrict__ dhq,
-                                                        const float* __restrict__ dcq, int B, float* __restrict__ dh0, float* __restrict__ dh1,
-                                                        float* __restrict__ dc0, float* __restrict__ dc1, int nc, const float* __restrict__ dp1,
-                                                        const float* __restrict__ z1, const float* __restrict__ w1, float* __restrict__ dz1_frag,
-                                                        float* __restrict__ dp1_stack, const float* __restrict__ mask) {
-    if ((int)blockIdx.x < nc) {
-        const int idx = blockIdx.x * 256 + threadIdx.x;
-        if (idx >= B * 512) return;
-        const int b = idx / 512, u = idx - b * 512;
-        dh0[idx] = d0x[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + u];
-        dh1[idx] = d01[(int64_t)b * 1024 + 512 + u] + dhq[(int64_t)b * 1024 + 512 + u];
-        dc0[idx] += dcq[(int64_t)b * 1024 + u];
-        dc1[idx] += dcq[(int64_t)b * 1024 + 512 + u];
-        return;
-    }
-    const int idx = ((int)blockIdx.x - nc) * 256 + threadIdx.x;
-    const int Bp = (B + 15) & ~15;
-    if (idx >= Bp * 256) return;
-    const int b = idx >> 8, c = idx & 255;
-    float dz = 0.f;
-    if (b < B) {
-        float d = dp1[idx];
-        if (mask) d *= mask[idx];
-        dp1_stack[idx] = d;
-        dz = d * cosf(z1[idx]) * w1[c];
-    }
-    dz1_frag[frag16_index(b, c, 256)] = dz;
-}
-
 // ---- attention + content attention backward, one 512-thread block per batch row (decoder.py:414-419, 262-271)
 struct AttnBwdP {
     const float* dav;                 // [B][512]
@@ -905,11 +825,13 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     float* f_du = bp.f((int64_t)Bp * 256); float* f_dzq = bp.f((int64_t)Bp * 512); float* f_dzc = bp.f((int64_t)Bp * 256);
     float* f_dz2 = bp.f((int64_t)Bp * 256); float* f_dz1 = bp.f((int64_t)Bp * 256);
     float* dh1lin = bp.f((int64_t)B * 512); float* d01 = bp.f((int64_t)B * 1024); float* d0x = bp.f((int64_t)B * 1024); float* dav = bp.f((int64_t)B * 512);
-    float* dhq = bp.f((int64_t)B * 1024); float* dcq = bp.f((int64_t)B * 1024); float* dp1 = bp.f((int64_t)B * 256); float* dyc = bp.f((int64_t)B * 80);
-    float* dh0c = bp.f((int64_t)B * 512); float* dh1c = bp.f((int64_t)B * 512); float* dc0c = bp.f((int64_t)B * 512); float* dc1c = bp.f((int64_t)B * 512);
+    float* dp1 = bp.f((int64_t)B * 256); float* dyc = bp.f((int64_t)B * 80);
+    // carries into the previous step, both layers side by side: (B,1024) = [layer 0 | layer 1], row pitch 1024
+    float* dhc = bp.f((int64_t)B * 1024); float* dcc = bp.f((int64_t)B * 1024);
+    float* dh0c = dhc; float* dh1c = dhc + 512; float* dc0c = dcc; float* dc1c = dcc + 512;
     float* partials = bp.f((int64_t)AB_RS * 3 * 2048); float* tmp96 = bp.f((int64_t)96 * 512); float* small = bp.f(4096);
     L2S_REQUIRE(!bp.overflow, "training backward workspace too small");
-    for (float* z : {dh0c, dh1c, dc0c, dc1c}) if (launch_fill(z, (int64_t)B * 512, 0.f, s)) return 1;
+    for (float* z : {dhc, dcc}) if (launch_fill(z, (int64_t)B * 1024, 0.f, s)) return 1;
     for (float* z : {f_dyt}) if (launch_fill(z, (int64_t)Bp * 96, 0.f, s)) return 1;
     if (launch_fill(dk, (int64_t)B * T * 512, 0.f, s) || launch_fill(dv, (int64_t)B * T * 512, 0.f, s)) return 1;
     if (launch_fill(dckey, (int64_t)B * sl.m * 256, 0.f, s) || launch_fill(dcval, (int64_t)B * sl.m * 256, 0.f, s)) return 1;
@@ -917,26 +839,31 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     const float* wq = m->canon(D + "Q.1.w"); const float* w1 = m->canon(D + "prenet.1.w"); const float* w2 = m->canon(D + "prenet.4.w");
     L2S_REQUIRE(wq && w1 && w2, "decoder parameters not bound");
 
-    bool use_carry = false;
+    // Seven launches per step, each a product whose epilogue also does the elementwise work that follows it: the LSTM-cell backwards ride on
+    // the products that yield their dh, d(attention_proj input) and prenet layer 2's PSine backward on the layer-0 product, the carries into
+    // step i-1 and prenet layer 1's PSine backward on the Q / content-Q / prenet-2 launch, and the total gradient of frame i-1 on the prenet-1
+    // product (were 10 launches: build_dy, du_dz2 and carry_dz1 kernels of their own - 231 dependent launches per pass less).
+    hipLaunchKernelGGL(build_dy_kernel, dim3(ew(Bp * 96)), dim3(256), 0, s, dmel, dstop, dyc, 0, B, S, S - 1, f_dyt, st_dyt + (int64_t)(S - 1) * B * 96);
     for (int i = S - 1; i >= 0; --i) {
         const int64_t r256 = (int64_t)i * B * 256, r512 = (int64_t)i * B * 512, r2048 = (int64_t)i * B * 2048;
-        hipLaunchKernelGGL(build_dy_kernel, dim3(ew(Bp * 96)), dim3(256), 0, s, dmel, dstop, dyc, use_carry ? 1 : 0, B, S, i, f_dyt, st_dyt + (int64_t)i * B * 96);
-        // the two LSTM-cell backwards ride in the epilogues of the GEMMs that produce their dh (were two more launches per step)
         {
             SkinnyTrain t{};
-            t.lb_gates = tp.g1 + r2048; t.lb_cprev = tp.c1 + r512; t.lb_cnew = tp.c1 + r512 + (int64_t)B * 512; t.lb_dc = dc1c;
+            t.lb_gates = tp.g1 + r2048; t.lb_cprev = tp.c1 + r512; t.lb_cnew = tp.c1 + r512 + (int64_t)B * 512; t.lb_dc = dc1c; t.lb_ld_dc = 1024;
             t.lb_frag = f_dg1; t.lb_stack = st_dg1 + r2048; t.lb_H = 512;
-            if (run1t(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 512), t, s, "train_bwd_fc")) return 1;
+            if (run1t(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 1024), t, s, "train_bwd_fc")) return 1;
         }
         {
             SkinnyTrain t{};
-            t.lb_gates = tp.g0 + r2048; t.lb_cprev = tp.c0 + r512; t.lb_cnew = tp.c0 + r512 + (int64_t)B * 512; t.lb_dc = dc0c;
-            t.lb_dha = dh0c; t.lb_ld_a = 512; t.lb_mask = drop.rnn ? drop.rnn + r512 : nullptr;
+            t.lb_gates = tp.g0 + r2048; t.lb_cprev = tp.c0 + r512; t.lb_cnew = tp.c0 + r512 + (int64_t)B * 512; t.lb_dc = dc0c; t.lb_ld_dc = 1024;
+            t.lb_dha = dh0c; t.lb_ld_a = 1024; t.lb_mask = drop.rnn ? drop.rnn + r512 : nullptr;
             t.lb_frag = f_dg0; t.lb_stack = st_dg0 + r2048; t.lb_H = 512;
             if (run1t(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), t, s, "train_bwd_lstm_dx")) return 1;
         }
-        if (run1(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), s, "train_bwd_lstm_dx")) return 1;
-        hipLaunchKernelGGL(du_dz2_kernel, dim3(ew(Bp * 256)), dim3(256), 0, s, d0x, 1024, tp.z2 + r256, w2, B, f_du, st_du + r256, f_dz2);
+        {
+            SkinnyTrain t{};                // columns 256..511 of d0x = d(u): fragment + stack, and through prenet layer 2's PSine
+            t.sd_lo = 256; t.sd_hi = 512; t.sd_z = tp.z2 + r256; t.sd_w = w2; t.sd_stack = st_du + r256; t.sd_frag_d = f_du; t.sd_frag_dz = f_dz2;
+            if (run1t(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), t, s, "train_bwd_lstm_dx")) return 1;
+        }
         if (run1(bsk(tw.ap, 512, 256, B, f_du, dav, 512), s, "train_bwd_attention_proj")) return 1;
         {
             AttnBwdP a{};
@@ -951,22 +878,30 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
         }
         {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
-            sb.p[0] = bsk(tw.q, 1024, 512, B, f_dzq, dhq, 1024); sb.ntiles[0] = 64;
-            sb.p[1] = bsk(tw.cq, 1024, 256, B, f_dzc, dcq, 1024); sb.ntiles[1] = 64;
+            // dh carries: [d0x[:,512:] | d01[:,512:]] + d(h) through Q; dc carries += d(c) through the content query; dp1 through prenet-1's PSine
+            sb.p[0] = bsk(tw.q, 1024, 512, B, f_dzq, dhc, 1024, d0x + 512, 1024); sb.ntiles[0] = 64;
+            tb.t[0].add_hi = d01; tb.t[0].add_hi_from = 512;
+            sb.p[1] = bsk(tw.cq, 1024, 256, B, f_dzc, dcc, 1024, dcc, 1024); sb.ntiles[1] = 64;
             sb.p[2] = bsk(tw.p2, 256, 256, B, f_dz2, dp1, 256); sb.ntiles[2] = 16;
+            tb.t[2].sd_lo = 0; tb.t[2].sd_hi = 256; tb.t[2].sd_z = tp.z1 + r256; tb.t[2].sd_w = w1; tb.t[2].sd_mask = drop.prenet ? drop.prenet + r256 : nullptr;
+            tb.t[2].sd_stack = st_dp1 + r256; tb.t[2].sd_frag_dz = f_dz1;
             sb.count = 3;
             if (launch_train_skinny(sb, tb, s, "train_bwd_q_cq_prenet2")) return 1;
         }
-        hipLaunchKernelGGL(carry_dz1_kernel, dim3(ew(B * 512) + ew(Bp * 256)), dim3(256), 0, s, d0x, d01, dhq, dcq, B, dh0c, dh1c, dc0c, dc1c, ew(B * 512),
-                           dp1, tp.z1 + r256, w1, f_dz1, st_dp1 + r256, drop.prenet ? drop.prenet + r256 : nullptr);
-        if (run1(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), s, "train_bwd_prenet1")) return 1;
-        const bool forced = (i == 0) || (mask && mask[i]);
-        use_carry = !forced;
+        {
+            SkinnyTrain t{};
+            if (i > 0) {                    // total gradient of frame i-1: its loss gradient, plus this step's carry unless step i was teacher-forced
+                const bool forced = mask && mask[i];
+                t.dy_dmel = dmel + (int64_t)(i - 1) * 80; t.dy_ld_mel = (int64_t)S * 80; t.dy_dstop = dstop + (i - 1); t.dy_ld_stop = S;
+                t.dy_use_carry = forced ? 0 : 1; t.dy_stack = st_dyt + (int64_t)(i - 1) * B * 96; t.dy_frag = f_dyt;
+            }
+            if (run1t(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), t, s, "train_bwd_prenet1")) return 1;
+        }
         L2S_CHECK_HIP(hipGetLastError());
     }
     // ---- state gradients
-    L2S_CHECK_HIP(hipMemcpyAsync(dh_init, dh0c, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
-    L2S_CHECK_HIP(hipMemcpyAsync(dh_init + (int64_t)B * 512, dh1c, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh0c, 1024, dh_init, 512, B, 512);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh1c, 1024, dh_init + (int64_t)B * 512, 512, B, 512);
     const float* ws_can = m->canon(D + "stop_token_layer.linear_layer.weight");
     float* g_ws = m->grad(D + "stop_token_layer.linear_layer.weight");
     hipLaunchKernelGGL(stop_tail_bwd_kernel, dim3(1), dim3(512), 0, s, dstop, B, S, ws_can, state + sl.ecell, de_c, g_ws ? g_ws + 512 : nullptr);
