@@ -18,4 +18,4 @@ for _ in range(2): step()
 native.profile_enable(True); native.profile_reset(); step(); torch.cuda.synchronize()
 prof = sorted(native.profile_read(), key=lambda r: -r[2]); tot = sum(r[2] for r in prof)
 print(f"bracketed GPU time {tot:.2f} ms over {sum(r[1] for r in prof)} launches")
-for name, cnt, ms in prof[:28]: print(f"  {name:40s} {cnt:6d} launches {ms:8.3f} ms  {100*ms/tot:5.1f}%")
+for name, cnt, ms in prof[:int(os.environ.get("TOP", 28))]: print(f"  {name:40s} {cnt:6d} launches {ms:8.3f} ms  {100*ms/tot:5.1f}%")
