@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int n = idx % N; const int64_t m = idx / N;
         float a = 0.f;
+#pragma unroll 8
         for (int z = 0; z < nsplit; ++z) a += partials[(int64_t)z * stride + m * ldp + n];
         float* dst = C + m * ldc + n;
         *dst = accumulate ? *dst + a : a;

@@ -154,7 +154,8 @@ int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipSt
 // Backward of a fused GEMM epilogue  y = act(z) [+ residual],  z = conv * s + shift  (s, shift = eval-mode BatchNorm and/or bias):
 //   dpre = dy * act'(z);  dconv = dpre * s;  per-column sums  r0 = sum dpre,  r1 = sum dpre * (z - beta)/gamma,
 //   r2 = sum dy * sin(z) (PSine) or sum dy * min(z, 0) (PReLU).  Two-stage column reduction, deterministic (train_decoder.hip).
-constexpr int AB_RS = 256;    // row splits: narrow layers (24-116 channels) have one column block, the splits are what fills the chip
+constexpr int AB_RS = 1024;   // row splits: narrow layers (24-116 channels) have one column block, the splits are what fills the chip (four blocks per CU:
+                              // a block keeps only 8 KB of loads in flight, and at one block per CU the pass ran at a quarter of the HBM rate)
 struct ActBwdP {
     const float* dy; const float* z; float* dconv;     // [rows][ld]
     int ld_dy, ld_z, ld_dconv;                          // 0 = C
@@ -182,7 +183,7 @@ int bn_stats_finalize(const float* partials, int nblk, int blk_stride, int64_t c
 int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z, int co_z, const float* gamma, const float* beta, const float* scale,
                  const float* totals, int64_t rows, int C, hipStream_t s);
 // depthwise 3x3 stats pass: partials[(rs*2 + k)*C + c], DWS_RS row splits
-constexpr int DWS_RS = 256;
+constexpr int DWS_RS = 1024;
 int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)

@@ -68,16 +68,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdP p, int nspli
 }
 
 // final stage: out_k[col] (+)= mul_k(col) * sum_rs partial[rs][k][col];   k=0 -> shift-like grad (BN beta or plain bias), conv bias = s * r0
-// block = 64 columns x 4 lanes striding over the row splits
-__global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restrict__ partials, int nsplit, int C, const float* __restrict__ scale,
+// block = 64 columns x 16 lanes striding over the row splits
+__global__ __launch_bounds__(1024) void act_bwd_final_kernel(const float* __restrict__ partials, int nsplit, int C, const float* __restrict__ scale,
                                                             float* __restrict__ d_shift, float* __restrict__ d_gamma, float* __restrict__ d_actw,
                                                             float* __restrict__ d_convbias, int accumulate, float* __restrict__ totals) {
-    __shared__ float sh[3][4][64];
+    __shared__ float sh[3][16][64];
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     float r[3] = {0.f, 0.f, 0.f};
     if (col < C)
-        for (int rs = lane; rs < nsplit; rs += 4)
+#pragma unroll 4
+        for (int rs = lane; rs < nsplit; rs += 16)
 #pragma unroll
             for (int k = 0; k < 3; ++k) r[k] += partials[((int64_t)rs * 3 + k) * C + col];
 #pragma unroll
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restr
     __syncthreads();
     if (lane != 0 || col >= C) return;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r[k] = (sh[k][0][cl] + sh[k][1][cl]) + (sh[k][2][cl] + sh[k][3][cl]);
+    for (int k = 0; k < 3; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[k][q][cl];
+        r[k] = t;
+    }
     auto put = [&](float* dst, float v) { if (dst) dst[col] = accumulate ? dst[col] + v : v; };
     put(d_shift, r[0]);
     put(d_gamma, r[1]);
@@ -97,9 +103,9 @@ __global__ __launch_bounds__(256) void act_bwd_final_kernel(const float* __restr
 int act_bwd(const ActBwdP& p, float* d_shift, float* d_gamma, float* d_actw, float* d_convbias, bool accumulate, hipStream_t s, float* totals) {
     ProfScope ps("train_act_bn_bwd", s);
     // row splits: the long, narrow maps of the encoder (24-116 channels = one or two column blocks) need them to fill the chip
-    const int nsplit = (int)std::min<int64_t>(AB_RS, std::max<int64_t>(32, (p.rows + 255) / 256));
+    const int nsplit = (int)std::min<int64_t>(AB_RS, std::max<int64_t>(32, (p.rows + 63) / 64));
     hipLaunchKernelGGL(act_bwd_kernel, dim3((p.C + 63) / 64, nsplit), dim3(256), 0, s, p, nsplit);
-    hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, nsplit, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,
+    hipLaunchKernelGGL(act_bwd_final_kernel, dim3((p.C + 63) / 64), dim3(1024), 0, s, p.partials, nsplit, p.C, p.scale, d_shift, d_gamma, d_actw, d_convbias,
                        accumulate ? 1 : 0, totals);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

@@ -187,37 +187,43 @@ __global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* __restr
 }
 
 // transposed depthwise 3x3 (pad 1): dx[n][ih][iw][c] (+)= sum_{kh,kw} gd[n][oh][ow][c] * w9[kh*3+kw][c], oh*stride + kh - 1 = ih
-__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restrict__ gd, int N, int Ho, int Wo, int C, int stride, const float* __restrict__ w9,
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restrict__ gd, int N, int Ho, int Wo, int C, const float* __restrict__ w9,
                                                             float* __restrict__ dx, int Hi, int Wi, int ldx, int xoff, int accumulate) {
-    const int64_t total = (int64_t)N * Hi * Wi * C;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c = idx % C;
-        int64_t r = idx / C;
+    // 32-bit index arithmetic (the maps hold < 2^31 elements; checked by the launcher), compile-time stride, and all nine taps fetched with
+    // clamped addresses before the first use (64-bit divisions and a branch per tap made this gather ALU- and round-trip-bound: 26 us for a 12x12 map)
+    const unsigned total = (unsigned)N * Hi * Wi * C;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned c = idx % C;
+        unsigned r = idx / C;
         const int iw = r % Wi; r /= Wi;
         const int ih = r % Hi;
-        const int n = r / Hi;
-        float acc = 0.f;
+        const unsigned n = r / Hi;
+        float g[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int th = ih + 1 - kh;
-            if (th < 0 || th % stride) continue;
-            const int oh = th / stride;
-            if (oh >= Ho) continue;
+            const int oh = th / STRIDE;
+            const bool okh = th >= 0 && (STRIDE == 1 || (th & 1) == 0) && oh < Ho;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int tw = iw + 1 - kw;
-                if (tw < 0 || tw % stride) continue;
-                const int ow = tw / stride;
-                if (ow >= Wo) continue;
-                acc = fmaf(gd[(((int64_t)n * Ho + oh) * Wo + ow) * C + c], w9[(kh * 3 + kw) * C + c], acc);
+                const int ow = tw / STRIDE;
+                const bool ok = okh && tw >= 0 && (STRIDE == 1 || (tw & 1) == 0) && ow < Wo;
+                const unsigned src = ok ? ((n * Ho + oh) * Wo + ow) * C + c : c;
+                const float v = gd[src];
+                g[kh * 3 + kw] = ok ? v : 0.f;
             }
         }
-        float* dst = dx + (((int64_t)n * Hi + ih) * Wi + iw) * ldx + xoff + c;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(g[k], w9[k * C + c], acc);
+        float* dst = dx + (size_t)((n * Hi + ih) * Wi + iw) * ldx + xoff + c;
         *dst = accumulate ? *dst + acc : acc;
     }
 }
 
-constexpr int DW_RS = 256;     // row splits of the per-tap reductions (58-232 channels = 1-4 column blocks: the splits fill the chip)
+constexpr int DW_RS = 1024;    // row splits of the per-tap reductions (58-232 channels = 1-4 column blocks: the splits fill the chip)
 // partial[rs][k][c] = sum over this split's output pixels of gd[.][c] * x[shifted by tap k][c]
 __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restrict__ gd, const float* __restrict__ x, int N, int Hi, int Wi, int ldx, int xoff,
                                                             int Ho, int Wo, int C, int stride, float* __restrict__ partials) {
@@ -471,7 +477,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     float* dconv = bp.f((int64_t)NF * Hc * Hc * 24);
     const int fd_strips = (Hc + FD_CR - 1) / FD_CR;
     float* fdp = bp.f((int64_t)NF * fd_strips * FD_PART);
-    const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];
+    const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];     // floats; 256 slices of a <= 232 x 232 gradient fit as well
     float* skp = bp.f(splitk_cap);
     float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)FB_BLOCKS * 3 * 24);
     float* totals = bp.f(2 * 1024);
@@ -484,7 +490,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         if (!out) return 0;
         BwdGemmP p = bwd_dw(dz, ldz, x, ldx, out, 1, (int)rows, (int)rows, nout, cin, 1, 1, 0, false);
         const int tiles = ((nout + 63) / 64) * ((cin + 63) / 64);
-        int splits = std::max(1, std::min(64, 1024 / tiles));
+        int splits = std::max(1, std::min(256, 2048 / tiles));        // 58-channel layers: one tile, 33 408 rows -> 256 slices of four K steps each
         while (splits > 1 && gemm_bwd_splitk_floats(p, splits) > splitk_cap) --splits;
         return launch_gemm_bwd_splitk(p, splits, skp, s, "train_bwd_encoder_dw");
     };
@@ -507,8 +513,10 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         const int64_t total = (int64_t)NF * hi * hi * C;
         {
             ProfScope ps("train_bwd_dwconv_dx", s);
-            hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, gdz, NF, ho, ho, C, stride, w9, dx, hi, hi,
-                               ld_dx, dxoff, acc ? 1 : 0);
+            L2S_REQUIRE(total < (int64_t)1 << 31 && (int64_t)NF * hi * hi * ld_dx < (int64_t)1 << 31, "depthwise backward: map too large for 32-bit indexing");
+            const dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 8192));
+            if (stride == 2) hipLaunchKernelGGL(dwconv_bwd_dx_kernel<2>, grid, dim3(256), 0, s, gdz, NF, ho, ho, C, w9, dx, hi, hi, ld_dx, dxoff, acc ? 1 : 0);
+            else hipLaunchKernelGGL(dwconv_bwd_dx_kernel<1>, grid, dim3(256), 0, s, gdz, NF, ho, ho, C, w9, dx, hi, hi, ld_dx, dxoff, acc ? 1 : 0);
         }
         if (gw) {
             ProfScope ps("train_bwd_dwconv_dw", s);

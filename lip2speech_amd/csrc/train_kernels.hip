@@ -167,8 +167,10 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 4
         for (int b = lane; b < nblk; b += 16) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
+    }
     sh[0][lane][cl] = s1; sh[1][lane][cl] = s2;
     __syncthreads();
     if (lane != 0 || c >= C) return;
@@ -225,22 +227,38 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
         float wk[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) wk[k] = w9[k * C + col];
-        for (int64_t r = r_begin + rl; r < r_end; r += 4) {
-            const int ow = r % Wo; const int64_t q = r / Wo;
-            const int oh = q % Ho, n = q / Ho;
-            float acc = 0.f;
+        // U rows per trip with their 9 x U loads in flight together (one row per trip was a chain of dependent round trips: 32 us for the
+        // 12x12 maps); rows ascending within the thread as before, so the sums are the same numbers
+        constexpr int U = 4;
+        for (int64_t r0 = r_begin + rl; r0 < r_end; r0 += 4 * U) {
+            float xv[U][9];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = oh * stride + kh - 1;
-                if (ih < 0 || ih >= Hi) continue;
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + 4 * u;
+                const bool live = r < r_end;
+                const int64_t rr = live ? r : r_begin;
+                const int ow = rr % Wo; const int64_t q = rr / Wo;
+                const int oh = q % Ho, n = q / Ho;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow * stride + kw - 1;
-                    if (iw < 0 || iw >= Wi) continue;
-                    acc = fmaf(in[(((int64_t)n * Hi + ih) * Wi + iw) * ldi + ci_off + col], wk[kh * 3 + kw], acc);
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = oh * stride + kh - 1;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int iw = ow * stride + kw - 1;
+                        const bool in_ = live && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+                        xv[u][kh * 3 + kw] = in_ ? in[(((int64_t)n * Hi + ih) * Wi + iw) * ldi + ci_off + col] : 0.f;
+                    }
                 }
             }
-            s1 += acc; s2 += acc * acc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r0 + 4 * u < r_end) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc = fmaf(xv[u][k], wk[k], acc);
+                    s1 += acc; s2 += acc * acc;
+                }
+            }
         }
     }
     sh[0][rl][threadIdx.x & 63] = s1; sh[1][rl][threadIdx.x & 63] = s2;
