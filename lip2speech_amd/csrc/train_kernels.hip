@@ -158,24 +158,25 @@ namespace l2s {
 
 // ------------------------------------------------------------------------------------------------ batch-statistics BatchNorm
 // partials[blk*blk_stride + k*C + c], k = 0: sum, 1: sum of squares of the raw conv output over the rows of block blk
-// one block = 64 channels x 16 lanes striding over the partial rows (up to ~8 000 of them for the widest maps), fp64 tree in LDS
+// one block = 16 channels x 64 lanes striding over the partial rows (up to ~8 000 of them for the widest maps), fp64 tree in LDS; with 64
+// channels x 16 lanes the 58-channel layers ran as ONE block walking 33 dependent trips
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ partials, int nblk, int blk_stride, double inv_n, double unbias,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
                                                               float* __restrict__ rvar, const float* __restrict__ conv_bias, float momentum, int C,
                                                               float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[2][16][64];
-    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double sh[2][64][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int b = lane; b < nblk; b += 16) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
+        for (int b = lane; b < nblk; b += 64) { s1 += partials[(int64_t)b * blk_stride + c]; s2 += partials[(int64_t)b * blk_stride + C + c]; }
     }
     sh[0][lane][cl] = s1; sh[1][lane][cl] = s2;
     __syncthreads();
     if (lane != 0 || c >= C) return;
     s1 = 0.0; s2 = 0.0;
-    for (int l = 0; l < 16; ++l) { s1 += sh[0][l][cl]; s2 += sh[1][l][cl]; }
+    for (int l = 0; l < 64; ++l) { s1 += sh[0][l][cl]; s2 += sh[1][l][cl]; }
     const double mean = s1 * inv_n;
     double var = s2 * inv_n - mean * mean;                   // biased (the normaliser); fp64 combination of fp32 tile sums
     var = var > 0.0 ? var : 0.0;
@@ -189,28 +190,48 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
 int bn_stats_finalize(const float* partials, int nblk, int blk_stride, int64_t count, const BnLayer& L, float momentum, hipStream_t s) {
     L2S_REQUIRE(L.gamma && L.beta && L.scale && L.shift && count > 1, "batch-norm layer not bound (l2s_train_bind incl. running statistics)");
     ProfScope ps("train_bn_stats_finalize", s);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((L.C + 63) / 64), dim3(1024), 0, s, partials, nblk, blk_stride, 1.0 / (double)count,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((L.C + 15) / 16), dim3(1024), 0, s, partials, nblk, blk_stride, 1.0 / (double)count,
                        (double)count / (double)(count - 1), L.gamma, L.beta, L.rmean, L.rvar, L.conv_bias, momentum, L.C, L.scale, L.shift);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // dconv[r][c] -= scale[c] * (r0[c]/n + xhat[r][c] * r1[c]/n),  xhat = (z - beta)/gamma   (totals = [r0 | r1])
+// block = 64 channels x 4 row lanes over one of `nsplit` row ranges: the per-channel constants sit in registers, no index division per element
 __global__ __launch_bounds__(256) void bn_train_fix_kernel(float* __restrict__ dconv, int ld_dconv, const float* __restrict__ z, int ld_z, int cs_z, int co_z,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
-                                                           const float* __restrict__ totals, float inv_n, int64_t rows, int C) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) {
-        const int c = i % C; const int64_t r = i / C;
-        const float xh = (z[r * ld_z + co_z + (int64_t)c * cs_z] - beta[c]) / gamma[c];
-        dconv[r * ld_dconv + c] -= scale[c] * (totals[c] + xh * totals[C + c]) * inv_n;
+                                                           const float* __restrict__ totals, float inv_n, int64_t rows, int C, int nsplit) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
+    if (c >= C) return;
+    const int64_t chunk = (rows + nsplit - 1) / nsplit;
+    const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+    const float be = beta[c], ga = gamma[c], sc = scale[c], t0 = totals[c], t1 = totals[C + c];
+    const float* zp = z + co_z + (int64_t)c * cs_z;
+    float* dp = dconv + c;
+    constexpr int U = 4;
+    for (int64_t r0 = r_begin + rl; r0 < r_end; r0 += 4 * U) {
+        float zz[U], dd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + 4 * u < r_end ? r0 + 4 * u : r_begin + rl;
+            zz[u] = zp[r * ld_z]; dd[u] = dp[r * ld_dconv];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + 4 * u;
+            if (r < r_end) {
+                const float xh = (zz[u] - be) / ga;
+                dp[r * ld_dconv] = dd[u] - sc * (t0 + xh * t1) * inv_n;
+            }
+        }
     }
 }
 int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z, int co_z, const float* gamma, const float* beta, const float* scale,
                  const float* totals, int64_t rows, int C, hipStream_t s) {
     ProfScope ps("train_bn_batchstat_bwd", s);
-    const int64_t n = rows * C;
-    hipLaunchKernelGGL(bn_train_fix_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, dconv, ld_dconv ? ld_dconv : C, z, ld_z ? ld_z : C,
-                       cs_z ? cs_z : 1, co_z, gamma, beta, scale, totals, 1.f / (float)rows, rows, C);
+    const int nsplit = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (rows + 63) / 64));
+    hipLaunchKernelGGL(bn_train_fix_kernel, dim3((C + 63) / 64, nsplit), dim3(256), 0, s, dconv, ld_dconv ? ld_dconv : C, z, ld_z ? ld_z : C,
+                       cs_z ? cs_z : 1, co_z, gamma, beta, scale, totals, 1.f / (float)rows, rows, C, nsplit);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
