@@ -841,8 +841,12 @@ int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     int rc = 1;
     if (p.h == 12 && p.half == 58) rc = launch_s1_inst<12, 58, 1>(p, s);
     else if (p.h == 11 && p.half == 58) rc = launch_s1_inst<11, 58, 1>(p, s);      // 88x88 crops
-    else if (p.h == 6 && p.half == 116) rc = launch_s1_inst<6, 116, 2>(p, s);
-    else if (p.h == 3 && p.half == 232) rc = launch_s1_inst<3, 232, 2>(p, s);
+    // frames per block: with many frames in the launch (grouped batches) more frames share one pass over the unit's weights, which every block
+    // streams from L2 (3x3 stage: 2 x 215 KB per block against 2 x 9 pixels of work) and the 16-row tiles fill better (18 of 32 rows -> 45 of 48):
+    // 273 -> 197 us per unit at 256 clips with five frames (four: 226, seven: 231 - registers).  A pixel's arithmetic does not depend on its
+    // block's other pixels, so the results are the same bits whatever the grouping
+    else if (p.h == 6 && p.half == 116) rc = launch_s1_inst<6, 116, 2>(p, s);         // three frames per block: 128 VGPRs + spills, 238 -> 267 us
+    else if (p.h == 3 && p.half == 232) rc = p.NF >= 2048 ? launch_s1_inst<3, 232, 5>(p, s) : launch_s1_inst<3, 232, 2>(p, s);
     else set_error("shuffle_s1: unsupported unit geometry");
     if (rc) return 1;
     L2S_CHECK_HIP(hipGetLastError());

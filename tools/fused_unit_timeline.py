@@ -1,16 +1,17 @@
 #!/usr/bin/env python
-"""Phase timeline of the fused stride-1 ShuffleNet units (B=32, T=29): the stamped build of one stage at a time; the last launch of
+"""Phase timeline of the fused stride-1 ShuffleNet units (B env, default 32, T=29): the stamped build of one stage at a time; the last launch of
 that stage leaves its stamps."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = {k: v for k, v in synth.synth_state_dict().items() if k.startswith("encoder.")}
 nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
-v = synth.synth_video(32, 29, tag="bench").cuda()
+B = int(os.environ.get("B", 32))
+v = synth.synth_video(32, 29, tag="bench").cuda().repeat(B // 32, 1, 1, 1, 1)
 for _ in range(3): nm.encoder_fwd(v)
 L = native.lib()
 names = ["entry", "input in LDS", "after barrier", "pw1 done", "dw taps done", "dw written", "pw2 done", "stores drained"]
-for h, nblk in ((12, 928), (6, 464), (3, 464)):
+for h, nblk in ((12, 29 * B), (6, 29 * B // 2), (3, 29 * B // 2)):
     ts = torch.zeros(nblk * 10, dtype=torch.int64, device="cuda")
     native.check(L.l2s_op_fused_unit_timeline(ts.data_ptr(), h))
     nm.encoder_fwd(v); torch.cuda.synchronize()
