@@ -689,9 +689,15 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
         if (m->r_tables) (void)hipFree(m->r_tables);
         L2S_CHECK_HIP(hipMalloc(&m->r_tables, total));
         m->r_tables_bytes = (int64_t)total;
+        m->r_tables_uploaded.clear();
     }
-    L2S_CHECK_HIP(hipMemcpyAsync(m->r_tables, m->r_tables_host.data(), total, hipMemcpyHostToDevice, s));
-    L2S_CHECK_HIP(hipStreamSynchronize(s));                             // pageable staging buffer: the copy must have left the host vector
+    // the tables only change when tensors are (re)bound: upload them then, not on every optimizer step (the upload comes from a pageable vector,
+    // so it ends in a stream synchronise - once per step that drained the pipeline between steps)
+    if (m->r_tables_host != m->r_tables_uploaded) {
+        L2S_CHECK_HIP(hipMemcpyAsync(m->r_tables, m->r_tables_host.data(), total, hipMemcpyHostToDevice, s));
+        L2S_CHECK_HIP(hipStreamSynchronize(s));                         // pageable staging buffer: the copy must have left the host vector
+        m->r_tables_uploaded = m->r_tables_host;
+    }
     char* T = (char*)m->r_tables;
     {
         ProfScope ps("train_refresh_gather", s);

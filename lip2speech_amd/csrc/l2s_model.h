@@ -93,7 +93,7 @@ struct l2s_model {
     std::vector<std::string> r_keys;
     int32_t* r_key = nullptr; int32_t* r_idx = nullptr;      // device [blob_floats]
     void* r_tables = nullptr; int64_t r_tables_bytes = 0;     // device scratch for the pointer / descriptor tables
-    std::vector<char> r_tables_host;
+    std::vector<char> r_tables_host, r_tables_uploaded;       // what the next refresh needs / what the device table holds
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics
     bool bn_batch = false; float bn_momentum = 0.1f;
