@@ -208,7 +208,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
         __syncthreads();
     }
 
-    if (p.stats) {      // batch-statistics pass: per-column sum and sum of squares of this tile's rows, nothing stored
+    if (p.stats) {      // batch-statistics pass: per-column sum and sum of squares of this tile's rows; the raw product is parked on request
+        if (p.stats_raw) {
+            const int colr = n0 + wn * 32 + li;
+            if (colr < p.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    if (row < p.M) p.Zout[(int64_t)row * p.ldc + (int64_t)colr * p.c_cstride] = acc[r];
+                }
+            }
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -248,6 +258,28 @@ __global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const GemmP p, 
     float v = 0.f;
     for (int i = 0; i < ksplit; ++i) v += part[(int64_t)i * p.M * p.N + idx];
     gemm_store(p, row, col, v, p.scale ? p.scale[col] : 1.0f, p.shift ? p.shift[col] : 0.0f);
+}
+
+// epilogue over parked raw products (launch_gemm_finish): thread = one output element
+__global__ __launch_bounds__(256) void gemm_finish_kernel(const GemmBatch b) {
+    const GemmP& p = b.p[blockIdx.y];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * p.N) return;
+    const int row = (int)(idx / p.N), col = (int)(idx - (int64_t)row * p.N);
+    const float raw = p.Zout[(int64_t)row * p.ldc + (int64_t)col * p.c_cstride];
+    gemm_store(p, row, col, raw, p.scale ? p.scale[col] : 1.0f, p.shift ? p.shift[col] : 0.0f);
+}
+int launch_gemm_finish(const GemmBatch& b, hipStream_t s, const char* name) {
+    L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP, "gemm group size");
+    int64_t maxe = 0;
+    for (int i = 0; i < b.count; ++i) {
+        L2S_REQUIRE(b.p[i].Zout && b.p[i].win_T == 0 && !b.p[i].stats, "gemm finish: needs the parked raw product (Zout), plain rows");
+        maxe = std::max<int64_t>(maxe, (int64_t)b.p[i].M * b.p[i].N);
+    }
+    ProfScope ps(name, s);
+    hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((maxe + 255) / 256), b.count), dim3(256), 0, s, b);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K) {

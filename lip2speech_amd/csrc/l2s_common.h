@@ -97,6 +97,8 @@ struct GemmP {
                           //   so a batch meets the same kernels alone and in a group (results stay bit-identical)
     float* stats;         // training, batch-statistics BatchNorm: STATS PASS - nothing is stored; per-column sums of the raw product
                           //   (no scale/shift) go to stats[(blockIdx.y*2 + {0: sum, 1: sum of squares})*N + n]
+    int stats_raw;        // STATS PASS with stats_raw: the raw product is also parked at the Zout addresses, and launch_gemm_finish runs the
+                          //   epilogue over it once this batch's scale/shift exist - ONE pass over the product instead of two
 };
 inline int64_t gemm_stats_floats(int M, int N) { return (int64_t)((M + 63) / 64) * 2 * N; }
 constexpr int GEMM_MAX_GROUP = 8;
@@ -129,6 +131,10 @@ int launch_gemm_splitk_group(const GemmBatch& g, int ksplit, float* part, hipStr
 // kernel per multi-tap layer. part: sum over the multi-tap layers of taps*M*N floats.
 int launch_gemm_tapsplit(const GemmBatch& convs, float* part, hipStream_t s, const char* name);
 int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name);
+// train() mode, convs in front of a batch-statistics BatchNorm: after a stats pass with stats_raw = 1 (and bn_stats_finalize), the fused epilogue
+// of `b` (scale/shift, Zout, activation, masks, addends, any store form) element by element over the parked raw products - the same gemm_store
+// on the same accumulator values as a second GEMM pass, bit for bit, for an M x N elementwise pass instead of the product
+int launch_gemm_finish(const GemmBatch& b, hipStream_t s, const char* name);
 int launch_gemm1(const GemmP& p, hipStream_t s, const char* name);
 
 // ---------------------------------------------------------------- backward GEMMs (gemm_bwd.hip)

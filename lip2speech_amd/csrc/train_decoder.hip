@@ -202,11 +202,14 @@ static int postnet_train_fwd(l2s_model* m, const float* mel, int B, int S, float
         p.mask = post_mask(drop, B, S, l); p.ldmask = cout; p.mask_pre = l == 4;     // the mel residual is added outside the Postnet module
         if (m->bn_batch) {                     // batch statistics: stats pass of the same conv, then this batch's scale/shift in the fused epilogue
             const std::string c = "decoder.postnet.convolutions." + std::to_string(l);
-            GemmP q = p; q.stats = t.stats; q.scale = nullptr; q.shift = nullptr;
+            GemmP q = p; q.stats = t.stats; q.stats_raw = 1; q.scale = nullptr; q.shift = nullptr;
             if (launch_gemm1(q, s, "train_postnet_conv_stats")) return 1;
             BnLayer L = dec_bn_layer(m, c + ".1", c + ".0.conv.bias", t.bn + l * 1024, cout);
             if (bn_stats_finalize(t.stats, (B * S + 63) / 64, 2 * cout, (int64_t)B * S, L, m->bn_momentum, s)) return 1;
             p.scale = L.scale; p.shift = L.shift;
+            GemmBatch fb{}; fb.p[0] = p; fb.count = 1;          // the product is parked at z_l: the epilogue runs over it, not a second conv
+            if (launch_gemm_finish(fb, s, "train_postnet_conv_epilogue")) return 1;
+            continue;
         }
         if (launch_gemm1(p, s, "train_postnet_conv_gemm")) return 1;
     }
@@ -1121,7 +1124,7 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
         for (int q = 0; q < 8; ++q) gb.p[q].Zout = tp.zcat + 512 + q * 512;       // Zout shares C's addressing (ld 4608)
         if (m->bn_batch) {
             GemmBatch sbt = gb;
-            for (int q = 0; q < 8; ++q) { sbt.p[q].stats = tp.stats + q * tp.stats_group; sbt.p[q].scale = nullptr; sbt.p[q].shift = nullptr; }
+            for (int q = 0; q < 8; ++q) { sbt.p[q].stats = tp.stats + q * tp.stats_group; sbt.p[q].stats_raw = 1; sbt.p[q].scale = nullptr; sbt.p[q].shift = nullptr; }
             if (launch_gemm(sbt, s, "train_multihop_conv_stats")) return 1;
             for (int q = 0; q < 8; ++q) {
                 const std::string c = std::string("decoder.") + (q < 4 ? "K" : "V") + ".0.conv." + std::to_string(q % 4);
@@ -1130,7 +1133,7 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
                 gb.p[q].scale = L.scale; gb.p[q].shift = L.shift;
             }
         }
-        if (launch_gemm(gb, s, "train_multihop_conv_gemm")) return 1;
+        if (m->bn_batch ? launch_gemm_finish(gb, s, "train_multihop_conv_epilogue") : launch_gemm(gb, s, "train_multihop_conv_gemm")) return 1;
         GemmBatch bb{};
         for (int kv = 0; kv < 2; ++kv) {
             GemmP p = gemm_plain(tp.cat, 4608, w.mh_bott[kv].W, state + (kv == 0 ? sl.k : sl.v), 512, BT, 512, 2560);
@@ -1148,7 +1151,7 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
         gb.count = 4;
         if (m->bn_batch) {
             GemmBatch sbt = gb;
-            for (int j = 0; j < 4; ++j) { sbt.p[j].stats = tp.stats + j * tp.stats_group; sbt.p[j].scale = nullptr; sbt.p[j].shift = nullptr; }
+            for (int j = 0; j < 4; ++j) { sbt.p[j].stats = tp.stats + j * tp.stats_group; sbt.p[j].stats_raw = 1; sbt.p[j].scale = nullptr; sbt.p[j].shift = nullptr; }
             if (launch_gemm(sbt, s, "train_content_agg_stats")) return 1;
             for (int j = 0; j < 4; ++j) {
                 const std::string c = "decoder.content.agg." + std::to_string(j);
@@ -1158,7 +1161,7 @@ static int prologue_train_fwd(l2s_model* m, const float* vis, const float* emb, 
                 gb.p[j].scale = L.scale; gb.p[j].shift = L.shift;
             }
         }
-        if (launch_gemm(gb, s, "train_content_agg_gemm")) return 1;
+        if (m->bn_batch ? launch_gemm_finish(gb, s, "train_content_agg_epilogue") : launch_gemm(gb, s, "train_content_agg_gemm")) return 1;
         PoolCatP pc{};
         pc.x[0] = tp.cat; pc.L[0] = T; pc.ld[0] = 4608;
         for (int j = 0; j < 4; ++j) { pc.x[j + 1] = tp.cmap[j]; pc.L[j + 1] = tp.L[j]; pc.ld[j + 1] = 512; }

@@ -95,11 +95,13 @@ static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int
         if (bnb) {
             p.Zout = zbuf;
             L2S_REQUIRE(gemm_stats_floats(p.M, p.N) <= tp.stats_floats, "statistics scratch too small");
-            GemmP q = p; q.stats = tp.stats; q.scale = nullptr; q.shift = nullptr;
+            GemmP q = p; q.stats = tp.stats; q.stats_raw = 1; q.scale = nullptr; q.shift = nullptr;
             if (launch_gemm1(q, s, "train_pw_gemm_stats")) return 1;
             BnLayer L = enc_bn_layer(m, tp, id, key, p.N);
             if (bn_stats_finalize(tp.stats, (p.M + 63) / 64, 2 * p.N, p.M, L, m->bn_momentum, s)) return 1;
             p.scale = L.scale; p.shift = L.shift;
+            GemmBatch fb{}; fb.p[0] = p; fb.count = 1;          // the product is parked at zbuf: epilogue pass, not a second product
+            return launch_gemm_finish(fb, s, name);
         }
         return launch_gemm1(p, s, name);
     };
