@@ -190,7 +190,9 @@ int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z,
                  const float* totals, int64_t rows, int C, hipStream_t s);
 // depthwise 3x3 stats pass: partials[(rs*2 + k)*C + c], DWS_RS row splits
 constexpr int DWS_RS = 1024;
-int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s);
+int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s,
+                        float* raw_out = nullptr, int ldo = 0, int co_off = 0);     // raw_out: also park the raw conv output (then launch_bn_apply instead of a second conv pass)
+int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
 struct FrontendW {          // device pointers into the weight blob

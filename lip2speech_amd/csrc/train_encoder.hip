@@ -109,10 +109,10 @@ static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int
         const float* sc = d.scale; const float* sh = d.shift;
         if (bnb) {
             const int ho = (h + 2 - 3) / stride + 1;
-            if (launch_dwconv_stats(in, NF, h, h, ldi, 0, C, stride, d.w9, tp.stats, s)) return 1;
+            if (launch_dwconv_stats(in, NF, h, h, ldi, 0, C, stride, d.w9, tp.stats, s, out, C, 0)) return 1;      // raw conv output parked in `out`
             BnLayer L = enc_bn_layer(m, tp, id, key, C);
             if (bn_stats_finalize(tp.stats, DWS_RS, 2 * C, (int64_t)NF * ho * ho, L, m->bn_momentum, s)) return 1;
-            sc = L.scale; sh = L.shift;
+            return launch_bn_apply(out, (int64_t)NF * ho * ho, C, C, 0, L.scale, L.shift, s);
         }
         return launch_dwconv(in, NF, h, h, ldi, 0, C, stride, d.w9, sc, sh, out, C, 0, s);
     };

@@ -238,7 +238,8 @@ int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z,
 
 // depthwise 3x3 (pad 1) statistics pass over channel-last maps: raw conv recomputed per output element, two-stage column sums
 __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restrict__ in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride,
-                                                           const float* __restrict__ w9, int Ho, int Wo, float* __restrict__ partials) {
+                                                           const float* __restrict__ w9, int Ho, int Wo, float* __restrict__ partials,
+                                                           float* __restrict__ raw_out, int ldo, int co_off) {
     __shared__ float sh[2][4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
     const int64_t rows = (int64_t)N * Ho * Wo, chunk = (rows + DWS_RS - 1) / DWS_RS;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
 #pragma unroll
                     for (int k = 0; k < 9; ++k) acc = fmaf(xv[u][k], wk[k], acc);
                     s1 += acc; s2 += acc * acc;
+                    if (raw_out) raw_out[(r0 + 4 * u) * ldo + co_off + col] = acc;     // parked for bn_apply_kernel: one pass over the conv
                 }
             }
         }
@@ -290,10 +292,38 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
         partials[((int64_t)rs * 2 + 1) * C + col] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
     }
 }
-int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s) {
+int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s,
+                        float* raw_out, int ldo, int co_off) {
     const int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
     ProfScope ps("train_dwconv_stats", s);
-    hipLaunchKernelGGL(dwconv_stats_kernel, dim3((C + 63) / 64, DWS_RS), dim3(256), 0, s, in, N, Hi, Wi, ldi, ci_off, C, stride, w9, Ho, Wo, partials);
+    hipLaunchKernelGGL(dwconv_stats_kernel, dim3((C + 63) / 64, DWS_RS), dim3(256), 0, s, in, N, Hi, Wi, ldi, ci_off, C, stride, w9, Ho, Wo, partials, raw_out, ldo, co_off);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// x[r][co_off + c] = x[r][co_off + c] * scale[c] + shift[c] over a channel-last map: the BatchNorm of a depthwise conv whose raw output the
+// statistics pass parked in place (the expression of dwconv3x3_kernel's last line)
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, int64_t rows, int C, int ld, int co_off, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int nsplit) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
+    if (c >= C) return;
+    const int64_t chunk = (rows + nsplit - 1) / nsplit;
+    const int64_t r_begin = rs * chunk, r_end = r_begin + chunk < rows ? r_begin + chunk : rows;
+    const float sc = scale[c], sh = shift[c];
+    float* xp = x + co_off + c;
+    constexpr int U = 4;
+    for (int64_t r0 = r_begin + rl; r0 < r_end; r0 += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xp[(r0 + 4 * u < r_end ? r0 + 4 * u : r_begin + rl) * ld];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r0 + 4 * u < r_end) { const float acc = v[u]; xp[(r0 + 4 * u) * ld] = acc * sc + sh; }
+    }
+}
+int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s) {
+    ProfScope ps("train_dwconv_bn_apply", s);
+    const int nsplit = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (rows + 63) / 64));
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((C + 63) / 64, nsplit), dim3(256), 0, s, x, rows, C, ld, co_off, scale, shift, nsplit);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
