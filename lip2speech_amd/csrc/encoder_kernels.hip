@@ -110,7 +110,11 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
                 for (int r = 0; r < 16; ++r) {
                     const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
                     const int lr = p / Wc, crow = 2 * p0 - 1 + lr;
-                    if (p < P && lr >= 1 && crow < Hc) { s1 += acc[j][r]; s2 += acc[j][r] * acc[j][r]; }    // the halo row belongs to the strip above
+                    if (p < P && lr >= 1 && crow < Hc) {                                                      // the halo row belongs to the strip above
+                        s1 += acc[j][r]; s2 = fmaf(acc[j][r], acc[j][r], s2);       // explicit: the contraction must not depend on the code around it
+                        // one pass over the conv: the raw map is parked where the tape keeps the pre-PReLU map; launch_bn_apply + frontend_pool finish it
+                        if (out && li < FE_CO) out[(((int64_t)f * Hc + crow) * Wc + (p - lr * Wc)) * FE_CO + li] = acc[j][r];
+                    }
                 }
             }
         }
@@ -422,15 +426,53 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
     return 0;
 }
 
-int launch_frontend_stats(const FrontendW& w, const float* video1, int B, int T, int H, int W, float* partials, int* nblocks, hipStream_t s) {
+// PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) over the pre-PReLU map z (NF,Hc,Wc,24) -> (NF,Hc/2,Wc/2,24): the tail of the fused front-end as a
+// kernel of its own (training, batch statistics: the conv ran once, in the statistics pass)
+__global__ __launch_bounds__(256) void frontend_pool_kernel(const float* __restrict__ z, const float* __restrict__ slope, int NF, int Hc, int Wc, float* __restrict__ out) {
+    const int Hp = Hc / 2, Wp = Wc / 2;
+    const unsigned total = (unsigned)NF * Hp * Wp * FE_CO;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int ch = idx % FE_CO;
+        unsigned r = idx / FE_CO;
+        const int pw = r % Wp; r /= Wp;
+        const int pr = r % Hp;
+        const unsigned f = r / Hp;
+        const float sl = slope[ch];
+        float m = -INFINITY;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr) {
+            const int crow = 2 * pr + dr;
+            if (crow < 0 || crow >= Hc) continue;
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int cc = 2 * pw + dc;
+                if (cc < 0 || cc >= Wc) continue;
+                float v = z[((size_t)(f * Hc + crow) * Wc + cc) * FE_CO + ch];
+                v = v >= 0.f ? v : sl * v;
+                m = fmaxf(m, v);
+            }
+        }
+        out[idx] = m;
+    }
+}
+int launch_frontend_pool(const float* z, const float* slope, int NF, int Hc, int Wc, float* out, hipStream_t s) {
+    const int64_t total = (int64_t)NF * (Hc / 2) * (Wc / 2) * FE_CO;
+    L2S_REQUIRE(total < (int64_t)1 << 31, "front-end pool: map too large for 32-bit indexing");
+    ProfScope ps("train_frontend_prelu_pool", s);
+    hipLaunchKernelGGL(frontend_pool_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s, z, slope, NF, Hc, Wc, out);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_frontend_stats(const FrontendW& w, const float* video1, int B, int T, int H, int W, float* partials, int* nblocks, hipStream_t s, float* raw_out) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
     FrameSrc video{}; video.p[0] = video1; video.per = B;
     const int Hp = H / 4;
     dim3 grid((Hp + FE_PR - 1) / FE_PR, B * T);
     *nblocks = (int)(grid.x * grid.y);
     ProfScope ps("train_frontend3d_stats", s);
-    if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 2>), grid, dim3(256), 0, s, w, video, T, (float*)nullptr, partials);
-    else hipLaunchKernelGGL((frontend3d_kernel<88, 2>), grid, dim3(256), 0, s, w, video, T, (float*)nullptr, partials);
+    if (H == 96) hipLaunchKernelGGL((frontend3d_kernel<96, 2>), grid, dim3(256), 0, s, w, video, T, raw_out, partials);
+    else hipLaunchKernelGGL((frontend3d_kernel<88, 2>), grid, dim3(256), 0, s, w, video, T, raw_out, partials);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -192,7 +192,7 @@ int bn_train_fix(float* dconv, int ld_dconv, const float* z, int ld_z, int cs_z,
 constexpr int DWS_RS = 1024;
 int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_off, int C, int stride, const float* w9, float* partials, hipStream_t s,
                         float* raw_out = nullptr, int ldo = 0, int co_off = 0);     // raw_out: also park the raw conv output (then launch_bn_apply instead of a second conv pass)
-int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s);
+int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s, bool fused = false);
 
 // ---------------------------------------------------------------- encoder kernels (encoder_kernels.hip)
 struct FrontendW {          // device pointers into the weight blob
@@ -215,7 +215,9 @@ inline int launch_frontend(const FrontendW& w, const float* video, int B, int T,
     return launch_frontend(w, f, B, T, H, W, out, s, zout);
 }
 // batch-statistics pass of the front-end conv (training): partials[(block*2 + k)*24 + ch], *nblocks blocks
-int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials /*[blocks][2][24]*/, int* nblocks, hipStream_t s);
+int launch_frontend_stats(const FrontendW& w, const float* video, int B, int T, int H, int W, float* partials /*[blocks][2][24]*/, int* nblocks, hipStream_t s, float* raw_out = nullptr);
+// raw_out (NF,H/2,W/2,24): the statistics pass also parks the raw conv map; launch_bn_apply on it + launch_frontend_pool then replace the second conv pass
+int launch_frontend_pool(const float* z, const float* slope, int NF, int Hc, int Wc, float* out, hipStream_t s);
 
 // data boundary: packed uint8 RGB clips (clip i = frames[i] x H x W x 3 bytes at packed + offsets[i]) -> video (B,3,T,H,W) fp32,
 // /255 then ImageNet mean/std, clips shorter than T zero-padded; offsets / frames are HOST arrays

@@ -119,14 +119,15 @@ static int encoder_train_fwd(l2s_model* m, const float* video, int B, int T, int
     {
         FrontendW fe = w.fe;
         fe.w3 = nullptr; fe.w1 = nullptr;     // training forward: f32 MFMA kernel (it also writes the pre-PReLU map)
-        if (bnb) {
+        if (bnb) {      // the conv runs once: its statistics pass parks the raw map in the tape's z0, BatchNorm is applied in place, PReLU + pool follow
             int nblk = 0;
-            if (launch_frontend_stats(w.fe, video, B, T, H, W, tp.stats, &nblk, s)) return 1;
+            if (launch_frontend_stats(w.fe, video, B, T, H, W, tp.stats, &nblk, s, tp.z0)) return 1;
             BnLayer L = enc_bn_layer(m, tp, 0, "frontend3D.1", 24);
-            if (bn_stats_finalize(tp.stats, nblk, 48, (int64_t)NF * (H / 2) * (W / 2), L, m->bn_momentum, s)) return 1;
-            fe.scale = L.scale; fe.shift = L.shift;
-        }
-        if (launch_frontend(fe, video, B, T, H, W, tp.x[0], s, tp.z0)) return 1;
+            const int64_t px = (int64_t)NF * (H / 2) * (W / 2);
+            if (bn_stats_finalize(tp.stats, nblk, 48, px, L, m->bn_momentum, s)) return 1;
+            if (launch_bn_apply(tp.z0, px, 24, 24, 0, L.scale, L.shift, s, true)) return 1;
+            if (launch_frontend_pool(tp.z0, w.fe.slope, NF, H / 2, W / 2, tp.x[0], s)) return 1;
+        } else if (launch_frontend(fe, video, B, T, H, W, tp.x[0], s, tp.z0)) return 1;
     }
     for (int u = 0; u < N_UNITS; ++u) {
         const UnitW& U = w.unit[u];

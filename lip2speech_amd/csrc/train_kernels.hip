@@ -302,6 +302,8 @@ int launch_dwconv_stats(const float* in, int N, int Hi, int Wi, int ldi, int ci_
 }
 // x[r][co_off + c] = x[r][co_off + c] * scale[c] + shift[c] over a channel-last map: the BatchNorm of a depthwise conv whose raw output the
 // statistics pass parked in place (the expression of dwconv3x3_kernel's last line)
+template <bool FUSED>        // FUSED: one rounding (fmaf) - what the front-end's fused epilogue compiles `acc * sc + sh` to; else product and sum rounded
+                             // separately - what dwconv3x3_kernel's last line compiles to (tools/hash_train_step.py tells them apart)
 __global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, int64_t rows, int C, int ld, int co_off, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int nsplit) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, rs = blockIdx.y;
@@ -317,13 +319,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, in
         for (int u = 0; u < U; ++u) v[u] = xp[(r0 + 4 * u < r_end ? r0 + 4 * u : r_begin + rl) * ld];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (r0 + 4 * u < r_end) { const float acc = v[u]; xp[(r0 + 4 * u) * ld] = acc * sc + sh; }
+            if (r0 + 4 * u < r_end) { const float acc = v[u]; xp[(r0 + 4 * u) * ld] = FUSED ? fmaf(acc, sc, sh) : __fadd_rn(__fmul_rn(acc, sc), sh); }
     }
 }
-int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s) {
-    ProfScope ps("train_dwconv_bn_apply", s);
+int launch_bn_apply(float* x, int64_t rows, int C, int ld, int co_off, const float* scale, const float* shift, hipStream_t s, bool fused) {
+    ProfScope ps("train_bn_apply", s);
     const int nsplit = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (rows + 63) / 64));
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((C + 63) / 64, nsplit), dim3(256), 0, s, x, rows, C, ld, co_off, scale, shift, nsplit);
+    if (fused) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((C + 63) / 64, nsplit), dim3(256), 0, s, x, rows, C, ld, co_off, scale, shift, nsplit);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((C + 63) / 64, nsplit), dim3(256), 0, s, x, rows, C, ld, co_off, scale, shift, nsplit);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
