@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void build_dy_kernel(const float* __restrict__
 
 // ---- attention + content attention backward, one 512-thread block per batch row (decoder.py:414-419, 262-271)
 struct AttnBwdP {
-    const float* dav;                 // [B][512]
+    const float* dav; int ld_dav;     // [B][ld_dav] (0 = 512)
     const float* dcc; int ld_dcc;     // [B][ld]
     const float* logits; int64_t ld_logit_b;   // logits of this step (after dropout): [b*ld + t]
     const float* lmask; int ld_lmask;          // dropout multiplier of the logits [b*ld + t] or null
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnBwdP p) {
     const float tau = p.tau[0], tau_c = p.tau_c[0];
     const float* kb = p.k + (int64_t)b * T * 512;
     const float* vb = p.v + (int64_t)b * T * 512;
-    s_dav[tid] = p.dav[(int64_t)b * 512 + tid];
+    s_dav[tid] = p.dav[(int64_t)b * (p.ld_dav ? p.ld_dav : 512) + tid];
     // softmax of the stored logits
     const bool on = tid < T;
     const float l = on ? p.logits[(int64_t)b * p.ld_logit_b + tid] : -INFINITY;
@@ -732,12 +732,13 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
 }
 
 // ---- transposed step weights for the backward products, packed on the device from the canonical parameters
-struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1, *bhh[2], *fc4; };
-static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 2 * (int64_t)512 * 2048 + 504 * 256 + 64 * 14; }
+struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1, *bhh[2], *fc4, *prod_ap; };     // prod_ap: W_ih_l0[:,256:512] @ W_ap (2048 x 512), canonical row order
+static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + 2 * (int64_t)512 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 2 * (int64_t)512 * 2048 + 504 * 256 + 64 * 14; }
 static TrainW train_w(float* base) {
     TrainW t; int64_t o = 0;
     auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
-    t.fc = take((int64_t)512 * 96); t.l1 = take((int64_t)1024 * 2048); t.l0 = take((int64_t)1024 * 2048); t.ap = take((int64_t)512 * 256);
+    t.fc = take((int64_t)512 * 96); t.l1 = take((int64_t)1024 * 2048); t.l0 = take((int64_t)1536 * 2048); t.ap = take((int64_t)512 * 256);
+    t.prod_ap = take((int64_t)2048 * 512);
     t.q = take((int64_t)1024 * 512); t.cq = take((int64_t)1024 * 256); t.p2 = take(256 * 256); t.p1 = take(80 * 256);
     t.bhh[0] = take((int64_t)512 * 2048); t.bhh[1] = take((int64_t)512 * 2048); t.fc4 = take(504 * 256);
     return t;
@@ -750,8 +751,13 @@ static int pack_train_weights(l2s_model* m, float* wbuf, hipStream_t s) {
     L2S_REQUIRE(P("fc_out.linear_layer.weight") && P("decoder_rnn.weight_ih_l0") && P("prenet.0.linear_layer.weight"), "decoder parameters not bound");
     if (pack_fragT(t.fc, 512, 96, PackSeg{P("fc_out.linear_layer.weight"), 512, 0, 512, 0, 80}, PackSeg{P("stop_token_layer.linear_layer.weight"), 1024, 0, 512, 80, 81}, none, s)) return 1;
     if (pack_fragT(t.l1, 1024, 2048, PackSeg{P("decoder_rnn.weight_ih_l1"), 512, 0, 512, 0, 2048}, PackSeg{P("decoder_rnn.weight_hh_l1"), 512, 512, 1024, 0, 2048}, none, s)) return 1;
-    if (pack_fragT(t.l0, 1024, 2048, PackSeg{P("decoder_rnn.weight_ih_l0"), 512, 0, 512, 0, 2048}, PackSeg{P("decoder_rnn.weight_hh_l0"), 512, 512, 1024, 0, 2048}, none, s)) return 1;
-    if (pack_fragT(t.ap, 512, 256, PackSeg{P("attention_proj.linear_layer.weight"), 512, 0, 512, 0, 256}, none, none, s)) return 1;
+    // layer 0's transposed block also yields d(a@v) directly: its last 512 output columns are (W_ih[:,256:512] W_ap)^T, so the attention_proj
+    // backward product does not need a launch of its own in the loop (d(u) still leaves as columns 256..511 for the parameter gradients)
+    L2S_REQUIRE(P("attention_proj.linear_layer.weight"), "decoder parameters not bound");
+    if (launch_gemm_bwd(bwd_dx(P("decoder_rnn.weight_ih_l0") + 256, 512, P("attention_proj.linear_layer.weight"), t.prod_ap, 512, 1, 2048, 2048, 256, 512, 1, 0, false), s,
+                        "train_merge_step_weights")) return 1;
+    if (pack_fragT(t.l0, 1536, 2048, PackSeg{P("decoder_rnn.weight_ih_l0"), 512, 0, 512, 0, 2048}, PackSeg{P("decoder_rnn.weight_hh_l0"), 512, 512, 1024, 0, 2048},
+                   PackSeg{t.prod_ap, 512, 1024, 1536, 0, 2048}, s)) return 1;
     if (pack_fragT(t.q, 1024, 512, PackSeg{P("Q.0.linear_layer.weight"), 1024, 0, 1024, 0, 512}, none, none, s)) return 1;
     if (pack_fragT(t.cq, 1024, 256, PackSeg{P("content.Q.0.weight"), 1024, 0, 1024, 0, 256}, none, none, s)) return 1;
     if (pack_fragT(t.p2, 256, 256, PackSeg{P("prenet.3.linear_layer.weight"), 256, 0, 256, 0, 256}, none, none, s)) return 1;
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
 
 static int64_t step_bwd_ws_floats(int B, int S) {
     const int64_t Bp = pad16(B), SB = (int64_t)S * B;
-    return SB * (96 + 2048 * 3 + 256 * 3 + 512 + 2 + 256 + 256) + Bp * (96 + 2048 * 2 + 256 * 4 + 512) + (int64_t)B * (512 * 6 + 1024 * 4 + 256 + 80) +
+    return SB * (96 + 2048 * 3 + 256 * 3 + 512 + 2 + 256 + 256) + Bp * (96 + 2048 * 2 + 256 * 4 + 512) + (int64_t)B * (512 * 6 + 1024 * 6 + 256 + 80) +
            (int64_t)AB_RS * 3 * 2048 + (int64_t)96 * 512 + 4096 + 64 * 60;
 }
 
@@ -831,9 +837,9 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     float* st_tmp = bp.f(SB * 2048); float* st_p1 = bp.f(SB * 256);
     // per-step fragments and plain buffers
     float* f_dyt = bp.f((int64_t)Bp * 96); float* f_dg1 = bp.f((int64_t)Bp * 2048); float* f_dg0 = bp.f((int64_t)Bp * 2048);
-    float* f_du = bp.f((int64_t)Bp * 256); float* f_dzq = bp.f((int64_t)Bp * 512); float* f_dzc = bp.f((int64_t)Bp * 256);
+    float* f_dzq = bp.f((int64_t)Bp * 512); float* f_dzc = bp.f((int64_t)Bp * 256);
     float* f_dz2 = bp.f((int64_t)Bp * 256); float* f_dz1 = bp.f((int64_t)Bp * 256);
-    float* dh1lin = bp.f((int64_t)B * 512); float* d01 = bp.f((int64_t)B * 1024); float* d0x = bp.f((int64_t)B * 1024); float* dav = bp.f((int64_t)B * 512);
+    float* dh1lin = bp.f((int64_t)B * 512); float* d01 = bp.f((int64_t)B * 1536); float* d0x = bp.f((int64_t)B * 1536);      // row pitch 1536 both: [dcc 256 | du 256 | dh0 512 | d(a@v) 512]; d01 uses 1024 of it
     float* dp1 = bp.f((int64_t)B * 256); float* dyc = bp.f((int64_t)B * 80);
     // carries into the previous step, both layers side by side: (B,1024) = [layer 0 | layer 1], row pitch 1024
     float* dhc = bp.f((int64_t)B * 1024); float* dcc = bp.f((int64_t)B * 1024);
@@ -866,17 +872,16 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
             t.lb_gates = tp.g0 + r2048; t.lb_cprev = tp.c0 + r512; t.lb_cnew = tp.c0 + r512 + (int64_t)B * 512; t.lb_dc = dc0c; t.lb_ld_dc = 1024;
             t.lb_dha = dh0c; t.lb_ld_a = 1024; t.lb_mask = drop.rnn ? drop.rnn + r512 : nullptr;
             t.lb_frag = f_dg0; t.lb_stack = st_dg0 + r2048; t.lb_H = 512;
-            if (run1t(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1024), t, s, "train_bwd_lstm_dx")) return 1;
+            if (run1t(bsk(tw.l1, 1024, 2048, B, f_dg1, d01, 1536), t, s, "train_bwd_lstm_dx")) return 1;
         }
         {
             SkinnyTrain t{};                // columns 256..511 of d0x = d(u): fragment + stack, and through prenet layer 2's PSine
-            t.sd_lo = 256; t.sd_hi = 512; t.sd_z = tp.z2 + r256; t.sd_w = w2; t.sd_stack = st_du + r256; t.sd_frag_d = f_du; t.sd_frag_dz = f_dz2;
-            if (run1t(bsk(tw.l0, 1024, 2048, B, f_dg0, d0x, 1024), t, s, "train_bwd_lstm_dx")) return 1;
+            t.sd_lo = 256; t.sd_hi = 512; t.sd_z = tp.z2 + r256; t.sd_w = w2; t.sd_stack = st_du + r256; t.sd_frag_dz = f_dz2;
+            if (run1t(bsk(tw.l0, 1536, 2048, B, f_dg0, d0x, 1536), t, s, "train_bwd_lstm_dx")) return 1;
         }
-        if (run1(bsk(tw.ap, 512, 256, B, f_du, dav, 512), s, "train_bwd_attention_proj")) return 1;
         {
             AttnBwdP a{};
-            a.dav = dav; a.dcc = d0x; a.ld_dcc = 1024; a.logits = attn_logits + (int64_t)i * T; a.ld_logit_b = (int64_t)S * T;
+            a.dav = d0x + 1024; a.ld_dav = 1536; a.dcc = d0x; a.ld_dcc = 1536; a.logits = attn_logits + (int64_t)i * T; a.ld_logit_b = (int64_t)S * T;
             if (drop.attn) { a.lmask = drop.attn + (int64_t)i * B * T; a.ld_lmask = T; }
             a.k = state + sl.k; a.v = state + sl.v; a.zq = tp.zq + r512; a.wq = wq; a.pos = w.pos + (int64_t)i * 512; a.tau = w.tau;
             a.alpha = tp.alpha + (int64_t)i * B * 16; a.ckey = state + sl.ckey; a.cval = state + sl.cval; a.zc = tp.zc + r256; a.tau_c = w.tau_c;
@@ -888,7 +893,7 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
         {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
             // dh carries: [d0x[:,512:] | d01[:,512:]] + d(h) through Q; dc carries += d(c) through the content query; dp1 through prenet-1's PSine
-            sb.p[0] = bsk(tw.q, 1024, 512, B, f_dzq, dhc, 1024, d0x + 512, 1024); sb.ntiles[0] = 64;
+            sb.p[0] = bsk(tw.q, 1024, 512, B, f_dzq, dhc, 1024, d0x + 512, 1536); sb.ntiles[0] = 64;
             tb.t[0].add_hi = d01; tb.t[0].add_hi_from = 512;
             sb.p[1] = bsk(tw.cq, 1024, 256, B, f_dzc, dcc, 1024, dcc, 1024); sb.ntiles[1] = 64;
             sb.p[2] = bsk(tw.p2, 256, 256, B, f_dz2, dp1, 256); sb.ntiles[2] = 16;
