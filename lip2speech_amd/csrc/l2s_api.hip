@@ -555,7 +555,7 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     bool want_enc = false, want_dec = false, want_spk = false;
     if (pack_host(m, P, want_enc, want_dec, want_spk)) return 1;
     if (m->opt.refresh_map && build_refresh_map(m, P, stream)) return 1;
-    m->folded_valid = true;
+    m->folded_valid = true; m->planes_valid = true;
 
     // upload and patch pointers
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -658,6 +658,58 @@ __global__ __launch_bounds__(256) void refresh_sum_kernel(const RSum* __restrict
     r.dst[np] = r.a[src] + r.b[src];
 }
 
+// ---- device-side re-merge of the two pre-multiplied step matrices (the host packer's fp64 products, here as fp32 MFMA products of the bound
+// parameters): prenet1 o fc_out -> w.pre1f, LSTM0 with attention_proj folded in -> w.lstm0f, both in the frag16 weight layout of the blob
+struct MergeSeg { const float* src; int ld, col0, k_lo, k_hi; };
+__global__ __launch_bounds__(256) void merge_pack_kernel(float* __restrict__ dst, int N, int K, MergeSeg s0, MergeSeg s1, MergeSeg s2, int perm_H) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int k = idx % K, np = idx / K;
+        const int r = perm_H ? (np & 3) * perm_H + (np >> 2) : np;
+        const MergeSeg* segs[3] = {&s0, &s1, &s2};
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const MergeSeg& g = *segs[q];
+            if (g.src && k >= g.k_lo && k < g.k_hi) v = g.src[(int64_t)r * g.ld + g.col0 + (k - g.k_lo)];
+        }
+        dst[frag16_index(np, k, K)] = v;
+    }
+}
+// out[np] = a[r] (+ b[r]) + sum_k W[r*ld + col0 + k] * x[k],  r = perm(np)
+__global__ __launch_bounds__(256) void merge_bias_kernel(float* __restrict__ out, int N, const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ W, int ld, int col0, int K, const float* __restrict__ x, int perm_H) {
+    const int np = blockIdx.x * 256 + threadIdx.x;
+    if (np >= N) return;
+    const int r = perm_H ? (np & 3) * perm_H + (np >> 2) : np;
+    double acc = (double)a[r] + (b ? (double)b[r] : 0.0);
+    for (int k = 0; k < K; ++k) acc += (double)W[(int64_t)r * ld + col0 + k] * (double)x[k];
+    out[np] = (float)acc;
+}
+static int remerge_step_weights(l2s_model* m, hipStream_t s) {
+    const std::string D = "decoder.";
+    auto P = [&](const char* k) { return m->canon(D + k); };
+    const float *wp1 = P("prenet.0.linear_layer.weight"), *bp1 = P("prenet.0.linear_layer.bias"), *wfc = P("fc_out.linear_layer.weight"), *bfc = P("fc_out.linear_layer.bias");
+    const float *wih = P("decoder_rnn.weight_ih_l0"), *whh = P("decoder_rnn.weight_hh_l0"), *bih = P("decoder_rnn.bias_ih_l0"), *bhh = P("decoder_rnn.bias_hh_l0");
+    const float *wap = P("attention_proj.linear_layer.weight"), *bap = P("attention_proj.linear_layer.bias");
+    if (!(wp1 && bp1 && wfc && bfc && wih && whh && bih && bhh && wap && bap) || !m->w.pre1f.W || !m->w.lstm0f.W) return 0;      // decoder not bound: stays invalid
+    if (!m->merge_scratch) L2S_CHECK_HIP(hipMalloc(&m->merge_scratch, sizeof(float) * ((int64_t)2048 * 512 + (int64_t)256 * 512)));
+    float* prod_ap = m->merge_scratch; float* prod_p1 = prod_ap + (int64_t)2048 * 512;
+    // (W_ih[:,256:512] @ W_ap) (2048 x 512) and (W_p1 @ W_out) (256 x 512): C = A . B with B row-major is the input-gradient form of the backward GEMM
+    if (launch_gemm_bwd(bwd_dx(wih + 256, 512, wap, prod_ap, 512, 1, 2048, 2048, 256, 512, 1, 0, false), s, "train_merge_step_weights")) return 1;
+    if (launch_gemm_bwd(bwd_dx(wp1, NM, wfc, prod_p1, 512, 1, 256, 256, NM, 512, 1, 0, false), s, "train_merge_step_weights")) return 1;
+    ProfScope ps("train_merge_step_weights", s);
+    const MergeSeg none{nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(merge_pack_kernel, dim3(4096), dim3(256), 0, s, const_cast<float*>(m->w.lstm0f.W), 2048, 1536, MergeSeg{wih, 512, 0, 0, 512},
+                       MergeSeg{prod_ap, 512, 0, 512, 1024}, MergeSeg{whh, 512, 0, 1024, 1536}, 512);
+    hipLaunchKernelGGL(merge_pack_kernel, dim3(512), dim3(256), 0, s, const_cast<float*>(m->w.pre1f.W), 256, 512, MergeSeg{prod_p1, 512, 0, 0, 512}, none, none, 0);
+    hipLaunchKernelGGL(merge_bias_kernel, dim3(8), dim3(256), 0, s, const_cast<float*>(m->w.lstm0f.bias), 2048, bih, bhh, wih, 512, 256, 256, bap, 512);
+    hipLaunchKernelGGL(merge_bias_kernel, dim3(1), dim3(256), 0, s, const_cast<float*>(m->w.pre1f.bias), 256, bp1, (const float*)nullptr, wp1, NM, 0, NM, bfc, 0);
+    L2S_CHECK_HIP(hipGetLastError());
+    m->folded_valid = true;
+    return 0;
+}
+
 static int refresh_weights(l2s_model* m, hipStream_t s) {
     L2S_REQUIRE(m->finalized && m->r_key && m->r_idx, "no refresh map: set option refresh_map=1 before l2s_model_finalize");
     const size_t nk = m->r_keys.size(), nb = m->r_bn.size(), ns = m->r_sum.size();
@@ -706,7 +758,9 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
     if (nb_live) hipLaunchKernelGGL(refresh_bn_kernel, dim3((maxc + 255) / 256, (unsigned)nb_live), dim3(256), 0, s, reinterpret_cast<const RBn*>(T + off_bn));
     if (ns_live) hipLaunchKernelGGL(refresh_sum_kernel, dim3((maxn + 255) / 256, (unsigned)ns_live), dim3(256), 0, s, reinterpret_cast<const RSum*>(T + off_sum));
     L2S_CHECK_HIP(hipGetLastError());
-    m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are fp64 products of the old parameters: the loop falls back to the literal step
+    m->planes_valid = false;        // the front-end's bf16 planes are splits of the old weights: inference falls back to the f32 front-end kernel
+    m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are products of the old parameters ...
+    if (remerge_step_weights(m, s)) return 1;      // ... rebuilt here when the decoder's tensors are bound (then the 4-launch step stays valid)
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     m->graphs.clear();
     return 0;
@@ -791,8 +845,8 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
     float* a = bp.f(pl.act_a); float* b = bp.f(pl.act_b); float* t1 = bp.f(pl.t1); float* t2 = bp.f(pl.t2); float* last = bp.f(pl.last);
     L2S_REQUIRE(!bp.overflow, "encoder workspace too small");
     FrontendW fe = w.fe;
-    if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale (like the merged step weights)
-    if (!m->opt.infer_bf16 || !m->folded_valid) fe.w1 = nullptr;
+    if (!m->opt.frontend_x3 || !m->planes_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale
+    if (!m->opt.infer_bf16 || !m->planes_valid) fe.w1 = nullptr;
     if (launch_frontend(fe, video, B, T, H, W, a, s)) return 1;
     float* x = a; float* y = b;
     int h = pl.Hp;
@@ -1312,6 +1366,7 @@ int l2s_model_destroy(l2s_model* m) {
     if (m->r_key) (void)hipFree(m->r_key);
     if (m->r_idx) (void)hipFree(m->r_idx);
     if (m->r_tables) (void)hipFree(m->r_tables);
+    if (m->merge_scratch) (void)hipFree(m->merge_scratch);
     delete m;
     return 0;
 }
@@ -1537,8 +1592,8 @@ int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* d
 int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream) {
     L2S_ENC_READY(m);
     FrontendW fe = m->w.fe;
-    if (!m->opt.frontend_x3 || !m->folded_valid) fe.w3 = nullptr;
-    if (!m->opt.infer_bf16 || !m->folded_valid) fe.w1 = nullptr;
+    if (!m->opt.frontend_x3 || !m->planes_valid) fe.w3 = nullptr;
+    if (!m->opt.infer_bf16 || !m->planes_valid) fe.w1 = nullptr;
     return launch_frontend(fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }
 

@@ -95,6 +95,8 @@ struct l2s_model {
     void* r_tables = nullptr; int64_t r_tables_bytes = 0;     // device scratch for the pointer / descriptor tables
     std::vector<char> r_tables_host, r_tables_uploaded;       // what the next refresh needs / what the device table holds
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
+    bool planes_valid = true;                                 // the front-end's bf16 operand planes (w3 / w1) match the current parameters
+    float* merge_scratch = nullptr;                           // device: the two products of the device-side re-merge (l2s_train_refresh_weights)
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics
     bool bn_batch = false; float bn_momentum = 0.1f;
     const float* canon(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.first; }
