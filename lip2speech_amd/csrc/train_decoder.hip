@@ -617,8 +617,12 @@ static SkinnyP tsk(const SkW& sw, int B) {
     return p;
 }
 
+__global__ __launch_bounds__(256) void psine_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t rows, int C, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) out[i] = sinf(z[i]) * w[i % C];
+}
+
 // ---- forward of the loop with the tape (the literal 6-phase step; eval-mode statistics, no dropout)
-static int64_t step_fwd_ws_floats(int B) { return (int64_t)pad16(B) * (512 * 8 + 256 * 3 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 20; }
+static int64_t step_fwd_ws_floats(int B) { return (int64_t)pad16(B) * (512 * 8 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 20; }
 
 // dropout multipliers of the loop (train mode; any may be null): prenet (S,B,256) after the first PSine (decoder.py:308), attention
 // logits (S,B,T) (:363), inter-layer LSTM dropout (S,B,512) on h0 as the input of layer 1 (:312)
@@ -638,12 +642,18 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
     float* yf = bp.f((int64_t)Bp * 96);
     float* q = bp.f((int64_t)B * 512); float* qc = bp.f((int64_t)B * 256); float* p2 = bp.f((int64_t)B * 256);
     float* h0d = bp.f((int64_t)Bp * 512);
+    float* p2f = bp.f((int64_t)Bp * 256);
     L2S_REQUIRE(!bp.overflow, "training decode workspace too small");
+    // The phase-merged step of inference (prenet1 o fc_out over h1, attention_proj folded into LSTM0's input weights) is used
+    // here too when the merged matrices are valid (packed by the host, or re-merged on the device by l2s_train_refresh_weights): 4 launches per
+    // step instead of 6.  The tape is the same (z1, z2, zq, zc, alpha, a@v, gates, cells, hidden states); u = attention_proj(a@v) + prenet is
+    // only needed by the parameter gradients and is rebuilt for all steps at once after the loop.
+    const bool fold = m->opt.fold != 0 && m->folded_valid && w.pre1f.W && w.lstm0f.W;
     if (launch_fill(h0d, (int64_t)Bp * 512, 0.f, s)) return 1;
     L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
     L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
     for (float* z : {h0[1], h1[1], c0, c1, av}) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
-    for (float* z : {p1, cc, uu}) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
+    for (float* z : {p1, cc, uu, p2f}) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
     if (launch_to_frag(w.bos, 0, B, 80, yf, 80, 0, 1, s)) return 1;
     // tape row 0 of the state sequences
     if (launch_from_frag(h0[0], 512, B, 512, tp.h0, 512, 0, s)) return 1;
@@ -658,8 +668,10 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             if (launch_to_frag(teacher + (int64_t)i * NM_, S * NM_, B, 80, yf, 80, 0, 0, s)) return 1;
         {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
-            SkinnyP a = tsk(w.pre1, B);
-            a.seg[0] = {yf, 5}; a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
+            const bool from_frame = !fold || i == 0 || (teacher && mask && mask[i]);      // prenet input is an explicit frame (BOS / teacher / unfolded y)
+            SkinnyP a = tsk(from_frame ? w.pre1 : w.pre1f, B);
+            if (from_frame) a.seg[0] = {yf, 5}; else a.seg[0] = {h1[cur], 32};
+            a.nseg = 1; a.act = ACT_PSINE; a.epi = SK_FRAG; a.out = p1; a.ldo = 256;
             tb.t[0].zsave = tp.z1 + r256; tb.t[0].ld_z = 256;
             if (drop.prenet) { tb.t[0].out_mask = drop.prenet + r256; tb.t[0].ld_mask = 256; }
             SkinnyP b = tsk(w.q, B);
@@ -670,7 +682,14 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             c.seg[0] = {c0, 32}; c.seg[1] = {c1, 32}; c.nseg = 2; c.act = ACT_SILU; c.out = qc; c.ldo = 256;
             tb.t[2].zsave = tp.zc + r256; tb.t[2].ld_z = 256;
             sb.p[0] = a; sb.ntiles[0] = 16; sb.p[1] = b; sb.ntiles[1] = w.q.tiles; sb.p[2] = c; sb.ntiles[2] = w.cq.tiles; sb.count = 3;
-            if (launch_train_skinny(sb, tb, s, "train_step_prenet1_q_cq")) return 1;
+            if (fold && i > 0) {          // mel frame + stop logit of step i-1 ride in this launch
+                SkinnyP f = tsk(w.fc, B);
+                f.seg[0] = {h1[cur], 32}; f.nseg = 1; f.epi = SK_MEL;
+                f.mel = mel + (int64_t)(i - 1) * NM_; f.ld_mel_b = (int64_t)S * NM_; f.stop = stop + (i - 1); f.ld_stop_b = S;
+                f.stop_const = state + sl.stopc; f.yfrag = nullptr;
+                sb.p[3] = f; sb.ntiles[3] = w.fc.tiles; sb.count = 4;
+            }
+            if (launch_train_skinny(sb, tb, s, fold ? "train_step_prenet1_q_cq_fc" : "train_step_prenet1_q_cq")) return 1;
         }
         {
             TrainStepB sb{};
@@ -683,13 +702,14 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             sb.att.alpha = tp.alpha + (int64_t)i * B * 16; sb.att.ld_alpha = 16; sb.att.av_plain = tp.av + r512; sb.att.cc_plain = tp.cc + r256;
             sb.pre2 = tsk(w.pre2, B);
             sb.pre2.seg[0] = {p1, 16}; sb.pre2.nseg = 1; sb.pre2.act = ACT_PSINE; sb.pre2.out = p2; sb.pre2.ldo = 256;
+            if (fold) { sb.pre2.epi = SK_FRAG; sb.pre2.out = p2f; }
             sb.pre2t.zsave = tp.z2 + r256; sb.pre2t.ld_z = 256;
             sb.pre2_tiles = w.pre2.tiles;
             ProfScope ps("train_step_attention_prenet2", s);
             hipLaunchKernelGGL(train_step_attn_kernel, dim3(2 * B + w.pre2.tiles * (Bp / 16)), dim3(512), 0, s, sb);
             L2S_CHECK_HIP(hipGetLastError());
         }
-        {
+        if (!fold) {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
             SkinnyP a = tsk(w.aproj, B);
             a.seg[0] = {av, 32}; a.nseg = 1; a.epi = SK_FRAG; a.out = uu; a.ldo = 256; a.add = p2; a.ld_add = 256;
@@ -699,8 +719,9 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
         }
         for (int layer = 0; layer < 2; ++layer) {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
-            SkinnyP a = tsk(layer == 0 ? w.lstm0 : w.lstm1, B);
-            if (layer == 0) { a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3; }
+            SkinnyP a = tsk(layer == 0 ? (fold ? w.lstm0f : w.lstm0) : w.lstm1, B);
+            if (layer == 0 && fold) { a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.seg[2] = {av, 32}; a.seg[3] = {h0[cur], 32}; a.nseg = 4; }
+            else if (layer == 0) { a.seg[0] = {cc, 16}; a.seg[1] = {uu, 16}; a.seg[2] = {h0[cur], 32}; a.nseg = 3; }
             else { a.seg[0] = {drop.rnn ? h0d : h0[nxt], 32}; a.seg[1] = {h1[cur], 32}; a.nseg = 2; }
             a.epi = SK_LSTM; a.H = 512;
             if (layer == 0 && drop.rnn) { tb.t[0].h_drop = h0d; tb.t[0].h_drop_K = 512; tb.t[0].h_mask = drop.rnn + r512; tb.t[0].ld_hmask = 512; }
@@ -712,7 +733,7 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
             if (launch_train_skinny(sb, tb, s, "train_step_lstm_cell")) return 1;
         }
-        {
+        if (!fold || i == S - 1) {
             SkinnyBatch sb{}; TrainSkinnyBatch tb{};
             SkinnyP a = tsk(w.fc, B);
             a.seg[0] = {h1[nxt], 32}; a.nseg = 1; a.epi = SK_MEL;
@@ -721,6 +742,16 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
             sb.p[0] = a; sb.ntiles[0] = w.fc.tiles; sb.count = 1;
             if (launch_train_skinny(sb, tb, s, "train_step_fc_out_stop")) return 1;
         }
+    }
+    if (fold) {      // u = attention_proj(a@v) + prenet for all S*B rows: PSine(z2) first, then the product with the prenet as its addend, in place
+        const float* wap = m->canon("decoder.attention_proj.linear_layer.weight"); const float* bap = m->canon("decoder.attention_proj.linear_layer.bias");
+        const float* w2 = m->canon("decoder.prenet.4.w");
+        L2S_REQUIRE(wap && bap && w2, "decoder parameters not bound");
+        const int64_t SB = (int64_t)S * B;
+        hipLaunchKernelGGL(psine_fwd_kernel, dim3((unsigned)std::min<int64_t>((SB * 256 + 255) / 256, 4096)), dim3(256), 0, s, tp.z2, w2, SB, 256, tp.u);
+        GemmP g = gemm_plain(tp.av, 512, wap, tp.u, 256, (int)SB, 256, 512);
+        g.shift = bap; g.R1 = tp.u; g.ldr1 = 256;
+        if (launch_gemm1(g, s, "train_rebuild_u")) return 1;
     }
     {
         const int64_t total = (int64_t)S * B * 96;
@@ -791,9 +822,6 @@ static int run1t(const SkinnyP& p, const SkinnyTrain& t, hipStream_t s, const ch
 }
 static int ew(int n) { return (n + 255) / 256; }
 
-__global__ __launch_bounds__(256) void psine_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t rows, int C, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C; i += (int64_t)gridDim.x * 256) out[i] = sinf(z[i]) * w[i % C];
-}
 // de_c[b][j] = (sum_i dstop[b][i]) * ws[512 + j];  d ws[512 + j] = sum_b (sum_i dstop[b][i]) * e_c[b][j]
 __global__ __launch_bounds__(512) void stop_tail_bwd_kernel(const float* __restrict__ dstop, int B, int S, const float* __restrict__ ws, const float* __restrict__ ecell,
                                                             float* __restrict__ de_c, float* __restrict__ dws_tail) {
