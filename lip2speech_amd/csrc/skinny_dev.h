@@ -23,10 +23,7 @@ struct SkinnyTrain {               // training-side stores of one skinny group (
     // -> sd_stack[b*C + c] and frag16 sd_frag_d (K = C; may be null); through a PSine, d * cos(sd_z[b*C + c]) * sd_w[c] -> frag16 sd_frag_dz
     // (what du_dz2_kernel and the second half of carry_dz1_kernel did in launches of their own)
     const float* sd_z; const float* sd_w; const float* sd_mask; float* sd_stack; float* sd_frag_d; float* sd_frag_dz; int sd_lo, sd_hi;
-    // SK_PLAIN, backward loop, the N = 80 product that yields the carry into the previous frame: total gradient of frame s-1 =
-    // dy_dmel[b*dy_ld_mel + n] (+ value when dy_use_carry), column 80 = dy_dstop[b*dy_ld_stop], columns 81..95 zero -> dy_stack[b*96 + n] and
-    // frag16 dy_frag (K = 96) (what build_dy_kernel did in a launch of its own)
-    const float* dy_dmel; int64_t dy_ld_mel; const float* dy_dstop; int64_t dy_ld_stop; int dy_use_carry; float* dy_stack; float* dy_frag;
+    float* sd_stack_dz;                // plain copy of the PSine-backward values [b*C + c] (may be null)
 };
 struct AttnTrain {
     const float* logit_mask; int ld_lmask;   // dropout multiplier on the attention logits [b*ld_lmask + t] (decoder.py:363)
@@ -174,8 +171,8 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
         }
     }
     // side outputs of the backward loop: their tape operands too are fetched under the operand round trip
-    float sd_zv = 0.f, sd_wv = 0.f, sd_mv = 1.f, dy_mv = 0.f, dy_sv = 0.f;
-    bool sd_on = false, dy_on = false;
+    float sd_zv = 0.f, sd_wv = 0.f, sd_mv = 1.f;
+    bool sd_on = false;
     if constexpr (TRAIN) {
         const bool live = tid < 256 && e_b < nB && e_np < N && epi == SK_PLAIN;
         sd_on = live && tr->sd_stack != nullptr && e_np >= tr->sd_lo && e_np < tr->sd_hi;
@@ -183,11 +180,6 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             const int C = tr->sd_hi - tr->sd_lo, c = e_np - tr->sd_lo;
             sd_zv = tr->sd_z[(int64_t)e_b * C + c]; sd_wv = tr->sd_w[c];
             if (tr->sd_mask) sd_mv = tr->sd_mask[(int64_t)e_b * C + c];
-        }
-        dy_on = live && tr->dy_frag != nullptr;
-        if (dy_on) {
-            dy_mv = tr->dy_dmel[(int64_t)e_b * tr->dy_ld_mel + e_np];
-            if (e_np == 0) dy_sv = tr->dy_dstop[(int64_t)e_b * tr->dy_ld_stop];
         }
     }
     L2S_STAMP(2);
@@ -305,18 +297,9 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             const float d = tr->sd_mask ? v * sd_mv : v;
             tr->sd_stack[(int64_t)b * C + c] = d;
             if (tr->sd_frag_d) tr->sd_frag_d[frag16_index(b, c, C)] = d;
-            tr->sd_frag_dz[frag16_index(b, c, C)] = d * cosf(sd_zv) * sd_wv;
-        }
-        if (dy_on) {
-            float t = dy_mv;
-            if (tr->dy_use_carry) t += v;
-            tr->dy_stack[(int64_t)b * 96 + np] = t;
-            tr->dy_frag[frag16_index(b, np, 96)] = t;
-            if (np < 16) {                               // columns 80..95 of the (B,96) gradient: the stop logit's, then zeros
-                const float s2 = np == 0 ? dy_sv : 0.f;
-                tr->dy_stack[(int64_t)b * 96 + 80 + np] = s2;
-                tr->dy_frag[frag16_index(b, 80 + np, 96)] = s2;
-            }
+            const float dz = d * cosf(sd_zv) * sd_wv;
+            tr->sd_frag_dz[frag16_index(b, c, C)] = dz;
+            if (tr->sd_stack_dz) tr->sd_stack_dz[(int64_t)b * C + c] = dz;
         }
     }
     if (epi == SK_FRAG)

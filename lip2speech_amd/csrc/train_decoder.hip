@@ -394,22 +394,33 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     }
 }
 
-// total gradient of the frame y_s: dyt = dmel_total[:, s] (+ dy_carry) with the stop-logit gradient in column 80 -> frag16 (K=96) + stack
-__global__ __launch_bounds__(256) void build_dy_kernel(const float* __restrict__ dmel, const float* __restrict__ dstop, const float* __restrict__ dy_carry,
-                                                       int use_carry, int B, int S, int sidx, float* __restrict__ frag, float* __restrict__ stack) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+// loss gradient of every frame: dmel[:, s] with the stop-logit gradient in column 80, as one frag16 (K = 96) per step and in the (S,B,96) stack
+__global__ __launch_bounds__(256) void build_dy_all_kernel(const float* __restrict__ dmel, const float* __restrict__ dstop, int B, int S, float* __restrict__ frags,
+                                                           float* __restrict__ stack) {
     const int Bp = (B + 15) & ~15;
-    if (idx >= Bp * 96) return;
-    const int b = idx / 96, n = idx - b * 96;
-    float v = 0.f;
-    if (b < B) {
-        if (n < 80) { v = dmel[((int64_t)b * S + sidx) * 80 + n]; if (use_carry) v += dy_carry[b * 80 + n]; }
-        else if (n == 80) v = dstop[(int64_t)b * S + sidx];
-        stack[b * 96 + n] = v;
+    const int64_t total = (int64_t)S * Bp * 96;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int n = idx % 96; const int64_t q = idx / 96;
+        const int b = q % Bp, sidx = q / Bp;
+        float v = 0.f;
+        if (b < B) {
+            if (n < 80) v = dmel[((int64_t)b * S + sidx) * 80 + n];
+            else if (n == 80) v = dstop[(int64_t)b * S + sidx];
+            stack[((int64_t)sidx * B + b) * 96 + n] = v;
+        }
+        frags[(int64_t)sidx * Bp * 96 + frag16_index(b, n, 96)] = v;
     }
-    frag[frag16_index(b, n, 96)] = v;
 }
-
+// the carries join the stack after the loop: stack[s][b][:80] += dyc[s+1][b][:] where step s+1 took its own previous output as input
+struct CarryFlags { uint8_t on[ATT_MAXT]; };
+__global__ __launch_bounds__(256) void add_carry_kernel(float* __restrict__ stack, const float* __restrict__ dyc, CarryFlags f, int B, int S) {
+    const int64_t total = (int64_t)(S - 1) * B * 80;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int n = idx % 80; const int64_t q = idx / 80;
+        const int b = q % B, sidx = q / B;
+        if (f.on[sidx]) stack[((int64_t)sidx * B + b) * 96 + n] += dyc[((int64_t)(sidx + 1) * B + b) * 80 + n];
+    }
+}
 // ---- attention + content attention backward, one 512-thread block per batch row (decoder.py:414-419, 262-271)
 struct AttnBwdP {
     const float* dav; int ld_dav;     // [B][ld_dav] (0 = 512)
@@ -763,14 +774,14 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
 }
 
 // ---- transposed step weights for the backward products, packed on the device from the canonical parameters
-struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1, *bhh[2], *fc4, *prod_ap; };     // prod_ap: W_ih_l0[:,256:512] @ W_ap (2048 x 512), canonical row order
-static int64_t train_w_floats() { return (int64_t)512 * 96 + 2 * (int64_t)1024 * 2048 + 2 * (int64_t)512 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 2 * (int64_t)512 * 2048 + 504 * 256 + 64 * 14; }
+struct TrainW { float *fc, *l1, *l0, *ap, *q, *cq, *p2, *p1, *bhh[2], *fc4, *prod_ap, *prod_p1, *fcp; };     // prod_ap: W_ih_l0[:,256:512] @ W_ap (2048 x 512); prod_p1: W_p1 @ W_out (256 x 512); fcp: [fc_out | stop | prod_p1]^T, K = 96 + 256
+static int64_t train_w_floats() { return (int64_t)512 * 96 + (int64_t)256 * 512 + (int64_t)512 * 352 + 2 * (int64_t)1024 * 2048 + 2 * (int64_t)512 * 2048 + (int64_t)512 * 256 + (int64_t)1024 * 512 + (int64_t)1024 * 256 + 256 * 256 + 80 * 256 + 2 * (int64_t)512 * 2048 + 504 * 256 + 64 * 14; }
 static TrainW train_w(float* base) {
     TrainW t; int64_t o = 0;
     auto take = [&](int64_t n) { float* r = base + o; o += align_up(n, 64); return r; };
     t.fc = take((int64_t)512 * 96); t.l1 = take((int64_t)1024 * 2048); t.l0 = take((int64_t)1536 * 2048); t.ap = take((int64_t)512 * 256);
-    t.prod_ap = take((int64_t)2048 * 512);
-    t.q = take((int64_t)1024 * 512); t.cq = take((int64_t)1024 * 256); t.p2 = take(256 * 256); t.p1 = take(80 * 256);
+    t.prod_ap = take((int64_t)2048 * 512); t.prod_p1 = take((int64_t)256 * 512); t.fcp = take((int64_t)512 * 352);
+    t.q = take((int64_t)1024 * 512); t.cq = take((int64_t)1024 * 256); t.p2 = take(256 * 256); t.p1 = take(80 * 256);      // p1: unused slot (kept for the layout)
     t.bhh[0] = take((int64_t)512 * 2048); t.bhh[1] = take((int64_t)512 * 2048); t.fc4 = take(504 * 256);
     return t;
 }
@@ -792,7 +803,12 @@ static int pack_train_weights(l2s_model* m, float* wbuf, hipStream_t s) {
     if (pack_fragT(t.q, 1024, 512, PackSeg{P("Q.0.linear_layer.weight"), 1024, 0, 1024, 0, 512}, none, none, s)) return 1;
     if (pack_fragT(t.cq, 1024, 256, PackSeg{P("content.Q.0.weight"), 1024, 0, 1024, 0, 256}, none, none, s)) return 1;
     if (pack_fragT(t.p2, 256, 256, PackSeg{P("prenet.3.linear_layer.weight"), 256, 0, 256, 0, 256}, none, none, s)) return 1;
-    if (pack_fragT(t.p1, 80, 256, PackSeg{P("prenet.0.linear_layer.weight"), 80, 0, 80, 0, 256}, none, none, s)) return 1;
+    // the carry of a frame gradient into the previous step, d(z1) -> prenet layer 1 -> fc_out -> d(h1), as ONE product with the loss gradient of
+    // that step: K = [96 loss columns | 256 d(z1) columns] against [fc_out ; stop ; W_p1 W_out]^T - the prenet-1 backward product leaves the loop
+    if (launch_gemm_bwd(bwd_dx(P("prenet.0.linear_layer.weight"), 80, P("fc_out.linear_layer.weight"), t.prod_p1, 512, 1, 256, 256, 80, 512, 1, 0, false), s,
+                        "train_merge_step_weights")) return 1;
+    if (pack_fragT(t.fcp, 512, 352, PackSeg{P("fc_out.linear_layer.weight"), 512, 0, 512, 0, 80}, PackSeg{P("stop_token_layer.linear_layer.weight"), 1024, 0, 512, 80, 81},
+                   PackSeg{t.prod_p1, 512, 0, 512, 96, 352}, s)) return 1;
     if (P("encoder_rnn.weight_hh_l0") && P("content.location_fc.4.weight")) {     // prologue backward operands
         if (pack_fragT(t.bhh[0], 512, 2048, PackSeg{P("encoder_rnn.weight_hh_l0"), 512, 0, 512, 0, 2048}, none, none, s)) return 1;
         if (pack_fragT(t.bhh[1], 512, 2048, PackSeg{P("encoder_rnn.weight_hh_l0_reverse"), 512, 0, 512, 0, 2048}, none, none, s)) return 1;
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
 
 static int64_t step_bwd_ws_floats(int B, int S) {
     const int64_t Bp = pad16(B), SB = (int64_t)S * B;
-    return SB * (96 + 2048 * 3 + 256 * 3 + 512 + 2 + 256 + 256) + Bp * (96 + 2048 * 2 + 256 * 4 + 512) + (int64_t)B * (512 * 6 + 1024 * 6 + 256 + 80) +
+    return SB * (96 + 2048 * 3 + 256 * 4 + 512 + 2 + 256 + 256) + (int64_t)S * Bp * 96 + Bp * (96 + 2048 * 2 + 256 * 4 + 512) + (int64_t)B * (512 * 6 + 1024 * 6 + 256 + 80) +
            (int64_t)AB_RS * 3 * 2048 + (int64_t)96 * 512 + 4096 + 64 * 60;
 }
 
@@ -864,36 +880,39 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     float* st_dq = bp.f(SB * 512); float* st_dqc = bp.f(SB * 256); float* st_dp1 = bp.f(SB * 256); float* st_dtau = bp.f(SB); float* st_dtauc = bp.f(SB);
     float* st_tmp = bp.f(SB * 2048); float* st_p1 = bp.f(SB * 256);
     // per-step fragments and plain buffers
-    float* f_dyt = bp.f((int64_t)Bp * 96); float* f_dg1 = bp.f((int64_t)Bp * 2048); float* f_dg0 = bp.f((int64_t)Bp * 2048);
+    float* f_dyl = bp.f((int64_t)S * Bp * 96); float* st_dz1 = bp.f(SB * 256); float* f_dg1 = bp.f((int64_t)Bp * 2048); float* f_dg0 = bp.f((int64_t)Bp * 2048);
     float* f_dzq = bp.f((int64_t)Bp * 512); float* f_dzc = bp.f((int64_t)Bp * 256);
     float* f_dz2 = bp.f((int64_t)Bp * 256); float* f_dz1 = bp.f((int64_t)Bp * 256);
     float* dh1lin = bp.f((int64_t)B * 512); float* d01 = bp.f((int64_t)B * 1536); float* d0x = bp.f((int64_t)B * 1536);      // row pitch 1536 both: [dcc 256 | du 256 | dh0 512 | d(a@v) 512]; d01 uses 1024 of it
-    float* dp1 = bp.f((int64_t)B * 256); float* dyc = bp.f((int64_t)B * 80);
+    float* dp1 = bp.f((int64_t)B * 256);
     // carries into the previous step, both layers side by side: (B,1024) = [layer 0 | layer 1], row pitch 1024
     float* dhc = bp.f((int64_t)B * 1024); float* dcc = bp.f((int64_t)B * 1024);
     float* dh0c = dhc; float* dh1c = dhc + 512; float* dc0c = dcc; float* dc1c = dcc + 512;
     float* partials = bp.f((int64_t)AB_RS * 3 * 2048); float* tmp96 = bp.f((int64_t)96 * 512); float* small = bp.f(4096);
     L2S_REQUIRE(!bp.overflow, "training backward workspace too small");
     for (float* z : {dhc, dcc}) if (launch_fill(z, (int64_t)B * 1024, 0.f, s)) return 1;
-    for (float* z : {f_dyt}) if (launch_fill(z, (int64_t)Bp * 96, 0.f, s)) return 1;
     if (launch_fill(dk, (int64_t)B * T * 512, 0.f, s) || launch_fill(dv, (int64_t)B * T * 512, 0.f, s)) return 1;
     if (launch_fill(dckey, (int64_t)B * sl.m * 256, 0.f, s) || launch_fill(dcval, (int64_t)B * sl.m * 256, 0.f, s)) return 1;
     const std::string D = "decoder.";
     const float* wq = m->canon(D + "Q.1.w"); const float* w1 = m->canon(D + "prenet.1.w"); const float* w2 = m->canon(D + "prenet.4.w");
     L2S_REQUIRE(wq && w1 && w2, "decoder parameters not bound");
 
-    // Seven launches per step, each a product whose epilogue also does the elementwise work that follows it: the LSTM-cell backwards ride on
-    // the products that yield their dh, d(attention_proj input) and prenet layer 2's PSine backward on the layer-0 product, the carries into
-    // step i-1 and prenet layer 1's PSine backward on the Q / content-Q / prenet-2 launch, and the total gradient of frame i-1 on the prenet-1
-    // product (were 10 launches: build_dy, du_dz2 and carry_dz1 kernels of their own - 231 dependent launches per pass less).
-    hipLaunchKernelGGL(build_dy_kernel, dim3(ew(Bp * 96)), dim3(256), 0, s, dmel, dstop, dyc, 0, B, S, S - 1, f_dyt, st_dyt + (int64_t)(S - 1) * B * 96);
+    // Five launches per step, each a product whose epilogue also does the elementwise work that follows it: the LSTM-cell backwards ride on the
+    // products that yield their dh, d(a@v), d(u) and prenet layer 2's PSine backward on the layer-0 product, the carries into step i-1 and prenet
+    // layer 1's PSine backward on the Q / content-Q / prenet-2 launch; the step's first product takes the loss gradient of frame i AND the carry
+    // d(z1) of step i+1 as two K segments (were 10 launches at the start of round 2).
+    hipLaunchKernelGGL(build_dy_all_kernel, dim3(ew(S * Bp * 96)), dim3(256), 0, s, dmel, dstop, B, S, f_dyl, st_dyt);
     for (int i = S - 1; i >= 0; --i) {
         const int64_t r256 = (int64_t)i * B * 256, r512 = (int64_t)i * B * 512, r2048 = (int64_t)i * B * 2048;
         {
             SkinnyTrain t{};
             t.lb_gates = tp.g1 + r2048; t.lb_cprev = tp.c1 + r512; t.lb_cnew = tp.c1 + r512 + (int64_t)B * 512; t.lb_dc = dc1c; t.lb_ld_dc = 1024;
             t.lb_frag = f_dg1; t.lb_stack = st_dg1 + r2048; t.lb_H = 512;
-            if (run1t(bsk(tw.fc, 512, 96, B, f_dyt, dh1lin, 512, dh1c, 1024), t, s, "train_bwd_fc")) return 1;
+            const float* dyl = f_dyl + (int64_t)i * Bp * 96;
+            const bool carry = i < S - 1 && !(mask && mask[i + 1]);         // step i+1 consumed this step's own output
+            SkinnyP p = carry ? bsk(tw.fcp, 512, 352, B, dyl, dh1lin, 512, dh1c, 1024) : bsk(tw.fc, 512, 96, B, dyl, dh1lin, 512, dh1c, 1024);
+            if (carry) { p.seg[0] = {dyl, 6}; p.seg[1] = {f_dz1, 16}; p.nseg = 2; }
+            if (run1t(p, t, s, "train_bwd_fc")) return 1;
         }
         {
             SkinnyTrain t{};
@@ -926,18 +945,9 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
             sb.p[1] = bsk(tw.cq, 1024, 256, B, f_dzc, dcc, 1024, dcc, 1024); sb.ntiles[1] = 64;
             sb.p[2] = bsk(tw.p2, 256, 256, B, f_dz2, dp1, 256); sb.ntiles[2] = 16;
             tb.t[2].sd_lo = 0; tb.t[2].sd_hi = 256; tb.t[2].sd_z = tp.z1 + r256; tb.t[2].sd_w = w1; tb.t[2].sd_mask = drop.prenet ? drop.prenet + r256 : nullptr;
-            tb.t[2].sd_stack = st_dp1 + r256; tb.t[2].sd_frag_dz = f_dz1;
+            tb.t[2].sd_stack = st_dp1 + r256; tb.t[2].sd_frag_dz = f_dz1; tb.t[2].sd_stack_dz = st_dz1 + r256;
             sb.count = 3;
             if (launch_train_skinny(sb, tb, s, "train_bwd_q_cq_prenet2")) return 1;
-        }
-        {
-            SkinnyTrain t{};
-            if (i > 0) {                    // total gradient of frame i-1: its loss gradient, plus this step's carry unless step i was teacher-forced
-                const bool forced = mask && mask[i];
-                t.dy_dmel = dmel + (int64_t)(i - 1) * 80; t.dy_ld_mel = (int64_t)S * 80; t.dy_dstop = dstop + (i - 1); t.dy_ld_stop = S;
-                t.dy_use_carry = forced ? 0 : 1; t.dy_stack = st_dyt + (int64_t)(i - 1) * B * 96; t.dy_frag = f_dyt;
-            }
-            if (run1t(bsk(tw.p1, 80, 256, B, f_dz1, dyc, 80), t, s, "train_bwd_prenet1")) return 1;
         }
         L2S_CHECK_HIP(hipGetLastError());
     }
@@ -947,6 +957,18 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
     const float* ws_can = m->canon(D + "stop_token_layer.linear_layer.weight");
     float* g_ws = m->grad(D + "stop_token_layer.linear_layer.weight");
     hipLaunchKernelGGL(stop_tail_bwd_kernel, dim3(1), dim3(512), 0, s, dstop, B, S, ws_can, state + sl.ecell, de_c, g_ws ? g_ws + 512 : nullptr);
+    // ---- the carries join the frame-gradient stack: dyc = d(z1) @ W_p1 for all steps at once, added where the next step was not teacher-forced
+    {
+        const float* wp1 = m->canon(D + "prenet.0.linear_layer.weight");
+        L2S_REQUIRE(wp1, "decoder parameters not bound");
+        if (launch_gemm_bwd(bwd_dx(st_dz1, 256, wp1, st_tmp, 80, 1, (int)SB, (int)SB, 256, 80, 1, 0, false), s, "train_bwd_prenet1_all")) return 1;
+        CarryFlags cf{};
+        L2S_REQUIRE(S <= ATT_MAXT, "too many decode steps");
+        for (int i = 0; i + 1 < S; ++i) cf.on[i] = (mask && mask[i + 1]) ? 0 : 1;
+        if (S > 1) hipLaunchKernelGGL(add_carry_kernel, dim3(ew((S - 1) * B * 80)), dim3(256), 0, s, st_dyt, st_tmp, cf, B, S);
+        // BOS is the frame of step 0: its gradient is the first B rows of the same product, summed over the batch
+        if (float* g = m->grad(D + "BOS")) { if (colsum(st_tmp, B, 80, partials, st_tmp + SB * 96, g, false, s)) return 1; }
+    }
     // ---- parameter gradients from the stacks
     auto dw = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int cin, float* out, int ldc) -> int {
         if (!out) return 0;
@@ -1013,8 +1035,6 @@ static int decode_train_bwd(l2s_model* m, float* state, int B, int T, int S, con
         if (act_bwd(a, m->grad(D + "prenet.0.linear_layer.bias"), nullptr, m->grad(D + "prenet.1.w"), nullptr, false, s)) return 1;
         if (dw(st_tmp, 256, 256, tp.yprev, 96, 80, m->grad(D + "prenet.0.linear_layer.weight"), 80)) return 1;
     }
-    // BOS: the frame of step 0; dyc now holds the gradient wrt that frame
-    if (float* g = m->grad(D + "BOS")) { if (colsum(dyc, B, 80, partials, st_tmp, g, false, s)) return 1; }
     if (float* g = m->grad(D + "temperature")) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(1), 0, s, st_dtau, (int)SB, g);
     if (float* g = m->grad(D + "content.temperature")) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(1), 0, s, st_dtauc, (int)SB, g);
     L2S_CHECK_HIP(hipGetLastError());
