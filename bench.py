@@ -515,7 +515,7 @@ def main():
                                  "fused ShuffleNet units and statistics fp32; same steps, grouping and chains as `value`; a different precision - never `value`"},
             "host_resident_uint8_frames": {"value": world * B * S * args.steps / u8_elapsed, "unit": "mel-frames/s", "ms_per_step": u8_elapsed / args.steps * 1e3,
                                            "note": "PCIe-inclusive with the data boundary on the device: every step's packed uint8 frames (25.7 MB per batch) are copied from "
-                                                   "pinned host memory and normalised + padded by l2s_normalise_pad_frames on the chain's stream; same grouping and chains as `value`"},
+                                                   "pinned host memory and normalised + padded by l2s_normalise_pad_frames one group ahead on the pool's copy stream; same grouping and chains as `value`"},
             "roofline": roof,
         }
         if world == 1 and not args.skip_cpu_baseline:
