@@ -17,6 +17,7 @@ struct SkinnyTrain {               // training-side stores of one skinny group (
     // epilogue's value, or lb_dha[b][n] + value * lb_mask[b][n] when lb_dha is set; gate gradients go out as frag16 (K = 4*lb_H) + stack
     const float* lb_gates; const float* lb_cprev; const float* lb_cnew; float* lb_dc; const float* lb_dha; int lb_ld_a; const float* lb_mask;
     float* lb_frag; float* lb_stack; int lb_H; int lb_ld_dc;     // lb_ld_dc: row pitch of lb_dc (0 = lb_H)
+    float* lb_stack2; int64_t lb_ld_stack2;                       // a second copy of the gate gradients with its own row pitch (may be null)
     // SK_PLAIN, backward loop: columns n >= add_hi_from take their addend from add_hi[b*ld_add + n] instead of add
     const float* add_hi; int add_hi_from;
     // SK_PLAIN, backward loop: side outputs on the column block [sd_lo, sd_hi), C = sd_hi - sd_lo, c = n - sd_lo: d = value (* sd_mask[b*C + c])
@@ -288,6 +289,7 @@ __device__ __forceinline__ void skinny_block(const SkinnyP& p, int tile, int mt,
             for (int k = 0; k < 4; ++k) {
                 tr->lb_frag[frag16_index(b, k * LH + np, 4 * LH)] = vals[k];
                 tr->lb_stack[(int64_t)b * 4 * LH + k * LH + np] = vals[k];
+                if (tr->lb_stack2) tr->lb_stack2[(int64_t)b * tr->lb_ld_stack2 + k * LH + np] = vals[k];
             }
         }
     }

@@ -1310,7 +1310,7 @@ static int64_t pro_bwd_ws_floats(int B, int T) {
     int L[4]; const int m = content_lens(T, L);
     const int64_t BT = (int64_t)B * T, R = (int64_t)B * m, Bp = pad16(B);
     int64_t n = BT * (4608 + 512 * 4 + 1024 + 2048 * 3) + (int64_t)512 * 11 * 512 + (int64_t)AB_RS * 3 * 4608 + R * (2560 + 504 * 3 + 256 * 6) + 504 * 256 +
-                (int64_t)B * (512 * 8 + 1024 * 2) + Bp * 2048 + 4 * BT * 512 + 8192 + 16 * BT * 512;
+                (int64_t)B * (512 * 10 + 1024 * 2) + Bp * 2048 * 4 + BT * 2048 + 4 * BT * 512 + 8192 + 16 * BT * 512;
     return n + 64 * 65;
 }
 
@@ -1327,14 +1327,15 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
     float* dcat = bp.f((int64_t)BT * 4608); float* gk = bp.f((int64_t)BT * 512); float* gconv = bp.f((int64_t)BT * 512);
     float* dxc = bp.f((int64_t)BT * 512); float* denc = bp.f((int64_t)BT * 512);
     float* drnn = bp.f((int64_t)BT * 1024); float* dgbt[2] = {bp.f((int64_t)BT * 2048), bp.f((int64_t)BT * 2048)};
-    float* dgk = bp.f((int64_t)BT * 2048);                      // processing-order stack (one direction at a time)
+    float* dgk2[2] = {bp.f((int64_t)BT * 2048), bp.f((int64_t)BT * 2048)};      // processing-order stacks of the two directions
     float* dwp = bp.f((int64_t)512 * 11 * 512); float* partials = bp.f((int64_t)AB_RS * 3 * 4608);
     float* dpooled = bp.f((int64_t)R * 2560); float* dzs = bp.f((int64_t)R * 504); float* dl = bp.f((int64_t)R * 504); float* dz4 = bp.f((int64_t)R * 504);
     float* r256[6]; for (auto& q : r256) q = bp.f((int64_t)R * 256);
     float* tmpE = bp.f(504 * 256);
     float* ds_a = bp.f((int64_t)B * 512); float* ds_e = bp.f((int64_t)B * 512); float* dzs_site = bp.f((int64_t)B * 512);
-    float* dcellcat = bp.f((int64_t)B * 1024); float* dhc = bp.f((int64_t)B * 512); float* dcc = bp.f((int64_t)B * 512); float* dhn = bp.f((int64_t)B * 512);
-    float* f_dg = bp.f((int64_t)Bp * 2048);
+    float* dcellcat = bp.f((int64_t)B * 1024); float* dhn = bp.f((int64_t)B * 512);
+    float* dhd[2] = {bp.f((int64_t)B * 512), bp.f((int64_t)B * 512)}; float* dccd[2] = {bp.f((int64_t)B * 512), bp.f((int64_t)B * 512)};
+    float* f_dgd[2][2] = {{bp.f((int64_t)Bp * 2048), bp.f((int64_t)Bp * 2048)}, {bp.f((int64_t)Bp * 2048), bp.f((int64_t)Bp * 2048)}};
     float* dmap[4]; for (int j = 0; j < 4; ++j) dmap[j] = bp.f((int64_t)B * tp.L[j] * 512);
     float* small = bp.f(8192);
     float* skp = bp.f((int64_t)16 * BT * 512);                  // split-K partials of the wide input gradients
@@ -1476,24 +1477,41 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
     if (float* g = G("E_C.linear_layer.bias")) { if (colsum(de_c, B, 512, partials, gconv, g, false, s)) return 1; }
     if (dX(de_c, 512, 512, w.e_c.W, 1024, dcellcat, 1024, 1024, B, false)) return 1;
     // ---- F. BiLSTM back-propagation through time (both directions; the decoder's initial hidden states are its final hidden states)
+    // Both directions advance in the same launches, and the cell backward of step-1 rides in the epilogue of the product that yields its dh
+    // (d h_{step-1} = dg_step @ W_hh + d rnn_out): one launch per time step for the pair (was four: cell kernel + product, per direction).
     if (launch_fill(ds_e, (int64_t)B * 512, 0.f, s)) return 1;
+    auto t_of = [&](int d, int step) { return d == 0 ? step : T - 1 - step; };
+    for (int d = 0; d < 2; ++d) {       // last processed step first: its dh is the decoder's initial-state gradient plus d rnn_out
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dcellcat + d * 512, 1024, dccd[d], 512, B, 512);
+        const int step = T - 1, t = t_of(d, step);
+        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dh_init + (int64_t)d * B * 512, 512, drnn + (int64_t)t * 1024 + d * 512, T * 1024, dccd[d],
+                           tp.gates[d] + (int64_t)step * B * 2048, tp.cproc[d] + (int64_t)step * B * 512, tp.cproc[d] + (int64_t)(step + 1) * B * 512, B, 512, f_dgd[d][0],
+                           dgk2[d] + (int64_t)step * B * 2048, dgbt[d] + (int64_t)t * 2048, (int64_t)T * 2048);
+    }
+    for (int step = T - 1; step >= 0; --step) {
+        const int cur = (T - 1 - step) & 1;
+        SkinnyBatch sb{}; TrainSkinnyBatch tb{};
+        for (int d = 0; d < 2; ++d) {
+            sb.p[d] = bsk(tw.bhh[d], 512, 2048, B, f_dgd[d][cur], dhd[d], 512); sb.ntiles[d] = 32;
+            if (step > 0) {             // the cell of step-1 in this product's epilogue
+                const int ps = step - 1, t = t_of(d, ps);
+                SkinnyTrain& q = tb.t[d];
+                q.lb_gates = tp.gates[d] + (int64_t)ps * B * 2048; q.lb_cprev = tp.cproc[d] + (int64_t)ps * B * 512; q.lb_cnew = tp.cproc[d] + (int64_t)(ps + 1) * B * 512;
+                q.lb_dc = dccd[d]; q.lb_dha = drnn + (int64_t)t * 1024 + d * 512; q.lb_ld_a = T * 1024;
+                q.lb_frag = f_dgd[d][cur ^ 1]; q.lb_stack = dgk2[d] + (int64_t)ps * B * 2048; q.lb_H = 512;
+                q.lb_stack2 = dgbt[d] + (int64_t)t * 2048; q.lb_ld_stack2 = (int64_t)T * 2048;
+            }
+        }
+        sb.count = 2;
+        if (launch_train_skinny(sb, tb, s, "train_bwd_bilstm_dx")) return 1;
+    }
     for (int d = 0; d < 2; ++d) {
         const std::string suf = d == 0 ? "l0" : "l0_reverse";
-        L2S_CHECK_HIP(hipMemcpyAsync(dhc, dh_init + (int64_t)d * B * 512, sizeof(float) * B * 512, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dcellcat + d * 512, 1024, dcc, 512, B, 512);
-        for (int step = T - 1; step >= 0; --step) {
-            const int t = d == 0 ? step : T - 1 - step;
-            hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dhc, 512, drnn + (int64_t)t * 1024 + d * 512, T * 1024, dcc,
-                               tp.gates[d] + (int64_t)step * B * 2048, tp.cproc[d] + (int64_t)step * B * 512, tp.cproc[d] + (int64_t)(step + 1) * B * 512, B, 512, f_dg,
-                               dgk + (int64_t)step * B * 2048, dgbt[d] + (int64_t)t * 2048, (int64_t)T * 2048);
-            if (run1(bsk(tw.bhh[d], 512, 2048, B, f_dg, dhn, 512), s, "train_bwd_bilstm_dx")) return 1;
-            std::swap(dhc, dhn);
-        }
-        hipLaunchKernelGGL(add3_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dhc, 512, dcc, 512, dhn, 512, (int64_t)B, 512);      // h0 = c0 = s_e
+        hipLaunchKernelGGL(add3_kernel, dim3(ew(B * 512)), dim3(256), 0, s, dhd[d], 512, dccd[d], 512, dhn, 512, (int64_t)B, 512);      // h0 = c0 = s_e
         if (add_into(dhn, ds_e, (int64_t)B * 512, s)) return 1;
-        if (dW(dgk, 2048, 2048, tp.hproc[d], 512, 512, BT, G("encoder_rnn.weight_hh_" + suf), 512)) return 1;
+        if (dW(dgk2[d], 2048, 2048, tp.hproc[d], 512, 512, BT, G("encoder_rnn.weight_hh_" + suf), 512)) return 1;
         if (dW(dgbt[d], 2048, 2048, vis, 1024, 1024, BT, G("encoder_rnn.weight_ih_" + suf), 1024)) return 1;
-        if (colsum(dgk, BT, 2048, partials, dcat /*scratch: dcat is dead by now*/, small, false, s)) return 1;
+        if (colsum(dgk2[d], BT, 2048, partials, dcat /*scratch: dcat is dead by now*/, small, false, s)) return 1;
         for (const std::string& k : {"encoder_rnn.bias_ih_" + suf, "encoder_rnn.bias_hh_" + suf})
             if (float* g = G(k)) hipLaunchKernelGGL(copy_rows_kernel, dim3(ew(2048)), dim3(256), 0, s, small, 2048, g, 2048, 1, 2048);
         if (dX(dgbt[d], 2048, 2048, w.wih_cat + (int64_t)d * 2048 * 1024, 1024, dvis, 1024, 1024, BT, true)) return 1;
