@@ -1351,6 +1351,11 @@ static int prologue_train_bwd(l2s_model* m, const float* vis, const float* emb, 
     auto dX = [&](const float* dz, int ldz, int nout, const float* Wf, int ldw, float* out, int ldo, int cin, int rows, bool acc) -> int {   // linear input gradient
         BwdGemmP p = bwd_dx(dz, ldz, Wf, out, ldo, 1, rows, rows, nout, cin, 1, 0, acc);
         p.ldb = ldw;
+        // B*T (or B) rows by <= 1024 columns are a few dozen 64x64 tiles with K up to 2048: split the reduction so that the grid fills the chip
+        const int tiles = ((rows + 63) / 64) * ((cin + 63) / 64);
+        int splits = nout >= 1024 && tiles < 128 ? std::min(8, 256 / tiles) : 1;
+        while (splits > 1 && gemm_bwd_splitk_floats(p, splits) > (int64_t)16 * BT * 512) --splits;
+        if (splits > 1) return launch_gemm_bwd_splitk(p, splits, skp, s, "train_bwd_prologue_dx");
         return launch_gemm_bwd(p, s, "train_bwd_prologue_dx");
     };
     auto act = [&](const float* dy, int ldy, const float* z, int ldz, float* dconv, int ldc, int64_t rows, int C, int actk, const float* aw, const float* scale,
