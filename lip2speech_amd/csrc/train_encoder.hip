@@ -307,58 +307,84 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 // Front-end backward: MaxPool(1x3x3, s 2, p 1) argmax gather + PReLU + BN(eval) backward over the saved pre-PReLU map z (NF,Hc,Wc,24).
 //   dy(pixel) = sum over the <= 4 pool windows that contain it and whose first maximum it is;  dz = dy * (z >= 0 ? 1 : slope)
 //   dconv = dz * bn_scale;  partial sums per block: [0] sum dz, [1] sum dz (z - beta)/gamma, [2] sum dy * min(z, 0)
-constexpr int FB_BLOCKS = 2048;
-__global__ __launch_bounds__(192) void frontend_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool, int NF, int Hc, int Wc,
-                                                           const float* __restrict__ slope, const float* __restrict__ scale, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ dconv, float* __restrict__ partials) {
-    __shared__ float sh[3][8][24];
-    const int ch = threadIdx.x % 24, pl = threadIdx.x / 24;
-    const int Hp = Hc / 2, Wp = Wc / 2;
-    const float sl = slope[ch], sc = scale[ch], be = beta[ch], ig = 1.f / gamma[ch];
-    auto act = [&](float v) { return v >= 0.f ? v : sl * v; };
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const int64_t total = (int64_t)NF * Hc * Wc;
-    for (int64_t px = (int64_t)blockIdx.x * 8 + pl; px < total; px += (int64_t)gridDim.x * 8) {
-        const int c = px % Wc; const int64_t q = px / Wc;
-        const int r = q % Hc; const int64_t f = q / Hc;
-        const float* zf = z + f * Hc * Wc * 24 + ch;
-        const float zv = zf[(r * Wc + c) * 24];
-        const float yv = act(zv);
-        float dy = 0.f;
-        const int pr0 = r >> 1, pr1 = (r & 1) ? pr0 + 1 : pr0;         // pool rows whose window holds conv row r
-        const int pc0 = c >> 1, pc1 = (c & 1) ? pc0 + 1 : pc0;
-        for (int pr = pr0; pr <= pr1; ++pr) {
-            if (pr >= Hp) continue;
-            for (int pc = pc0; pc <= pc1; ++pc) {
-                if (pc >= Wp) continue;
-                // is (r,c) the first maximum of window (pr,pc) in row-major scan order?
-                bool mine = true;
-                for (int dr = -1; dr <= 1 && mine; ++dr) {
-                    const int rr = 2 * pr + dr;
-                    if (rr < 0 || rr >= Hc) continue;
-                    for (int dc = -1; dc <= 1; ++dc) {
-                        const int cc = 2 * pc + dc;
-                        if (cc < 0 || cc >= Wc || (rr == r && cc == c)) continue;
-                        const float o = act(zf[(rr * Wc + cc) * 24]);
-                        const bool before = rr < r || (rr == r && cc < c);
-                        if (o > yv || (before && o == yv)) { mine = false; break; }
-                    }
-                }
-                if (mine) dy += dpool[((f * Hp + pr) * Wp + pc) * 24 + ch];
+// One block = one frame x FB_PR pooled rows: the z rows its windows touch are staged in LDS ONCE (2*FB_PR + 3 conv rows), every window's first
+// maximum is found by one thread per (window, channel), and the block's 2*FB_PR conv rows gather their <= 4 windows from that table.  (The
+// first version walked the nine neighbours of each of a pixel's four windows in global memory behind data-dependent branches: 470 us for 232
+// frames; this one streams z once.)  Per pixel the arithmetic - window order of the dy sum, dz, the three partial-sum terms - is the same.
+constexpr int FB_PR = 4;
+__host__ __device__ constexpr int fb_strips(int Hc) { return (Hc / 2 + FB_PR - 1) / FB_PR; }
+template <int HC>
+__global__ __launch_bounds__(256) void frontend_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool, int NF, const float* __restrict__ slope,
+                                                           const float* __restrict__ scale, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dconv, float* __restrict__ partials) {
+    constexpr int Hc = HC, Wc = HC, Hp = HC / 2, Wp = HC / 2, ROWS = 2 * FB_PR + 3, WR = FB_PR + 1;
+    __shared__ float zs[ROWS * Wc * 24];                  // z rows r_lo .. r_lo + ROWS - 1 (rows outside the map are never read)
+    __shared__ unsigned char win[WR * Wp * 24];           // per (window row, window col, channel): 3*dr + dc of the first maximum (dr, dc in 0..2)
+    __shared__ float red[3][8][24];
+    const int f = blockIdx.y, p0 = blockIdx.x * FB_PR;    // pooled rows p0 .. p0 + FB_PR (the extra one: windows of the block's last odd conv row)
+    const int r_lo = 2 * p0 - 1;                          // conv row of tile row 0
+    const int tid = threadIdx.x;
+    const float* zf = z + (int64_t)f * Hc * Wc * 24;
+    for (int i = tid; i < ROWS * Wc * 6; i += 256) {      // float4 = 4 channels
+        const int row = i / (Wc * 6), q = i - row * (Wc * 6), r = r_lo + row;
+        if (r >= 0 && r < Hc) *reinterpret_cast<float4*>(&zs[row * Wc * 24 + q * 4]) = *reinterpret_cast<const float4*>(zf + (int64_t)r * Wc * 24 + q * 4);
+    }
+    __syncthreads();
+    for (int i = tid; i < WR * Wp * 24; i += 256) {
+        const int ch = i % 24, pc = (i / 24) % Wp, wr = i / (24 * Wp), pr = p0 + wr;
+        if (pr >= Hp) continue;
+        const float sl = slope[ch];
+        float best = 0.f; int code = -1;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+            const int rr = 2 * pr - 1 + dr;
+            if (rr < 0 || rr >= Hc) continue;
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) {
+                const int cc = 2 * pc - 1 + dc;
+                if (cc < 0 || cc >= Wc) continue;
+                float v = zs[((rr - r_lo) * Wc + cc) * 24 + ch];
+                v = v >= 0.f ? v : sl * v;
+                if (code < 0 || v > best) { best = v; code = 3 * dr + dc; }     // strict: the FIRST maximum in row-major order wins
             }
         }
-        const float dz = zv >= 0.f ? dy : dy * sl;
-        a0 += dz; a1 += dz * (zv - be) * ig; a2 += zv >= 0.f ? 0.f : dy * zv;
-        dconv[px * 24 + ch] = dz * sc;
+        win[i] = (unsigned char)code;
     }
-    sh[0][pl][ch] = a0; sh[1][pl][ch] = a1; sh[2][pl][ch] = a2;
+    __syncthreads();
+    const int ch = tid % 24, pl = tid / 24;               // 10 pixel lanes x 24 channels (threads 240..255 idle)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (pl < 10) {
+        const float sl = slope[ch], sc = scale[ch], be = beta[ch], ig = 1.f / gamma[ch];
+        for (int px = pl; px < 2 * FB_PR * Wc; px += 10) {
+            const int lr = px / Wc, c = px - lr * Wc, r = 2 * p0 + lr;
+            if (r >= Hc) break;
+            const float zv = zs[((r - r_lo) * Wc + c) * 24 + ch];
+            float dy = 0.f;
+            const int pr0 = r >> 1, pr1 = (r & 1) ? pr0 + 1 : pr0;         // pool rows whose window holds conv row r
+            const int pc0 = c >> 1, pc1 = (c & 1) ? pc0 + 1 : pc0;
+            for (int pr = pr0; pr <= pr1; ++pr) {
+                if (pr >= Hp) continue;
+                for (int pc = pc0; pc <= pc1; ++pc) {
+                    if (pc >= Wp) continue;
+                    const int code = 3 * (r - (2 * pr - 1)) + (c - (2 * pc - 1));
+                    if (win[((pr - p0) * Wp + pc) * 24 + ch] == code) dy += dpool[(((int64_t)f * Hp + pr) * Wp + pc) * 24 + ch];
+                }
+            }
+            const float dz = zv >= 0.f ? dy : dy * sl;
+            a0 += dz; a1 += dz * (zv - be) * ig; a2 += zv >= 0.f ? 0.f : dy * zv;
+            dconv[(((int64_t)f * Hc + r) * Wc + c) * 24 + ch] = dz * sc;
+        }
+    }
+    if (pl < 8) { red[0][pl][ch] = a0; red[1][pl][ch] = a1; red[2][pl][ch] = a2; }
+    __syncthreads();
+    if (pl >= 8 && pl < 10) { red[0][pl - 8][ch] += a0; red[1][pl - 8][ch] += a1; red[2][pl - 8][ch] += a2; }
     __syncthreads();
     if (pl == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float t = 0.f;
-            for (int j = 0; j < 8; ++j) t += sh[k][j][ch];
-            partials[((int64_t)blockIdx.x * 3 + k) * 24 + ch] = t;
+            for (int j = 0; j < 8; ++j) t += red[k][j][ch];
+            partials[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + k) * 24 + ch] = t;
         }
     }
 }
@@ -461,7 +487,7 @@ static int64_t enc_bwd_ws_floats(int B, int T, int H) {
     n += NF * Hc * Hc * 24;                                            // dconv of the front-end
     n += NF * ((Hc + FD_CR - 1) / FD_CR) * FD_PART;                    // per-block partials of the Conv3d weight gradient
     n += (int64_t)64 * LAST_CH * STAGE_CH[3] + (int64_t)24 * 736;      // split-K partials (largest: conv_last with <= 64 splits ... bounded below), dW staging
-    n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + (int64_t)FB_BLOCKS * 3 * 24 + 2 * 1024;
+    n += (int64_t)DW_RS * 9 * 512 + (int64_t)AB_RS * 3 * 1024 + NF * fb_strips((int)Hc) * 3 * 24 + 2 * 1024;
     return n + 64 * 32;
 }
 
@@ -482,7 +508,7 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     float* fdp = bp.f((int64_t)NF * fd_strips * FD_PART);
     const int64_t splitk_cap = (int64_t)64 * LAST_CH * STAGE_CH[3];     // floats; 256 slices of a <= 232 x 232 gradient fit as well
     float* skp = bp.f(splitk_cap);
-    float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)FB_BLOCKS * 3 * 24);
+    float* dwp = bp.f((int64_t)DW_RS * 9 * 512); float* abp = bp.f((int64_t)AB_RS * 3 * 1024); float* fbp = bp.f((int64_t)NF * fb_strips(Hc) * 3 * 24);
     float* totals = bp.f(2 * 1024);
     L2S_REQUIRE(!bp.overflow, "encoder training backward workspace too small");
     auto G = [&](const std::string& k) { return m->grad(E + k); };
@@ -584,11 +610,13 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         L2S_REQUIRE(gamma && beta, "encoder parameters not bound (l2s_train_bind)");
         ProfScope ps("train_bwd_frontend_pool_prelu_bn", s);
         const float* fscale = bnb ? bn_scale(tp, 0) : w.fe.scale;
-        hipLaunchKernelGGL(frontend_bwd_kernel, dim3(FB_BLOCKS), dim3(192), 0, s, tp.z0, dy, NF, Hc, Hc, w.fe.slope, fscale, gamma, beta, dconv, fbp);
+        const int fb_blocks = NF * fb_strips(Hc);
+        if (Hc == 48) hipLaunchKernelGGL(frontend_bwd_kernel<48>, dim3(fb_strips(Hc), NF), dim3(256), 0, s, tp.z0, dy, NF, w.fe.slope, fscale, gamma, beta, dconv, fbp);
+        else hipLaunchKernelGGL(frontend_bwd_kernel<44>, dim3(fb_strips(Hc), NF), dim3(256), 0, s, tp.z0, dy, NF, w.fe.slope, fscale, gamma, beta, dconv, fbp);
         float* outs[3] = {G("frontend3D.1.bias"), G("frontend3D.1.weight"), G("frontend3D.2.weight")};
         for (int k = 0; k < 3; ++k) {
             float* dst = k < 2 ? totals + k * 24 : outs[2];                  // r0, r1 are needed by the batch-statistics correction as well
-            if (dst) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, fbp + k * 24, FB_BLOCKS, 72, 1, 24, dst, 0, 1, 0);
+            if (dst) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, fbp + k * 24, fb_blocks, 72, 1, 24, dst, 0, 1, 0);
             if (k < 2 && outs[k]) L2S_CHECK_HIP(hipMemcpyAsync(outs[k], totals + k * 24, 24 * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
         if (bnb) { if (bn_train_fix(dconv, 24, tp.z0, 24, 1, 0, gamma, beta, fscale, totals, (int64_t)NF * Hc * Hc, 24, s)) return 1; }
