@@ -32,11 +32,10 @@ __device__ __forceinline__ void stage_transposed_bf16(unsigned char* S, int r0, 
     }
 }
 
-template <int MODE, bool BF16 = false>
-__global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
-    const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
-    __shared__ __attribute__((aligned(16))) float As[TB * TLD];
-    __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
+// one 64x64 output tile (bx, by) of K slice bz; As / Bs: the block's two LDS tiles
+template <int MODE, bool BF16>
+__device__ __forceinline__ void gemm_bwd_block(const BwdGemmP& p, const int bx, const int by, const int bz, float* As, float* Bs) {
+    const int m0 = by * TB, n0 = bx * TB;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, li = lane & 31, lg = lane >> 5;
     f32x16 acc;
@@ -47,9 +46,9 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
     float* Cout = p.C;
     if (p.ksplit > 1) {                                // split-K: slice z of the reduction -> its own partial matrix
         const int per = (nkt_all + p.ksplit - 1) / p.ksplit;
-        kt_begin = blockIdx.z * per;
+        kt_begin = bz * per;
         kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
-        Cout += (int64_t)blockIdx.z * p.c_split_stride;
+        Cout += (int64_t)bz * p.c_split_stride;
     }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool vec = p.vec != 0;
@@ -169,6 +168,31 @@ __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
+template <int MODE, bool BF16 = false>
+__global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
+    __shared__ __attribute__((aligned(16))) float As[TB * TLD];
+    __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
+    gemm_bwd_block<MODE, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+// The weight gradient and the input gradient of ONE layer in one launch: they read the same dZ and are independent of each other, and at 8 clips
+// per GPU neither fills the chip - blocks [0, wx*wy*wz) are the (split-K) weight-gradient tiles, the rest the input-gradient tiles.
+template <bool BF16>
+__global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(const BwdGemmP pw, const BwdGemmP px, int wx, int wy, int wz, int xx) {
+    __shared__ __attribute__((aligned(16))) float As[TB * TLD];
+    __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
+    int id = blockIdx.x;
+    const int nw = wx * wy * wz;
+    if (id < nw) gemm_bwd_block<BWD_DW, BF16>(pw, id % wx, (id / wx) % wy, id / (wx * wy), As, Bs);
+    else { id -= nw; gemm_bwd_block<BWD_DX, BF16>(px, id % xx, id / xx, 0, As, Bs); }
+}
+
+static bool bwd_vec_ok(const BwdGemmP& p) {
+    bool vec = al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+    if (p.mode == BWD_DX) vec = vec && p.Nout % 4 == 0 && p.N % 4 == 0 && p.Cin % 4 == 0;
+    else vec = vec && p.M % 4 == 0 && p.Cin % 4 == 0 && p.N % 4 == 0;
+    return vec;
+}
+
 int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
     L2S_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "bwd gemm dims");
     BwdGemmP q = p;
@@ -219,6 +243,29 @@ int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipSt
     const int64_t total = (int64_t)p.M * p.N;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, partials, splits, q.c_split_stride, p.M, p.N,
                        p.N, p.C, p.ldc, p.accumulate);
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_bwd_dw_dx(const BwdGemmP& pdw, int splits, float* partials, const BwdGemmP& pdx, hipStream_t s, const char* name) {
+    L2S_REQUIRE(pdw.mode == BWD_DW && pdx.mode == BWD_DX && pdw.c_T == 0 && pdx.ksplit <= 1 && pdw.taps == 1 && pdx.taps == 1, "dW + dX pair: 1x1 layers, plain outputs");
+    const int nkt = (pdw.K + TK - 1) / TK;
+    if (splits > nkt) splits = nkt;
+    if (splits < 1) splits = 1;
+    BwdGemmP qw = pdw, qx = pdx;
+    if (splits > 1) { qw.C = partials; qw.ldc = pdw.N; qw.ksplit = splits; qw.c_split_stride = (int64_t)pdw.M * pdw.N; qw.accumulate = 0; }
+    qw.vec = bwd_vec_ok(pdw) ? 1 : 0; qx.vec = bwd_vec_ok(pdx) ? 1 : 0;
+    const int wx = (pdw.N + TB - 1) / TB, wy = (pdw.M + TB - 1) / TB, xx = (pdx.N + TB - 1) / TB, xy = (pdx.M + TB - 1) / TB;
+    {
+        ProfScope ps(name, s);
+        if (gemm_bf16_mode() != 0) hipLaunchKernelGGL(gemm_bwd_pair_kernel<true>, dim3(wx * wy * splits + xx * xy), dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+        else hipLaunchKernelGGL(gemm_bwd_pair_kernel<false>, dim3(wx * wy * splits + xx * xy), dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+    }
+    if (splits > 1) {
+        const int64_t total = (int64_t)pdw.M * pdw.N;
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, partials, splits, qw.c_split_stride, pdw.M,
+                           pdw.N, pdw.N, pdw.C, pdw.ldc, pdw.accumulate);
+    }
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -156,6 +156,8 @@ BwdGemmP bwd_dw(const float* dZ, int ldz, const float* X, int ldx, float* dWp, i
 int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name);
 int64_t gemm_bwd_splitk_floats(const BwdGemmP& p, int splits);
 int launch_gemm_bwd_splitk(const BwdGemmP& p, int splits, float* partials, hipStream_t s, const char* name);
+// weight gradient (split-K as above) and input gradient of one 1x1 layer in ONE launch (they share dZ and are independent)
+int launch_gemm_bwd_dw_dx(const BwdGemmP& pdw, int splits, float* partials, const BwdGemmP& pdx, hipStream_t s, const char* name);
 
 // Backward of a fused GEMM epilogue  y = act(z) [+ residual],  z = conv * s + shift  (s, shift = eval-mode BatchNorm and/or bias):
 //   dpre = dy * act'(z);  dconv = dpre * s;  per-column sums  r0 = sum dpre,  r1 = sum dpre * (z - beta)/gamma,

@@ -514,17 +514,17 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
     auto G = [&](const std::string& k) { return m->grad(E + k); };
     auto Cn = [&](const std::string& k) { return m->canon(E + k); };
 
-    // 1x1 conv weight gradient: dW[N][K] = dz^T x, reduction over `rows` pixels split so that the grid fills the chip
-    auto dW = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int cin, int64_t rows, float* out) -> int {
-        if (!out) return 0;
-        BwdGemmP p = bwd_dw(dz, ldz, x, ldx, out, 1, (int)rows, (int)rows, nout, cin, 1, 1, 0, false);
-        const int tiles = ((nout + 63) / 64) * ((cin + 63) / 64);
-        int splits = std::max(1, std::min(256, 2048 / tiles));        // 58-channel layers: one tile, 33 408 rows -> 256 slices of four K steps each
-        while (splits > 1 && gemm_bwd_splitk_floats(p, splits) > splitk_cap) --splits;
-        return launch_gemm_bwd_splitk(p, splits, skp, s, "train_bwd_encoder_dw");
-    };
     auto dX = [&](const float* dz, int ldz, int nout, const float* Wf, float* out, int ldo, int cin, int64_t rows, bool acc) -> int {
         return launch_gemm_bwd(bwd_dx(dz, ldz, Wf, out, ldo, 1, (int)rows, (int)rows, nout, cin, 1, 0, acc), s, "train_bwd_encoder_dx");
+    };
+    // both gradients of a 1x1 conv in one launch: they read the same dz, are independent, and neither fills the chip at 8 clips per GPU
+    auto dWX = [&](const float* dz, int ldz, int nout, const float* x, int ldx, int xcin, float* gw, const float* Wf, float* dxo, int ldo, int cin, int64_t rows) -> int {
+        if (!gw) return dX(dz, ldz, nout, Wf, dxo, ldo, cin, rows, false);
+        BwdGemmP pw = bwd_dw(dz, ldz, x, ldx, gw, 1, (int)rows, (int)rows, nout, xcin, 1, 1, 0, false);
+        const int tiles = ((nout + 63) / 64) * ((xcin + 63) / 64);
+        int splits = std::max(1, std::min(256, 2048 / tiles));        // 58-channel layers: one tile, 33 408 rows -> 256 slices of four K steps each
+        while (splits > 1 && gemm_bwd_splitk_floats(pw, splits) > splitk_cap) --splits;
+        return launch_gemm_bwd_dw_dx(pw, splits, skp, bwd_dx(dz, ldz, Wf, dxo, ldo, 1, (int)rows, (int)rows, nout, cin, 1, 0, false), s, "train_bwd_encoder_dw_dx");
     };
     // epilogue backward of "conv (+BN) (+ReLU)": dy/z may sit at shuffled channel positions
     const bool bnb = m->bn_batch;
@@ -565,9 +565,8 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(NF), dim3(256), 0, s, tp.last, P, LAST_CH, dfeat, ld_df, dlast);
     }
     if (epi(dlast, LAST_CH, 1, 0, bnb ? tp.lastz : tp.last, LAST_CH, 1, 0, gconv, pxl, LAST_CH, ACT_RELU, w.conv_last.scale, "trunk.1.1", 81)) return 1;
-    if (dW(gconv, LAST_CH, LAST_CH, tp.x[N_UNITS], STAGE_CH[3], STAGE_CH[3], pxl, G("trunk.1.0.weight"))) return 1;
     float* dy = dA; float* dx = dB;
-    if (dX(gconv, LAST_CH, LAST_CH, w.conv_last.W, dy, STAGE_CH[3], STAGE_CH[3], pxl, false)) return 1;
+    if (dWX(gconv, LAST_CH, LAST_CH, tp.x[N_UNITS], STAGE_CH[3], STAGE_CH[3], G("trunk.1.0.weight"), w.conv_last.W, dy, STAGE_CH[3], STAGE_CH[3], pxl)) return 1;
 
     // ---- ShuffleNet units, last to first
     for (int u = N_UNITS - 1; u >= 0; --u) {
@@ -580,24 +579,20 @@ static int encoder_train_bwd(l2s_model* m, const float* video, int B, int T, int
         const int id = 1 + 5 * u;
         // banch2 tail: pw2 (+BN+ReLU) at the odd output channels, then the depthwise conv (+BN)
         if (epi(dy, cout, 2, 1, y, cout, 2, 1, g, out_px, half, ACT_RELU, U.pw2.scale, p + "banch2.6", id + 4)) return 1;
-        if (dW(g, half, half, tp.t2[u], half, half, out_px, G(p + "banch2.5.weight"))) return 1;
-        if (dX(g, half, half, U.pw2.W, dt, half, half, out_px, false)) return 1;
+        if (dWX(g, half, half, tp.t2[u], half, half, G(p + "banch2.5.weight"), U.pw2.W, dt, half, half, out_px)) return 1;
         if (epi(dt, half, 1, 0, tp.t2[u], half, 1, 0, gd, out_px, half, ACT_NONE, U.dw.scale, p + "banch2.4", id + 3)) return 1;
         if (dwconv_bwd(gd, tp.t1[u], half, 0, h, ho, half, U.stride2 ? 2 : 1, U.dw.w9, dt1, half, 0, false, G(p + "banch2.3.weight"))) return 1;
         if (epi(dt1, half, 1, 0, t1v, half, 1, 0, g, in_px, half, ACT_RELU, U.pw1.scale, p + "banch2.1", id + 2)) return 1;
         if (U.stride2) {
             const int cin = U.cin;
-            if (dW(g, half, half, tp.x[u], cin, cin, in_px, G(p + "banch2.0.weight"))) return 1;
-            if (dX(g, half, half, U.pw1.W, dx, cin, cin, in_px, false)) return 1;
+            if (dWX(g, half, half, tp.x[u], cin, cin, G(p + "banch2.0.weight"), U.pw1.W, dx, cin, cin, in_px)) return 1;
             // banch1: dw (+BN) -> pw (+BN+ReLU) at the even output channels
             if (epi(dy, cout, 2, 0, y, cout, 2, 0, g, out_px, half, ACT_RELU, U.b1_pw.scale, p + "banch1.3", id + 1)) return 1;
-            if (dW(g, half, half, tp.b1[u], cin, cin, out_px, G(p + "banch1.2.weight"))) return 1;
-            if (dX(g, half, half, U.b1_pw.W, dt, cin, cin, out_px, false)) return 1;
+            if (dWX(g, half, half, tp.b1[u], cin, cin, G(p + "banch1.2.weight"), U.b1_pw.W, dt, cin, cin, out_px)) return 1;
             if (epi(dt, cin, 1, 0, tp.b1[u], cin, 1, 0, gd, out_px, cin, ACT_NONE, U.b1_dw.scale, p + "banch1.1", id + 0)) return 1;
             if (dwconv_bwd(gd, tp.x[u], cin, 0, h, ho, cin, 2, U.b1_dw.w9, dx, cin, 0, true, G(p + "banch1.0.weight"))) return 1;
         } else {
-            if (dW(g, half, half, tp.x[u] + half, cout, half, in_px, G(p + "banch2.0.weight"))) return 1;
-            if (dX(g, half, half, U.pw1.W, dx + half, cout, half, in_px, false)) return 1;
+            if (dWX(g, half, half, tp.x[u] + half, cout, half, G(p + "banch2.0.weight"), U.pw1.W, dx + half, cout, half, in_px)) return 1;
             // passthrough half: out[2k] = x1[k]
             hipLaunchKernelGGL(copy2d_kernel, blocks(in_px * half), dim3(256), 0, s, dy, cout, 0, 2, dx, cout, 0, in_px, half, 0);
         }
