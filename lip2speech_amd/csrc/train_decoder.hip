@@ -660,11 +660,10 @@ static int decode_train_fwd(l2s_model* m, float* state, int B, int T, int S, con
     // step instead of 6.  The tape is the same (z1, z2, zq, zc, alpha, a@v, gates, cells, hidden states); u = attention_proj(a@v) + prenet is
     // only needed by the parameter gradients and is rebuilt for all steps at once after the loop.
     const bool fold = m->opt.fold != 0 && m->folded_valid && w.pre1f.W && w.lstm0f.W;
-    if (launch_fill(h0d, (int64_t)Bp * 512, 0.f, s)) return 1;
+    // every buffer above starts at zero (padded rows of the fragments must not hold NaN garbage): ONE fill over the whole run, then the initial state
+    if (launch_fill(h0[0], bp.off / (int64_t)sizeof(float), 0.f, s)) return 1;
     L2S_CHECK_HIP(hipMemcpyAsync(h0[0], state + sl.h, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
     L2S_CHECK_HIP(hipMemcpyAsync(h1[0], state + sl.h + (int64_t)Bp * 512, sizeof(float) * Bp * 512, hipMemcpyDeviceToDevice, s));
-    for (float* z : {h0[1], h1[1], c0, c1, av}) if (launch_fill(z, (int64_t)Bp * 512, 0.f, s)) return 1;
-    for (float* z : {p1, cc, uu, p2f}) if (launch_fill(z, (int64_t)Bp * 256, 0.f, s)) return 1;
     if (launch_to_frag(w.bos, 0, B, 80, yf, 80, 0, 1, s)) return 1;
     // tape row 0 of the state sequences
     if (launch_from_frag(h0[0], 512, B, 512, tp.h0, 512, 0, s)) return 1;
