@@ -506,3 +506,33 @@ def test_decoder_batchnorm_train_mode_matches_autograd(synth_sd):
     for k in par:
         if k.endswith((".0.bias", ".0.conv.bias")) and (".conv." in k or ".agg." in k or "postnet.convolutions" in k):
             assert float(grads[k].abs().max()) == 0.0, k
+
+
+@pytest.mark.gpu
+def test_training_step_is_deterministic(synth_sd):
+    """Two train()-mode forward + backward passes from the same parameters, inputs and masks give the same bits: outputs, loss terms and every
+    parameter gradient (all reductions are two-stage with a fixed order, no atomics) - the property tools/hash_train_step.py relies on."""
+    import parity_common as pc
+    from lip2speech_amd import synth, training
+    B, T, S = 4, 29, 24
+    nm = pc.fresh_native_model(synth_sd)
+    bound = {k: v.clone().cuda() for k, v in synth_sd.items() if k.startswith(("encoder.", "decoder.")) and v.is_floating_point()}
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "pos_table"))      # noqa: E731
+    grads = {k: torch.zeros_like(v) for k, v in bound.items() if not is_buf(k)}
+    nm.train_bind(bound, grads)
+    nm.train_set_bn(True, 0.1)
+    video = synth.synth_video(B, T, tag="det").cuda(); emb = synth.synth_speaker_embedding(B, tag="det").cuda()
+    gum = synth.synth_gumbel(B * 4, tag="det").cuda(); mels = synth.synth_mels(B, S, tag="det").cuda()
+    gate = torch.zeros(B, S, device="cuda"); gate[:, -1] = 1
+    torch.manual_seed(11)
+    drop = training.draw_dropout(B, T, S, "cuda")
+    mask = torch.zeros(S, dtype=torch.bool); mask[1::3] = True
+    runs = []
+    for _ in range(2):
+        out = training.model_forward_backward(nm, video, emb, gum, mels, gate, teacher_mask=mask, bos=bound["decoder.BOS"], drop=drop)
+        runs.append(({k: out[k].detach().clone() for k in ("loss", "mel", "mel_post", "stop")}, {k: v.clone() for k, v in grads.items()}))
+    (o0, g0), (o1, g1) = runs
+    assert all(torch.equal(o0[k], o1[k]) for k in o0), "outputs differ between two identical passes"
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, f"gradients differ between two identical passes: {bad[:5]}"
+    assert all(torch.isfinite(v).all() for v in g0.values()) and float(sum(v.abs().sum() for v in g0.values())) > 0
