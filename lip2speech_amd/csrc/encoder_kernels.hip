@@ -216,7 +216,7 @@ typedef __bf16 fx_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned fx_rne2(float a, float b) { fx_bf16x2 v = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, v); }
 
 template <int HW, int TERMS>
-__global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
+__global__ __launch_bounds__(256, 3) void frontend3d_x3_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
     constexpr int FX_WSLAB = 4 * TERMS * 32 * FX_WROW;   // bytes of weights per slab: 18 432 with three planes, 6 144 with one
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
     constexpr int P = FE_CR * Wc;                    // conv pixels per strip
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
     constexpr int XLD = FxGeom<HW>::XLD, PLANE = FxGeom<HW>::PLANE;
     static_assert((2 * (XLD / 2)) % 32 == Wc % 32 && XLD >= W + 8, "row pitch: conflict-free straddling tiles");
     constexpr int XS = TERMS * PLANE;                // bytes: input planes
-    constexpr int CS = P * FE_CO * 4;                // bytes: conv tile (aliases the operand area)
+    constexpr int CS = P * (FE_CO / 2) * 4;          // bytes: conv tile of HALF the channels (aliases the operand area; the pooling runs in two passes)
     constexpr int SMEM = (XS + FX_WSLAB) > CS ? (XS + FX_WSLAB) : CS;
     constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
     constexpr int NWL = (FX_WSLAB / 16 + 255) / 256;                 // weight uint4 per thread per slab
@@ -356,48 +356,53 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3_kernel(const FrontendW w
     }
     __syncthreads();                                 // operands dead; reuse LDS as the conv tile
 
-    // BN + PReLU, conv tile Cs[pixel][24]
+    // BN + PReLU -> conv tile Cs[pixel][12] -> 3x3 / stride 2 / pad 1 max pool (padding never wins: -inf) -> channel-last output, twelve channels at a
+    // time: the whole 24-channel tile (60 KB) was what kept the block at two per CU; with half of it the operand area (41 KB) sets the LDS size
+    // and three blocks fit, i.e. one more block's MFMAs to cover another's staging.  Per output the arithmetic is unchanged.
     float* Cs = reinterpret_cast<float*>(smem);
-    if (li < FE_CO) {
-        const float sc = w.scale[li], sh = w.shift[li], sl = w.slope[li];
+    constexpr int CH = FE_CO / 2;
+    const float sc = li < FE_CO ? w.scale[li] : 0.f, sh = li < FE_CO ? w.shift[li] : 0.f, sl = li < FE_CO ? w.slope[li] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            if (wave + 4 * j < NT) {
+    for (int half = 0; half < 2; ++half) {
+        if (li >= half * CH && li < (half + 1) * CH) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                    if (p < P) {
-                        float v = acc[j][r] * sc + sh;
-                        v = v >= 0.f ? v : sl * v;
-                        Cs[p * FE_CO + li] = v;
+            for (int j = 0; j < TPW; ++j) {
+                if (wave + 4 * j < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                        if (p < P) {
+                            float v = acc[j][r] * sc + sh;
+                            v = v >= 0.f ? v : sl * v;
+                            Cs[p * CH + (li - half * CH)] = v;
+                        }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-
-    // 3x3 / stride 2 / pad 1 max pool (padding never wins: -inf) -> channel-last output
-    for (int i = tid; i < FE_PR * Wp * FE_CO; i += 256) {
-        const int ch = i % FE_CO;
-        const int pw = (i / FE_CO) % Wp;
-        const int prl = i / (FE_CO * Wp);
-        const int pr = p0 + prl;
-        if (pr >= Hp) continue;
-        float m = -INFINITY;
+        __syncthreads();
+        for (int i = tid; i < FE_PR * Wp * CH; i += 256) {
+            const int ch = i % CH;
+            const int pw = (i / CH) % Wp;
+            const int prl = i / (CH * Wp);
+            const int pr = p0 + prl;
+            if (pr >= Hp) continue;
+            float m = -INFINITY;
 #pragma unroll
-        for (int dr = 0; dr < 3; ++dr) {
-            const int crow = 2 * pr - 1 + dr;        // global conv row
-            if (crow < 0 || crow >= Hc) continue;
-            const int lrow = 2 * prl + dr;           // local conv row (local row 0 = conv row 2*p0-1)
+            for (int dr = 0; dr < 3; ++dr) {
+                const int crow = 2 * pr - 1 + dr;        // global conv row
+                if (crow < 0 || crow >= Hc) continue;
+                const int lrow = 2 * prl + dr;           // local conv row (local row 0 = conv row 2*p0-1)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                const int cc = 2 * pw + dc;
-                if (cc < 0 || cc >= Wc) continue;
-                m = fmaxf(m, Cs[(lrow * Wc + cc) * FE_CO + ch]);
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int cc = 2 * pw + dc;
+                    if (cc < 0 || cc >= Wc) continue;
+                    m = fmaxf(m, Cs[(lrow * Wc + cc) * CH + ch]);
+                }
             }
+            out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + half * CH + ch] = m;
         }
-        out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + ch] = m;
+        __syncthreads();
     }
 }
 
