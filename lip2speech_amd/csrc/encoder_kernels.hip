@@ -24,7 +24,7 @@ constexpr int FE_CO = 24;
 // MODE 0: inference; 1: also save the pre-PReLU map (training tape); 2: batch-statistics pass (training): nothing is stored but the
 // per-channel sum / sum of squares of the RAW conv output over this block's own conv rows -> zout[(block*2 + k)*24 + ch]
 template <int HW, int MODE>
-__global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, const FrameSrc vsrc,
+__global__ __launch_bounds__(256, 3) void frontend3d_kernel(const FrontendW w, const FrameSrc vsrc,
                                                             int T, float* __restrict__ out, float* __restrict__ zout) {
     constexpr bool SAVE_Z = MODE == 1;
     constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
     constexpr int TPW = (NT + 3) / 4;                // tiles per wave
     constexpr int XS = FE_XROWS * FE_XLD;            // floats in the input slab
     constexpr int WS = FE_KP * 32;                   // floats in the weight slab
-    constexpr int CS = P * FE_CO;                    // floats in the conv tile (aliases the slabs)
-    constexpr int SMEM = (XS + WS) > CS ? (XS + WS) : CS;
+    constexpr int CS = MODE == 2 ? 0 : P * (FE_CO / 2);    // floats in the conv tile of HALF the channels (aliases the slabs; pooling in two passes; none in the statistics pass)
+    constexpr int SMEM = (XS + WS) > CS ? (XS + WS) : CS;  // 20 KB of operands or 30 KB of tile: three blocks per CU (the 24-channel tile held it at two)
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* Xs = smem;
     float* Ws = smem + XS;
@@ -130,52 +130,55 @@ __global__ __launch_bounds__(256, 2) void frontend3d_kernel(const FrontendW w, c
         }
         return;
     }
-    // BN + PReLU, conv tile Cs[pixel][24]
+    // BN + PReLU -> conv tile Cs[pixel][12] -> 3x3 / stride 2 / pad 1 max pool (padding never wins: -inf) -> channel-last output, twelve channels at a time
     float* Cs = smem;
-    if (li < FE_CO) {
-        const float sc = w.scale[li], sh = w.shift[li], sl = w.slope[li];
+    constexpr int CH = FE_CO / 2;
+    const float sc = li < FE_CO ? w.scale[li] : 0.f, sh = li < FE_CO ? w.shift[li] : 0.f, sl = li < FE_CO ? w.slope[li] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            if (wave + 4 * j < NT) {
+    for (int half = 0; half < 2; ++half) {
+        if (li >= half * CH && li < (half + 1) * CH) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                    if (p < P) {
-                        float v = acc[j][r] * sc + sh;
-                        if (SAVE_Z) {                // training tape: pre-PReLU map (B*T, H/2, W/2, 24); the halo row belongs to the strip above
-                            const int lr = p / Wc, crow = 2 * p0 - 1 + lr;
-                            if (lr >= 1 && crow < Hc) zout[(((int64_t)f * Hc + crow) * Wc + (p - lr * Wc)) * FE_CO + li] = v;
+            for (int j = 0; j < TPW; ++j) {
+                if (wave + 4 * j < NT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = (wave + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                        if (p < P) {
+                            float v = acc[j][r] * sc + sh;
+                            if (SAVE_Z) {            // training tape: pre-PReLU map (B*T, H/2, W/2, 24); the halo row belongs to the strip above
+                                const int lr = p / Wc, crow = 2 * p0 - 1 + lr;
+                                if (lr >= 1 && crow < Hc) zout[(((int64_t)f * Hc + crow) * Wc + (p - lr * Wc)) * FE_CO + li] = v;
+                            }
+                            v = v >= 0.f ? v : sl * v;
+                            Cs[p * CH + (li - half * CH)] = v;
                         }
-                        v = v >= 0.f ? v : sl * v;
-                        Cs[p * FE_CO + li] = v;
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-
-    // 3x3 / stride 2 / pad 1 max pool (padding never wins: -inf) -> channel-last output
-    for (int i = tid; i < FE_PR * Wp * FE_CO; i += 256) {
-        const int ch = i % FE_CO;
-        const int pw = (i / FE_CO) % Wp;
-        const int prl = i / (FE_CO * Wp);
-        const int pr = p0 + prl;
-        if (pr >= Hp) continue;
-        float m = -INFINITY;
+        __syncthreads();
+        for (int i = tid; i < FE_PR * Wp * CH; i += 256) {
+            const int ch = i % CH;
+            const int pw = (i / CH) % Wp;
+            const int prl = i / (CH * Wp);
+            const int pr = p0 + prl;
+            if (pr >= Hp) continue;
+            float m = -INFINITY;
 #pragma unroll
-        for (int dr = 0; dr < 3; ++dr) {
-            const int crow = 2 * pr - 1 + dr;        // global conv row
-            if (crow < 0 || crow >= Hc) continue;
-            const int lrow = 2 * prl + dr;           // local conv row (local row 0 = conv row 2*p0-1)
+            for (int dr = 0; dr < 3; ++dr) {
+                const int crow = 2 * pr - 1 + dr;        // global conv row
+                if (crow < 0 || crow >= Hc) continue;
+                const int lrow = 2 * prl + dr;           // local conv row (local row 0 = conv row 2*p0-1)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                const int cc = 2 * pw + dc;
-                if (cc < 0 || cc >= Wc) continue;
-                m = fmaxf(m, Cs[(lrow * Wc + cc) * FE_CO + ch]);
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int cc = 2 * pw + dc;
+                    if (cc < 0 || cc >= Wc) continue;
+                    m = fmaxf(m, Cs[(lrow * Wc + cc) * CH + ch]);
+                }
             }
+            out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + half * CH + ch] = m;
         }
-        out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + ch] = m;
+        __syncthreads();
     }
 }
 
