@@ -33,7 +33,7 @@ __device__ __forceinline__ void stage_transposed_bf16(unsigned char* S, int r0, 
 }
 
 // one 64x64 output tile (bx, by) of K slice bz; As / Bs: the block's two LDS tiles
-template <int MODE, bool BF16>
+template <int MODE, bool BF16, bool VEC>
 __device__ __forceinline__ void gemm_bwd_block(const BwdGemmP& p, const int bx, const int by, const int bz, float* As, float* Bs) {
     const int m0 = by * TB, n0 = bx * TB;
     const int tid = threadIdx.x;
@@ -50,15 +50,22 @@ __device__ __forceinline__ void gemm_bwd_block(const BwdGemmP& p, const int bx, 
         kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
         Cout += (int64_t)bz * p.c_split_stride;
     }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool vec = p.vec != 0;
-    auto ld4 = [&](const float* q, int nvalid) -> float4 {      // vec: dimensions and strides are multiples of 4, pointers 16-byte aligned
-        if (vec) return *reinterpret_cast<const float4*>(q);
-        float4 v = zero4;
-        if (nvalid > 0) v.x = q[0];
-        if (nvalid > 1) v.y = q[1];
-        if (nvalid > 2) v.z = q[2];
-        if (nvalid > 3) v.w = q[3];
+    // VEC (a template constant: with a run-time flag the compiler merged both forms into four 4-byte FLAT loads per quad, and kept the zero quad in
+    // scratch to select between pointers): dimensions and strides are multiples of 4 and the pointers 16-byte aligned -> one 16-byte global load.
+    // Out-of-range quads load from the (always valid) base of their matrix and are zeroed afterwards: a value select, not a pointer select.
+    auto ld4 = [&](const float* q, const float* base, bool ok, int nvalid) -> float4 {
+        float4 v;
+        if constexpr (VEC) {
+            v = *reinterpret_cast<const float4*>(ok ? q : base);
+        } else {
+            const float* qq = ok ? q : base;
+            const int nv = ok ? nvalid : 0;
+            v.x = nv > 0 ? qq[0] : 0.f;
+            v.y = nv > 1 ? qq[1] : 0.f;
+            v.z = nv > 2 ? qq[2] : 0.f;
+            v.w = nv > 3 ? qq[3] : 0.f;
+        }
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
         return v;
     };
 
@@ -70,35 +77,39 @@ __device__ __forceinline__ void gemm_bwd_block(const BwdGemmP& p, const int bx, 
 
     auto load_dx_a = [&](int j, int k) -> float4 {     // dZcol(m, r..r+3), r = tap'*Nout + n, 4 consecutive n
         const int m = m0 + lr + 32 * j;
-        if (m >= p.M || k >= p.K) return zero4;
-        const int b = m / p.Tx, t = m - b * p.Tx;
-        int tap = 0, n = k;
-        if (p.taps > 1) { tap = k / p.Nout; n = k - tap * p.Nout; }
+        bool ok = m < p.M && k < p.K;
+        const int mm = ok ? m : 0, kk = ok ? k : 0;
+        const int b = mm / p.Tx, t = mm - b * p.Tx;
+        int tap = 0, n = kk;
+        if (p.taps > 1) { tap = kk / p.Nout; n = kk - tap * p.Nout; }
         const int tz = t + tap - p.padp;
-        if (tz < 0 || tz >= p.Tz) return zero4;
-        return ld4(p.A + ((int64_t)b * p.Tz + tz) * p.lda + n, p.K - k);
+        ok = ok && tz >= 0 && tz < p.Tz;
+        return ld4(p.A + ((int64_t)b * p.Tz + (ok ? tz : 0)) * p.lda + n, p.A, ok, p.K - kk);
     };
     auto load_dx_b = [&](int j, int k0) -> float4 {    // Wp[n(r)][(taps-1-tap')*Cin + col..col+3] for reduction row r = k0 + r0 + 16j
         const int r = k0 + r0 + 16 * j, col = n0 + c4;
-        if (r >= p.K || col >= p.N) return zero4;
-        int tap = 0, n = r;
-        if (p.taps > 1) { tap = r / p.Nout; n = r - tap * p.Nout; }
-        return ld4(p.B + (int64_t)n * p.ldb + (p.taps - 1 - tap) * p.Cin + col, p.N - col);
+        const bool ok = r < p.K && col < p.N;
+        const int rr = ok ? r : 0, cc = ok ? col : 0;
+        int tap = 0, n = rr;
+        if (p.taps > 1) { tap = rr / p.Nout; n = rr - tap * p.Nout; }
+        return ld4(p.B + (int64_t)n * p.ldb + (p.taps - 1 - tap) * p.Cin + cc, p.B, ok, p.N - cc);
     };
     auto load_dw_a = [&](int j, int k0) -> float4 {    // dZ[m][n0 + c4 ..], m = k0 + r0 + 16j
         const int m = k0 + r0 + 16 * j, col = m0 + c4;
-        if (m >= p.K || col >= p.M) return zero4;
-        return ld4(p.A + (int64_t)m * p.lda + col, p.M - col);
+        const bool ok = m < p.K && col < p.M;
+        const int mm = ok ? m : 0, cc = ok ? col : 0;
+        return ld4(p.A + (int64_t)mm * p.lda + cc, p.A, ok, p.M - cc);
     };
     auto load_dw_b = [&](int j, int k0) -> float4 {    // Xcol(m, jcol..jcol+3), jcol = (tap, ci)
         const int m = k0 + r0 + 16 * j, col = n0 + c4;
-        if (m >= p.K || col >= p.N) return zero4;
-        const int b = m / p.Tz, t = m - b * p.Tz;
-        int tap = 0, ci = col;
-        if (p.taps > 1) { tap = col / p.Cin; ci = col - tap * p.Cin; }
+        bool ok = m < p.K && col < p.N;
+        const int mm = ok ? m : 0, cc = ok ? col : 0;
+        const int b = mm / p.Tz, t = mm - b * p.Tz;
+        int tap = 0, ci = cc;
+        if (p.taps > 1) { tap = cc / p.Cin; ci = cc - tap * p.Cin; }
         const int tx = t * p.stride + tap - p.pad;
-        if (tx < 0 || tx >= p.Tx) return zero4;
-        return ld4(p.B + ((int64_t)b * p.Tx + tx) * p.ldb + ci, p.N - col);
+        ok = ok && tx >= 0 && tx < p.Tx;
+        return ld4(p.B + ((int64_t)b * p.Tx + (ok ? tx : 0)) * p.ldb + ci, p.B, ok, p.N - cc);
     };
 
     float4 ra[2], rb[2];
@@ -168,22 +179,22 @@ __device__ __forceinline__ void gemm_bwd_block(const BwdGemmP& p, const int bx, 
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
-template <int MODE, bool BF16 = false>
+template <int MODE, bool BF16, bool VEC>
 __global__ __launch_bounds__(256) void gemm_bwd_kernel(const BwdGemmP p) {
     __shared__ __attribute__((aligned(16))) float As[TB * TLD];
     __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
-    gemm_bwd_block<MODE, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+    gemm_bwd_block<MODE, BF16, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 // The weight gradient and the input gradient of ONE layer in one launch: they read the same dZ and are independent of each other, and at 8 clips
 // per GPU neither fills the chip - blocks [0, wx*wy*wz) are the (split-K) weight-gradient tiles, the rest the input-gradient tiles.
-template <bool BF16>
+template <bool BF16, bool VEC>
 __global__ __launch_bounds__(256) void gemm_bwd_pair_kernel(const BwdGemmP pw, const BwdGemmP px, int wx, int wy, int wz, int xx) {
     __shared__ __attribute__((aligned(16))) float As[TB * TLD];
     __shared__ __attribute__((aligned(16))) float Bs[TB * TLD];
     int id = blockIdx.x;
     const int nw = wx * wy * wz;
-    if (id < nw) gemm_bwd_block<BWD_DW, BF16>(pw, id % wx, (id / wx) % wy, id / (wx * wy), As, Bs);
-    else { id -= nw; gemm_bwd_block<BWD_DX, BF16>(px, id % xx, id / xx, 0, As, Bs); }
+    if (id < nw) gemm_bwd_block<BWD_DW, BF16, VEC>(pw, id % wx, (id / wx) % wy, id / (wx * wy), As, Bs);
+    else { id -= nw; gemm_bwd_block<BWD_DX, BF16, VEC>(px, id % xx, id / xx, 0, As, Bs); }
 }
 
 static bool bwd_vec_ok(const BwdGemmP& p) {
@@ -205,10 +216,12 @@ int launch_gemm_bwd(const BwdGemmP& p, hipStream_t s, const char* name) {
     dim3 grid((p.N + TB - 1) / TB, (p.M + TB - 1) / TB, p.ksplit > 1 ? p.ksplit : 1);
     ProfScope ps(name, s);
     const bool bf16 = gemm_bf16_mode() != 0;                 // option "train_bf16"
-    if (p.mode == BWD_DX && bf16) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DX, true>), grid, dim3(256), 0, s, q);
-    else if (p.mode == BWD_DX) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DX, false>), grid, dim3(256), 0, s, q);
-    else if (bf16) hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DW, true>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((gemm_bwd_kernel<BWD_DW, false>), grid, dim3(256), 0, s, q);
+#define L2S_BWD_LAUNCH(MODE_, BF_, VEC_) hipLaunchKernelGGL((gemm_bwd_kernel<MODE_, BF_, VEC_>), grid, dim3(256), 0, s, q)
+    if (p.mode == BWD_DX) { if (bf16) { if (vec) L2S_BWD_LAUNCH(BWD_DX, true, true); else L2S_BWD_LAUNCH(BWD_DX, true, false); }
+                            else { if (vec) L2S_BWD_LAUNCH(BWD_DX, false, true); else L2S_BWD_LAUNCH(BWD_DX, false, false); } }
+    else { if (bf16) { if (vec) L2S_BWD_LAUNCH(BWD_DW, true, true); else L2S_BWD_LAUNCH(BWD_DW, true, false); }
+           else { if (vec) L2S_BWD_LAUNCH(BWD_DW, false, true); else L2S_BWD_LAUNCH(BWD_DW, false, false); } }
+#undef L2S_BWD_LAUNCH
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -254,12 +267,17 @@ int launch_gemm_bwd_dw_dx(const BwdGemmP& pdw, int splits, float* partials, cons
     if (splits < 1) splits = 1;
     BwdGemmP qw = pdw, qx = pdx;
     if (splits > 1) { qw.C = partials; qw.ldc = pdw.N; qw.ksplit = splits; qw.c_split_stride = (int64_t)pdw.M * pdw.N; qw.accumulate = 0; }
-    qw.vec = bwd_vec_ok(pdw) ? 1 : 0; qx.vec = bwd_vec_ok(pdx) ? 1 : 0;
+    const bool vec = bwd_vec_ok(pdw) && bwd_vec_ok(pdx);          // one instance for the pair: 16-byte loads only when both halves allow them
+    qw.vec = vec ? 1 : 0; qx.vec = qw.vec;
     const int wx = (pdw.N + TB - 1) / TB, wy = (pdw.M + TB - 1) / TB, xx = (pdx.N + TB - 1) / TB, xy = (pdx.M + TB - 1) / TB;
     {
         ProfScope ps(name, s);
-        if (gemm_bf16_mode() != 0) hipLaunchKernelGGL(gemm_bwd_pair_kernel<true>, dim3(wx * wy * splits + xx * xy), dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
-        else hipLaunchKernelGGL(gemm_bwd_pair_kernel<false>, dim3(wx * wy * splits + xx * xy), dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+        const dim3 grid(wx * wy * splits + xx * xy);
+        const bool bf16 = gemm_bf16_mode() != 0;
+        if (bf16 && vec) hipLaunchKernelGGL((gemm_bwd_pair_kernel<true, true>), grid, dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+        else if (bf16) hipLaunchKernelGGL((gemm_bwd_pair_kernel<true, false>), grid, dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+        else if (vec) hipLaunchKernelGGL((gemm_bwd_pair_kernel<false, true>), grid, dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
+        else hipLaunchKernelGGL((gemm_bwd_pair_kernel<false, false>), grid, dim3(256), 0, s, qw, qx, wx, wy, splits, xx);
     }
     if (splits > 1) {
         const int64_t total = (int64_t)pdw.M * pdw.N;
