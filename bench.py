@@ -54,10 +54,12 @@ def kernel_model(name, rows=B):
     w4 = 4
     R = rows
     table = {
-        # both decoder LSTM layers run the same kernel (600 launches per pass): layer 0 has K=1536 (attention_proj folded in),
-        # layer 1 K=1024; figures are the per-launch mean of the two
-        "step_lstm_cell": (2 * R * 2048 * (1536 + 1024) / 2,
-                           ((2048 * (1536 + 1024) / 2 + 2048) * w4 + R * ((1536 + 1024) / 2 + 3 * 512) * w4)),
+        # both decoder LSTM layers run the same kernel (600 launches per pass); figures are the per-launch mean of the two layers.
+        # ALGORITHMIC work (decoder.py:423): each layer is [x | h] (K = 512 + 512) against 2048 gate rows, and the
+        # 512 -> 256 attention_proj of decoder.py:420 that the phase-merged layer 0 absorbs is credited to it.  What the kernel EXECUTES is
+        # more (layer 0 runs K = 1536 after the W_ih * W_ap fold): `executed` below, reported under roofline.frac_executed - never as frac.
+        "step_lstm_cell": (2 * R * (2048 * 1024 + 2048 * 1024 + 256 * 512) / 2,
+                           ((2048 * (1024 + 1024) / 2 + 256 * 512 / 2 + 2048) * w4 + R * (1024 + 3 * 512) * w4)),
         "step_prenet1_q_cq_fc": (2 * R * (256 * 512 + 512 * 1024 + 256 * 1024 + 81 * 512),
                                  (256 * 512 + 512 * 1024 + 256 * 1024 + 96 * 512 + 1024) * w4 + R * (2048 + 256 + 512 + 256 + 81) * w4),
         "step_attention_prenet2": (2 * R * (2 * T * 512 + 2 * m * 256 + 256 * 256),
@@ -68,6 +70,11 @@ def kernel_model(name, rows=B):
         "postnet_conv_gemm": (2 * 4.34e6 * S * R / 5, (R * S * (80 + 512 * 4 * 2 + 80) + 4.35e6) * w4 / 5),
     }
     return table.get(name)
+
+
+def executed_flops(name, rows=B):
+    """FLOPs the launch really issues where they differ from the algorithmic count (phase-merged weights)."""
+    return {"step_lstm_cell": 2 * rows * 2048 * (1536 + 1024) / 2}.get(name)
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -383,13 +390,14 @@ def main():
     torch.cuda.synchronize()
     group_latency = time.perf_counter() - t0
 
+    # the evaluate.py path: forward(tf_ratio=1) with S = 77 target frames per clip - the same grouping and chains as
+    # `value`, through the entry the reference-facing callers use (InflightPool.imap -> l2s_forward_eval_multi)
+    S77 = 77
+    fwd_job = lambda b: {"entry": "forward", "video": b[0], "emb": b[1], "gumbel": b[2], "S": S77}      # noqa: E731
+    list(pool.imap(work(2 * n_distinct), fwd_job))
+    fwd_elapsed, _ = timed(lambda: list(pool.imap(work(args.steps), fwd_job)))
     # secondary figures on a pool of four single-batch chains (the entry points below are per batch)
     pool4 = pool if (G == 1 and NI == 4) else InflightPool(model=nm, n_inflight=4, group=1)
-    # the evaluate.py path: forward(tf_ratio=1) with S = 77 target frames per clip
-    S77 = 77
-    fwd = lambda model, b: model.forward_eval(b[0], b[1], b[2], S77)      # noqa: E731
-    pool4.map(work(4), fn=fwd)
-    fwd_elapsed, _ = timed(lambda: pool4.map(work(args.steps), fn=fwd))
     # the boundary handed HOST buffers (pinned): every step first copies its 102.6 MB of frames, the speaker embedding and the Gumbel
     # noise to the GPU on its own stream, overlapping the other chains' compute.  Never `value` (inputs resident there).
     host_batches = [tuple(t.cpu().pin_memory() for t in batches[i % n_distinct]) for i in range(4)]
@@ -450,20 +458,27 @@ def main():
             roof["algorithmic_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
             roof["arithmetic_intensity"] = ai
+            ex = executed_flops(name, rows)
+            if ex and roof["bound"] == "mfma":
+                roof["executed_flops"] = ex
+                roof["frac_executed"] = ex / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
+                roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj) / measured "
+                                "duration / peak; frac_executed counts the K=1536 products the phase-merged layer 0 really runs")
         # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
         # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_decode.json")))
+            pmc_file = next(f for f in ("r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k = pmc["kernels"].get(name)
             if k and pmc.get("rows_per_launch") == rows:
                 roof["traffic"] = k["traffic_bytes_per_launch"]
-                roof["traffic_source"] = "offline: profiles/r02_pmc_decode.json (rocprofv3 --pmc, same kernel and rows per launch), not measured in this run"
+                roof["traffic_source"] = f"offline: profiles/{pmc_file} (rocprofv3 --pmc, same kernel and rows per launch), not measured in this run"
                 roof["l2_hit_rate_offline"] = k.get("l2_hit_rate")
                 if k.get("avg_us_rocprofv3"):
                     roof["avg_us_rocprofv3_offline"] = k["avg_us_rocprofv3"]
                     roof["frac_at_rocprofv3_duration"] = roof["frac"] * roof["avg_us"] / k["avg_us_rocprofv3"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         # the other kernels with a closed-form cost model, same pass (per-launch HIP-event brackets: us-scale kernels carry ~1.8 us of it)
         others = []
@@ -506,7 +521,9 @@ def main():
             "one_batch_at_a_time": {"value": world * B * S * args.steps / seq_elapsed, "ms_per_step": seq_elapsed / args.steps * 1e3,
                                     "note": "the same K steps as K calls of l2s_inference, strictly sequential (one B=32 batch per launch chain)"},
             "evaluate_forward_S77": {"value": world * B * S77 * args.steps / fwd_elapsed, "unit": "mel-frames/s", "ms_per_step": fwd_elapsed / args.steps * 1e3,
-                                     "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), four single-batch chains in flight"},
+                                     "tflops_algorithmic": world * B * S77 * args.steps / fwd_elapsed * 85.28e6 / 1e12,
+                                     "note": "Lip2Speech.forward(tf_ratio=1) in eval mode, S=77 (evaluate.py:38), through the callers' streaming entry "
+                                             "(InflightPool.imap -> l2s_forward_eval_multi), same batches per chain and chains in flight as `value`"},
             "host_resident_inputs": {"value": world * B * S * args.steps / h2d_elapsed, "unit": "mel-frames/s", "ms_per_step": h2d_elapsed / args.steps * 1e3,
                                      "note": "PCIe-inclusive: each step copies its batch from pinned host memory on its own stream first; four single-batch chains in flight"},
             "bf16_leg": {"value": world * B * S * args.steps / bf16_elapsed, "unit": "mel-frames/s", "ms_per_step": bf16_elapsed / args.steps * 1e3,

@@ -156,6 +156,28 @@ int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const fl
                         float* mel_post, int64_t* lengths, float* attn,
                         void* ws, int64_t ws_bytes, void* stream);
 
+/* Lip2Speech.forward(..., tf_ratio) in eval() mode (model/model.py:23-40 + model/modules/decoder.py:320-379) - what evaluate.py:32-38 runs on
+ * every batch at tf_ratio = 1 - as ONE launch chain: encoder, prologue, S = mels.shape[2] steps, post-net.
+ *   teacher      dev (B,S,80) or NULL: cat(BOS, mels)[:, i] (decoder.py:349), fed at the steps whose teacher_mask byte is set
+ *   teacher_mask host (S) bytes or NULL: the caller's scheduled-sampling draws (decoder.py:355-357); both or neither
+ *   mel_cf       dev (B,80,S) or NULL  pre-postnet mel, the reference's layout (outputs[0])
+ *   mel_post     dev (B,80,S)          (outputs[1])
+ *   stop         dev (B,S)             stop-token logits (outputs[2] without its trailing 1)
+ *   attn_logits  dev (B,S,T) or NULL   tau * q.k, PRE-softmax (outputs[4]; train.py:244 applies the softmax itself)
+ *   content_dis  dev (B*min_T,501) or NULL  (outputs[5])
+ * Workspace: l2s_workspace_bytes(B,T,H,W,S).  Same kernels as the staged calls l2s_encoder_fwd .. l2s_postnet: bit-identical to them. */
+int l2s_forward_eval(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                     const float* teacher, const uint8_t* teacher_mask, float* mel_cf, float* mel_post, float* stop, float* attn_logits,
+                     float* content_dis, void* ws, int64_t ws_bytes, void* stream);
+/* The grouped form (see l2s_inference_multi): G batches of evaluate.py's loop (evaluate.py:32-38 iterates them one by one) as rows
+ * g*B .. g*B+B-1 of ONE launch chain; per batch bit-identical to l2s_forward_eval.  video / emb / gumbel / teacher: host arrays of G device
+ * pointers (teacher NULL = free-running).  The batches of a group share S and teacher_mask - at tf_ratio = 1 the mask is empty, so any G
+ * batches of one shape group.  Outputs are (G*B, ...) tensors, batch g = the g-th slice of B rows (content_dis: of B*min_T rows).
+ * Workspace: l2s_workspace_bytes_multi(G,B,T,H,W,S). */
+int l2s_forward_eval_multi(l2s_model* m, int G, const float* const* video, const float* const* emb, const float* const* gumbel,
+                           const float* const* teacher, const uint8_t* teacher_mask, int B, int T, int H, int W, int S, float* mel_cf,
+                           float* mel_post, float* stop, float* attn_logits, float* content_dis, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- training-side primitives of the data-parallel step (train.py:102-104,172-193; train_utils/losses.py:69-77) ----------
  * scratch: l2s_train_scratch_bytes() of device memory.  Reductions are two-stage fp64 (deterministic). */
 int64_t l2s_train_scratch_bytes(void);
@@ -297,7 +319,10 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
 /* l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.
  * Launch sequences only ever read their own model's copy, so a thread that flips a switch cannot disturb batches other threads have in
- * flight on other models (lip2speech_amd.parallel keeps several in flight).
+ * flight on other models.  Several host threads may also drive ONE model at once (lip2speech_amd.parallel.InflightPool: chains in flight on
+ * one weight blob): the blob is read-only, every workspace is its caller's, the per-model side stream / events / graph cache behind
+ * "overlap_postnet" and "use_graph" are serialised by a per-model mutex (those chains enqueue one after the other), and the l2s_profile_*
+ * accumulators are guarded - only changing an option of a model WHILE other threads run batches on it is the caller's race.
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
  *   "frontend_x3"       (1)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path; 0 = f32 MFMA kernel

@@ -1,8 +1,13 @@
 """The model-facing halves of the reference's caller loops, without their I/O:
 
-  * ``demo_clip``      - demo.py:60-90: per clip, speaker embedding from the VOICE tower (``--encoding voice``) or a
+  * ``demo_clips`` / ``demo_clip`` - demo.py:60-90: per clip, speaker embedding from the VOICE tower (``--encoding voice``) or a
                          supplied one, ``net.inference(..., return_attention_map=True)``, truncate to ``output_lengths[0]``.
-  * ``evaluate_mels``  - evaluate.py:22-51: ``net(..., tf_ratio=1)[1]`` in eval mode over collated batches.
+  * ``evaluate_mels`` / ``evaluate_net`` - evaluate.py:22-51: ``net(..., tf_ratio=1)[1]`` in eval mode over collated batches.
+  * ``train_iterations`` - train.py:150-193.
+
+The inference-side loops run on the GROUPED path by default: the loader's batches are prefetched ``group`` at a time into one launch chain
+(``l2s_inference_multi`` / ``l2s_forward_eval_multi``) with ``n_inflight`` chains on the GPU (``Lip2Speech.inference_many`` /
+``forward_many`` over ``parallel.InflightPool.imap``); results come back in loader order, each bit-identical to the single-batch call.
 
 The reference then vocodes the mels (InverseMelScale + Griffin-Lim, torchaudio) and scores ESTOI (pystoi); both are
 third-party, stochastic and out of scope here - these functions return the mels.
@@ -15,38 +20,65 @@ import torch
 
 
 def demo_clip(net, batch, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda"):
-    """``batch`` = one item of ``DataLoader(ds, batch_size=1, collate_fn=test_collate_fn_pad)``."""
-    (videos, _), (audios, _), _, face_crops, _ = batch
-    with torch.no_grad():
-        if speaker_embedding is None:
-            if speaker_encoder is None:
-                raise ValueError("pass a SpeakerEncoder (voice route) or a speaker_embedding")
-            speaker_embedding = speaker_encoder.inference(audios.to(device))
-        mel, lengths, attn = net.inference(videos.to(device), face_crops.to(device), speaker_embedding.to(device),
-                                           return_attention_map=True)
-    n = int(lengths[0])
-    return mel[:1, :, :n], lengths, attn[:, :n]
+    """``batch`` = one item of ``DataLoader(ds, batch_size=1, collate_fn=test_collate_fn_pad)`` (one iteration of demo.py:60-90)."""
+    return list(demo_clips(net, [batch], speaker_encoder=speaker_encoder, speaker_embedding=speaker_embedding, device=device, group=1, n_inflight=1))[0]
 
 
-def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda") -> List[torch.Tensor]:
-    """Post-net mels of ``net(..., tf_ratio=1)[1]`` for every collated batch (``train_collate_fn_pad`` layout)."""
+def demo_clips(net, batches: Iterable, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda",
+               group: int = 8, n_inflight: int = 2):
+    """demo.py:60-90 over a whole loader: per clip the speaker embedding from the VOICE tower (``--encoding voice``) or a supplied one,
+    ``net.inference(..., return_attention_map=True)``, truncation to ``output_lengths[0]``.  The clips are advanced ``group`` per launch
+    chain with ``n_inflight`` chains on the GPU (``Lip2Speech.inference_many``); yields ``(mel, lengths, attention)`` per clip, in order."""
+    if speaker_embedding is None and speaker_encoder is None:
+        raise ValueError("pass a SpeakerEncoder (voice route) or a speaker_embedding")
+
+    def calls():
+        for (videos, _), (audios, _), _, face_crops, _ in batches:
+            with torch.no_grad():
+                emb = speaker_embedding if speaker_embedding is not None else speaker_encoder.inference(audios.to(device, non_blocking=True))
+            yield videos, face_crops, emb, True
+
+    for mel, lengths, attn in net.inference_many(calls(), group=group, n_inflight=n_inflight):
+        n = int(lengths[0])
+        yield mel[:1, :, :n], lengths, attn[:, :n]
+
+
+def _evaluate_outputs(net, batches: Iterable, speaker_encoder, device, group: int, n_inflight: int):
+    """The eval-mode ``net(..., tf_ratio=1)`` of evaluate.py:32-38 for every collated batch (``train_collate_fn_pad`` layout), on the grouped
+    path: yields ``(batch, outputs)`` in loader order."""
+    kept = []
+
+    def calls():
+        for batch in batches:
+            (videos, vlen), (audios, alen), (melspecs, mlen, _gate), face_crops = batch
+            kept.append(batch)
+            with torch.no_grad():
+                emb = speaker_encoder.inference(audios.to(device, non_blocking=True)) if speaker_encoder is not None else None
+            yield videos, face_crops, audios, melspecs, vlen, alen, mlen, 1, {"speaker_embedding": emb}
+
+    for out in net.forward_many(calls(), group=group, n_inflight=n_inflight):
+        yield kept.pop(0), out
+
+
+def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda", group: int = 8, n_inflight: int = 2) -> List[torch.Tensor]:
+    """Post-net mels of ``net(..., tf_ratio=1)[1]`` for every collated batch (``train_collate_fn_pad`` layout; evaluate.py:32-38), ``group``
+    loader batches per launch chain (``l2s_forward_eval_multi``), ``n_inflight`` chains in flight."""
     was_training = net.training
     net.eval()
-    outs = []
-    with torch.no_grad():
-        for (videos, vlen), (audios, alen), (melspecs, mlen, _gate), face_crops in batches:
-            emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
-            out = net(videos.to(device), face_crops.to(device), audios.to(device), melspecs.to(device), vlen, alen, mlen, 1,
-                      speaker_embedding=emb)
-            outs.append(out[1])
-    net.train(was_training)
-    return outs
+    try:
+        return [out[1] for _, out in _evaluate_outputs(net, batches, speaker_encoder, device, group, n_inflight)]
+    finally:
+        net.train(was_training)
 
 
-def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", max_iters: int = 256, sampling_rate: int = None) -> float:
+def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", max_iters: int = 256, sampling_rate: int = None,
+                 group: int = 8, n_inflight: int = 2, timings: Optional[dict] = None) -> float:
     """Mean ESTOI of the vocoded predictions against the ground-truth audio (reference: evaluate.py:22-51): `net(..., tf_ratio=1)[1]`
     -> `MelSpec2Audio` (InverseMelScale + Griffin-Lim, `max_iters` each) -> `stoi(gt, pred, fs, extended=True)` per clip.  Vocoder and
-    metric are restatements of third-party algorithms (parity unpinned); the mels come from the HIP path."""
+    metric are restatements of third-party algorithms (parity unpinned); the mels come from the HIP path, `group` loader batches per launch
+    chain, and the next groups' chains run while this thread vocodes and scores.  `timings` (a dict) receives the wall seconds spent waiting
+    for the model, in the vocoder and in the metric."""
+    import time
     from .datasets.spectrograms import MelSpec2Audio
     from .hparams import create_hparams
     from .metrics import stoi
@@ -56,17 +88,32 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
     scores = []
     was_training = net.training
     net.eval()
-    with torch.no_grad():
-        for (videos, vlen), (audios, alen), (melspecs, mlen, _gate), face_crops in batches:
-            emb = speaker_encoder.inference(audios.to(device)) if speaker_encoder is not None else None
-            mel = net(videos.to(device), face_crops.to(device) if face_crops is not None else None, audios.to(device), melspecs.to(device), vlen, alen,
-                      mlen, 1, speaker_embedding=emb)[1]
-            pred = vocoder(mel).cpu().numpy()
-            gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
-            for i in range(gt.shape[0]):
-                n = min(gt.shape[1], pred.shape[1])
-                scores.append(stoi(gt[i, :n], pred[i, :n], fs, extended=True))
-    net.train(was_training)
+    t = {"model_wait_s": 0.0, "vocoder_s": 0.0, "estoi_s": 0.0, "clips": 0}
+    try:
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            for batch, out in _evaluate_outputs(net, batches, speaker_encoder, device, group, n_inflight):
+                audios = batch[1][0]
+                mel = out[1]
+                if timings is not None:
+                    torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                pred = vocoder(mel).cpu().numpy()
+                t2 = time.perf_counter()
+                gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
+                for i in range(gt.shape[0]):
+                    n = min(gt.shape[1], pred.shape[1])
+                    scores.append(stoi(gt[i, :n], pred[i, :n], fs, extended=True))
+                t3 = time.perf_counter()
+                t["model_wait_s"] += t1 - t0
+                t["vocoder_s"] += t2 - t1
+                t["estoi_s"] += t3 - t2
+                t["clips"] += gt.shape[0]
+                t0 = t3
+    finally:
+        net.train(was_training)
+    if timings is not None:
+        timings.update(t)
     return sum(scores) / max(1, len(scores))
 
 

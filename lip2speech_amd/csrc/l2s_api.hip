@@ -41,11 +41,13 @@ struct ProfEntry { std::string name; int64_t launches = 0; double total_ms = 0; 
 bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
 static std::map<std::string, int> g_prof_idx;
-static int g_prof_cur = -1;
-static hipEvent_t g_prof_start;
+static thread_local int g_prof_cur = -1;          // a begin/end pair runs on one host thread; several threads may drive launches (InflightPool)
+static thread_local hipEvent_t g_prof_start;
+static std::mutex g_prof_mu;                      // guards g_prof / g_prof_idx
 
 void prof_begin(const char* name, hipStream_t s) {
     if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_prof_idx.find(name);
     int idx;
     if (it == g_prof_idx.end()) {
@@ -64,11 +66,13 @@ void prof_end(hipStream_t s) {
     hipEvent_t stop;
     (void)hipEventCreate(&stop);
     (void)hipEventRecord(stop, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof[g_prof_cur].pending.emplace_back(g_prof_start, stop);
     g_prof[g_prof_cur].launches++;
     g_prof_cur = -1;
 }
 static void prof_drain() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& e : g_prof) {
         for (auto& pr : e.pending) {
             (void)hipEventSynchronize(pr.second);
@@ -658,6 +662,27 @@ __global__ __launch_bounds__(256) void refresh_sum_kernel(const RSum* __restrict
     r.dst[np] = r.a[src] + r.b[src];
 }
 
+// ---- the front-end conv's bf16 operand planes (FrontendW::w3 / w1), re-derived from the bound Conv3d weight exactly as pack_host derives
+// them: per slab (ci, kt), step st = kernel rows 2st, 2st+1 (row 7: zeros), 8 taps per row = one zero tap + the 7 real ones; w3 = the
+// truncation split hi + mid + lo (exact), w1 = one plane rounded to nearest even
+__global__ __launch_bounds__(256) void refresh_frontend_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ w3, uint16_t* __restrict__ w1) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 15 * 4 * 32 * 16) return;
+    const int k = idx & 15, n = (idx >> 4) & 31, st = (idx >> 9) & 3, slab = idx >> 11;
+    const int kh = 2 * st + (k >> 3), kw = (k & 7) - 1, ci = slab / 5, kt = slab % 5;
+    float x = 0.f;
+    if (n < 24 && kh < 7 && kw >= 0) x = w[(((int64_t)n * 3 + ci) * 5 + kt) * 49 + kh * 7 + kw];
+    const uint32_t xb = __float_as_uint(x), hb = xb & 0xFFFF0000u;
+    const float r1 = __fsub_rn(x, __uint_as_float(hb));
+    const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = __fsub_rn(r1, __uint_as_float(mb));
+    const uint32_t lb = __float_as_uint(r2);
+    const uint16_t planes[3] = {(uint16_t)(hb >> 16), (uint16_t)(mb >> 16), (uint16_t)(lb >> 16)};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) w3[(int64_t)slab * 9216 + ((st * 3 + pl) * 32 + n) * 24 + k] = planes[pl];      // byte offsets / 2 (18432-byte slabs, 48-byte rows)
+    w1[(int64_t)slab * 3072 + (st * 32 + n) * 24 + k] = (uint16_t)((xb + 0x7FFFu + ((xb >> 16) & 1u)) >> 16);
+}
+
 // ---- device-side re-merge of the two pre-multiplied step matrices (the host packer's fp64 products, here as fp32 MFMA products of the bound
 // parameters): prenet1 o fc_out -> w.pre1f, LSTM0 with attention_proj folded in -> w.lstm0f, both in the frag16 weight layout of the blob
 struct MergeSeg { const float* src; int ld, col0, k_lo, k_hi; };
@@ -758,7 +783,14 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
     if (nb_live) hipLaunchKernelGGL(refresh_bn_kernel, dim3((maxc + 255) / 256, (unsigned)nb_live), dim3(256), 0, s, reinterpret_cast<const RBn*>(T + off_bn));
     if (ns_live) hipLaunchKernelGGL(refresh_sum_kernel, dim3((maxn + 255) / 256, (unsigned)ns_live), dim3(256), 0, s, reinterpret_cast<const RSum*>(T + off_sum));
     L2S_CHECK_HIP(hipGetLastError());
-    m->planes_valid = false;        // the front-end's bf16 planes are splits of the old weights: inference falls back to the f32 front-end kernel
+    // the front-end's bf16 operand planes are splits of the old weights: re-split them from the bound Conv3d weight (an encoder that is not
+    // bound keeps its packed planes, like every other unbound module)
+    if (const float* w3d = m->canon("encoder.frontend3D.0.weight"); w3d && m->w.fe.w3 && m->w.fe.w1) {
+        ProfScope ps("train_refresh_frontend_planes", s);
+        hipLaunchKernelGGL(refresh_frontend_planes_kernel, dim3(15 * 4 * 32 * 16 / 256), dim3(256), 0, s, w3d,
+                           reinterpret_cast<uint16_t*>(const_cast<float*>(m->w.fe.w3)), reinterpret_cast<uint16_t*>(const_cast<float*>(m->w.fe.w1)));
+        L2S_CHECK_HIP(hipGetLastError());
+    }
     m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are products of the old parameters ...
     if (remerge_step_weights(m, s)) return 1;      // ... rebuilt here when the decoder's tensors are bound (then the 4-launch step stays valid)
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -1203,6 +1235,7 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
     const bool use_graph = m->opt.graph && !teacher && !g_prof_on;
     if (!use_graph) return decode_launches(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, s, fold);
 
+    std::lock_guard<std::mutex> side_lock(m->side_mu);      // graph cache, side stream and events are per model; chains of other threads wait here
     if (!m->side) {
         L2S_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
         L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
@@ -1336,7 +1369,7 @@ using namespace l2s;
 
 extern "C" {
 
-int l2s_abi_version(void) { return 1; }
+int l2s_abi_version(void) { return 2; }
 const char* l2s_last_error(void) { return g_err.c_str(); }
 
 int l2s_model_create(l2s_model** out) {
@@ -1454,26 +1487,35 @@ int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* 
     return launch_output_lengths(stop, B, S, lengths, (hipStream_t)stream);
 }
 
-static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
-                         float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, hipStream_t s) {
+// What one pass over a batch hands back.  inference(): mel_post + lengths (+ post-softmax attention); forward(tf_ratio) in eval mode
+// (decoder.py:320-379): mel_cf, mel_post, stop, attention LOGITS, content_dis.
+struct PathOut {
+    float* mel_post = nullptr; float* mel_cf = nullptr; float* stop = nullptr; int64_t* lengths = nullptr;
+    float* attn = nullptr; int attn_logits = 0; float* content_dis = nullptr;
+};
+
+static int path_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                    const float* teacher, const uint8_t* teacher_mask, const PathOut& o, void* ws, int64_t ws_bytes, hipStream_t s) {
     X3Scope x3scope(m->opt.infer_bf16 ? 0 : m->opt.gemm_x3);
     Bf16Scope bf16scope(m->opt.infer_bf16);      // the bf16 leg: bf16-operand GEMM / Conv1d kernels instead of the f32 / split-bf16 ones
     Bump bp(ws, ws_bytes);
     float* vis = bp.f((int64_t)B * T * 1024);
     float* state = bp.f(l2s_state_floats(B, T));
     float* mel = bp.f((int64_t)B * S * NM);
-    float* stop = bp.f((int64_t)B * S);
+    float* stop = o.stop ? o.stop : bp.f((int64_t)B * S);
     L2S_REQUIRE(!bp.overflow, "workspace too small (l2s_workspace_bytes)");
     void* rest = (char*)ws + bp.off;
     const int64_t rest_bytes = ws_bytes - bp.off;
     if (encoder_run(m, video, B, T, H, W, emb, vis, nullptr, rest, rest_bytes, s)) return 1;
-    if (prologue_run(m, vis, emb, gumbel, B, T, state, nullptr, rest, rest_bytes, s)) return 1;
-    if (!m->opt.overlap_postnet || g_prof_on || m->opt.graph) {
-        if (decode_run(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s)) return 1;
-        if (postnet_run(m, mel, B, S, mel_post, nullptr, rest, rest_bytes, s)) return 1;
+    if (prologue_run(m, vis, emb, gumbel, B, T, state, o.content_dis, rest, rest_bytes, s)) return 1;
+    const bool plain = !m->opt.overlap_postnet || g_prof_on || m->opt.graph || teacher || o.mel_cf;
+    if (plain) {
+        if (decode_run(m, state, B, T, S, teacher, teacher_mask, mel, stop, o.attn, o.attn_logits, rest, rest_bytes, s)) return 1;
+        if (postnet_run(m, mel, B, S, o.mel_post, o.mel_cf, rest, rest_bytes, s)) return 1;
     } else {
         // The decode loop is a chain of small latency-bound launches that leaves most CUs idle, and the post-net of frame t
         // only needs mel frames t-10..t+10: run the post-net in time windows on a second stream while later steps decode.
+        std::lock_guard<std::mutex> side_lock(m->side_mu);      // the side stream and its events are per model: one chain at a time enqueues on them
         if (!m->side) {
             L2S_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
             L2S_CHECK_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
@@ -1498,7 +1540,7 @@ static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, 
             L2S_CHECK_HIP(hipStreamWaitEvent(m->side, ev, 0));
             for (int layer = 0; layer < 5; ++layer) {
                 const int end = n == S ? S : std::max(done[layer], n - 2 * (layer + 1));
-                if (postnet_layer(m->w, layer, mel, pb, mel_post, B, S, done[layer], end, m->side)) return 1;
+                if (postnet_layer(m->w, layer, mel, pb, o.mel_post, B, S, done[layer], end, m->side)) return 1;
                 done[layer] = end;
             }
             return 0;
@@ -1506,11 +1548,18 @@ static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, 
         // the side stream must not start before earlier work on `s` (previous users of these buffers) is done
         L2S_CHECK_HIP(hipEventRecord(m->ev_in, s));
         L2S_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_in, 0));
-        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, attn, 0, rest, rest_bytes, s, m->opt.fold != 0 && m->folded_valid, &on_frames)) return 1;
+        if (decode_launches(m, state, B, T, S, nullptr, nullptr, mel, stop, o.attn, o.attn_logits, rest, rest_bytes, s, m->opt.fold != 0 && m->folded_valid, &on_frames)) return 1;
         L2S_CHECK_HIP(hipEventRecord(m->ev_out, m->side));
         L2S_CHECK_HIP(hipStreamWaitEvent(s, m->ev_out, 0));
     }
-    return launch_output_lengths(stop, B, S, lengths, s);
+    return o.lengths ? launch_output_lengths(stop, B, S, o.lengths, s) : 0;
+}
+
+static int inference_run(l2s_model* m, const FrameSrc& video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                         float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, hipStream_t s) {
+    PathOut o;
+    o.mel_post = mel_post; o.lengths = lengths; o.attn = attn;
+    return path_run(m, video, emb, gumbel, B, T, H, W, S, nullptr, nullptr, o, ws, ws_bytes, s);
 }
 
 int l2s_inference(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
@@ -1526,7 +1575,8 @@ int l2s_inference(l2s_model* m, const float* video, const float* emb, const floa
 int64_t l2s_workspace_bytes_multi(int G, int B, int T, int H, int W, int S) {
     int L[4];
     const int64_t rows = (int64_t)G * B;
-    return l2s_workspace_bytes((int)rows, T, H, W, S) + align_up(rows * L2S_D_EMB * 4, 256) + align_up(rows * content_lens(T, L) * VOC * 4, 256);
+    return l2s_workspace_bytes((int)rows, T, H, W, S) + align_up(rows * L2S_D_EMB * 4, 256) + align_up(rows * content_lens(T, L) * VOC * 4, 256) +
+           align_up(rows * S * NM * 4, 256);      // + the gathered teacher frames of l2s_forward_eval_multi
 }
 int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const float* const* emb, const float* const* gumbel, int B, int T, int H,
                         int W, int S, float* mel_post, int64_t* lengths, float* attn, void* ws, int64_t ws_bytes, void* stream) {
@@ -1551,6 +1601,55 @@ int l2s_inference_multi(l2s_model* m, int G, const float* const* video, const fl
     }
     X3Group x3group(G);
     return inference_run(m, src, emb_all, gum_all, G * B, T, H, W, S, mel_post, lengths, attn, (char*)ws + bp.off, ws_bytes - bp.off, s);
+}
+
+// Lip2Speech.forward(..., tf_ratio) in eval() mode / under no_grad (model.py:23-40 + decoder.py:320-379; what evaluate.py:38 runs at
+// tf_ratio = 1): S = mels.shape[2] steps, attention LOGITS out, optional teacher frames for the steps the caller's scheduled-sampling
+// draws selected.  One launch chain, like l2s_inference.
+int l2s_forward_eval(l2s_model* m, const float* video, const float* emb, const float* gumbel, int B, int T, int H, int W, int S,
+                     const float* teacher, const uint8_t* teacher_mask, float* mel_cf, float* mel_post, float* stop, float* attn_logits,
+                     float* content_dis, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(video && emb && gumbel && mel_post && stop && ws && B > 0, "bad arguments");
+    L2S_REQUIRE((teacher != nullptr) == (teacher_mask != nullptr), "teacher frames and teacher_mask come together");
+    PathOut o;
+    o.mel_post = mel_post; o.mel_cf = mel_cf; o.stop = stop; o.attn = attn_logits; o.attn_logits = 1; o.content_dis = content_dis;
+    return path_run(m, frame_src(video, B), emb, gumbel, B, T, H, W, S, teacher, teacher_mask, o, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// The grouped form: G batches of the evaluate loop as rows of ONE launch chain (see l2s_inference_multi).  The batches of a group share S
+// and the scheduled-sampling mask (at tf_ratio = 1 - evaluate.py - no step is ever teacher-forced, so any G batches group).
+int l2s_forward_eval_multi(l2s_model* m, int G, const float* const* video, const float* const* emb, const float* const* gumbel,
+                           const float* const* teacher, const uint8_t* teacher_mask, int B, int T, int H, int W, int S, float* mel_cf,
+                           float* mel_post, float* stop, float* attn_logits, float* content_dis, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_ENC_READY(m);
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(G >= 1 && G <= L2S_MAX_GROUP && video && emb && gumbel && mel_post && stop && ws && B > 0, "bad arguments");
+    L2S_REQUIRE((teacher != nullptr) == (teacher_mask != nullptr), "teacher frames and teacher_mask come together");
+    L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
+    hipStream_t s = (hipStream_t)stream;
+    int L[4];
+    const int mT = content_lens(T, L);
+    Bump bp(ws, ws_bytes);
+    float* emb_all = bp.f((int64_t)G * B * L2S_D_EMB);
+    float* gum_all = bp.f((int64_t)G * B * mT * VOC);
+    float* teach_all = teacher ? bp.f((int64_t)G * B * S * NM) : nullptr;
+    L2S_REQUIRE(!bp.overflow, "workspace too small (l2s_workspace_bytes_multi)");
+    FrameSrc src{};
+    src.per = B;
+    for (int g = 0; g < G; ++g) {
+        L2S_REQUIRE(video[g] && emb[g] && gumbel[g] && (!teacher || teacher[g]), "null batch pointer");
+        src.p[g] = video[g];
+        L2S_CHECK_HIP(hipMemcpyAsync(emb_all + (int64_t)g * B * L2S_D_EMB, emb[g], sizeof(float) * B * L2S_D_EMB, hipMemcpyDeviceToDevice, s));
+        L2S_CHECK_HIP(hipMemcpyAsync(gum_all + (int64_t)g * B * mT * VOC, gumbel[g], sizeof(float) * B * mT * VOC, hipMemcpyDeviceToDevice, s));
+        if (teacher)
+            L2S_CHECK_HIP(hipMemcpyAsync(teach_all + (int64_t)g * B * S * NM, teacher[g], sizeof(float) * B * S * NM, hipMemcpyDeviceToDevice, s));
+    }
+    X3Group x3group(G);
+    PathOut o;
+    o.mel_post = mel_post; o.mel_cf = mel_cf; o.stop = stop; o.attn = attn_logits; o.attn_logits = 1; o.content_dis = content_dis;
+    return path_run(m, src, emb_all, gum_all, G * B, T, H, W, S, teach_all, teacher_mask, o, (char*)ws + bp.off, ws_bytes - bp.off, s);
 }
 
 // ---- operator-level entry points

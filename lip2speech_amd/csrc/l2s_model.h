@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -81,6 +82,7 @@ struct l2s_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<hipEvent_t> ev_pool;
+    std::mutex side_mu;          // guards side / ev_in / ev_out / ev_pool / graphs: several host threads may drive ONE model (parallel.InflightPool)
     // training: device pointers of the canonical (PyTorch-layout) parameters and of their gradient slots, bound by key
     std::unordered_map<std::string, std::pair<float*, float*>> bound;
     // training: device-side refresh of the packed blob from the bound tensors (l2s_train_refresh_weights).  Built by l2s_model_finalize

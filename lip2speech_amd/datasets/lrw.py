@@ -41,11 +41,19 @@ def normalise_mouth(frames_u8: np.ndarray) -> torch.Tensor:
     return (x - mean) / std
 
 
+def face_recog_resize(frame_u8: torch.Tensor) -> torch.Tensor:
+    """dataset.py:76-79: `transforms.Resize((160, 160))` on a uint8 (3,H,W) tensor - bilinear, half-pixel centres, rounded back to uint8
+    (torchvision's tensor path; the package is absent here, its published behaviour is restated) - then `(x - 127.5) / 128`."""
+    x = torch.nn.functional.interpolate(frame_u8[None].float(), size=(160, 160), mode="bilinear", align_corners=False)[0]
+    return (x.round().clamp(0, 255).to(torch.uint8).float() - 127.5) / 128.0
+
+
 class LRW(Dataset):
     def __init__(self, rootpth, face_size=(96, 96), mode="train", demo=False, duration=1, face_augmentation=None, *args, raw_frames=False, **kwargs):
         """`raw_frames=True` (an extension): items carry the decoded uint8 clip `(T,H,W,3)` instead of the normalised fp32 one - the
-        normalisation then runs on the device (`datasets.device.device_collate_fn_pad` + `PackedFrames.to_device`)."""
-        super().__init__(*args, **kwargs)
+        normalisation then runs on the device (`datasets.device.device_collate_fn_pad` + `PackedFrames.to_device`).  Extra positional /
+        keyword arguments are accepted and ignored (the reference forwards them to `Dataset.__init__`, which takes none)."""
+        super().__init__()
         self.raw_frames = raw_frames
         assert mode in ("train", "test", "val")
         self.rootpth, self.mode, self.demo = rootpth, mode, demo
@@ -72,9 +80,13 @@ class LRW(Dataset):
         mouth = torch.from_numpy(np.ascontiguousarray(frames)) if self.raw_frames else normalise_mouth(frames)
         speech = torch.from_numpy(np.load(audio_path)["data"][np.newaxis])
         melspec = self.melspec_g(speech).squeeze(0)
-        # two random face frames resized to 160x160 feed the third-party face tower (outside this path); a zero
-        # placeholder keeps the collate layout when the face file or torchvision is unavailable
+        # two random face frames resized to 160x160 feed the third-party face tower (dataset.py:139-141).  The tower is outside this path,
+        # but the draw is part of an epoch's RNG consumption: `torch.rand(2)` is taken exactly where the reference takes it, face file or not
+        draw = torch.rand(2)
         face_crop = torch.zeros(2, 3, 160, 160)
+        if os.path.exists(face_path):
+            faces = torch.from_numpy(np.ascontiguousarray(load_frames(face_path))).permute(0, 3, 1, 2)
+            face_crop = torch.stack([face_recog_resize(faces[int(i)]) for i in (draw * len(faces)).int()], dim=0)
         if self.demo:
             return mouth, speech, melspec, face_crop, (face_path, audio_path)
         return mouth, speech, melspec, face_crop

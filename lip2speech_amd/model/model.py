@@ -149,12 +149,97 @@ class Lip2Speech(NativeBacked):
                 tf_ratio, speaker_embedding=None, gumbel_noise=None, dropout_masks=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.decoder.parameters()):
             return self._forward_train(video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise, dropout_masks)
-        video_features = F.dropout(self.encoder(video_frames), 0.1, self.training)
-        emb = self._speaker(face_frames, speaker_embedding)
-        vis = native.build_visual(video_features, emb)
-        face = emb.unsqueeze(1).expand(-1, vis.shape[1], -1)
-        outputs = self.decoder(vis, face, melspecs, video_lengths, melspec_lengths, tf_ratio, gumbel_noise=gumbel_noise)
-        return outputs + [video_lengths]
+        if self.training:
+            # a no_grad call on a train()-mode module: the feature dropout of model.py:26 is live - the staged route through the sub-modules
+            video_features = F.dropout(self.encoder(video_frames), 0.1, True)
+            emb = self._speaker(face_frames, speaker_embedding)
+            vis = native.build_visual(video_features, emb)
+            face = emb.unsqueeze(1).expand(-1, vis.shape[1], -1)
+            outputs = self.decoder(vis, face, melspecs, video_lengths, melspec_lengths, tf_ratio, gumbel_noise=gumbel_noise)
+            return outputs + [video_lengths]
+        job = self._forward_job(video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise)
+        out = self.native_model().forward_eval(job["video"], job["emb"], job["gumbel"], job["S"], teacher=job.get("teacher"), teacher_mask=job.get("mask"))
+        return job["finish"](out)
+
+    def _forward_job(self, video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding=None, gumbel_noise=None):
+        """One eval-mode `forward` call as a job of the native path (`l2s_forward_eval`; model.py:23-40 + decoder.py:320-379): the speaker
+        embedding, the Gumbel noise (drawn on the device unless supplied) and the scheduled-sampling mask (one host `torch.rand(1)` per
+        step) are fixed here, in the reference's order; `finish` shapes the native outputs into the reference's list of 7."""
+        dev = self.decoder.BOS.device
+        with torch.no_grad():
+            video = video_frames.to(dev, non_blocking=True)
+            emb = self._speaker(face_frames.to(dev, non_blocking=True) if face_frames is not None else None,
+                                speaker_embedding.to(dev, non_blocking=True) if speaker_embedding is not None else None)
+            B, _, T, _, _ = video.shape
+            S = melspecs.shape[2]
+            if gumbel_noise is None:
+                gumbel_noise = Decoder.draw_gumbel(B * native.min_T(T), dev)
+            mask = Decoder.sampling_mask(S, tf_ratio)
+            job = {"entry": "forward", "video": video, "emb": emb, "gumbel": gumbel_noise.to(dev, non_blocking=True), "S": S, "mask": mask}
+            if mask is not None:
+                job["teacher"] = self.decoder.teacher_frames(melspecs.to(dev, non_blocking=True))
+        job["finish"] = lambda o: [o[0], o[1], o[2].unsqueeze(2), emb, o[3], o[4], video_lengths]
+        return job
+
+    def _inference_job(self, video_frames, face_frames, speaker_embedding=None, return_attention_map=False, gumbel_noise=None):
+        dev = self.decoder.BOS.device
+        with torch.no_grad():
+            video = video_frames.to(dev, non_blocking=True)
+            emb = self._speaker(face_frames.to(dev, non_blocking=True) if face_frames is not None else None,
+                                speaker_embedding.to(dev, non_blocking=True) if speaker_embedding is not None else None)
+            B, _, T, _, _ = video.shape
+            if gumbel_noise is None:
+                gumbel_noise = Decoder.draw_gumbel(B * native.min_T(T), dev)
+        return {"entry": "inference", "video": video, "emb": emb, "gumbel": gumbel_noise.to(dev, non_blocking=True),
+                "S": self.decoder.hparams.max_decoder_steps, "want_attn": bool(return_attention_map),
+                "finish": (lambda o: (o[0], o[1], o[2])) if return_attention_map else (lambda o: (o[0], o[1]))}
+
+    # ------------------------------------------------------------------ loader-driven callers: G batches per launch chain, chains in flight
+    def pool(self, group: int = 8, n_inflight: int = 2):
+        """The `parallel.InflightPool` of this model's weight blob (cached per shape of concurrency)."""
+        from ..parallel import InflightPool
+        nm = self.native_model()
+        pools = self.__dict__.setdefault("_pools", {})
+        key = (id(nm), group, n_inflight)
+        if key not in pools:
+            pools[key] = InflightPool(model=nm, n_inflight=n_inflight, group=group)
+        return pools[key]
+
+    @staticmethod
+    def _call(item):
+        """An item of `*_many`: the positional arguments of the single-batch method, optionally followed by a dict of keyword arguments."""
+        if isinstance(item, dict):
+            return (), item
+        item = tuple(item)
+        if item and isinstance(item[-1], dict):
+            return item[:-1], item[-1]
+        return item, {}
+
+    def inference_many(self, calls, group: int = 8, n_inflight: int = 2):
+        """`inference` over a stream of batches - the loop of demo.py:60-90 - with `group` batches advanced per launch chain
+        (`l2s_inference_multi`) and `n_inflight` chains on the GPU at once.  `calls` is any iterable (e.g. a generator over a DataLoader) of
+        argument tuples `(video_frames, face_frames[, speaker_embedding[, return_attention_map[, gumbel_noise]]])`, optionally ending in a
+        dict of keyword arguments; inputs may live on the host (they are copied on the pool's copy stream, one group ahead).  Yields, in
+        order, exactly what `inference(*call)` returns for each - bit-identical when the Gumbel noise is supplied."""
+        self.native_model()
+        prep = lambda item: (lambda a, k: self._inference_job(*a, **k))(*self._call(item))      # noqa: E731
+        return self.pool(group, n_inflight).imap(calls, prep)
+
+    def forward_many(self, calls, group: int = 8, n_inflight: int = 2):
+        """Eval-mode `forward` over a stream of batches - the loop of evaluate.py:22-51 (`net(..., tf_ratio=1)` per DataLoader batch) - on the
+        grouped path (`l2s_forward_eval_multi`).  `calls`: iterable of `forward`'s argument tuples `(video_frames, face_frames, audio_frames,
+        melspecs, video_lengths, audio_lengths, melspec_lengths, tf_ratio)`, optionally ending in a dict (`speaker_embedding=`,
+        `gumbel_noise=`).  Yields the reference's list of 7 per call, in order, bit-identical to `forward(*call)` under `torch.no_grad()`.
+        Batches group when they share shape, S and scheduled-sampling mask (always at tf_ratio = 1: no step is teacher-forced)."""
+        if self.training:
+            raise RuntimeError("forward_many is the evaluate path: call .eval() first (train() mode trains through forward / backward)")
+        self.native_model()
+
+        def prep(item):
+            a, k = self._call(item)
+            video, face, _audio, mels, vlen, _alen, _mlen, tf = a
+            return self._forward_job(video, face, mels, vlen, tf, **k)
+        return self.pool(group, n_inflight).imap(calls, prep)
 
     def _forward_train(self, video_frames, face_frames, melspecs, video_lengths, tf_ratio, speaker_embedding, gumbel_noise, dropout_masks=None):
         """The differentiable route (train.py:167-184): same outputs as `forward`, attached to autograd through `_HipTrainStep`.

@@ -66,18 +66,23 @@ class NativeBacked(nn.Module):
     def _collect_tensors(self):
         return {self._key_prefix + k: v for k, v in self.state_dict(keep_vars=True).items()}
 
-    def _apply(self, fn, *a, **k):
-        self.__dict__["_tensor_cache"] = None
+    def _drop_tensor_caches(self):
+        """This module's cached key -> tensor dict, its descendants' and - `encoder.cuda()` / `decoder.load_state_dict(...)` on a CHILD
+        replaces tensor objects the parent `Lip2Speech` has cached too - the owning parent's."""
         for mod in self.modules():
             if isinstance(mod, NativeBacked):
                 mod.__dict__["_tensor_cache"] = None
+        parent = self.__dict__.get("_native_parent")
+        if parent is not None:
+            parent.__dict__["_tensor_cache"] = None
+
+    def _apply(self, fn, *a, **k):
+        self._drop_tensor_caches()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
-        for mod in self.modules():
-            if isinstance(mod, NativeBacked):
-                mod.__dict__["_tensor_cache"] = None
+        self._drop_tensor_caches()
         return out
 
     def _signature(self, tensors):

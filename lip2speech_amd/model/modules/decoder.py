@@ -57,24 +57,32 @@ class Decoder(ParamTree, NativeBacked):
             raise NotImplementedError("a stand-alone Decoder is forward-only: train through Lip2Speech.forward (one autograd node over "
                                       "the HIP forward/backward of encoder + decoder) or call .eval() / torch.no_grad()")
 
+    @staticmethod
+    def sampling_mask(S: int, tf_ratio):
+        """The scheduled-sampling decisions of one `forward` call, drawn exactly as decoder.py:355-357 draws them: one `torch.rand(1)` per
+        step on the host; step i is fed the ground-truth previous frame iff `rand > tf_ratio and consumed < int(tf_ratio * S)`.  Returns the
+        per-step byte list, or None when no step is forced (always the case at tf_ratio = 1, evaluate.py:38)."""
+        mask, consumed = [], 0
+        for _ in range(S):
+            take = bool(torch.rand(1) > tf_ratio) and consumed < int(tf_ratio * S)
+            consumed += int(take)
+            mask.append(1 if take else 0)
+        return mask if any(mask) else None
+
+    def teacher_frames(self, mels: torch.Tensor) -> torch.Tensor:
+        """`cat(BOS, mels)[:, :S]` channel-last (decoder.py:349): the frame fed at step i when the mask selects it."""
+        B, _, S = mels.shape
+        bos = self.BOS.detach().to(torch.float32).expand(B, 1, -1)
+        return torch.cat([bos, mels.detach().to(torch.float32).permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
+
     def forward(self, encoder_outputs, face_features, mels, text_lengths, output_lengths, tf_ratio,
                 gumbel_noise: Optional[torch.Tensor] = None):
         self._no_training()
         nm, state, dis, emb, B, T = self._prologue(encoder_outputs, face_features, gumbel_noise)
         S = mels.shape[2]
-        # scheduled sampling, decided per step exactly as decoder.py:355-357
-        mask, consumed, any_teacher = [], 0, False
-        for _ in range(S):
-            take = bool(torch.rand(1) > tf_ratio) and consumed < int(tf_ratio * S)
-            consumed += int(take)
-            any_teacher |= take
-            mask.append(1 if take else 0)
-        teacher = None
-        if any_teacher:
-            bos = self.BOS.detach().to(torch.float32).expand(B, 1, -1)
-            teacher = torch.cat([bos, mels.detach().to(torch.float32).permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous()
-        mel, stop, attn = nm.decode_steps(state, B, T, S, teacher=teacher, teacher_mask=mask if any_teacher else None,
-                                          want_attn=True, attn_logits=True)
+        mask = self.sampling_mask(S, tf_ratio)
+        teacher = self.teacher_frames(mels) if mask is not None else None
+        mel, stop, attn = nm.decode_steps(state, B, T, S, teacher=teacher, teacher_mask=mask, want_attn=True, attn_logits=True)
         mel_post, mel_cf = nm.postnet(mel, want_cf=True)
         return [mel_cf, mel_post, stop.unsqueeze(2), emb, attn, dis]
 

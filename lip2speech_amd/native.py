@@ -8,6 +8,7 @@ library.  There is no fallback: if the library is missing or a call fails, a
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
@@ -25,7 +26,7 @@ ABI_SYMBOLS = (
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
-    "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
+    "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
@@ -80,6 +81,9 @@ def lib() -> ctypes.CDLL:
     L.l2s_workspace_bytes_multi.argtypes = [_i] * 6
     L.l2s_workspace_bytes_multi.restype = _i64
     L.l2s_inference_multi.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _fp, _vp, _fp, _vp, _i64, _vp]
+    L.l2s_forward_eval.argtypes = [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
+    L.l2s_forward_eval_multi.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp,
+                                         _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_model_set_option.argtypes = [_vp, ctypes.c_char_p, _i]
     L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
     L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
@@ -166,6 +170,7 @@ class NativeModel:
         self._h = _vp()
         check(lib().l2s_model_create(ctypes.byref(self._h)))
         self._tls = threading.local()      # the workspace is per host thread: several threads may run batches on ONE model (one weight blob)
+        self.calls = collections.Counter()  # whole-path entry points used, by C-ABI name (tests assert which route a caller took)
 
     def set_option(self, name: str, value: int) -> None:
         """Run-time option of THIS model (include/l2s.h "run-time options"); `native.set_option` changes the defaults of models created later."""
@@ -250,9 +255,55 @@ class NativeModel:
         check(lib().l2s_postnet(self._h, _ptr(mel), B, S, _ptr(out), _ptr(cf), _ptr(ws), ws.numel(), _stream()))
         return out, cf
 
-    def forward_eval(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int):
-        """`Lip2Speech.forward(..., tf_ratio=1)` in eval mode, what evaluate.py runs (evaluate.py:38): S = mels.shape[2] free-running
-        steps; returns (mel (B,80,S), mel_post (B,80,S), stop (B,S), attention LOGITS (B,S,T), content_dis)."""
+    def forward_eval(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int, teacher: Optional[torch.Tensor] = None,
+                     teacher_mask=None):
+        """`Lip2Speech.forward(..., tf_ratio)` in eval mode as ONE native call (`l2s_forward_eval`; what evaluate.py runs, evaluate.py:38):
+        S = mels.shape[2] steps, free-running unless `teacher` (B,S,80) = cat(BOS, mels)[:, :S] and the per-step `teacher_mask` are given.
+        Returns (mel (B,80,S), mel_post (B,80,S), stop (B,S), attention LOGITS (B,S,T), content_dis)."""
+        return self.forward_eval_multi([(video, emb, gumbel, teacher)], S, teacher_mask=teacher_mask)[0]
+
+    def forward_eval_multi(self, batches, S: int, teacher_mask=None):
+        """Grouped `forward_eval` (`l2s_forward_eval_multi`): up to 8 (video, emb, gumbel[, teacher]) tuples of one shape through ONE launch
+        chain; the batches share S and the scheduled-sampling mask.  Returns per batch (mel, mel_post, stop, attn_logits, content_dis) -
+        views of one allocation, each bit-identical to `forward_eval` on that batch alone."""
+        G = len(batches)
+        assert 1 <= G <= 8, "1..8 batches per group"
+        vids = [_f32(b[0]) for b in batches]
+        embs = [_f32(b[1]) for b in batches]
+        gums = [_f32(b[2]) for b in batches]
+        B, _, T, H, W = vids[0].shape
+        m = min_T(T)
+        assert all(v.shape == vids[0].shape for v in vids) and all(e.shape == (B, 256) for e in embs), "the batches of a group share one shape"
+        assert all(g.shape == (B * m, 501) for g in gums), f"gumbel noise must be {(B * m, 501)}"
+        teach = mask_buf = mask_np = None
+        if teacher_mask is not None and any(teacher_mask):
+            mask_np = np.ascontiguousarray(np.asarray(teacher_mask, dtype=np.uint8))
+            assert mask_np.shape == (S,)
+            mask_buf = mask_np.ctypes.data_as(_vp)
+            teach = [_f32(b[3]) for b in batches]
+            assert all(t.shape == (B, S, 80) for t in teach), "teacher frames are (B,S,80) = cat(BOS, mels)[:, :S]"
+        dev = vids[0].device
+        mel_cf = torch.empty(G * B, 80, S, dtype=torch.float32, device=dev)
+        mel_post = torch.empty(G * B, 80, S, dtype=torch.float32, device=dev)
+        stop = torch.empty(G * B, S, dtype=torch.float32, device=dev)
+        attn = torch.empty(G * B, S, T, dtype=torch.float32, device=dev)
+        dis = torch.empty(G * B * m, 501, dtype=torch.float32, device=dev)
+        arr = lambda ts: (_vp * G)(*[t.data_ptr() for t in ts])      # noqa: E731
+        self.calls["l2s_forward_eval" if G == 1 else "l2s_forward_eval_multi"] += 1
+        if G == 1:
+            ws = self.workspace(B, T, H, W, S, dev)
+            check(lib().l2s_forward_eval(self._h, _ptr(vids[0]), _ptr(embs[0]), _ptr(gums[0]), B, T, H, W, S, _ptr(teach[0]) if teach else None, mask_buf,
+                                         _ptr(mel_cf), _ptr(mel_post), _ptr(stop), _ptr(attn), _ptr(dis), _ptr(ws), ws.numel(), _stream()))
+        else:
+            ws = self.workspace(B, T, H, W, S, dev, G=G)
+            check(lib().l2s_forward_eval_multi(self._h, G, arr(vids), arr(embs), arr(gums), arr(teach) if teach else None, mask_buf, B, T, H, W, S,
+                                               _ptr(mel_cf), _ptr(mel_post), _ptr(stop), _ptr(attn), _ptr(dis), _ptr(ws), ws.numel(), _stream()))
+        return [(mel_cf[g * B:(g + 1) * B], mel_post[g * B:(g + 1) * B], stop[g * B:(g + 1) * B], attn[g * B:(g + 1) * B],
+                 dis[g * B * m:(g + 1) * B * m]) for g in range(G)]
+
+    def forward_eval_staged(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int):
+        """The same pass as five staged C-ABI calls (encoder, visual cat, prologue, loop, post-net) - the route `net.encoder` / `net.decoder`
+        take when a caller uses them separately; the tests hold it bit-identical to `forward_eval`."""
         B, _, T, _, _ = video.shape
         feat = self.encoder_fwd(video)
         vis = build_visual(feat, emb)
@@ -267,6 +318,7 @@ class NativeModel:
         mel_post = torch.empty(B, 80, S, dtype=torch.float32, device=video.device)
         lengths = torch.empty(B, dtype=torch.int64, device=video.device)
         attn = torch.empty(B, S, T, dtype=torch.float32, device=video.device) if want_attn else None
+        self.calls["l2s_inference"] += 1
         ws = self.workspace(B, T, H, W, S, video.device)
         check(lib().l2s_inference(self._h, _ptr(video), _ptr(emb), _ptr(gumbel), B, T, H, W, S, _ptr(mel_post),
                                   _ptr(lengths), _ptr(attn), _ptr(ws), ws.numel(), _stream()))
@@ -287,6 +339,7 @@ class NativeModel:
         mel_post = torch.empty(G * B, 80, S, dtype=torch.float32, device=dev)
         lengths = torch.empty(G * B, dtype=torch.int64, device=dev)
         attn = torch.empty(G * B, S, T, dtype=torch.float32, device=dev) if want_attn else None
+        self.calls["l2s_inference_multi"] += 1
         ws = self.workspace(B, T, H, W, S, dev, G=G)
         arr = lambda ts: (_vp * G)(*[t.data_ptr() for t in ts])      # noqa: E731
         check(lib().l2s_inference_multi(self._h, G, arr(vids), arr(embs), arr(gums), B, T, H, W, S, _ptr(mel_post), _ptr(lengths), _ptr(attn),

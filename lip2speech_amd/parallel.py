@@ -11,11 +11,12 @@ single-process run would have used and results are identical to it.
 """
 from __future__ import annotations
 
+import collections
 import os
 import queue
 import threading
 import warnings
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, Iterable, Iterator, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -93,6 +94,21 @@ class InflightPool:
         self.model = model
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_inflight))]
         self.copy_stream = None                       # created on first use of map(prepare=...): ONE stream for every chain's input staging
+        self.stats = collections.Counter()            # imap(): groups / batches issued, by entry point ("inference_groups", "forward_batches", ...)
+
+    @staticmethod
+    def balanced_groups(run: List[int], group: int, chains: int) -> List[List[int]]:
+        """Cut `run` into consecutive groups of at most `group` items whose count is a multiple of `chains` (when the run is long enough)
+        and whose sizes differ by at most one."""
+        k = len(run)
+        n = min(k, chains * -(-k // (chains * group)))
+        base, extra = divmod(k, n)
+        out, pos = [], 0
+        for g in range(n):
+            size = base + (1 if g < extra else 0)
+            out.append(run[pos:pos + size])
+            pos += size
+        return out
 
     @property
     def n_inflight(self) -> int:
@@ -104,8 +120,8 @@ class InflightPool:
         return [self.model] * len(self.streams)
 
     def map(self, batches: Sequence, S: int = 300, want_attn: bool = False, fn: Callable = None, prepare: Callable = None, shape_of: Callable = None) -> List:
-        """Run `inference` on every (video, emb, gumbel) of `batches`.  Consecutive batches form groups of `self.group` (the last one may be
-        smaller; batches of a group must share one shape, so a shape change also closes a group); worker i takes the next unclaimed group
+        """Run `inference` on every (video, emb, gumbel) of `batches`.  Consecutive batches of one shape form groups of at most `self.group`,
+        balanced over the chains in flight (`balanced_groups`; a shape change closes a group); worker i takes the next unclaimed group
         (dynamic schedule).  `fn(model, batch)` replaces the default call and is applied batch by batch (no grouping).
         `prepare(batch) -> (video, emb, gumbel)` stages a batch on the device - e.g. the host-to-device copy of packed uint8 frames and their
         normalisation (`datasets.device.PackedFrames.to_device`).  It runs on the pool's copy stream ONE GROUP AHEAD: a worker stages its next
@@ -117,14 +133,17 @@ class InflightPool:
         if fn is not None or self.group == 1:
             items = [[i] for i in range(len(batches))]
         else:
-            cur: List[int] = []
+            # runs of same-shape batches, each cut into groups of at most `self.group` - a multiple of the chains in flight, sizes differing
+            # by at most one, so every chain gets the same rows per round and no chain idles behind a short tail group (20 batches on two
+            # chains of up to 8: four groups of 5, not 8 + 8 + 4)
+            runs: List[List[int]] = []
             for i, b in enumerate(batches):
-                if cur and (len(cur) == self.group or shape(batches[cur[0]]) != shape(b)):
-                    items.append(cur)
-                    cur = []
-                cur.append(i)
-            if cur:
-                items.append(cur)
+                if runs and shape(batches[runs[-1][0]]) == shape(b):
+                    runs[-1].append(i)
+                else:
+                    runs.append([i])
+            for run in runs:
+                items.extend(self.balanced_groups(run, self.group, self.n_inflight))
         todo: "queue.Queue[List[int]]" = queue.Queue()
         for it in items:
             todo.put(it)
@@ -201,3 +220,146 @@ class InflightPool:
         for st in self.streams:                                     # results are consumed on the caller's stream
             cur_stream.wait_stream(st)
         return out
+
+    # ------------------------------------------------------------------------------------------------ streaming form
+    @staticmethod
+    def _job_key(job: dict):
+        mask = job.get("mask")
+        return (job["entry"], tuple(job["video"].shape), int(job["S"]), bool(job.get("want_attn", False)),
+                bytes(bytearray(mask)) if mask is not None else None)
+
+    def _run_group(self, jobs: List[dict]) -> List[tuple]:
+        j0 = jobs[0]
+        self.stats[j0["entry"] + "_groups"] += 1
+        self.stats[j0["entry"] + "_batches"] += len(jobs)
+        self.stats["max_group"] = max(self.stats["max_group"], len(jobs))
+        if j0["entry"] == "inference":
+            if len(jobs) == 1:
+                return [self.model.inference(j0["video"], j0["emb"], j0["gumbel"], S=j0["S"], want_attn=j0.get("want_attn", False))]
+            return self.model.inference_multi([(j["video"], j["emb"], j["gumbel"]) for j in jobs], S=j0["S"], want_attn=j0.get("want_attn", False))
+        if j0["entry"] == "forward":
+            return self.model.forward_eval_multi([(j["video"], j["emb"], j["gumbel"], j.get("teacher")) for j in jobs], j0["S"], teacher_mask=j0.get("mask"))
+        raise ValueError(f"unknown entry {j0['entry']!r}")
+
+    def imap(self, items: Iterable, prepare: Callable, depth: int = 2) -> Iterator:
+        """Streaming `map` for loader-driven callers (the reference's demo.py:60-90 / evaluate.py:22-51 loops take one batch per iteration):
+        `items` is any iterable (a DataLoader), `prepare(item)` turns an item into a job - a dict with `entry` ("inference" =
+        `Lip2Speech.inference`, "forward" = eval-mode `Lip2Speech.forward`), device tensors `video`, `emb`, `gumbel`, the step count `S`, and
+        optionally `want_attn` (inference), `teacher` + `mask` (forward: scheduled sampling) and `finish(result) -> value`.  Yields one value per
+        item, IN ORDER, each bit-identical to the single-batch call.
+
+        Consecutive jobs with the same entry / shape / S / mask run `self.group` per launch chain (`l2s_inference_multi` /
+        `l2s_forward_eval_multi`), `n_inflight` chains at once.  The iterator and `prepare` are only ever touched under one lock, in item order
+        (host RNG draws inside `prepare` - the scheduled-sampling `torch.rand(1)`s - are consumed exactly as a sequential loop consumes them);
+        `prepare` runs on the pool's copy stream, so its host-to-device copies and the voice tower travel under the chains' compute.  A worker
+        keeps at most `depth` groups enqueued and the pool runs at most `depth + 1` rounds ahead of the consumer."""
+        it = iter(items)
+        caller_stream = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(caller_stream)
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.copy_stream.wait_event(ready)
+        lock = threading.Lock()
+        cond = threading.Condition()
+        results: Dict[int, tuple] = {}
+        st = {"next": 0, "pending": None, "exhausted": False, "errors": [], "live": 0, "consumed": 0, "stop": False}
+        window = self.group * self.n_inflight * (depth + 1)
+
+        def claim():
+            with lock:
+                if st["stop"] or (st["exhausted"] and st["pending"] is None):
+                    return None
+                group = []
+                with torch.cuda.stream(self.copy_stream):
+                    while len(group) < self.group:
+                        if st["pending"] is not None:
+                            idx, job = st["pending"]
+                            st["pending"] = None
+                        else:
+                            try:
+                                item = next(it)
+                            except StopIteration:
+                                st["exhausted"] = True
+                                break
+                            job = prepare(item)
+                            idx = st["next"]
+                            st["next"] += 1
+                        if group and self._job_key(job) != self._job_key(group[0][1]):
+                            st["pending"] = (idx, job)          # another shape / S / mask closes the running group
+                            break
+                        group.append((idx, job))
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                return (group, ev) if group else None
+
+        def worker(w: int):
+            try:
+                torch.cuda.set_device(self.device)
+                stream = self.streams[w]
+                enq = collections.deque()
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    while True:
+                        while len(enq) >= depth:
+                            enq.popleft().synchronize()
+                        with cond:                               # do not run further ahead of the consumer than `window` items
+                            while not st["stop"] and st["next"] - st["consumed"] >= window:
+                                cond.wait(0.05)
+                        got = claim()
+                        if got is None:
+                            break
+                        group, ev = got
+                        stream.wait_event(ev)
+                        for _, job in group:                     # staged on the copy stream, read on this one
+                            for t in job.values():
+                                if isinstance(t, torch.Tensor) and t.is_cuda:
+                                    t.record_stream(stream)
+                        outs = self._run_group([job for _, job in group])
+                        done = torch.cuda.Event()
+                        done.record(stream)
+                        enq.append(done)
+                        with cond:
+                            for (idx, job), r in zip(group, outs):
+                                results[idx] = (job, r, done)
+                            cond.notify_all()
+            except BaseException as e:      # noqa: BLE001 - re-raised on the consumer's thread
+                with cond:
+                    st["errors"].append(e)
+                    cond.notify_all()
+            finally:
+                with cond:
+                    st["live"] -= 1
+                    cond.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(self.n_inflight)]
+        st["live"] = len(threads)
+        for t in threads:
+            t.start()
+        i = 0
+        try:
+            while True:
+                with cond:
+                    while i not in results and not st["errors"] and st["live"] > 0:
+                        cond.wait(0.05)
+                    if st["errors"]:
+                        raise st["errors"][0]
+                    if i not in results:
+                        break                                    # every worker has finished: the iterable is exhausted
+                    job, r, done = results.pop(i)
+                caller_stream.wait_event(done)
+                for t in r:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(caller_stream)
+                finish = job.get("finish")
+                yield finish(r) if finish is not None else r
+                i += 1
+                with cond:
+                    st["consumed"] = i
+                    cond.notify_all()
+        finally:
+            with cond:
+                st["stop"] = True
+                cond.notify_all()
+            for t in threads:
+                t.join()

@@ -26,7 +26,7 @@ def test_header_symbols_exported(built_lib):
     assert declared == set(native.ABI_SYMBOLS), declared ^ set(native.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(built_lib, sym), f"{sym} not exported"
-    assert built_lib.l2s_abi_version() == 1
+    assert built_lib.l2s_abi_version() == 2
 
 
 def test_sizes_and_errors(built_lib):

@@ -97,3 +97,57 @@ def test_device_collate_packs_raw_clips(tmp_path):
     # ragged clips: offsets stay 4-byte aligned
     p2 = PackedFrames([torch.zeros(3, 6, 6, 3, dtype=torch.uint8), torch.ones(5, 6, 6, 3, dtype=torch.uint8)], pin=False)
     assert p2.frames == [3, 5] and p2.offsets == [0, 324] and p2.lengths.tolist() == [3, 5]
+
+
+def test_lrw_face_crops_and_rng_consumption(tmp_path):
+    """datasets/lrw/dataset.py:139-141: every item draws `torch.rand(2)` face-frame indices and resizes those frames to 160x160 for the
+    (third-party) face tower.  An epoch's RNG consumption must equal the reference's whether or not the face file is there."""
+    import bz2
+    import io
+    import pickle
+    import shutil
+    from PIL import Image
+    d = tmp_path / "LRW_Faces" / "ABOUT" / "test"
+    a = tmp_path / "lipread_audio" / "ABOUT" / "test"
+    d.mkdir(parents=True); a.mkdir(parents=True)
+    for i in (1, 2):
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}_mouth.npz"), d / f"ABOUT_0000{i}_mouth.npz")
+        shutil.copy(os.path.join(SAMPLE, f"ABOUT_0000{i}.npz"), a / f"ABOUT_0000{i}.npz")
+    # a face file in the reference's format (bz2 pickle of JPEG byte arrays, variable size) for clip 1 only: frame f is a flat grey level 8*f
+    blobs = []
+    for f in range(29):
+        buf = io.BytesIO()
+        Image.fromarray(np.full((146, 120, 3), 8 * f, dtype=np.uint8)).save(buf, format="JPEG", quality=95)
+        blobs.append(np.frombuffer(buf.getvalue(), dtype=np.uint8).reshape(-1, 1))
+    with bz2.BZ2File(str(d / "ABOUT_00001_face.npz"), "w") as fh:
+        pickle.dump(blobs, fh)
+    ds = LRW(str(tmp_path), (96, 96), "test", False, 1, None, "stray", extra="ignored")   # stray positional / keyword arguments do not break construction
+    torch.manual_seed(5)
+    want = (torch.rand(2) * 29).int().tolist()
+    after_two = torch.rand(1)
+    torch.manual_seed(5)
+    after_four = (torch.rand(2), torch.rand(2), torch.rand(1))[2]
+    torch.manual_seed(5)
+    with_face = ds[0][3]
+    assert torch.equal(torch.rand(1), after_two)                    # exactly two draws, like the reference
+    assert with_face.shape == (2, 3, 160, 160)
+    for k, f in enumerate(want):                                    # the drawn frames, resized, then (x - 127.5) / 128
+        assert abs(float(with_face[k].mean()) - (8 * f - 127.5) / 128.0) < 2 / 128.0
+    torch.manual_seed(5)
+    ds[0]; no_face = ds[1][3]                                       # clip 2 has no face file: zeros, but the draw is still consumed
+    assert torch.equal(no_face, torch.zeros(2, 3, 160, 160)) and torch.equal(torch.rand(1), after_four)
+
+
+def test_per_corpus_collate_pads_mels_with_zeros():
+    """datasets.{grid,avspeech,wild}.av_speech_collate_fn_pad (datasets/grid/dataset.py:28-68): zero-padded mel targets, unlike the top-level
+    collate's ln(1e-5); av_speech_collate_fn_trim trims to the batch minimum (datasets/avspeech/dataset.py:30-50)."""
+    from datasets.avspeech import av_speech_collate_fn_pad, av_speech_collate_fn_trim
+    from datasets.grid import av_speech_collate_fn_pad as grid_pad
+    assert grid_pad is av_speech_collate_fn_pad
+    batch = [_item(25, 16000, 63, 0), _item(29, 19456, 77, 1)]
+    (video, vlen), (audio, alen), (mels, mlen, gate), faces = av_speech_collate_fn_pad(batch)
+    ref = train_collate_fn_pad(batch)
+    assert torch.equal(video, ref[0][0]) and torch.equal(audio, ref[1][0]) and torch.equal(gate, ref[2][2])
+    assert torch.all(mels[0, :, 63:] == 0) and torch.equal(mels[:, :, :63], ref[2][0][:, :, :63])
+    (frames, flen), (speech, slen), faces = av_speech_collate_fn_trim(batch)
+    assert frames.shape == (2, 25, 3, 96, 96) and flen == [25, 25] and speech.shape == (2, 1, 16000) and slen == [16000, 16000]

@@ -551,11 +551,23 @@ def test_caller_loops_voice_route(synth_sd):
     spk = SpeakerEncoder(state_dict={k[len("speaker_encoder."):]: v for k, v in spk_sd.items()}).cuda()
     # demo: batch_size 1, file paths appended by the test collate
     one = test_collate_fn_pad([items[0] + (("face.npz", "audio.npz"),)])
+    two = test_collate_fn_pad([items[1] + (("face.npz", "audio.npz"),)])
     mel, lengths, attn = callers.demo_clip(net, one, speaker_encoder=spk)
     assert mel.shape[0] == 1 and mel.shape[1] == 80 and mel.shape[2] == int(lengths[0]) and attn.shape[2] == 29
-    # evaluate: B=2 batch, tf_ratio=1 -> S = 77 target frames
-    outs = callers.evaluate_mels(net, [train_collate_fn_pad(items)], speaker_encoder=spk)
-    assert outs[0].shape == (2, 80, 77) and torch.isfinite(outs[0]).all()
+    # the loader-driven form runs on the GROUPED path (three clips = one l2s_inference_multi chain) and returns the clips in order
+    nm = net.native_model()
+    nm.calls.clear()
+    clips = list(callers.demo_clips(net, [one, two, one], speaker_encoder=spk, group=8, n_inflight=2))
+    assert nm.calls["l2s_inference_multi"] == 1 and nm.calls["l2s_inference"] == 0
+    assert len(clips) == 3 and all(c[0].shape[2] == int(c[1][0]) for c in clips)
+    assert clips[0][0].shape == clips[2][0].shape and clips[0][2].shape[2] == 29
+    # evaluate: B=2 batches, tf_ratio=1 -> S = 77 target frames; three loader batches = ONE l2s_forward_eval_multi chain
+    batch = train_collate_fn_pad(items)
+    nm.calls.clear()
+    outs = callers.evaluate_mels(net, [batch, batch, batch], speaker_encoder=spk)
+    assert nm.calls["l2s_forward_eval_multi"] == 1 and nm.calls["l2s_forward_eval"] == 0
+    assert len(outs) == 3 and outs[0].shape == (2, 80, 77) and torch.isfinite(outs[0]).all()
+    # the Gumbel noise is drawn per batch (decoder.py:257), so identical batches differ in their content path only: same embedding route
     # same embedding computed by the oracle -> same first mel frames through the oracle path
     with torch.no_grad():
         emb_ref = orc.speaker_encoder_inference(spk_sd, torch.cat([it[1] for it in items], dim=0))
@@ -644,4 +656,85 @@ def test_model_inference_pool_matches_model_inference():
     got = inference_pool(net, n_inflight=2).map(batches, want_attn=True)
     torch.cuda.synchronize()
     for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 8])
+def test_grouped_forward_eval_is_bit_identical_per_batch(synth_sd, G):
+    """`l2s_forward_eval_multi` at BASELINE.json's evaluate shape (B=32, T=29, S=77; evaluate.py:32-38 at tf_ratio=1): G loader batches as
+    rows of ONE launch chain return, batch by batch, exactly what `l2s_forward_eval` returns on the batch alone - pre/post-net mel, stop
+    logits, attention LOGITS and the content distribution, bit for bit - and the one-call form equals the five staged C-ABI calls."""
+    import parity_common as pc
+    B, T, S = 32, 29, 77
+    batches = [(synth.synth_video(B, T, tag=f"fe{g}").cuda(), synth.synth_speaker_embedding(B, tag=f"fe{g}").cuda(),
+                synth.synth_gumbel(B * 4, tag=f"fe{g}").cuda()) for g in range(G)]
+    nm = pc.native_model(synth_sd)
+    want = [tuple(t.clone() for t in nm.forward_eval(*b, S)) for b in batches]
+    staged = nm.forward_eval_staged(*batches[0], S)
+    assert all(torch.equal(a, b) for a, b in zip(staged, want[0])), "one-call forward_eval differs from the staged calls"
+    got = nm.forward_eval_multi(batches, S)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert len(g) == 5 and all(torch.equal(a, b) for a, b in zip(g, w))
+    # against the oracle: the first batch's first two clips (the whole batch would take the CPU a minute)
+    with torch.no_grad():
+        ref = orc.forward_eval(synth_sd, batches[0][0][:2].cpu(), batches[0][1][:2].cpu(), synth.synth_mels(2, S, tag="fe"), batches[0][2][:8].cpu())
+    assert pc.maxdiff(got[0][1][:2], ref[1]) < MEL_TOL and pc.maxdiff(got[0][2][:2], ref[2][:, :, 0]) < 1e-4
+    # teacher-forced steps (scheduled sampling at tf_ratio < 1): the group shares the mask, every batch brings its own frames
+    mask = [1 if i % 3 == 1 else 0 for i in range(S)]
+    bos = synth_sd["decoder.BOS"].expand(B, 1, -1)
+    tb = [b + (torch.cat([bos, synth.synth_mels(B, S, tag=f"fet{g}").permute(0, 2, 1)[:, :S - 1]], dim=1).contiguous().cuda(),) for g, b in enumerate(batches[:3])]
+    want_t = [tuple(t.clone() for t in nm.forward_eval(*b[:3], S, teacher=b[3], teacher_mask=mask)) for b in tb]
+    got_t = nm.forward_eval_multi(tb, S, teacher_mask=mask)
+    for g, w in zip(got_t, want_t):
+        assert all(torch.equal(a, b) for a, b in zip(g, w))
+    assert not torch.equal(want_t[0][0], want[0][0])                       # the forced frames do change the result
+
+
+@pytest.mark.gpu
+def test_forward_many_matches_forward_per_batch(synth_sd):
+    """`Lip2Speech.forward_many` (evaluate.py's loop on the grouped path, `InflightPool.imap`): 11 loader batches of B=32, S=77 run as
+    chains of 8 + 3 (ragged last group) on two streams and come back in order, each bit-identical to `net(..., tf_ratio=1)`; a batch
+    with another S closes the running group; host-resident inputs are staged by the pool."""
+    from model.model import get_network
+    B, T, S = 32, 29, 77
+    net = get_network("test")
+    net.load_state_dict(synth_sd, strict=True)
+    net = net.cuda()
+    n = 11
+    vids = [synth.synth_video(B, T, tag=f"fm{i % 4}") for i in range(n)]                 # host tensors: the pool copies them
+    embs = [synth.synth_speaker_embedding(B, tag=f"fm{i}").cuda() for i in range(n)]
+    gums = [synth.synth_gumbel(B * 4, tag=f"fm{i}").cuda() for i in range(n)]
+    mels = [torch.zeros(B, 80, S if i != 5 else 40) for i in range(n)]                   # batch 5: S = 40 -> groups 5 + 1 + 5
+    lens = torch.full((B,), T)
+    calls = [(vids[i], None, None, mels[i], lens, None, None, 1, {"speaker_embedding": embs[i], "gumbel_noise": gums[i]}) for i in range(n)]
+    with torch.no_grad():
+        want = [[t.clone() if isinstance(t, torch.Tensor) else t for t in net(vids[i].cuda(), None, None, mels[i].cuda(), lens, None, None, 1,
+                                                                             speaker_embedding=embs[i], gumbel_noise=gums[i])] for i in range(n)]
+    nm = net.native_model()
+    nm.calls.clear()
+    got = list(net.forward_many(iter(calls), group=8, n_inflight=2))
+    torch.cuda.synchronize()
+    assert len(got) == n
+    for g, w in zip(got, want):
+        assert len(g) == 7 and g[6] is lens
+        assert all(torch.equal(a, b) for a, b in zip(g[:6], w[:6]))
+    assert nm.calls["l2s_forward_eval_multi"] == 2 and nm.calls["l2s_forward_eval"] == 1
+    stats = net.pool(8, 2).stats
+    assert stats["forward_batches"] == n and stats["max_group"] == 5
+    # no S change: 8 + 3
+    calls2 = [c for i, c in enumerate(calls) if i != 5] + [calls[0]]
+    nm.calls.clear()
+    net.pool(8, 2).stats.clear()
+    got2 = list(net.forward_many(calls2, group=8, n_inflight=2))
+    assert net.pool(8, 2).stats["max_group"] == 8 and nm.calls["l2s_forward_eval_multi"] == 2
+    for g, w in zip(got2, [w for i, w in enumerate(want) if i != 5] + [want[0]]):
+        assert all(torch.equal(a, b) for a, b in zip(g[:6], w[:6]))
+    # inference_many: the same for demo.py's loop (S = 300 cut to a short clip count here)
+    icalls = [(vids[i][:4], None, embs[i][:4], True, gums[i][:16]) for i in range(5)]
+    with torch.no_grad():
+        iwant = [net.inference(vids[i][:4].cuda(), None, embs[i][:4], True, gums[i][:16]) for i in range(5)]
+    igot = list(net.inference_many(icalls, group=4, n_inflight=2))
+    for g, w in zip(igot, iwant):
         assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])

@@ -40,3 +40,16 @@ def test_run_sharded_world2():
             out, n_mine = ret[rank]
             assert out == expect                       # every rank sees all batches, in order, exactly once
             assert n_mine == (4 if rank == 0 else 3)
+
+
+def test_balanced_groups():
+    """`InflightPool.map` cuts K same-shape batches into a multiple-of-chains number of groups whose sizes differ by at most one
+    (bench.py's 20-step driver run: four groups of 5 on two chains, not 8 + 8 + 4)."""
+    from lip2speech_amd.parallel import InflightPool
+    for k, g, c in [(20, 8, 2), (192, 8, 2), (21, 8, 2), (3, 8, 2), (1, 8, 2), (7, 3, 2), (8, 8, 1), (17, 8, 2), (5, 8, 4)]:
+        groups = InflightPool.balanced_groups(list(range(k)), g, c)
+        sizes = [len(x) for x in groups]
+        assert [i for x in groups for i in x] == list(range(k))
+        assert max(sizes) <= g and max(sizes) - min(sizes) <= 1
+        assert len(groups) % c == 0 or k < c
+    assert [len(x) for x in InflightPool.balanced_groups(list(range(20)), 8, 2)] == [5, 5, 5, 5]
