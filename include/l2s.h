@@ -333,8 +333,12 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
  *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every
  *                            activation in HBM stay fp32.  Outside the 1e-3 fp32 gate by construction (mel: 5e-3 mean, 4e-2 max absolute deviation)
+ *   "skinny_flat"       (1)  batch-row launches that carry several GEMM groups (the step's first phase) at >= 64 rows: every group gets its own
+ *                            block shape, all groups together at most one block per CU, one flat grid, longest blocks first; 0 = one shape for all groups
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
- *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (2): chunks per operand batch (2 or 4) */
+ *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (0): operand batching of those blocks - 0 = 4x2 blocks one chunk per
+ *                            batch with four batches in flight (20.2 -> 19.4 us per LSTM launch at 256 rows), smaller shapes two chunks per batch with two in
+ *                            flight; 2 / 4 = that many chunks per batch, two in flight, for every shape; 15 = 4x2 with five one-chunk batches in flight */
 int l2s_set_option(const char* name, int value);
 int l2s_model_set_option(l2s_model* m, const char* name, int value);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with

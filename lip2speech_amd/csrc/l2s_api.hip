@@ -28,7 +28,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
         {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void refresh_bn_kernel(const RBn* __restrict__
     const float s = __fdiv_rn(r.g[i], __fsqrt_rn(r.var[i] + BN_EPS));   // correctly rounded, like the host packer's expression
     const float cb = r.bias ? r.bias[i] : 0.f;
     r.scale[i] = s;
-    r.shift[i] = (cb - r.mu[i]) * s + r.b[i];
+    r.shift[i] = __fadd_rn(__fmul_rn(__fsub_rn(cb, r.mu[i]), s), r.b[i]);      // no fused multiply-add: the host packer's x86 code has none either
 }
 __global__ __launch_bounds__(256) void refresh_sum_kernel(const RSum* __restrict__ recs) {
     const RSum r = recs[blockIdx.y];

@@ -53,7 +53,9 @@ struct Options {
     int skinny_split = 2;       // "skinny_split": operand-load batches of the K <= 1536 instance
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
-    int rc_jb = 2;              // "skinny_rc_jb": chunks per operand batch of the 2x1 / 2x2 blocks (2 or 4)
+    int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
+    int skinny_flat = 1;        // "skinny_flat": launches with several GEMM groups at >= 64 rows run per-group block shapes in one flat grid of at most one
+                                //   block per CU (the step's first phase), instead of one block shape for every group
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
     int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)

@@ -12,6 +12,8 @@
 #include "l2s_common.h"
 #include "skinny_dev.h"
 
+#include <algorithm>
+
 namespace l2s {
 
 // segment layouts with their own instance (chunks of 16 columns per segment): the decode step's and the BiLSTM's operand shapes
@@ -51,25 +53,115 @@ __global__ __launch_bounds__(512, WPS) void skinny_kernel_split(const SkinnyBatc
 }
 
 // register-blocked instances for many batch rows (grouped decode, skinny_dev.h skinny_block_rc): RT x CT tiles of 16x16 per block
-template <int RT, int CT, int MAXC, int JB, int WPS>
+template <int RT, int CT, int MAXC, int JB, int WPS, int DEPTH = 2>
 __global__ __launch_bounds__(512, WPS) void skinny_rc_kernel(const SkinnyBatch batch, int mts) {
     __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
     const int g = blockIdx.z;
-    skinny_block_rc<RT, CT, MAXC, JB>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+    skinny_block_rc<RT, CT, MAXC, JB, DEPTH>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
 }
 template <int RT, int CT>
 static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(512);
-    constexpr int JBW = RT * CT >= 8 ? 2 : 4;            // the 4x2 form holds 6 fragments per chunk: batches of two chunks
-    if constexpr (RT * CT < 8) if (rc_jb == 2) {
+    if constexpr (RT * CT >= 8) {
+        // the 4x2 form holds 6 fragments per chunk and runs alone on its CU.  Default ("skinny_rc_jb" = 0): one-chunk operand batches, four in
+        // flight - the registers of two two-chunk batches, 1.5x the latency tolerance: 20.2 -> 19.4 us per LSTM launch at 256 rows; five in flight
+        // (15): 19.9; 2 / 4: the two-chunk batches, two in flight, of round 2
+        if (rc_jb == 2 || rc_jb == 4) {
+            if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 2, 2>), grid, blk, 0, s, bl, mts);
+            else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 2, 2>), grid, blk, 0, s, bl, mts);
+            else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 2, 2>), grid, blk, 0, s, bl, mts);
+        } else if (rc_jb == 15) {
+            if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 1, 2, 4>), grid, blk, 0, s, bl, mts);
+            else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 1, 2, 5>), grid, blk, 0, s, bl, mts);
+            else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 1, 2, 5>), grid, blk, 0, s, bl, mts);
+        } else {
+            if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 1, 2, 4>), grid, blk, 0, s, bl, mts);
+            else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 1, 2, 4>), grid, blk, 0, s, bl, mts);
+            else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 1, 2, 4>), grid, blk, 0, s, bl, mts);
+        }
+    } else if (rc_jb == 4) {
+        if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 4, 2>), grid, blk, 0, s, bl, mts);
+        else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 4, 2>), grid, blk, 0, s, bl, mts);
+        else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 4, 2>), grid, blk, 0, s, bl, mts);
+    } else {
         if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 2, 2>), grid, blk, 0, s, bl, mts);
         else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 2, 2>), grid, blk, 0, s, bl, mts);
         else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, 2, 2>), grid, blk, 0, s, bl, mts);
-        return;
     }
-    if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, JBW, 2>), grid, blk, 0, s, bl, mts);
-    else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, JBW, 2>), grid, blk, 0, s, bl, mts);
-    else hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 12, JBW, 2>), grid, blk, 0, s, bl, mts);
+}
+
+// ---- balanced flat launch for phases that carry several GEMM groups (the step's first phase: prenet1 o fc_out, Q, content Q, fc_out+stop).
+// A (tiles x rows x groups) grid with ONE block shape leaves the chip unbalanced: at 256 rows the 2x2 grid has 280 live blocks for 256 CUs, so
+// 24 CUs run two blocks - two K = 1024 blocks pull 524 KB through one CU's vector-memory path while others pull 131 KB - and the launch lasts as
+// long as its slowest CU.  Here every group gets its OWN block shape, chosen so that all groups together have at most one block per CU and the
+// largest block moves the fewest bytes (K = 1024 groups as 2x2 = 262 KB, K = 512 groups as 4x2 = 197 KB at 256 rows: 236 blocks, each alone on
+// its CU); the blocks sit in one flat grid, longest first.  Per output element the arithmetic is unchanged (skinny_block_rc): same bits.
+struct SkinnyFlat {
+    int first[SKINNY_MAX_GROUP + 1];     // first[k] .. first[k+1]: the flat block range of the k-th longest group
+    int gid[SKINNY_MAX_GROUP];           // which group (index into SkinnyBatch::p) that is
+    int ncol[SKINNY_MAX_GROUP];          // by rank k: column blocks (ceil(tiles / CT))
+    int wide[SKINNY_MAX_GROUP];          // by rank k: 1 = a K <= 1024 group (shape S8), 0 = a K <= 512 group (shape S4)
+};
+// One instance per pair of shapes (S8 for the K <= 1024 groups, S4 for the K <= 512 groups; RT * 10 + CT): an instance that carries every
+// shape is 60 KB of code and pays ~2.5 us of instruction fetch per launch.
+template <int S8, int S4>
+__global__ __launch_bounds__(512, 2) void skinny_flat_kernel(const SkinnyBatch batch, const SkinnyFlat fl, int mts) {
+    constexpr int R8 = S8 / 10, C8 = S8 % 10, R4 = S4 / 10, C4 = S4 % 10;
+    constexpr int RED = SkRc<R8, C8>::RED_FLOATS > SkRc<R4, C4>::RED_FLOATS ? SkRc<R8, C8>::RED_FLOATS : SkRc<R4, C4>::RED_FLOATS;
+    __shared__ float red[RED];
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < SKINNY_MAX_GROUP; ++i) k += (i < batch.count && b >= fl.first[i]) ? 1 : 0;
+    const int g = fl.gid[k];
+    const int local = b - fl.first[k], nc = fl.ncol[k];
+    const int tp = local % nc, mg = local / nc;
+    const SkinnyP& p = batch.p[g];
+    // (every chunk of a wave requested before its first MFMA - eight / four batches in flight - measured the same: 13.1 vs 12.9 us at 256 rows)
+    if (fl.wide[k]) skinny_block_rc<R8, C8, 8, 2>(p, tp, mg, red, batch.ntiles[g], mts);
+    else skinny_block_rc<R4, C4, 4, 2>(p, tp, mg, red, batch.ntiles[g], mts);
+}
+// choose the pair of shapes: at most `cap` blocks in total (one per CU) and the shortest longest block.  A block's time is modelled from the
+// measurements of tools/time_step_phases.py as bytes / 36.5 GB/s (what one block streams through its CU's vector-memory path) plus its MFMA
+// work at 350 GFLOP/s per CU (not overlapped: a 4x2 block of a K = 512 group has twice the matrix work of a 2x1 block of a K = 1024 group with
+// the same bytes, and lasts longer).  Returns 0 when nothing fits (then the uniform grid runs), else S8 * 100 + S4.
+static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl) {
+    static const int S8[2] = {21, 22}, S4[3] = {21, 22, 42};
+    const int n = bl.count;
+    auto shape_of = [&](int g, int s8, int s4) { return bl.p[g].K > 512 ? s8 : s4; };
+    auto nblocks = [&](int g, int sh) { return ((bl.ntiles[g] + sh % 10 - 1) / (sh % 10)) * ((mts + sh / 10 - 1) / (sh / 10)); };
+    auto nbytes = [&](int g, int sh) { return (int64_t)(16 * (sh / 10) + 16 * (sh % 10)) * bl.p[g].K * 4; };
+    auto cost = [&](int g, int sh) { return (double)nbytes(g, sh) / 36.5e3 + 2.0 * 256 * (sh / 10) * (sh % 10) * bl.p[g].K / 350e3; };      // us
+    int best8 = 0, best4 = 0;
+    double best_max = -1;
+    int64_t best_sum = 0;
+    for (int s8 : S8)
+        for (int s4 : S4) {
+            int blocks = 0; double mx = 0; int64_t sum = 0;
+            for (int g = 0; g < n; ++g) {
+                const int sh = shape_of(g, s8, s4);
+                blocks += nblocks(g, sh); mx = std::max(mx, cost(g, sh)); sum += nbytes(g, sh) * nblocks(g, sh);
+            }
+            if (blocks <= cap && (best_max < 0 || mx < best_max - 1e-9 || (mx < best_max + 1e-9 && sum < best_sum))) { best_max = mx; best_sum = sum; best8 = s8; best4 = s4; }
+        }
+    if (best_max < 0) return 0;
+    // longest blocks first (the dispatcher hands blocks out in grid order)
+    int order[SKINNY_MAX_GROUP] = {0, 1, 2, 3};
+    std::stable_sort(order, order + n, [&](int a, int b) { return nbytes(a, shape_of(a, best8, best4)) > nbytes(b, shape_of(b, best8, best4)); });
+    int pos = 0;
+    for (int k = 0; k < n; ++k) {
+        const int g = order[k], sh = shape_of(g, best8, best4);
+        fl.first[k] = pos; fl.gid[k] = g;
+        fl.ncol[k] = (bl.ntiles[g] + sh % 10 - 1) / (sh % 10);
+        fl.wide[k] = bl.p[g].K > 512 ? 1 : 0;
+        pos += nblocks(g, sh);
+    }
+    for (int k = n; k <= SKINNY_MAX_GROUP; ++k) fl.first[k] = pos;
+    return best8 * 100 + best4;
+}
+template <int S8, int S4>
+static void launch_flat(const SkinnyBatch& bl, const SkinnyFlat& fl, int mts, hipStream_t s) {
+    hipLaunchKernelGGL((skinny_flat_kernel<S8, S4>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
 }
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
@@ -122,6 +214,24 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
             if (blocks(4, 2) >= 224) shape = 42;
             else if (blocks(2, 2) >= 224) shape = 22;
             else if (blocks(2, 1) >= 224) shape = 21;
+        }
+    }
+    // several groups, >= 128 rows (below that the 1x1 / 2x1 uniform grids with two blocks per CU are faster, tools/time_step_phases.py): per-group
+    // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
+    if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024) {      // a forced block shape wins
+        SkinnyFlat fl{};
+        const int plan = plan_flat(bl, mts, 256, fl);
+        if (plan) {
+            switch (plan) {
+                case 2121: launch_flat<21, 21>(bl, fl, mts, s); break;
+                case 2122: launch_flat<21, 22>(bl, fl, mts, s); break;
+                case 2142: launch_flat<21, 42>(bl, fl, mts, s); break;
+                case 2221: launch_flat<22, 21>(bl, fl, mts, s); break;
+                case 2222: launch_flat<22, 22>(bl, fl, mts, s); break;
+                default: launch_flat<22, 42>(bl, fl, mts, s); break;
+            }
+            L2S_CHECK_HIP(hipGetLastError());
+            return 0;
         }
     }
     if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);

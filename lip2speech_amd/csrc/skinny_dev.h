@@ -325,10 +325,13 @@ constexpr int SK_RED_FLOATS = (SK_WAVES + 1) * 16 * 17;
 template <int RT, int CT>
 struct SkRc { static constexpr int NT = RT * CT, RED_FLOATS = (SK_WAVES + 1) * NT * 16 * 17; };
 
-template <int RT, int CT, int MAXC, int JB>
+// DEPTH = operand batches in flight: a wave requests batch b + DEPTH right after the MFMAs of batch b, so the round trip of a batch may take
+// DEPTH - 1 batch-compute times before the matrix pipe waits for it.  JB = 1 with DEPTH = 4 holds the same four chunks in registers as JB = 2
+// with DEPTH = 2 but tolerates 1.5x the latency; a 4x2 block runs alone on its CU (8 waves, two per SIMD: 256 VGPRs each), so five chunks fit.
+template <int RT, int CT, int MAXC, int JB, int DEPTH = 2>
 __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts) {
     static_assert(MAXC % JB == 0, "chunk batches");
-    constexpr int NT = RT * CT, NBATCH = MAXC / JB, NQ = (NT + 1) / 2;
+    constexpr int NT = RT * CT, NBATCH = MAXC / JB, NQ = (NT + 1) / 2, PRE = NBATCH < DEPTH ? NBATCH : DEPTH;
     const float* const W = p.W;
     const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
     const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
@@ -366,7 +369,7 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
         }
     };
 #pragma unroll
-    for (int j = 0; j < (NBATCH > 1 ? 2 * JB : JB); ++j) load_chunk(j);
+    for (int j = 0; j < PRE * JB; ++j) load_chunk(j);
     // ---- everything else the block needs: one batch of scalar loads under the operand loads already in flight
     const int epi = p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
     const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
@@ -422,10 +425,10 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
                     for (int i = 0; i < CT; ++i) acc[r * CT + i][j & 1] = mfma4(a[j][r], w[j][i], acc[r * CT + i][j & 1]);
             }
         }
-        if (bt + 2 < NBATCH) {                    // the registers of this batch are free again: request the batch after the next
+        if (bt + PRE < NBATCH) {                  // the registers of this batch are free again: request the batch DEPTH ahead
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = (bt + 2) * JB; j < (bt + 3) * JB; ++j) load_chunk(j);
+            for (int j = (bt + PRE) * JB; j < (bt + PRE + 1) * JB; ++j) load_chunk(j);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -242,8 +242,9 @@ def test_full_size_avspeech_shaped_matches_reference_golden(synth_sd, nm):
 
 # the bf16 leg (BASELINE.json configs[4] "... bf16"): the 1e-3 fp32 gate does not apply to it (judged on throughput and a
 # stated band).  Bands: bf16 operands carry 2^-9 relative rounding; measured on the LRW batch: encoder features 1.5e-3 rms, mel frames
-# 5e-3 mean / 4e-2 max absolute on frames of mean magnitude 1.07, flat along the 300 steps (tools/check_bf16_leg.py)
-BF16_MEAN, BF16_MAX = 2e-2, 0.15
+# 5e-3 mean / 4e-2 max absolute on frames of mean magnitude 1.07, flat along the 300 steps (tools/check_bf16_leg.py).  The gates are TWICE
+# the measured deviation, so a regression that doubles the bf16 error fails
+BF16_MEAN, BF16_MAX = 1e-2, 8e-2
 
 
 def test_bf16_leg_tracks_the_reference_b2(synth_sd, nm):
@@ -268,7 +269,8 @@ def test_bf16_leg_tracks_the_reference_b2(synth_sd, nm):
 
 def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     """BASELINE.json configs[4], bf16 leg at full size: B=32, clips of 26..50 frames zero-padded, stored speaker embeddings - mel inside the
-    stated band of the reference's fp32 golden, the same output lengths, attention argmax equal on >= 99 % of the confident positions."""
+    stated band of the reference's fp32 golden, the same output lengths, attention argmax equal on >= 99.5 % of the positions whose
+    top-2 margin exceeds 1e-3."""
     g = pc.golden("inference_avspeech_b32_full.npz")
     B, S = 32, 300
     lens = synth.synth_clip_lengths(B, 25, 50, "avs32")
@@ -279,8 +281,11 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     assert d.mean().item() < BF16_MEAN and d.max().item() < BF16_MAX
     assert torch.equal(lengths.cpu(), g["output_lengths"])
     amax, _ = pc.top2(attn.cpu())
-    sure = g["attn_margin"] > 1e-2
-    assert (amax[sure] == g["attn_argmax"][sure].to(torch.int32)).float().mean().item() > 0.99
+    sure = g["attn_margin"] > 1e-3
+    agree = (amax[sure] == g["attn_argmax"][sure].to(torch.int32)).float().mean().item()
+    print(f"bf16 leg, AVSpeech-shaped B=32: mel mean |d| {d.mean().item():.2e} max {d.max().item():.2e}; attention argmax agreement {agree:.4f} on "
+          f"{int(sure.sum())} positions with margin > 1e-3")
+    assert agree >= 0.995
 
 
 @pytest.mark.parametrize("opts,exact", [
@@ -613,7 +618,7 @@ def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,B", [(1, 32), (2, 32), (4, 32), (8, 32), (3, 17)])
+@pytest.mark.parametrize("G,B", [(1, 32), (2, 32), (4, 32), (5, 32), (8, 32), (3, 17), (7, 20)])
 def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
     """`l2s_inference_multi`: G batches as rows of ONE launch chain (register-blocked 2x1 / 2x2 / 4x2 step kernels from 64 rows on) return,
     batch by batch, exactly what `l2s_inference` returns - mel, lengths and attention, bit for bit (B=32 is BASELINE.json's batch;
@@ -633,11 +638,18 @@ def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
     own = pc.fresh_native_model(synth_sd)
     for shape in (11, 21, 22, 42):
         own.set_option("skinny_rc", shape)
-        for jb in (2, 4):
+        for jb in (0, 2, 4, 15):
             own.set_option("skinny_rc_jb", jb)
             alt = own.inference_multi(batches, S=S, want_attn=True)
             for a, w in zip(alt, want):
                 assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[2], w[2]), (shape, jb)
+    # the step's first phase as one flat grid of per-group block shapes (default from 128 rows on) against the uniform grid
+    own.set_option("skinny_rc", 0)
+    own.set_option("skinny_rc_jb", 0)
+    own.set_option("skinny_flat", 0)
+    alt = own.inference_multi(batches, S=S, want_attn=True)
+    for a, w in zip(alt, want):
+        assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[2], w[2]), "skinny_flat=0"
 
 
 @pytest.mark.gpu
