@@ -89,27 +89,43 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
     was_training = net.training
     net.eval()
     t = {"model_wait_s": 0.0, "vocoder_s": 0.0, "estoi_s": 0.0, "clips": 0}
+    def vocode_and_score(pending):
+        """One vocoder pass over the mels of up to `group` loader batches (the 256 + 256 iterations are ~5 000 small launches whatever the
+        batch size: vocoding a group at once amortises them), then ESTOI per clip on the host."""
+        t1 = time.perf_counter()
+        same = all(m.shape[0] == pending[0][1].shape[0] for _, m in pending)
+        if same:        # InverseMelScale's SGD normalises by the call's own B*L: the loader batches stay separate calls inside the one pass
+            pred = vocoder(torch.cat([m for _, m in pending], dim=0), rows_per_call=pending[0][1].shape[0]).cpu().numpy()
+        else:
+            pred = torch.cat([vocoder(m) for _, m in pending], dim=0).cpu().numpy()
+        t2 = time.perf_counter()
+        row = 0
+        for audios, m in pending:
+            gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
+            for i in range(gt.shape[0]):
+                n = min(gt.shape[1], pred.shape[1])
+                scores.append(stoi(gt[i, :n], pred[row + i, :n], fs, extended=True))
+            row += gt.shape[0]
+        t3 = time.perf_counter()
+        t["vocoder_s"] += t2 - t1
+        t["estoi_s"] += t3 - t2
+        t["clips"] += row
+
     try:
         with torch.no_grad():
             t0 = time.perf_counter()
+            pending = []
             for batch, out in _evaluate_outputs(net, batches, speaker_encoder, device, group, n_inflight):
-                audios = batch[1][0]
                 mel = out[1]
-                if timings is not None:
-                    torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                pred = vocoder(mel).cpu().numpy()
-                t2 = time.perf_counter()
-                gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
-                for i in range(gt.shape[0]):
-                    n = min(gt.shape[1], pred.shape[1])
-                    scores.append(stoi(gt[i, :n], pred[i, :n], fs, extended=True))
-                t3 = time.perf_counter()
-                t["model_wait_s"] += t1 - t0
-                t["vocoder_s"] += t2 - t1
-                t["estoi_s"] += t3 - t2
-                t["clips"] += gt.shape[0]
-                t0 = t3
+                if pending and (len(pending) == max(1, group) or pending[0][1].shape[1:] != mel.shape[1:]):
+                    t["model_wait_s"] += time.perf_counter() - t0
+                    vocode_and_score(pending)
+                    pending = []
+                    t0 = time.perf_counter()
+                pending.append((batch[1][0], mel))
+            t["model_wait_s"] += time.perf_counter() - t0
+            if pending:
+                vocode_and_score(pending)
     finally:
         net.train(was_training)
     if timings is not None:
@@ -144,6 +160,10 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
     # GEMMs / Conv1d stacks of encoder, prologue and post-net on the bf16 matrix cores, fp32 accumulation, fp32 master weights, fp32 loop
     net.native_model().set_option("train_bf16", 1 if bf16 else 0)
     reducer = GradAllReducer(flat.grad)          # no-op without a process group; both optimizer routes reduce (ranks must not diverge)
+    # the decoder's buckets (the flat buffer holds the decoder group first) are reduced while the encoder backward still runs: the model's
+    # backward calls this hook as soon as every decoder gradient is final (same overlap as bench.py --mode train)
+    n_dec_buckets = reducer.buckets_covering(net._n_decoder_elems())
+    net.__dict__["_on_decoder_grads"] = lambda: reducer.start(0, n_dec_buckets)
     reconstruction_criterion = Loss()
     if fused_optimizer:
         optim = AdamWAmsgrad(flat, lr=lr, weight_decay=weight_decay)
@@ -165,12 +185,11 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
         loss = sum(losses.values())
         optim.zero_grad()
         loss.backward()
+        reducer.start(n_dec_buckets)                 # the encoder's buckets; the decoder's are already travelling
         if fused_optimizer:
-            reducer.start()
             grad_norm = optim.step(max_norm=grad_clip, grad_mul=reducer.wait())
             net.mark_weights_changed()
         else:
-            reducer.start()
             mul = reducer.wait()
             if mul != 1.0:
                 flat.grad.mul_(mul)                  # average over ranks before the clip (train.py:191 clips the reduced gradient)
@@ -179,4 +198,5 @@ def train_iterations(net, batches: List, n_iters: int, speaker_encoder=None, tf_
         rec = {k: float(v.detach()) for k, v in losses.items()}
         rec.update(loss=float(loss.detach()), grad_norm=float(grad_norm), tf_ratio=tf_ratio, epoch=epoch)
         log.append(rec)
+    net.__dict__["_on_decoder_grads"] = None
     return log

@@ -65,7 +65,8 @@ static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStre
     if constexpr (RT * CT >= 8) {
         // the 4x2 form holds 6 fragments per chunk and runs alone on its CU.  Default ("skinny_rc_jb" = 0): one-chunk operand batches, four in
         // flight - the registers of two two-chunk batches, 1.5x the latency tolerance: 20.2 -> 19.4 us per LSTM launch at 256 rows; five in flight
-        // (15): 19.9; 2 / 4: the two-chunk batches, two in flight, of round 2
+        // (15): 19.9; 2 / 4: the two-chunk batches, two in flight, of round 2.  (Two 2x2 blocks SHARING a CU - one-chunk batches, three in flight,
+        // 118 VGPRs - are slower, 21.2 us: the same CU then pulls 786 KB instead of 590 KB; what bounds these launches is bytes per CU.)
         if (rc_jb == 2 || rc_jb == 4) {
             if (cls == 4) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 4, 2, 2>), grid, blk, 0, s, bl, mts);
             else if (cls == 8) hipLaunchKernelGGL((skinny_rc_kernel<RT, CT, 8, 2, 2>), grid, blk, 0, s, bl, mts);

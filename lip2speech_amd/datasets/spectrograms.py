@@ -78,23 +78,33 @@ class MelSpec2Audio(torch.nn.Module):
         self.register_buffer("fb", mel_filterbank(self.n_fft // 2 + 1, hp.mel_fmin, hp.mel_fmax, hp.n_mel_channels, self.sr))
 
     # -- torchaudio.transforms.InverseMelScale.forward (0.9.0)
-    def inverse_mel(self, mel: torch.Tensor, generator=None) -> torch.Tensor:
-        """mel (B, n_mels, L) power-mel -> power spectrogram (B, n_freqs, L) >= 0."""
-        B, _, L = mel.shape
-        target = mel.transpose(1, 2)                                              # (B, L, n_mels)
-        spec = torch.rand(B, L, self.fb.shape[0], device=mel.device, dtype=mel.dtype, generator=generator)
+    def inverse_mel(self, mel: torch.Tensor, generator=None, rows_per_call: int = None) -> torch.Tensor:
+        """mel (B, n_mels, L) power-mel -> power spectrogram (B, n_freqs, L) >= 0.  The reference's loop reads its loss on the host every
+        iteration (`new_loss.item()`) for the two stopping rules; here the rules are evaluated on the device and freeze the iterate from the
+        stopping iteration on, so the 256 iterations are enqueued without a single host synchronisation and end at the same iterate.
+        `rows_per_call`: the rows are G independent calls of that many rows each (several loader batches vocoded in one pass): the loss mean,
+        the 1/(B*L) gradient scale and the stopping rules are per call, exactly as G separate calls would have them."""
+        N, _, L = mel.shape
+        R = rows_per_call or N
+        assert N % R == 0, "rows_per_call must divide the batch"
+        G = N // R
+        target = mel.transpose(1, 2).reshape(G, R * L, -1)                        # (G, R*L, n_mels)
+        spec = torch.rand(G, R * L, self.fb.shape[0], device=mel.device, dtype=mel.dtype, generator=generator)
         vel = torch.zeros_like(spec)
-        loss = float("inf")
+        loss = torch.full((G, 1, 1), float("inf"), device=mel.device, dtype=mel.dtype)
+        active = torch.ones((G, 1, 1), device=mel.device, dtype=torch.bool)
+        fbt = self.fb.t().contiguous()
         for _ in range(self.max_iters):
             diff = target - spec @ self.fb
-            new_loss = float(diff.pow(2).sum(dim=-1).mean())
-            grad = (-2.0 / (B * L)) * (diff @ self.fb.t())                        # d/dspec of mean over (B, L) of the per-frame squared error
-            vel = 0.9 * vel + grad                                                # torch.optim.SGD(lr=0.1, momentum=0.9)
-            spec = (spec - 0.1 * vel).clamp_(min=0)
-            if new_loss < 1e-5 or abs(loss - new_loss) < 1e-8:
-                break
+            new_loss = diff.pow(2).sum(dim=-1).mean(dim=-1).view(G, 1, 1)
+            grad = (-2.0 / (R * L)) * (diff @ fbt)                                # d/dspec of the call's mean over (B, L) of the per-frame squared error
+            new_vel = 0.9 * vel + grad                                            # torch.optim.SGD(lr=0.1, momentum=0.9)
+            new_spec = (spec - 0.1 * new_vel).clamp_(min=0)
+            vel = torch.where(active, new_vel, vel)                               # the update of the iteration that meets a rule is still applied
+            spec = torch.where(active, new_spec, spec)
+            active = active & ~((new_loss < 1e-5) | ((loss - new_loss).abs() < 1e-8))
             loss = new_loss
-        return spec.transpose(1, 2)
+        return spec.reshape(N, L, -1).transpose(1, 2)
 
     # -- torchaudio.functional.griffinlim (0.9.0): power 2, momentum 0.99, rand_init
     def griffin_lim(self, power_spec: torch.Tensor, generator=None) -> torch.Tensor:
@@ -114,7 +124,7 @@ class MelSpec2Audio(torch.nn.Module):
             prev = rebuilt
         return istft(mag * ang)
 
-    def forward(self, melspec: torch.Tensor, generator=None) -> torch.Tensor:
-        """(B, n_mels, L) log-mel -> (B, hop*(L-1)) waveform."""
+    def forward(self, melspec: torch.Tensor, generator=None, rows_per_call: int = None) -> torch.Tensor:
+        """(B, n_mels, L) log-mel -> (B, hop*(L-1)) waveform.  `rows_per_call`: see `inverse_mel` (Griffin-Lim is per clip anyway)."""
         mel = spectral_de_normalize(melspec.to(torch.float32))
-        return self.griffin_lim(self.inverse_mel(mel, generator), generator)
+        return self.griffin_lim(self.inverse_mel(mel, generator, rows_per_call), generator)

@@ -58,8 +58,10 @@ class _HipTrainStep(torch.autograd.Function):
         video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, fdrop = ctx.tapes
         B, S = mel.shape[0], mel.shape[1]
         flat = model._flat
-        live = model._grads_live()
+        live = model._grads_live() and not getattr(flat, "cleared", False)      # a fused zero_grad() just zeroed the buffer: nothing to accumulate
+        flat.cleared = False
         prev = flat.grad.clone() if live else None                    # gradient accumulation across backward() calls
+        n_dec = model._n_decoder_elems()
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g  # noqa: E731
         wbuf = nm.train_pack_weights(video.device)
         dmel = nm.train_postnet_bwd(mel, z(dmel_post, mel.permute(0, 2, 1)), post_tape, pdrop)
@@ -69,9 +71,16 @@ class _HipTrainStep(torch.autograd.Function):
         dvis = nm.train_prologue_bwd(vis, emb, state, ptape, sg, dcontent_dis=ddis, wbuf=wbuf)
         if fdrop is not None:
             dvis[:, :, :768] *= fdrop
+        # every decoder gradient is final here (the flat buffer holds the decoder group first): a data-parallel caller's hook starts the
+        # all-reduce of those buckets now, under the encoder backward (train.py:184-193's hook point; bench.py --mode train does the same)
+        if prev is not None:
+            flat.grad[:n_dec] += prev[:n_dec]
+        hook = model.__dict__.get("_on_decoder_grads")
+        if hook is not None:
+            hook()
         nm.train_encoder_bwd(video, dvis, etape)
         if prev is not None:
-            flat.grad += prev
+            flat.grad[n_dec:] += prev[n_dec:]
         model._attach_grads()
         return (None,) * 8
 
@@ -124,6 +133,12 @@ class Lip2Speech(NativeBacked):
             nm.train_bind(bound, grads)
             self.__dict__["_refresh_on_device"] = True
         return self._flat
+
+    def _n_decoder_elems(self) -> int:
+        """Elements of the decoder group = the leading range of the flat parameter / gradient buffers."""
+        if self.__dict__.get("_n_dec") is None:
+            self.__dict__["_n_dec"] = sum(p.numel() for p in self.decoder.parameters())
+        return self.__dict__["_n_dec"]
 
     def _count_batch(self):
         """num_batches_tracked += 1 on every BatchNorm (what nn.BatchNorm does in train mode; the running statistics themselves are updated

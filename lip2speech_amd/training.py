@@ -51,6 +51,7 @@ class AdamWAmsgrad:
 
     def zero_grad(self):
         self.flat.grad.zero_()
+        self.flat.cleared = True          # the next backward() overwrites: no clone + add of a zero buffer (154 MB each) for "accumulation"
 
     def step(self, max_norm: Optional[float] = 1.0, grad_mul: float = 1.0) -> torch.Tensor:
         """Returns the (unclipped, averaged) total gradient norm as a device scalar - no host synchronisation."""

@@ -86,3 +86,38 @@ def test_evaluate_net_end_to_end():
             return synth.synth_speaker_embedding(a.shape[0], tag="ev").to(a.device)
     score = callers.evaluate_net(net, [batch], speaker_encoder=Spk(), max_iters=8)
     assert isinstance(score, float) and -1.0 <= score <= 1.0
+
+
+def test_inverse_mel_device_stopping_rule_and_grouped_calls():
+    """`inverse_mel` evaluates torchaudio 0.9's two stopping rules on the device (no host read per iteration) and must end at the iterate
+    the host-checked loop ends at; and G loader batches vocoded in one pass (`rows_per_call`) must equal G separate calls."""
+    from lip2speech_amd.datasets import MelSpec2Audio
+    voc = MelSpec2Audio(max_iters=64)
+    g = torch.Generator().manual_seed(3)
+    mel = torch.rand(4, 80, 9, generator=g) * 2.0
+
+    def host_loop(m, seed):                      # torchaudio.transforms.InverseMelScale.forward, 0.9.0, with its `.item()` checks
+        B, _, L = m.shape
+        target = m.transpose(1, 2)
+        spec = torch.rand(1, B * L, voc.fb.shape[0], generator=torch.Generator().manual_seed(seed)).reshape(B, L, -1)
+        vel, loss, iters = torch.zeros_like(spec), float("inf"), 0
+        for _ in range(voc.max_iters):
+            diff = target - spec @ voc.fb
+            new_loss = float(diff.pow(2).sum(dim=-1).mean())
+            vel = 0.9 * vel + (-2.0 / (B * L)) * (diff @ voc.fb.t())
+            spec = (spec - 0.1 * vel).clamp_(min=0)
+            iters += 1
+            if new_loss < 1e-5 or abs(loss - new_loss) < 1e-8:
+                break
+            loss = new_loss
+        return spec.transpose(1, 2), iters
+    want, iters = host_loop(mel, 11)
+    got = voc.inverse_mel(mel, generator=torch.Generator().manual_seed(11))
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    # two calls of 2 rows in one pass == the two calls on their own (own loss mean, own 1/(B*L), own stop)
+    both = torch.cat([mel[:2], mel[2:]], dim=0)
+    one_pass = voc.inverse_mel(both, generator=torch.Generator().manual_seed(5), rows_per_call=2)
+    gen = torch.Generator().manual_seed(5)
+    sep = torch.cat([voc.inverse_mel(mel[:2], generator=gen), voc.inverse_mel(mel[2:], generator=gen)], dim=0)
+    assert torch.allclose(one_pass, sep, rtol=1e-5, atol=1e-6)
+    assert 1 <= iters <= voc.max_iters
