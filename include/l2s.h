@@ -301,6 +301,9 @@ int l2s_op_skinny_timeline(void* ts_dev);
 /* measurement: the same for the fused stride-1 ShuffleNet units of spatial size h (12, 6 or 3; the last such launch leaves its stamps) - 10 x 64-bit words per block to ts_dev[block*10 ..]: 8 stamps (entry,
  * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID */
 int l2s_op_fused_unit_timeline(void* ts_dev, int h);
+/* measurement: n back-to-back launches of the decode step's attention kernel alone on the state of l2s_decoder_prologue (zero queries): whether a
+ * clip's K / V survive in its XCD's L2 between launches when nothing else runs in between (tools/attn_l2_probe.py; workspace: l2s_workspace_bytes) */
+int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launches, void* ws, int64_t ws_bytes, void* stream);
 /* the same chain issued alternately on two streams (two independent dependency chains): does a second chain hide the launch floor? */
 int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b);
 /* run-time options (A/B switches kept for measurement; defaults are the fastest measured):

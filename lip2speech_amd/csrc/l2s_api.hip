@@ -1767,6 +1767,32 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
 }
 
 /* measurement: ts_dev != NULL routes every skinny launch to the stamped build (8 wall-clock stamps per block into ts_dev); NULL restores */
+// measurement: n back-to-back launches of the step's attention kernel alone (same K / V / content state every launch, zero queries) - does a
+// clip's 119 KB of K / V stay in its XCD's L2 from one launch to the next when no weight stream runs in between?  (tools/attn_l2_probe.py)
+int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launches, void* ws, int64_t ws_bytes, void* stream) {
+    L2S_DEC_READY(m);
+    L2S_REQUIRE(state && ws && B >= 1 && n_launches >= 1, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const Weights& w = m->w;
+    StateLayout sl = state_layout(B, T);
+    const int Bp = pad16(B);
+    Bump bp(ws, ws_bytes);
+    float* q = bp.f((int64_t)B * 512); float* qc = bp.f((int64_t)B * 256);
+    float* av = bp.f((int64_t)Bp * 512); float* cc = bp.f((int64_t)Bp * 256); float* p1 = bp.f((int64_t)Bp * 256); float* p2f = bp.f((int64_t)Bp * 256);
+    L2S_REQUIRE(!bp.overflow, "workspace too small");
+    if (launch_fill(q, (int64_t)B * 512, 0.f, s) || launch_fill(qc, (int64_t)B * 256, 0.f, s) || launch_fill(p1, (int64_t)Bp * 256, 0.f, s)) return 1;
+    for (int i = 0; i < n_launches; ++i) {
+        AttnP at{};
+        at.q = q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = av;
+        at.attn_out = nullptr; at.ld_attn_b = 0; at.attn_logits = 0;
+        at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
+        at.B = B; at.T = T; at.m = sl.m;
+        SkinnyP pr = sk_base(w.pre2, B);
+        pr.seg[0] = {p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE; pr.epi = SK_FRAG; pr.out = p2f; pr.ldo = 256;
+        if (launch_step_attn(at, pr, w.pre2.tiles, s)) return 1;
+    }
+    return 0;
+}
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
 

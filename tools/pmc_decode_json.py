@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn the rocprofv3 passes of tools/prof_decode.py (kernel trace + three --pmc passes: TCC_HIT_sum TCC_MISS_sum / FETCH_SIZE / WRITE_SIZE)
-into profiles/r02_pmc_decode.json: per decode-step kernel role, HBM-side bytes per launch (FETCH_SIZE x 2 - the gfx950 correction of
+into profiles/rNN_pmc_decode.json: per decode-step kernel role, HBM-side bytes per launch (FETCH_SIZE x 2 - the gfx950 correction of
 MI355X_MICROARCH.md - + WRITE_SIZE, both KiB), L2 hit rate and the kernel-trace average duration.
 usage: pmc_decode_json.py <trace.db> <hitmiss.db> <fetch.db> <write.db> <rows> > out.json"""
 import json, sqlite3, sys
@@ -13,7 +13,7 @@ def table(db):
     return list(c.execute(f"select kernel_name, grid_size_x, grid_size_y, grid_size_z, counter_name, avg(value), count(*) from {t} group by 1,2,3,4,5"))
 def role_of(name, gz, n_launch):
     if "step_attn_kernel" in name: return "step_attention_prenet2"
-    if "skinny" in name and gz == 4: return "step_prenet1_q_cq_fc"
+    if "skinny_flat" in name or ("skinny" in name and gz == 4): return "step_prenet1_q_cq_fc"
     if "skinny" in name and gz == 1 and n_launch >= 250: return "step_lstm_cell"
     return None
 out = {}
