@@ -59,9 +59,75 @@ __global__ __launch_bounds__(512, WPS) void skinny_rc_kernel(const SkinnyBatch b
     const int g = blockIdx.z;
     skinny_block_rc<RT, CT, MAXC, JB, DEPTH>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
 }
-template <int RT, int CT>
-static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb) {
+// the straight-line form (skinny_dev.h skinny_block_rcs) for launches whose groups all have one of the decode step's K layouts
+template <int LAYID> struct SkLay;
+template <> struct SkLay<1> { using T = SegLay<32, 0, 0, 0>; };
+template <> struct SkLay<2> { using T = SegLay<32, 32, 0, 0>; };
+template <> struct SkLay<3> { using T = SegLay<16, 16, 32, 32>; };
+template <int RT, int CT, int LAYID, int DEPTH, int WPS, bool IS_LSTM>
+__global__ __launch_bounds__(512, WPS) void skinny_rcs_kernel(const SkinnyBatch batch, int mts) {
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, IS_LSTM>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
+// four real waves per block (one per SIMD, each playing two K slices): skinny_block_rcs<..., NW = 4>
+template <int RT, int CT, int LAYID, int DEPTH, bool IS_LSTM>
+__global__ __launch_bounds__(256, 1) void skinny_rc4_kernel(const SkinnyBatch batch, int mts) {
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, IS_LSTM, false, 4>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
+template <int RT, int CT, int DEPTH>
+static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s) {
+    const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(256);
+    if (kind == 2) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 1, DEPTH, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 2, DEPTH, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 3) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 3, DEPTH, true>), grid, blk, 0, s, bl, mts);
+        else return false;
+    } else if (kind == 1) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 1, DEPTH, false>), grid, blk, 0, s, bl, mts);
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 2, DEPTH, false>), grid, blk, 0, s, bl, mts);
+        else return false;
+    } else return false;
+    return true;
+}
+// measurement build of the 4x2 LSTM form: thread 0 of every block stamps its phases (8 x 64-bit per block, tools/skinny_timeline.py ROWS=256)
+template <int LAYID>
+__global__ __launch_bounds__(256, 1) void skinny_rcs_timed_kernel(const SkinnyBatch batch, int mts, unsigned long long* ts) {
+    __shared__ float red[SkRc<4, 2>::RED_FLOATS];
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, 4>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
+}
+// lay: the K layout every group shares; kind: 2 = every group is an LSTM cell, 1 = none is
+template <int RT, int CT, int DEPTH>
+static bool launch_rcs(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(512);
+    if (kind == 2) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 1, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 2, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 3) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 3, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
+        else return false;
+    } else if (kind == 1) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 1, DEPTH, 2, false>), grid, blk, 0, s, bl, mts);
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 2, DEPTH, 2, false>), grid, blk, 0, s, bl, mts);
+        else return false;
+    } else return false;
+    return true;
+}
+
+template <int RT, int CT>
+static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb, int lay, int kind) {
+    const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(512);
+    // every group in one of the decode step's K layouts and no forced batching: the straight-line form (exact waits, DEPTH - 1 chunks in flight
+    // under every chunk's MFMAs)
+    // Default ("skinny_rc_jb" = 0) where every group has one of the decode step's K layouts: FOUR waves per block, one per SIMD, each playing two of
+    // the eight K slices, straight-line code with exact waits and four chunks in flight (skinny_block_rcs<.., NW = 4>).  With eight waves the two
+    // waves of a SIMD do not share the matrix pipe evenly: the older one runs ahead, the younger follows in its shadow and finishes ~4 us later,
+    // alone (stamped build, tools/skinny_timeline.py ROWS=256: block lifetime 14.3 us, kernel span 19.4 us at K = 1024); with one wave per SIMD the
+    // pipe is 90 % busy through the K loop and every block ends within 0.2 us of the others (span 12.4 us).  Same bits.
+    if (rc_jb == 0 && lay && launch_rc4<RT, CT, 4>(bl, lay, kind, maxt, mts, s)) return;
+    if (rc_jb == 28 && lay && launch_rcs<RT, CT, (RT * CT >= 8 ? 4 : 6)>(bl, lay, kind, maxt, mts, s)) return;      // the same straight-line form on eight waves
     if constexpr (RT * CT >= 8) {
         // the 4x2 form holds 6 fragments per chunk and runs alone on its CU.  Default ("skinny_rc_jb" = 0): one-chunk operand batches, four in
         // flight - the registers of two two-chunk batches, 1.5x the latency tolerance: 20.2 -> 19.4 us per LSTM launch at 256 rows; five in flight
@@ -105,8 +171,8 @@ struct SkinnyFlat {
 };
 // One instance per pair of shapes (S8 for the K <= 1024 groups, S4 for the K <= 512 groups; RT * 10 + CT): an instance that carries every
 // shape is 60 KB of code and pays ~2.5 us of instruction fetch per launch.
-template <int S8, int S4>
-__global__ __launch_bounds__(512, 2) void skinny_flat_kernel(const SkinnyBatch batch, const SkinnyFlat fl, int mts) {
+template <int S8, int S4, int STATIC = 0>
+__global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void skinny_flat_kernel(const SkinnyBatch batch, const SkinnyFlat fl, int mts) {
     constexpr int R8 = S8 / 10, C8 = S8 % 10, R4 = S4 / 10, C4 = S4 % 10;
     constexpr int RED = SkRc<R8, C8>::RED_FLOATS > SkRc<R4, C4>::RED_FLOATS ? SkRc<R8, C8>::RED_FLOATS : SkRc<R4, C4>::RED_FLOATS;
     __shared__ float red[RED];
@@ -118,9 +184,16 @@ __global__ __launch_bounds__(512, 2) void skinny_flat_kernel(const SkinnyBatch b
     const int local = b - fl.first[k], nc = fl.ncol[k];
     const int tp = local % nc, mg = local / nc;
     const SkinnyP& p = batch.p[g];
-    // (every chunk of a wave requested before its first MFMA - eight / four batches in flight - measured the same: 13.1 vs 12.9 us at 256 rows)
-    if (fl.wide[k]) skinny_block_rc<R8, C8, 8, 2>(p, tp, mg, red, batch.ntiles[g], mts);
-    else skinny_block_rc<R4, C4, 4, 2>(p, tp, mg, red, batch.ntiles[g], mts);
+    if constexpr (STATIC == 2) {  // every wide group is [h | h] (K = 1024), every narrow one [h] (K = 512): straight-line four-wave blocks (256 threads)
+        if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
+        else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
+    } else if constexpr (STATIC == 1) {      // the same on eight waves
+        if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 8, false>(p, tp, mg, red, batch.ntiles[g], mts);
+        else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false>(p, tp, mg, red, batch.ntiles[g], mts);
+    } else {
+        if (fl.wide[k]) skinny_block_rc<R8, C8, 8, 2>(p, tp, mg, red, batch.ntiles[g], mts);
+        else skinny_block_rc<R4, C4, 4, 2>(p, tp, mg, red, batch.ntiles[g], mts);
+    }
 }
 // choose the pair of shapes: at most `cap` blocks in total (one per CU) and the shortest longest block.  A block's time is modelled from the
 // measurements of tools/time_step_phases.py as bytes / 36.5 GB/s (what one block streams through its CU's vector-memory path) plus its MFMA
@@ -161,8 +234,10 @@ static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl) {
     return best8 * 100 + best4;
 }
 template <int S8, int S4>
-static void launch_flat(const SkinnyBatch& bl, const SkinnyFlat& fl, int mts, hipStream_t s) {
-    hipLaunchKernelGGL((skinny_flat_kernel<S8, S4>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
+static void launch_flat(const SkinnyBatch& bl, const SkinnyFlat& fl, int mts, hipStream_t s, int stat) {
+    if (stat == 2) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 2>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(256), 0, s, bl, fl, mts);
+    else if (stat == 1) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
+    else hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 0>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
 }
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
@@ -222,23 +297,40 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024) {      // a forced block shape wins
         SkinnyFlat fl{};
         const int plan = plan_flat(bl, mts, 256, fl);
+        // 0 = general blocks, 1 = straight-line eight-wave blocks (default: 12.4 us at 256 rows against 12.9 general), 2 = straight-line four-wave
+        // blocks ("skinny_rc_jb" = 44: 14.9 us - these blocks move 262 KB for 3.4 us of matrix work; eight waves keep more loads in flight)
+        int stat = o.rc_jb == 0 || o.rc_jb == 28 ? 1 : o.rc_jb == 44 ? 2 : 0;
+        for (int i = 0; i < bl.count; ++i) if (!(skinny_layout_of(bl.p[i]) == (bl.p[i].K > 512 ? 2 : 1) && bl.p[i].epi != SK_LSTM)) stat = 0;
         if (plan) {
             switch (plan) {
-                case 2121: launch_flat<21, 21>(bl, fl, mts, s); break;
-                case 2122: launch_flat<21, 22>(bl, fl, mts, s); break;
-                case 2142: launch_flat<21, 42>(bl, fl, mts, s); break;
-                case 2221: launch_flat<22, 21>(bl, fl, mts, s); break;
-                case 2222: launch_flat<22, 22>(bl, fl, mts, s); break;
-                default: launch_flat<22, 42>(bl, fl, mts, s); break;
+                case 2121: launch_flat<21, 21>(bl, fl, mts, s, stat); break;
+                case 2122: launch_flat<21, 22>(bl, fl, mts, s, stat); break;
+                case 2142: launch_flat<21, 42>(bl, fl, mts, s, stat); break;
+                case 2221: launch_flat<22, 21>(bl, fl, mts, s, stat); break;
+                case 2222: launch_flat<22, 22>(bl, fl, mts, s, stat); break;
+                default: launch_flat<22, 42>(bl, fl, mts, s, stat); break;
             }
             L2S_CHECK_HIP(hipGetLastError());
             return 0;
         }
     }
-    if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
-    else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb);
-    else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb);
-    else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb);
+    // one of the decode step's K layouts shared by every group of the launch (1: [32], 2: [32|32], 3: [16|16|32|32] chunks), else 0
+    int rc_lay = skinny_layout_of(bl.p[0]);
+    for (int i = 1; i < bl.count; ++i) if (skinny_layout_of(bl.p[i]) != rc_lay) rc_lay = 0;
+    if (rc_lay == 4) rc_lay = 0;
+    int n_lstm = 0;
+    for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
+    const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
+    if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
+        const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
+        if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
+        else hipLaunchKernelGGL(skinny_rcs_timed_kernel<2>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
+    }
+    else if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
+    else if (shape == 11 && o.rc_jb == 0 && rc_lay && rc_kind && launch_rc4<1, 1, 4>(bl, rc_lay, rc_kind, maxt, mts, s)) {}      // 16 x 16 tiles, four waves
+    else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
+    else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
+    else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
     else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8 && o.skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);

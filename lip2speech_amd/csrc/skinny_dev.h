@@ -4,6 +4,9 @@
 #pragma once
 #include "l2s_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace l2s {
 
 struct SkinnyTrain {               // training-side stores of one skinny group (any pointer may be null)
@@ -32,6 +35,15 @@ struct AttnTrain {
     float* av_plain;                   // [b*512 + c]
     float* cc_plain;                   // [b*256 + c]
 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 __device__ __forceinline__ float act_apply(float v, int act, const float* actw, int n) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -492,6 +504,214 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
         if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
         if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
     }
+}
+
+// The same block with NOTHING conditional between its operand loads and its MFMAs: the K-segment layout is a template constant (LAY, every
+// boundary a multiple of the 8 waves, K a multiple of 128 so that every wave owns exactly LAY::NC / 8 chunks) and the epilogue's own operands
+// are requested BEFORE the first operand batch.  Why it matters (ISA of the general form, round 3): its per-chunk `if (c < NC)` guards and
+// segment-select branches sit between the loads and the MFMAs that consume them, the compiler cannot count the younger loads across those
+// joins and waits `s_waitcnt vmcnt(0)` before EVERY chunk's MFMAs - the just-issued prefetch included - so the block ran load -> wait ->
+// compute with nothing in flight: 36.5 GB/s per CU where a plain streaming kernel with the same operand reuse gets > 70 (tools/membw).  Here the
+// waits are exact (`vmcnt(6 * (DEPTH - 1))`), DEPTH - 1 chunks stay in flight under every chunk's MFMAs.  Arithmetic per output element is
+// unchanged: bit-identical.
+// IS_LSTM: the launch's groups are all SK_LSTM (true) or none is (false) - a compile-time fact of the caller, so that the epilogue's operand
+// requests are straight-line too (with the kind decided at run time the compiler guards each of them with its own `s_waitcnt vmcnt(0)`).
+// NW = real waves of the block: 8, or 4 (one per SIMD: no partner on the matrix pipe, 512 VGPRs per lane - room for many chunks in flight); with 4
+// every wave plays TWO of the eight K slices (w and w + 4) with their own accumulators, so the partial sums that reach the reduction - and
+// every output bit - are the eight-wave block's.
+template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES>
+__device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr) {
+    static_assert(NW == 8 || NW == 4, "eight waves, or four that each play two");
+    constexpr int VW = SK_WAVES / NW, NH = NW / 4;       // K slices per real wave; 256-thread epilogue teams
+    L2S_STAMP(0);
+    static_assert(LAY::STATIC && LAY::NC % SK_WAVES == 0, "static layout, every wave the same number of chunks");
+    constexpr int NT = RT * CT, MAXC = LAY::NC / SK_WAVES, TC = MAXC * VW, NQ = (NT + NH - 1) / NH, PRE = TC < DEPTH ? TC : DEPTH, NC = LAY::NC;
+    constexpr int E0 = LAY::n0, E1 = E0 + LAY::n1, E2 = E1 + LAY::n2;
+    const float* const W = p.W;
+    const float* const sa0 = p.seg[0].a; const float* const sa1 = p.seg[1].a; const float* const sa2 = p.seg[2].a; const float* const sa3 = p.seg[3].a;
+    L2S_PIN_S("s"(W), "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "s"(ntiles), "s"(mts));
+    if (tp * CT >= ntiles) return;                   // block-uniform: grid x is sized for the widest group of the launch
+    L2S_STAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- operand streams: one base pointer per (segment, row tile) and per column tile; everything per chunk is a compile-time offset
+    // (tiles past the end of the group / batch are computed on the last valid tile's operands and dropped in the epilogue)
+    const float4* wb[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wb[i] = reinterpret_cast<const float4*>(W) + ((int64_t)min(tp * CT + i, ntiles - 1) * NC + wave) * 64 + lane;
+    const float4* ab[4][RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int64_t rt = min(mg * RT + r, mts - 1);
+        ab[0][r] = reinterpret_cast<const float4*>(sa0) + (rt * LAY::n0 + wave) * 64 + lane;
+        ab[1][r] = reinterpret_cast<const float4*>(sa1) + (rt * LAY::n1 + wave) * 64 + lane;
+        ab[2][r] = reinterpret_cast<const float4*>(sa2) + (rt * LAY::n2 + wave) * 64 + lane;
+        ab[3][r] = reinterpret_cast<const float4*>(sa3) + (rt * LAY::n3 + wave) * 64 + lane;
+    }
+    float4 a[TC][RT], w[TC][CT];
+    auto load_chunk = [&](auto jc) {          // slot t: K slice h = t % VW (wave + NW * h), its j-th chunk (j = t / VW)
+        constexpr int t_ = decltype(jc)::value, j = t_;
+        constexpr int cj = SK_WAVES * (t_ / VW) + NW * (t_ % VW);
+        constexpr int sg = cj >= E2 ? 3 : cj >= E1 ? 2 : cj >= E0 ? 1 : 0;
+        constexpr int off = cj - (sg == 3 ? E2 : sg == 2 ? E1 : sg == 1 ? E0 : 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[j][r] = ab[sg][r][off * 64];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) w[j][i] = wb[i][cj * 64];
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, PRE>([&](auto jc) { load_chunk(jc); });
+    __builtin_amdgcn_sched_barrier(0);               // every one of the first DEPTH chunks is requested before anything else
+
+    // ---- the epilogue's operands, under the operand loads already in flight.  Every request is ONE load from an always-valid address (a null
+    // table is replaced by W, indices are clamped into the table) whose value is kept or dropped by a select afterwards: no load sits inside a
+    // branch, so the waits of the K loop below count the younger loads exactly
+    const int epi = IS_LSTM ? (int)SK_LSTM : p.epi, nB = p.B, N = p.N, H = p.H, act = p.act;
+    const float* const bias = p.bias; const float* const pre = p.pre; const int64_t ld_pre = p.ld_pre;
+    const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
+    L2S_PIN_S("s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act), "s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow));
+    const int half = tid >> 8, l256 = tid & 255, e_row = l256 >> 4, e_col = l256 & 15;
+    float pf_bias[NQ], pf_add[NQ], pf_row[NQ];
+    const float* const bias_p = bias ? bias : W;
+    const float* const add_p = IS_LSTM ? (pre ? pre : W) : (add ? add : W);
+    const float* const row_p = addrow ? addrow : W;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q = min(half + NH * n, NT - 1);
+        const int t = min(tp * CT + q % CT, ntiles - 1), rt = min(mg * RT + q / CT, mts - 1);
+        const int e_b = min(rt * 16 + e_row, nB - 1), e_np = t * 16 + e_col;
+        const float vb = bias_p[bias ? e_np : 0];
+        pf_bias[n] = bias ? vb : 0.f;
+        if constexpr (IS_LSTM) {
+            const float va = add_p[pre ? (int64_t)e_b * ld_pre + (e_col & 3) * H + t * 4 + (e_col >> 2) : 0];
+            pf_add[n] = pre ? va : 0.f;
+            pf_row[n] = 0.f;
+        } else {
+            const int e_nc = min(e_np, N - 1);       // SK_MEL groups read (and drop) element N - 1: they have neither table
+            const float va = add_p[add ? (int64_t)e_b * ld_add + e_nc : 0];
+            const float vr = row_p[addrow ? e_nc : 0];
+            pf_add[n] = add ? va : 0.f;
+            pf_row[n] = addrow ? vr : 0.f;
+        }
+    }
+    constexpr int NCR = (NT + NW - 1) / NW;
+    const int t64 = tid & 63;
+    float pf_c[NCR];
+    bool cell_on[NCR];
+#pragma unroll
+    for (int cr = 0; cr < NCR; ++cr) {
+        const int q2 = (tid >> 6) + NW * cr;
+        const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
+        const int b2 = rt2 * 16 + (t64 >> 2);
+        cell_on[cr] = IS_LSTM && q2 < NT && t2 < ntiles && rt2 < mts && b2 < nB;
+        if constexpr (IS_LSTM) {
+            const int q2c = min(q2, NT - 1);
+            const int t2c = min(tp * CT + q2c % CT, ntiles - 1), rt2c = min(mg * RT + q2c / CT, mts - 1);
+            pf_c[cr] = c_in[frag16_index(min(rt2c * 16 + (t64 >> 2), nB - 1), t2c * 4 + (t64 & 3), H)];
+        } else {
+            pf_c[cr] = 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    L2S_STAMP(2);
+
+    f32x4 acc[NT][2][VW];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int h = 0; h < VW; ++h) { acc[q][0][h] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static_for<0, TC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, par = (j / VW) & 1, hh = j % VW;
+        // element-major issue order: the four dependent MFMAs of a tile (x, y, z, w into one accumulator) are NT instructions apart, so none waits
+        // for its predecessor's result; per accumulator the order of the additions is mfma4's
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) {
+                        const float av = e == 0 ? a[j][r].x : e == 1 ? a[j][r].y : e == 2 ? a[j][r].z : a[j][r].w;
+                        const float wv = e == 0 ? w[j][i].x : e == 1 ? w[j][i].y : e == 2 ? w[j][i].z : w[j][i].w;
+                        acc[r * CT + i][par][hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc[r * CT + i][par][hh], 0, 0, 0);
+                    }
+        }
+        if constexpr (j + PRE < TC) {                // the registers of this chunk are free again: request the chunk DEPTH ahead
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(std::integral_constant<int, j + PRE>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TIMED && j == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0][0][0])); L2S_STAMP(3); }      // first operands landed, first chunk computed
+    });
+    if constexpr (TIMED) { asm volatile("s_nop 0" :: "v"(acc[0][0][0][0]), "v"(acc[NT - 1][1][VW - 1][0])); }
+    L2S_STAMP(4);
+    // D layout: col = lane&15, row = 4*(lane>>4) + r
+    {
+        const int col = lane & 15, rb = 4 * (lane >> 4);
+#pragma unroll
+        for (int h = 0; h < VW; ++h)
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave + NW * h) * NT + q) * 16 + rb + r) * 17 + col] = acc[q][0][h][r] + acc[q][1][h][r];
+    }
+    __syncthreads();
+    L2S_STAMP(5);
+    float* gt = red + SK_WAVES * NT * 16 * 17;          // reduced tiles [NT][16][17]
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q = half + NH * n;
+        if (q >= NT) continue;
+        const int t = tp * CT + q % CT, rt = mg * RT + q / CT;
+        if (t >= ntiles || rt >= mts) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q) * 16 + e_row) * 17 + e_col];
+        v += pf_bias[n];
+        const int b = rt * 16 + e_row, np = t * 16 + e_col;
+        if (epi == SK_LSTM) {
+            v += pf_add[n];
+            gt[(q * 16 + e_row) * 17 + e_col] = v;
+            continue;
+        }
+        if (b >= nB) continue;
+        if (epi == SK_MEL) {
+            if (np < 80) {
+                p.mel[(int64_t)b * p.ld_mel_b + np] = v;
+                if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
+            } else if (np == 80) {
+                p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
+            }
+            continue;
+        }
+        if (np >= N) continue;
+        v = act_apply(v, act, p.actw, np);
+        v += pf_add[n] + pf_row[n];                  // the general form adds (add + addrow) as one pre-summed value: same order
+        if (epi == SK_FRAG) p.out[frag16_index(b, np, p.ldo)] = v;
+        else p.out[(int64_t)b * p.ldo + np] = v;
+    }
+    if (epi != SK_LSTM) return;
+    __syncthreads();
+    L2S_STAMP(6);
+#pragma unroll
+    for (int cr = 0; cr < NCR; ++cr) {
+        if (!cell_on[cr]) continue;
+        const int q2 = (tid >> 6) + NW * cr;
+        const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
+        const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
+        const int r2 = t64 >> 2, u2 = t64 & 3;
+        const float* g4 = gt + (q2 * 16 + r2) * 17 + 4 * u2;
+        const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
+        const float cn = sigmoidf_(gf) * pf_c[cr] + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        p.c_out[frag16_index(b2, unit2, H)] = cn;
+        p.h_out[frag16_index(b2, p.h_out_off + unit2, p.h_out_K)] = hn;
+        if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
+        if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
+    }
+    if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    L2S_STAMP(7);
 }
 
 __device__ __forceinline__ double wave_sum_d(double x) {

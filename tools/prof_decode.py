@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
 nm = native.NativeModel()
+for kv in os.environ.get("L2S_OPT", "").split(","):      # e.g. L2S_OPT=skinny_rc_jb=2,skinny_flat=0
+    if kv:
+        nm.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
 B, T, S = int(os.environ.get("ROWS", "256")), 29, 300
 G = B // 32

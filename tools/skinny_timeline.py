@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
 nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
-B = 32
+B = int(os.environ.get("ROWS", "32"))      # ROWS=256: the straight-line 4x2 form (skinny_block_rcs), one block per CU
 L = native.lib()
 ts = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
 print("production chain:", nm.lstm_cell_chain_us(B, 300), "us/launch")
@@ -23,3 +23,15 @@ for i, n in enumerate(names):
 d = np.diff(t, axis=1)
 print("per-block phase durations (median us):", " | ".join(f"{names[i+1]}: {np.median(d[:, i]):.2f}" for i in range(7)))
 print(f"kernel span: {t[:, 7].max():.2f} us; block lifetime median {np.median(t[:, 7] - t[:, 0]):.2f} us")
+if B >= 256:
+    # 4x2 blocks: block index = y * 64 + x (x = column pair 0..63 -> XCD x % 8, y = row group 0..3); which blocks are late?
+    x, y = np.arange(256) % 64, np.arange(256) // 64
+    done = t[:, 4]
+    print("MFMAs-done by XCD (median / max us):", " | ".join(f"{c}: {np.median(done[x % 8 == c]):.1f}/{done[x % 8 == c].max():.1f}" for c in range(8)))
+    print("MFMAs-done by row group (median / max):", " | ".join(f"{r}: {np.median(done[y == r]):.1f}/{done[y == r].max():.1f}" for r in range(4)))
+    order = np.argsort(-t[:, 7])[:12]
+    print("latest blocks (x, y, xcd): entry / loads issued / first landed / MFMAs done / end")
+    for b in order:
+        print(f"   ({x[b]:2d},{y[b]},{x[b] % 8})  {t[b,0]:5.2f} {t[b,2]:5.2f} {t[b,3]:5.2f} {t[b,4]:6.2f} {t[b,7]:6.2f}")
+    print("wave-0 compute time (first landed -> MFMAs done) percentiles 10/50/90:", np.percentile(t[:, 4] - t[:, 3], [10, 50, 90]).round(2),
+          "; barrier wait (MFMAs done -> after reduction barrier) 10/50/90:", np.percentile(t[:, 5] - t[:, 4], [10, 50, 90]).round(2))
