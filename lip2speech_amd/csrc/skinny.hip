@@ -292,9 +292,16 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
             else if (blocks(2, 1) >= 224) shape = 21;
         }
     }
+    // one of the decode step's K layouts shared by every group of the launch (1: [32], 2: [32|32], 3: [16|16|32|32] chunks), else 0
+    int rc_lay = skinny_layout_of(bl.p[0]);
+    for (int i = 1; i < bl.count; ++i) if (skinny_layout_of(bl.p[i]) != rc_lay) rc_lay = 0;
+    if (rc_lay == 4) rc_lay = 0;
+    int n_lstm = 0;
+    for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
+    const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
     // several groups, >= 128 rows (below that the 1x1 / 2x1 uniform grids with two blocks per CU are faster, tools/time_step_phases.py): per-group
     // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
-    if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024) {      // a forced block shape wins
+    if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024 && rc_kind == 1) {      // a forced block shape wins; LSTM groups (the BiLSTM's two directions) keep the uniform grid of four-wave blocks
         SkinnyFlat fl{};
         const int plan = plan_flat(bl, mts, 256, fl);
         // 0 = general blocks, 1 = straight-line eight-wave blocks (default: 12.4 us at 256 rows against 12.9 general), 2 = straight-line four-wave
@@ -314,13 +321,6 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
             return 0;
         }
     }
-    // one of the decode step's K layouts shared by every group of the launch (1: [32], 2: [32|32], 3: [16|16|32|32] chunks), else 0
-    int rc_lay = skinny_layout_of(bl.p[0]);
-    for (int i = 1; i < bl.count; ++i) if (skinny_layout_of(bl.p[i]) != rc_lay) rc_lay = 0;
-    if (rc_lay == 4) rc_lay = 0;
-    int n_lstm = 0;
-    for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
-    const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
