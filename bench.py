@@ -57,7 +57,7 @@ def kernel_model(name, rows=B):
         # both decoder LSTM layers run the same kernel (600 launches per pass); figures are the per-launch mean of the two layers.
         # ALGORITHMIC work (decoder.py:423): each layer is [x | h] (K = 512 + 512) against 2048 gate rows, and the
         # 512 -> 256 attention_proj of decoder.py:420 that the phase-merged layer 0 absorbs is credited to it.  What the kernel EXECUTES is
-        # more (layer 0 runs K = 1536 after the W_ih * W_ap fold): `executed` below, reported under roofline.frac_executed - never as frac.
+        # more (layer 0 runs K = 1280: the u columns of W_ih twice, once for the prenet output and once for o = a @ V'): `executed` below, reported under roofline.frac_executed - never as frac.
         "step_lstm_cell": (2 * R * (2048 * 1024 + 2048 * 1024 + 256 * 512) / 2,
                            ((2048 * (1024 + 1024) / 2 + 256 * 512 / 2 + 2048) * w4 + R * (1024 + 3 * 512) * w4)),
         "step_prenet1_q_cq_fc": (2 * R * (256 * 512 + 512 * 1024 + 256 * 1024 + 81 * 512),
@@ -74,7 +74,7 @@ def kernel_model(name, rows=B):
 
 def executed_flops(name, rows=B):
     """FLOPs the launch really issues where they differ from the algorithmic count (phase-merged weights)."""
-    return {"step_lstm_cell": 2 * rows * 2048 * (1536 + 1024) / 2}.get(name)
+    return {"step_lstm_cell": 2 * rows * 2048 * (1280 + 1024) / 2}.get(name)      # layer 0 runs K = 1280: [content | prenet | a.V' | h0] (option hoist_vproj)
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -463,7 +463,7 @@ def main():
                 roof["executed_flops"] = ex
                 roof["frac_executed"] = ex / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
                 roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj) / measured "
-                                "duration / peak; frac_executed counts the K=1536 products the phase-merged layer 0 really runs")
+                                "duration / peak; frac_executed counts the K=1280 products the phase-merged layer 0 really runs")
         # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
         # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None

@@ -76,9 +76,11 @@ int64_t l2s_state_floats(int B, int T);
  *   L2S_ST_CVAL   (B,m,256)   content values (reference: self.value)
  *   L2S_ST_ECELL  (B,512)     encoder_cell
  *   L2S_ST_H / L2S_ST_C   decoder LSTM state, 2 layers, fragment layout
- *   L2S_ST_ENC    (B,T,512)   encoder_outputs after encoder_proj + site + residual */
+ *   L2S_ST_ENC    (B,T,512)   encoder_outputs after encoder_proj + site + residual
+ *   L2S_ST_VP     (B,T,256)   V' = values W_ap^T + b_ap: attention_proj (decoder.py:420) applied to the values once, so that the step's
+ *                             a @ V' IS attention_proj(a @ v) (the attention weights sum to one) */
 enum { L2S_ST_K = 0, L2S_ST_V = 1, L2S_ST_CKEY = 2, L2S_ST_CVAL = 3, L2S_ST_ECELL = 4,
-       L2S_ST_H = 5, L2S_ST_C = 6, L2S_ST_ENC = 7, L2S_ST_STOPC = 8 };
+       L2S_ST_H = 5, L2S_ST_C = 6, L2S_ST_ENC = 7, L2S_ST_STOPC = 8, L2S_ST_VP = 9 };
 int64_t l2s_state_offset(int B, int T, int field);
 
 /* ---- stages ---------------------------------------------------------------------------------------- */
@@ -336,6 +338,9 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
  *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every
  *                            activation in HBM stay fp32.  Outside the 1e-3 fp32 gate by construction (mel: 5e-3 mean, 4e-2 max absolute deviation)
+ *   "hoist_vproj"       (1)  the phase-merged step with attention_proj (decoder.py:420) applied to the VALUES once per clip in the prologue
+ *                            (V' = V W_ap^T + b_ap; the attention weights sum to one, so a @ V' = attention_proj(a @ v)): the step's attention reads 256
+ *                            instead of 512 value columns and LSTM layer 0 runs K = 1280 instead of 1536; 0 = a @ v through the pre-multiplied W_ih W_ap
  *   "skinny_flat"       (1)  batch-row launches that carry several GEMM groups (the step's first phase) at >= 64 rows: every group gets its own
  *                            block shape, all groups together at most one block per CU, one flat grid, longest blocks first; 0 = one shape for all groups
  *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,

@@ -28,7 +28,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
         {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
@@ -486,6 +486,21 @@ static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bo
             for (int np = 0; np < 2048; ++np) P.blob.data[o + np] = badd[lstm_perm_row(np, 512)];
             P.bind(&w.lstm0f.bias, o);
             w.lstm0f.N = 2048; w.lstm0f.K = 1536; w.lstm0f.tiles = 128;
+            // the same step with attention_proj applied to the VALUES once, in the prologue (V' = V W_ap^T + b_ap; the attention weights sum
+            // to one, so a @ V' = W_ap (a @ v) + b_ap): LSTM0 then reads o = a @ V' (256 wide) through a second copy of W_ih's u columns -
+            // K = 1280 instead of 1536, verbatim copies of the parameters only (the device-side refresh keeps them current by itself)
+            P.frag16(2048, 1280, [&](int np, float* rowp) {
+                int r = lstm_perm_row(np, 512);
+                std::memcpy(rowp, wi->data() + (int64_t)r * 512, sizeof(float) * 512);                 // [cc | p2] columns of W_ih
+                std::memcpy(rowp + 512, wi->data() + (int64_t)r * 512 + 256, sizeof(float) * 256);     // o: the u columns again
+                std::memcpy(rowp + 768, wh->data() + (int64_t)r * 512, sizeof(float) * 512);           // h0 columns
+                return true;
+            }, &w.lstm0v.W);
+            for (size_t fi = 0; fi < P.fixups.size(); ++fi)      // the plain LSTM0 bias (b_ih + b_hh, kept current by the refresh's bias-sum records)
+                if (P.fixups[fi].first == &w.lstm0.bias) { P.bind(&w.lstm0v.bias, P.fixups[fi].second); break; }
+            w.lstm0v.N = 2048; w.lstm0v.K = 1280; w.lstm0v.tiles = 128;
+            P.copy(Dk + "attention_proj.linear_layer.weight", (int64_t)256 * D, &w.vproj.W);
+            P.copy(Dk + "attention_proj.linear_layer.bias", 256, &w.vproj.shift);
         }
     }
     P.copy(Dk + "BOS", NM, &w.bos);
@@ -1073,6 +1088,12 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
         bb.count = 2;
         // 2 x 120 tiles with K = 2560 is one block per CU and 80 dependent K iterations: four K slices each
         if (launch_gemm_splitk_group(bb, 4, bott_part, s, "multihop_bottleneck_gemm")) return 1;
+        // V' = V W_ap^T + b_ap: attention_proj (decoder.py:420) applied to the values once per clip instead of to a @ v at every step
+        if (w.vproj.W) {
+            GemmP p = gemm_plain(state + sl.v, 512, w.vproj.W, state + sl.vp, 256, BT, 256, 512);
+            p.shift = w.vproj.shift;
+            if (launch_gemm1(p, s, "prologue_gemm")) return 1;
+        }
     }
     // Content.encode (decoder.py:239-260)
     {
@@ -1130,6 +1151,8 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
     const Weights& w = m->w;
     StateLayout sl = state_layout(B, T);
     const int Bp = pad16(B);
+    const bool vhoist = fold && m->opt.hoist_vproj && w.lstm0v.W && w.vproj.W;      // attention_proj applied to the values in the prologue (option "hoist_vproj")
+    const bool vsum = vhoist && m->opt.hoist_vproj >= 2 && skinny_sum_supported(m->opt);     // ... and u = prenet + o formed by LSTM0's operand loader (K = 1024)
     Bump bp(ws, ws_bytes);
     DecodeBufs d;
     for (int i = 0; i < 2; ++i) d.h0[i] = bp.f((int64_t)Bp * 512);
@@ -1185,6 +1208,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
         {   // phase B: attention + content attention per batch row; prenet layer 2
             AttnP at{};
             at.q = d.q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = d.av;
+            if (fold && vhoist) at.vp = state + sl.vp;      // d.av then holds o = a @ V' (frag16, K = 256)
             at.attn_out = attn ? attn + (int64_t)i * T : nullptr; at.ld_attn_b = (int64_t)S * T; at.attn_logits = attn_logits;
             at.qc = d.qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = d.cc;
             at.B = B; at.T = T; at.m = sl.m;
@@ -1203,8 +1227,9 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
         }
         {   // phase D: LSTM layer 0 on cat(content, u), h0  (folded: cat(content, prenet, a@v) against [W_ih | W_ih_u W_ap | W_hh])
             SkinnyBatch sb{};
-            SkinnyP a = sk_base(fold ? w.lstm0f : w.lstm0, B);
-            if (fold) { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.p2f, 16}; a.seg[2] = {d.av, 32}; a.seg[3] = {d.h0[cur], 32}; a.nseg = 4; }
+            SkinnyP a = sk_base(fold ? (vsum ? w.lstm0 : vhoist ? w.lstm0v : w.lstm0f) : w.lstm0, B);
+            if (vsum) { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.p2f, 16}; a.a_sum = d.av; a.seg[2] = {d.h0[cur], 32}; a.nseg = 3; }      // u = prenet + o, summed by the loader
+            else if (fold) { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.p2f, 16}; a.seg[2] = {d.av, vhoist ? 16 : 32}; a.seg[3] = {d.h0[cur], 32}; a.nseg = 4; }
             else { a.seg[0] = {d.cc, 16}; a.seg[1] = {d.uu, 16}; a.seg[2] = {d.h0[cur], 32}; a.nseg = 3; }
             a.epi = SK_LSTM; a.H = 512; a.c_in = d.c0; a.c_out = d.c0; a.h_out = d.h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
             sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
@@ -1426,6 +1451,7 @@ int64_t l2s_state_offset(int B, int T, int field) {
         case L2S_ST_C: return s.c;
         case L2S_ST_ENC: return s.enc;
         case L2S_ST_STOPC: return s.stopc;
+        case L2S_ST_VP: return s.vp;
     }
     return -1;
 }
@@ -1742,8 +1768,11 @@ int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t w
     auto pair = [&](int cur) -> int {
         const int nxt = cur ^ 1;
         SkinnyBatch sb{};
-        SkinnyP a = sk_base(w.lstm0f, B);
-        a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.seg[2] = {av, 32}; a.seg[3] = {h0[cur], 32}; a.nseg = 4;
+        const bool vhoist = m->opt.hoist_vproj && w.lstm0v.W && w.vproj.W;      // the layer-0 launch of the production step (decode_launches)
+        const bool vsum = vhoist && m->opt.hoist_vproj >= 2 && skinny_sum_supported(m->opt);
+        SkinnyP a = sk_base(vsum ? w.lstm0 : vhoist ? w.lstm0v : w.lstm0f, B);
+        if (vsum) { a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.a_sum = av; a.seg[2] = {h0[cur], 32}; a.nseg = 3; }
+        else { a.seg[0] = {cc, 16}; a.seg[1] = {p2f, 16}; a.seg[2] = {av, vhoist ? 16 : 32}; a.seg[3] = {h0[cur], 32}; a.nseg = 4; }
         a.epi = SK_LSTM; a.H = 512; a.c_in = c0; a.c_out = c0; a.h_out = h0[nxt]; a.h_out_K = 512; a.h_out_off = 0;
         sb.p[0] = a; sb.ntiles[0] = 128; sb.count = 1;
         if (launch_skinny(sb, s, "step_lstm_cell", m->opt)) return 1;

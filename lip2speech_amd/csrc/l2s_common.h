@@ -54,6 +54,10 @@ struct Options {
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
+    int hoist_vproj = 2;        // "hoist_vproj": the phase-merged step reads o = a @ V' with V' = V W_ap^T + b_ap computed once in the prologue: 2 = LSTM0 on
+                                //   [content | prenet + o | h0] (K = 1024, the sum formed by the operand loader: the reference's own u = prenet + o), 1 = on
+                                //   [content | prenet | o | h0] through a second copy of W_ih's u columns (K = 1280; every block form), 0 = a @ v through the
+                                //   pre-multiplied W_ih W_ap (K = 1536)
     int skinny_flat = 1;        // "skinny_flat": launches with several GEMM groups at >= 64 rows run per-group block shapes in one flat grid of at most one
                                 //   block per CU (the step's first phase), instead of one block shape for every group
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
@@ -279,6 +283,8 @@ struct SkinnySeg { const float* a; int nchunks; };   // one K segment of A in fr
 struct SkinnyP {
     SkinnySeg seg[4];
     int nseg;
+    const float* a_sum;    // optional second frag16 source of segment 1 (same shape): the segment's operand is seg[1].a + a_sum, added by the loader
+                           //   (the decode step's u = prenet + attention_proj(a @ v), decoder.py:421; straight-line four-wave blocks only)
     int layout;            // set by launch_skinny: index of a compile-time segment layout the kernel has an instance for (0 = general path)
     const float* W;        // packed frag16 of the [Npad][K] weight, K = sum of segments
     const float* bias;     // [Npad] (permuted order for SK_LSTM)
@@ -312,6 +318,7 @@ struct SkinnyP {
 constexpr int SKINNY_MAX_GROUP = 4;
 struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o = Options());
+bool skinny_sum_supported(const Options& o);           // launches with SkinnyP::a_sum need the straight-line four-wave blocks: default operand batching, no stamped build
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);
@@ -321,6 +328,7 @@ struct AttnP {
     const float* q; int ldq;          // [B][512]
     const float* k;                   // [B][T][512]
     const float* v;                   // [B][T][512]
+    const float* vp;                  // optional [B][T][256] = V W_ap^T + b_ap: then av_frag receives o = a @ V' (frag16, K = 256) instead of a @ v
     const float* tau;                 // device scalar
     float* av_frag;                   // frag16, K = 512
     float* attn_out; int64_t ld_attn_b; int attn_logits;   // optional [b*ld + t]

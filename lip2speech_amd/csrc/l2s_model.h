@@ -55,6 +55,9 @@ struct Weights {
     // decode step
     SkW pre1, pre2, q, cq, aproj, lstm0, lstm1, fc;
     SkW pre1f, lstm0f;                 // phase-merged forms: prenet1 o fc_out over h1; LSTM0 with attention_proj folded in
+    SkW lstm0v;                        // LSTM0 over [content | prenet | o | h0] (K = 1280), o = a @ V' with V' = V W_ap^T + b_ap hoisted into the prologue:
+                                       //   [W_ih[:, :256] | W_ih[:, 256:] | W_ih[:, 256:] | W_hh], the plain LSTM0 bias
+    ConvW vproj;                       // attention_proj as a row-major [256][512] GEMM weight + bias (the prologue's V' = V W_ap^T + b_ap)
     const float* stop_tail = nullptr; const float* stop_bias = nullptr;
     const float* bos = nullptr; const float* tau = nullptr; const float* tau_c = nullptr;
     // postnet
@@ -130,7 +133,7 @@ inline int content_lens(int T, int L[4]) {
     return m;
 }
 
-struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, total; int m; };
+struct StateLayout { int64_t k, v, ckey, cval, ecell, h, c, enc, stopc, vp, total; int m; };
 inline StateLayout state_layout(int B, int T) {
     StateLayout s{};
     int L[4];
@@ -146,6 +149,7 @@ inline StateLayout state_layout(int B, int T) {
     s.c = take((int64_t)pad16(B) * 512 * 2);
     s.enc = take((int64_t)B * T * 512);
     s.stopc = take(B);
+    s.vp = take((int64_t)B * T * 256);      // V' = V W_ap^T + b_ap (decoder.py:420 applied to the values once instead of to a @ v every step)
     s.total = o;
     return s;
 }

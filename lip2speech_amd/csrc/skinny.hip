@@ -21,12 +21,16 @@ namespace l2s {
 //   2: [32 | 32]       K = 1024  LSTM1 on [h0' | h1], Q on [h0 | h1], content Q on [c0 | c1]
 //   3: [16|16|32|32]   K = 1536  LSTM0 on [content | prenet | a.v | h0] (attention_proj folded in)
 //   4: [16]            K = 256   prenet layers
+//   5: [16|16|16|32]   K = 1280  LSTM0 on [content | prenet | a.V' | h0] (attention_proj hoisted into the prologue)
+//   6: [16|16+16|32]   K = 1024  LSTM0 on [content | prenet + a.V' | h0]: segment 1 summed from two sources by the loader (SkinnyP::a_sum)
 static int skinny_layout_of(const SkinnyP& p) {
     const int n0 = p.seg[0].nchunks, n1 = p.seg[1].nchunks, n2 = p.seg[2].nchunks, n3 = p.seg[3].nchunks;
     if (n0 == 32 && n1 == 0 && n2 == 0 && n3 == 0) return 1;
     if (n0 == 32 && n1 == 32 && n2 == 0 && n3 == 0) return 2;
     if (n0 == 16 && n1 == 16 && n2 == 32 && n3 == 32) return 3;
     if (n0 == 16 && n1 == 0 && n2 == 0 && n3 == 0) return 4;
+    if (n0 == 16 && n1 == 16 && n2 == 16 && n3 == 32) return 5;
+    if (n0 == 16 && n1 == 16 && n2 == 32 && n3 == 0 && p.a_sum) return 6;
     return 0;
 }
 
@@ -64,6 +68,8 @@ template <int LAYID> struct SkLay;
 template <> struct SkLay<1> { using T = SegLay<32, 0, 0, 0>; };
 template <> struct SkLay<2> { using T = SegLay<32, 32, 0, 0>; };
 template <> struct SkLay<3> { using T = SegLay<16, 16, 32, 32>; };
+template <> struct SkLay<5> { using T = SegLay<16, 16, 16, 32>; };
+template <> struct SkLay<6> { using T = SegLay<16, 16, 32, 0, true>; };
 template <int RT, int CT, int LAYID, int DEPTH, int WPS, bool IS_LSTM>
 __global__ __launch_bounds__(512, WPS) void skinny_rcs_kernel(const SkinnyBatch batch, int mts) {
     __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
@@ -84,6 +90,8 @@ static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
         if (lay == 1) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 1, DEPTH, true>), grid, blk, 0, s, bl, mts);
         else if (lay == 2) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 2, DEPTH, true>), grid, blk, 0, s, bl, mts);
         else if (lay == 3) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 3, DEPTH, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 5) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 5, DEPTH, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 6) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 6, DEPTH, true>), grid, blk, 0, s, bl, mts);
         else return false;
     } else if (kind == 1) {
         if (lay == 1) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 1, DEPTH, false>), grid, blk, 0, s, bl, mts);
@@ -107,6 +115,7 @@ static bool launch_rcs(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
         if (lay == 1) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 1, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
         else if (lay == 2) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 2, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
         else if (lay == 3) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 3, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
+        else if (lay == 5) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 5, DEPTH, 2, true>), grid, blk, 0, s, bl, mts);
         else return false;
     } else if (kind == 1) {
         if (lay == 1) hipLaunchKernelGGL((skinny_rcs_kernel<RT, CT, 1, DEPTH, 2, false>), grid, blk, 0, s, bl, mts);
@@ -256,6 +265,8 @@ static unsigned long long* g_skinny_ts = nullptr;
 // "skinny_split" / "skinny_split8" = operand loads of the K <= 1536 / K <= 1024 instance in this many batches
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
+bool skinny_sum_supported(const Options& o) { return o.rc_jb == 0 && g_skinny_ts == nullptr; }
+
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o) {
     L2S_REQUIRE(b.count >= 1 && b.count <= SKINNY_MAX_GROUP, "skinny group size");
     int maxt = 0, mts = 0;
@@ -295,7 +306,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     // one of the decode step's K layouts shared by every group of the launch (1: [32], 2: [32|32], 3: [16|16|32|32] chunks), else 0
     int rc_lay = skinny_layout_of(bl.p[0]);
     for (int i = 1; i < bl.count; ++i) if (skinny_layout_of(bl.p[i]) != rc_lay) rc_lay = 0;
-    if (rc_lay == 4) rc_lay = 0;
+    if (rc_lay == 4) rc_lay = 0;      // the 256-wide prenet layers: two chunks per slice, general blocks
     int n_lstm = 0;
     for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
     const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
@@ -321,6 +332,8 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
             return 0;
         }
     }
+    for (int i = 0; i < bl.count; ++i)
+        L2S_REQUIRE(!bl.p[i].a_sum || (rc_lay == 6 && rc_kind == 2 && skinny_sum_supported(o)), "skinny: a summed segment needs the straight-line four-wave LSTM blocks");
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);

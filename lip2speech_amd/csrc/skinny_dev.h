@@ -78,9 +78,10 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& w, f32x4 a
 // chunk belongs to is then a constant, and the block's load-issue phase loses its per-chunk compare / branch / 64-bit address chains
 // (24 loads used to sit behind ~250 scalar instructions and ~50 branches per wave).  SegRuntime keeps the general path.
 struct SegRuntime { static constexpr bool STATIC = false; static constexpr int n0 = 0, n1 = 0, n2 = 0, n3 = 0, NC = 0; };
-template <int A0, int A1, int A2, int A3>
+template <int A0, int A1, int A2, int A3, bool SUM1_ = false>
 struct SegLay {
     static constexpr bool STATIC = true;
+    static constexpr bool SUM1 = SUM1_;          // segment 1 has a second source (SkinnyP::a_sum) added by the loader
     static constexpr int n0 = A0, n1 = A1, n2 = A2, n3 = A3, NC = A0 + A1 + A2 + A3;
     static_assert(A0 % SK_WAVES == 0 && A1 % SK_WAVES == 0 && A2 % SK_WAVES == 0 && A3 % SK_WAVES == 0, "segment boundaries on wave multiples");
 };
@@ -549,7 +550,16 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         ab[2][r] = reinterpret_cast<const float4*>(sa2) + (rt * LAY::n2 + wave) * 64 + lane;
         ab[3][r] = reinterpret_cast<const float4*>(sa3) + (rt * LAY::n3 + wave) * 64 + lane;
     }
-    float4 a[TC][RT], w[TC][CT];
+    // the slots of segment 1 when it has a second source (LAY::SUM1): its fragments travel beside the first source's and are added right before the MFMAs
+    constexpr int NS1 = LAY::SUM1 ? (LAY::n1 / SK_WAVES) * VW : 1;          // slots whose chunk lies in segment 1 (first slot: FS1)
+    constexpr int FS1 = (E0 / SK_WAVES) * VW;
+    const float4* ab2[RT];
+    if constexpr (LAY::SUM1) {
+        const float* const s1b = p.a_sum;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) ab2[r] = reinterpret_cast<const float4*>(s1b) + ((int64_t)min(mg * RT + r, mts - 1) * LAY::n1 + wave) * 64 + lane;
+    }
+    float4 a[TC][RT], w[TC][CT], a2[NS1][RT];
     auto load_chunk = [&](auto jc) {          // slot t: K slice h = t % VW (wave + NW * h), its j-th chunk (j = t / VW)
         constexpr int t_ = decltype(jc)::value, j = t_;
         constexpr int cj = SK_WAVES * (t_ / VW) + NW * (t_ % VW);
@@ -557,6 +567,10 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         constexpr int off = cj - (sg == 3 ? E2 : sg == 2 ? E1 : sg == 1 ? E0 : 0);
 #pragma unroll
         for (int r = 0; r < RT; ++r) a[j][r] = ab[sg][r][off * 64];
+        if constexpr (LAY::SUM1 && sg == 1) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a2[j - FS1][r] = ab2[r][off * 64];
+        }
 #pragma unroll
         for (int i = 0; i < CT; ++i) w[j][i] = wb[i][cj * 64];
     };
@@ -626,6 +640,12 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         // element-major issue order: the four dependent MFMAs of a tile (x, y, z, w into one accumulator) are NT instructions apart, so none waits
         // for its predecessor's result; per accumulator the order of the additions is mfma4's
         {
+            if constexpr (LAY::SUM1 && (SK_WAVES * (j / VW) + NW * (j % VW)) >= E0 && (SK_WAVES * (j / VW) + NW * (j % VW)) < E1) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    a[j][r].x += a2[j - FS1][r].x; a[j][r].y += a2[j - FS1][r].y; a[j][r].z += a2[j - FS1][r].z; a[j][r].w += a2[j - FS1][r].w;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -762,12 +782,15 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T;
-    const float* const pq = p.q; const float* const pk = p.k; const float* const pv = p.v; const float* const ptau = p.tau;
+    // values: v (512 columns) or, when the caller hoisted attention_proj into the prologue, V' = V W_ap^T + b_ap (256 columns: waves 4-7 have none)
+    const int vcols = p.vp ? 256 : 512;
+    const float* const pq = p.q; const float* const pk = p.k; const float* const pv = p.vp ? p.vp : p.v; const float* const ptau = p.tau;
     float* const pav = p.av_frag; float* const pattn = p.attn_out;
     const int ldq = p.ldq, logits = p.attn_logits; const int64_t ld_attn = p.ld_attn_b;
-    L2S_PIN_S("s"(T), "s"(pq), "s"(pk), "s"(pv), "s"(ptau), "s"(pav), "s"(pattn), "s"(ldq), "s"(logits), "s"(ld_attn));
+    L2S_PIN_S("s"(T), "s"(pq), "s"(pk), "s"(pv), "s"(ptau), "s"(pav), "s"(pattn), "s"(ldq), "s"(logits), "s"(ld_attn), "s"(vcols));
     const float* kb = pk + (int64_t)b * T * 512 + lane * 8;
-    const float* vb = pv + (int64_t)b * T * 512 + tid;
+    const bool vlane = tid < vcols;                  // wave-uniform
+    const float* vb = pv + (int64_t)b * T * vcols + (vlane ? tid : 0);
     // ---- loads
     const float qv = pq[(int64_t)b * ldq + tid];
     const float tau = ptau[0];
@@ -782,7 +805,7 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     }
     float vv[32];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) vv[e] = e < T ? vb[(int64_t)e * 512] : 0.f;
+    for (int e = 0; e < 32; ++e) vv[e] = (vlane && e < T) ? vb[(int64_t)e * vcols] : 0.f;
     // ---- logits
     qs[tid] = qv * tau;
     __syncthreads();
@@ -848,12 +871,12 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     for (int t0 = 32; t0 < T; t0 += 16) {
         float v2[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v2[e] = (t0 + e < T) ? vb[(int64_t)(t0 + e) * 512] : 0.f;
+        for (int e = 0; e < 16; ++e) v2[e] = (vlane && t0 + e < T) ? vb[(int64_t)(t0 + e) * vcols] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             if (t0 + e < T) acc = fmaf(sc[t0 + e], v2[e], acc);
     }
-    pav[frag16_index(b, tid, 512)] = acc;
+    if (vlane) pav[frag16_index(b, tid, vcols)] = acc;
     if constexpr (TRAIN) { if (tr->av_plain) tr->av_plain[(int64_t)b * 512 + tid] = acc; }
 }
 

@@ -297,6 +297,9 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     ({"fuse_trunk": 0}, False), ({"fuse_s2": 0}, False),      # unfused ShuffleNet units: GEMM kernel instead of in-LDS MFMA chain
     ({"gemm_x3": 0}, False),               # f32-MFMA GEMMs everywhere (at B=2 every GEMM is below the split-bf16 threshold anyway)
     ({"use_graph": 1, "fold_step_weights": 0}, False),
+    ({"hoist_vproj": 1}, False), ({"hoist_vproj": 0}, False),      # attention_proj on the values (K = 1280 layer 0) / on a @ v through W_ih W_ap (K = 1536)
+    ({"skinny_flat": 0}, True),            # uniform first-phase grid
+    ({"skinny_rc_jb": 28}, False),         # the straight-line blocks on eight waves (they do not sum u in the loader: layer 0 on K = 1280, other bits)
 ])
 def test_runtime_options_keep_parity(synth_sd, nm, opts, exact):
     """Every run-time option of include/l2s.h against the reference golden (B=2, S=300, same Gumbel noise), on a model of its own
@@ -634,8 +637,13 @@ def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
     torch.cuda.synchronize()
     for g, w in zip(got, want):
         assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
-    # and the forced block shapes agree with each other (options are per model: this handle only)
+    # and the forced block shapes agree with each other (options are per model: this handle only).  The general block forms ("skinny_rc_jb" != 0)
+    # cannot sum u = prenet + o in the loader, so LSTM layer 0 runs on [content | prenet | o | h0] (hoist_vproj = 1: another, equally valid, order of
+    # additions): every form is compared on THAT layout - bit for bit among themselves - and the default layout against the single-batch calls above
     own = pc.fresh_native_model(synth_sd)
+    own.set_option("hoist_vproj", 1)
+    want = [tuple(t.clone() for t in own.inference(*b, S=S, want_attn=True)) for b in batches]
+    assert all(pc.maxdiff(w[0], g[0]) < 1e-4 for w, g in zip(want, got))      # the two layouts agree to rounding
     for shape in (11, 21, 22, 42):
         own.set_option("skinny_rc", shape)
         for jb in (0, 2, 4, 15):
