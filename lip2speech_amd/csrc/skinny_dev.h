@@ -586,22 +586,19 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     const float* const c_in = p.c_in; const float* const add = p.add; const int ld_add = p.ld_add; const float* const addrow = p.addrow;
     L2S_PIN_S("s"(epi), "s"(nB), "s"(N), "s"(H), "s"(act), "s"(bias), "s"(pre), "s"(ld_pre), "s"(c_in), "s"(add), "s"(ld_add), "s"(addrow));
     const int half = tid >> 8, l256 = tid & 255, e_row = l256 >> 4, e_col = l256 & 15;
-    float pf_bias[NQ], pf_add[NQ], pf_row[NQ];
+    constexpr int NQE = IS_LSTM ? 1 : NQ;            // LSTM blocks finish in their cell threads (below): no per-element epilogue operands
+    float pf_bias[NQE], pf_add[NQE], pf_row[NQE];
     const float* const bias_p = bias ? bias : W;
     const float* const add_p = IS_LSTM ? (pre ? pre : W) : (add ? add : W);
     const float* const row_p = addrow ? addrow : W;
+    if constexpr (!IS_LSTM) {
 #pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const int q = min(half + NH * n, NT - 1);
-        const int t = min(tp * CT + q % CT, ntiles - 1), rt = min(mg * RT + q / CT, mts - 1);
-        const int e_b = min(rt * 16 + e_row, nB - 1), e_np = t * 16 + e_col;
-        const float vb = bias_p[bias ? e_np : 0];
-        pf_bias[n] = bias ? vb : 0.f;
-        if constexpr (IS_LSTM) {
-            const float va = add_p[pre ? (int64_t)e_b * ld_pre + (e_col & 3) * H + t * 4 + (e_col >> 2) : 0];
-            pf_add[n] = pre ? va : 0.f;
-            pf_row[n] = 0.f;
-        } else {
+        for (int n = 0; n < NQ; ++n) {
+            const int q = min(half + NH * n, NT - 1);
+            const int t = min(tp * CT + q % CT, ntiles - 1), rt = min(mg * RT + q / CT, mts - 1);
+            const int e_b = min(rt * 16 + e_row, nB - 1), e_np = t * 16 + e_col;
+            const float vb = bias_p[bias ? e_np : 0];
+            pf_bias[n] = bias ? vb : 0.f;
             const int e_nc = min(e_np, N - 1);       // SK_MEL groups read (and drop) element N - 1: they have neither table
             const float va = add_p[add ? (int64_t)e_b * ld_add + e_nc : 0];
             const float vr = row_p[addrow ? e_nc : 0];
@@ -609,9 +606,12 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
             pf_row[n] = addrow ? vr : 0.f;
         }
     }
+    // LSTM cells: thread (q2 = tid>>6 (+NW per round), t64) owns (row t64>>2, unit t64&3) of tile q2 and finishes it alone: the eight K-slice
+    // partials of its four gate columns are summed in slice order, bias and pre-gates added, in the order of the element epilogue - same bits,
+    // one LDS round and one barrier less than staging the reduced tile first
     constexpr int NCR = (NT + NW - 1) / NW;
     const int t64 = tid & 63;
-    float pf_c[NCR];
+    float pf_c[NCR], pf_gb[IS_LSTM ? NCR : 1][4], pf_gp[IS_LSTM ? NCR : 1][4];
     bool cell_on[NCR];
 #pragma unroll
     for (int cr = 0; cr < NCR; ++cr) {
@@ -622,7 +622,15 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         if constexpr (IS_LSTM) {
             const int q2c = min(q2, NT - 1);
             const int t2c = min(tp * CT + q2c % CT, ntiles - 1), rt2c = min(mg * RT + q2c / CT, mts - 1);
-            pf_c[cr] = c_in[frag16_index(min(rt2c * 16 + (t64 >> 2), nB - 1), t2c * 4 + (t64 & 3), H)];
+            const int b2c = min(rt2c * 16 + (t64 >> 2), nB - 1), u2 = t64 & 3;
+            pf_c[cr] = c_in[frag16_index(b2c, t2c * 4 + u2, H)];
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_p + (bias ? t2c * 16 + 4 * u2 : 0));      // the unit's four gate rows are adjacent (permuted weight rows)
+            pf_gb[cr][0] = bias ? b4.x : 0.f; pf_gb[cr][1] = bias ? b4.y : 0.f; pf_gb[cr][2] = bias ? b4.z : 0.f; pf_gb[cr][3] = bias ? b4.w : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float va = add_p[pre ? (int64_t)b2c * ld_pre + g * H + t2c * 4 + u2 : 0];
+                pf_gp[cr][g] = pre ? va : 0.f;
+            }
         } else {
             pf_c[cr] = 0.f;
         }
@@ -678,41 +686,36 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     }
     __syncthreads();
     L2S_STAMP(5);
-    float* gt = red + SK_WAVES * NT * 16 * 17;          // reduced tiles [NT][16][17]
+    if constexpr (!IS_LSTM) {
 #pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const int q = half + NH * n;
-        if (q >= NT) continue;
-        const int t = tp * CT + q % CT, rt = mg * RT + q / CT;
-        if (t >= ntiles || rt >= mts) continue;
-        float v = 0.f;
+        for (int n = 0; n < NQ; ++n) {
+            const int q = half + NH * n;
+            if (q >= NT) continue;
+            const int t = tp * CT + q % CT, rt = mg * RT + q / CT;
+            if (t >= ntiles || rt >= mts) continue;
+            float v = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q) * 16 + e_row) * 17 + e_col];
-        v += pf_bias[n];
-        const int b = rt * 16 + e_row, np = t * 16 + e_col;
-        if (epi == SK_LSTM) {
-            v += pf_add[n];
-            gt[(q * 16 + e_row) * 17 + e_col] = v;
-            continue;
-        }
-        if (b >= nB) continue;
-        if (epi == SK_MEL) {
-            if (np < 80) {
-                p.mel[(int64_t)b * p.ld_mel_b + np] = v;
-                if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
-            } else if (np == 80) {
-                p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
+            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q) * 16 + e_row) * 17 + e_col];
+            v += pf_bias[n];
+            const int b = rt * 16 + e_row, np = t * 16 + e_col;
+            if (b >= nB) continue;
+            if (epi == SK_MEL) {
+                if (np < 80) {
+                    p.mel[(int64_t)b * p.ld_mel_b + np] = v;
+                    if (p.yfrag) p.yfrag[frag16_index(b, np, 80)] = v;
+                } else if (np == 80) {
+                    p.stop[(int64_t)b * p.ld_stop_b] = v + p.stop_const[b];
+                }
+                continue;
             }
-            continue;
+            if (np >= N) continue;
+            v = act_apply(v, act, p.actw, np);
+            v += pf_add[n] + pf_row[n];                  // the general form adds (add + addrow) as one pre-summed value: same order
+            if (epi == SK_FRAG) p.out[frag16_index(b, np, p.ldo)] = v;
+            else p.out[(int64_t)b * p.ldo + np] = v;
         }
-        if (np >= N) continue;
-        v = act_apply(v, act, p.actw, np);
-        v += pf_add[n] + pf_row[n];                  // the general form adds (add + addrow) as one pre-summed value: same order
-        if (epi == SK_FRAG) p.out[frag16_index(b, np, p.ldo)] = v;
-        else p.out[(int64_t)b * p.ldo + np] = v;
+        return;
     }
-    if (epi != SK_LSTM) return;
-    __syncthreads();
     L2S_STAMP(6);
 #pragma unroll
     for (int cr = 0; cr < NCR; ++cr) {
@@ -721,7 +724,16 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         const int t2 = tp * CT + q2 % CT, rt2 = mg * RT + q2 / CT;
         const int b2 = rt2 * 16 + (t64 >> 2), unit2 = t2 * 4 + (t64 & 3);
         const int r2 = t64 >> 2, u2 = t64 & 3;
-        const float* g4 = gt + (q2 * 16 + r2) * 17 + 4 * u2;
+        float g4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q2) * 16 + r2) * 17 + 4 * u2 + g];
+            v += pf_gb[cr][g];
+            v += pf_gp[cr][g];
+            g4[g] = v;
+        }
         const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
         const float cn = sigmoidf_(gf) * pf_c[cr] + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
