@@ -300,6 +300,9 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
  * writes 8 x 64-bit 100 MHz wall-clock stamps (entry, parameters in SGPRs, loads issued, first operands landed, MFMAs done, after the
  * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
 int l2s_op_skinny_timeline(void* ts_dev);
+/* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
+   ([wave][96 K tiles][4 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
+int l2s_op_gemm_x3_timeline(void* ts_dev, int block);
 /* measurement: the same for the fused stride-1 ShuffleNet units of spatial size h (12, 6 or 3; the last such launch leaves its stamps) - 10 x 64-bit words per block to ts_dev[block*10 ..]: 8 stamps (entry,
  * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID */
 int l2s_op_fused_unit_timeline(void* ts_dev, int h);

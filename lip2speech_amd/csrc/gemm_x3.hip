@@ -53,8 +53,14 @@ struct X3LoadP { int K, Cin, taps, Tin, lda, a_split, a_gap; };
 // Wave-specialised: waves 0-3 (one per SIMD) only read operands from LDS and issue MFMAs, waves 4-7 only fetch, split and stage the next
 // K tile into the other LDS stage - the split's VALU work and the global-load latency run beside the matrix pipe instead of in front of
 // it, and there is ONE barrier per K tile (stage kt+1 written / stage kt read).
-__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch) {
+// TIMED: the measurement build (l2s_op_gemm_x3_timeline): lane 0 of every wave of ONE block stamps the shader clock at the points marked
+// X3_STAMP - [wave][K tile][slot] - so that a K tile's time splits into producer work (fetch issue / loads landed / split + LDS writes),
+// consumer work (MFMA groups) and the time either side waits at the barrier.  Same arithmetic; the product launches TIMED = false.
+#define X3_STAMP(kt_, slot_) do { if constexpr (TIMED) { if (stamp_on && lane == 0 && (kt_) < 96) ts[((wave * 96) + (kt_)) * 4 + (slot_)] = clock64(); } } while (0)
+template <bool TIMED>
+__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, unsigned long long* __restrict__ ts, int stamp_block) {
     const GemmP& p = batch.p[blockIdx.z];
+    const bool stamp_on = TIMED && (int)(blockIdx.y * gridDim.x + blockIdx.x) == stamp_block && blockIdx.z == 0;
     // XCD-aware tile order (see gemm_nt.hip): each XCD gets a contiguous run of tiles, N index fastest
     int bx, by;
     {
@@ -161,14 +167,24 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch) 
         __syncthreads();                                     // stage 0 = tile 0
         for (int kt = 0; kt < nkt; kt += 2) {
             // iteration kt: consumers read stage 0; stage 1 <- tile kt+1 (registers set 1), request tile kt+2 into set 0
+            X3_STAMP(kt, 0);
             if (kt + 2 < nkt) { advance(); fetch((kt + 2) * XK + kq, ra0, rb0); }
+            if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); X3_STAMP(kt, 1); }      // the older register set has landed
             if (kt + 1 < nkt) stage(ra1, rb1, 1);
+            if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            X3_STAMP(kt, 2);
             __syncthreads();
+            X3_STAMP(kt, 3);
             if (kt + 1 >= nkt) break;
             // iteration kt+1: consumers read stage 1; stage 0 <- tile kt+2 (set 0), request tile kt+3 into set 1
+            X3_STAMP(kt + 1, 0);
             if (kt + 3 < nkt) { advance(); fetch((kt + 3) * XK + kq, ra1, rb1); }
+            if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); X3_STAMP(kt + 1, 1); }
             if (kt + 2 < nkt) stage(ra0, rb0, 0);
+            if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            X3_STAMP(kt + 1, 2);
             __syncthreads();
+            X3_STAMP(kt + 1, 3);
         }
     } else {
         // ------------------------------------------------------------------------------------------------ consumers
@@ -198,15 +214,19 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch) 
         read_frags(f0, 0, 0);
         for (int kt = 0; kt < nkt; ++kt) {
             const int so = (kt & 1) * STAGE;
+            X3_STAMP(kt, 0);
             read_frags(f1, so, 1);
             __builtin_amdgcn_sched_barrier(0);
             L2S_X3_MMA(f0)
             __builtin_amdgcn_sched_barrier(0);
+            X3_STAMP(kt, 1);                                 // the 24 MFMAs of step 0 are issued (not necessarily retired)
             __syncthreads();                                 // this stage is read (f1 has landed: the barrier waits for it); the other one is written
+            X3_STAMP(kt, 2);
             if (kt + 1 < nkt) read_frags(f0, STAGE - so, 0);
             __builtin_amdgcn_sched_barrier(0);
             L2S_X3_MMA(f1)
             __builtin_amdgcn_sched_barrier(0);
+            X3_STAMP(kt, 3);
         }
 #undef L2S_X3_MMA
 #undef L2S_X3_TERM
@@ -265,6 +285,10 @@ bool gemm_x3_eligible(const GemmBatch& b) {
     return tiles >= (b.count > 1 ? 256 : 100) || b.p[0].x3 == 2;
 }
 
+static unsigned long long* g_x3_ts = nullptr;
+static int g_x3_stamp_block = 0;
+void gemm_x3_set_timeline(unsigned long long* ts, int block) { g_x3_ts = ts; g_x3_stamp_block = block; }
+
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP && gemm_x3_eligible(b), "split-bf16 gemm: group not eligible");
     int maxM = 0, maxN = 0;
@@ -275,10 +299,16 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     }
     dim3 grid((maxN + XN - 1) / XN, (maxM + XM - 1) / XM, b.count);
     constexpr int LDS_BYTES = 2 * 6 * XPLANE;              // 122 880: two operand stages (one block per CU)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     L2S_CHECK_HIP(attr);
     ProfScope ps(name, s);
-    hipLaunchKernelGGL(gemm_x3_kernel, grid, dim3(512), LDS_BYTES, s, b);
+    if (g_x3_ts) {
+        static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        L2S_CHECK_HIP(attr_t);
+        hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
+    } else {
+        hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(512), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
+    }
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
