@@ -56,7 +56,7 @@ struct X3LoadP { int K, Cin, taps, Tin, lda, a_split, a_gap; };
 // TIMED: the measurement build (l2s_op_gemm_x3_timeline): lane 0 of every wave of ONE block stamps the shader clock at the points marked
 // X3_STAMP - [wave][K tile][slot] - so that a K tile's time splits into producer work (fetch issue / loads landed / split + LDS writes),
 // consumer work (MFMA groups) and the time either side waits at the barrier.  Same arithmetic; the product launches TIMED = false.
-#define X3_STAMP(kt_, slot_) do { if constexpr (TIMED) { if (stamp_on && lane == 0 && (kt_) < 96) ts[((wave * 96) + (kt_)) * 4 + (slot_)] = clock64(); } } while (0)
+#define X3_STAMP(kt_, slot_) do { if constexpr (TIMED) { if (stamp_on && lane == 0 && (kt_) < 96) ts[((wave * 96) + (kt_)) * 8 + (slot_)] = clock64(); } } while (0)
 template <bool TIMED>
 __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, unsigned long long* __restrict__ ts, int stamp_block) {
     const GemmP& p = batch.p[blockIdx.z];
@@ -148,8 +148,25 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
             for (int j = 0; j < 4; ++j) woff[j] += wvalid[j] ? XK * 4u : 0u;
         };
         const int st_off = lr * XLDB + kq * 2;                              // byte offset of this thread's first staged row inside a plane
-        auto stage = [&](const float4* ra, const float4* rb, int st) {
+        auto stage = [&](const float4* ra, const float4* rb, int st, int kt_stamp) {
             unsigned char* base = smem + st * STAGE + st_off;
+            if constexpr (TIMED) {                           // measurement build: all splits, stamp, all stores, stamp
+                X3Split sa[4], sb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sa[j] = x3_split(ra[j]); sb[j] = x3_split(rb[j]); }
+                asm volatile("" :: "v"(sa[0].hi.x), "v"(sa[1].hi.x), "v"(sa[2].hi.x), "v"(sa[3].lo.y), "v"(sb[0].hi.x), "v"(sb[1].hi.x), "v"(sb[2].hi.x), "v"(sb[3].lo.y));
+                __builtin_amdgcn_sched_barrier(0);
+                X3_STAMP(kt_stamp, 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned char* ad = base + 32 * j * XLDB;
+                    unsigned char* bd = ad + 3 * XPLANE;
+                    *reinterpret_cast<uint2*>(ad) = sa[j].hi; *reinterpret_cast<uint2*>(ad + XPLANE) = sa[j].mid; *reinterpret_cast<uint2*>(ad + 2 * XPLANE) = sa[j].lo;
+                    *reinterpret_cast<uint2*>(bd) = sb[j].hi; *reinterpret_cast<uint2*>(bd + XPLANE) = sb[j].mid; *reinterpret_cast<uint2*>(bd + 2 * XPLANE) = sb[j].lo;
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const X3Split sa = x3_split(ra[j]), sb = x3_split(rb[j]);
@@ -159,18 +176,23 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
                 *reinterpret_cast<uint2*>(bd) = sb.hi; *reinterpret_cast<uint2*>(bd + XPLANE) = sb.mid; *reinterpret_cast<uint2*>(bd + 2 * XPLANE) = sb.lo;
             }
         };
-        // two register sets: tile kt+2 is requested before tile kt+1 is split, so a fetch has a whole K tile of MFMA time to land
+        // two register sets: tile kt+2 is requested before tile kt+1 is split, so a fetch has a whole K tile of MFMA time to land.  The loop body
+        // is BRANCH-FREE on purpose: fetches past the last tile are range-checked to zero (kbad) and the stage they are written to is never
+        // read.  With `if (kt + 2 < nkt)` guards around the fetches the compiler has to assume at the join that the newer register set may not
+        // have been requested and waits for the OLDER set with vmcnt(7..0) - i.e. for the loads it has just issued as well: every K tile
+        // then paid a full memory round trip under load (stamped build: 2 650 of the tile's 3 060 clk in the producers).
         float4 ra0[4], rb0[4], ra1[4], rb1[4];
         fetch(kq, ra0, rb0);
-        if (nkt > 1) { advance(); fetch(XK + kq, ra1, rb1); }
-        stage(ra0, rb0, 0);
+        advance(); fetch(XK + kq, ra1, rb1);
+        stage(ra0, rb0, 0, 95);
         __syncthreads();                                     // stage 0 = tile 0
         for (int kt = 0; kt < nkt; kt += 2) {
             // iteration kt: consumers read stage 0; stage 1 <- tile kt+1 (registers set 1), request tile kt+2 into set 0
             X3_STAMP(kt, 0);
-            if (kt + 2 < nkt) { advance(); fetch((kt + 2) * XK + kq, ra0, rb0); }
+            advance(); fetch((kt + 2) * XK + kq, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE the older set is waited for and split
             if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); X3_STAMP(kt, 1); }      // the older register set has landed
-            if (kt + 1 < nkt) stage(ra1, rb1, 1);
+            stage(ra1, rb1, 1, kt);
             if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             X3_STAMP(kt, 2);
             __syncthreads();
@@ -178,9 +200,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
             if (kt + 1 >= nkt) break;
             // iteration kt+1: consumers read stage 1; stage 0 <- tile kt+2 (set 0), request tile kt+3 into set 1
             X3_STAMP(kt + 1, 0);
-            if (kt + 3 < nkt) { advance(); fetch((kt + 3) * XK + kq, ra1, rb1); }
+            advance(); fetch((kt + 3) * XK + kq, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); X3_STAMP(kt + 1, 1); }
-            if (kt + 2 < nkt) stage(ra0, rb0, 0);
+            stage(ra0, rb0, 0, kt + 1);
             if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             X3_STAMP(kt + 1, 2);
             __syncthreads();
@@ -263,6 +286,259 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ wide tile: 128(M) x 256(N) x 16(K)
+// What the stamped build of the kernel above showed (tools/gemm_x3_timeline.py, profiles/r03_gemm_x3_timeline.txt): per K tile of 32 the four MFMA
+// waves are busy ~1 950 clk (1 536 of matrix time) and the four staging waves ~2 430 - 540 to issue the next fetch, 240 of split VALU and **1 510 clk
+// for their 24 ds_write_b64**: the LDS STORE path (VGPR -> LDS, 2 clk per source dword per instruction, MI355X_MICROARCH.md section LDS) moves the
+// tile's 48 KB of planes at 32 B/clk and that, not the operand fetch, sets the pace.  A 128x128 tile needs 32 B of LDS fill per clk of MFMA time;
+// this one needs 24.  Block = 768 threads: EIGHT MFMA waves (2 x 4, two per SIMD, each 64x64 exactly as above: the pipe of a SIMD stays fed while
+// one of its two waves waits) + the same four staging waves; a stage is ONE K step (rows of 48 bytes = 16 bf16 + pad: conflict-free for the
+// ds_read_b128 lane groups), 2 x 54 KB of LDS.  A step runs as two column halves so that every LDS read has MFMAs to hide behind: B half 1 is read
+// while half 0's 12 MFMAs issue, the barrier sits between the halves, and the next step's A (into its second register set) and B half 0 are read
+// while half 1's MFMAs issue - 136 registers of accumulators and fragments, three waves per SIMD.  Per output element the accumulation order is the
+// narrow kernel's (K steps ascending, the six terms in the same order): bit-identical results.
+constexpr int WM = 128, WN = 256, WK = 16;
+constexpr int WLDB = 48;                         // bytes per LDS row (16 bf16 + pad)
+constexpr int WPA = WM * WLDB, WPB = WN * WLDB;  // bytes per plane
+constexpr int WSTAGE = 3 * WPA + 3 * WPB;        // 55 296
+constexpr int WTHREADS = 768;
+
+template <bool TIMED>
+__global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batch, unsigned long long* __restrict__ ts, int stamp_block) {
+    const GemmP& p = batch.p[blockIdx.z];
+    const bool stamp_on = TIMED && (int)(blockIdx.y * gridDim.x + blockIdx.x) == stamp_block && blockIdx.z == 0;
+    int bx, by;
+    {
+        const int gx = gridDim.x, total = gx * gridDim.y;
+        const int L = blockIdx.y * gx + blockIdx.x;
+        const int xcd = L & 7, local = L >> 3;
+        const int chunk = total >> 3, rem = total & 7;
+        const int tile = xcd * chunk + (xcd < rem ? xcd : rem) + local;
+        bx = tile % gx; by = tile / gx;
+    }
+    const int m0 = by * WM, n0 = bx * WN;
+    if (m0 >= p.M || n0 >= p.N) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x {A planes, B planes}
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nks = (p.K + WK - 1) / WK;
+    const int wm = (wave >> 2) & 1, wn = wave & 3;
+    const int li = lane & 31, lg = lane >> 5;
+
+    // the accumulators leave through LDS, one 32-row sub-tile of both wave rows (64 rows x 256 columns, 64 KB) at a time; all twelve waves run
+    // the fused epilogue over it (rows of 256 consecutive columns).  The accumulators are declared in the consumer branch only: live across the
+    // producer branch as well they cost it 64 registers and the allocator spills
+    float* const ct = reinterpret_cast<float*>(smem);
+    const GemmP pl = p;
+    auto store_rows = [&](int i) {
+        const int cl = tid & 255, col = n0 + cl;
+        if (col < pl.N) {
+            const float sc = pl.scale ? pl.scale[col] : 1.0f;
+            const float sh = pl.shift ? pl.shift[col] : 0.0f;
+#pragma unroll 2
+            for (int q = tid >> 8; q < 64; q += 3) {
+                const int row = m0 + (q >> 5) * 64 + i * 32 + (q & 31);
+                if (row < pl.M) gemm_store(pl, row, col, ct[q * WN + cl], sc, sh);
+            }
+        }
+    };
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------------ producers
+        const int pt = tid - 512;
+        // 4 lanes per row (16 k); the four rows of a 16-lane ds_write group are 2 apart: with 48-byte rows their 8-dword spans tile the 32 banks
+        const int slot = pt >> 2;
+        const int lr = (slot & ~7) + ((slot & 3) << 1) + ((slot >> 2) & 1), kq = (pt & 3) * 4;
+        bool avalid[2];
+        int atbase[2];
+        unsigned arow_off[2];
+        const X3LoadP lp{p.K, p.Cin, p.taps, p.Tin, p.lda, p.a_split, p.a_gap};
+        asm volatile("" ::"s"(lp.K), "s"(lp.Cin), "s"(lp.taps), "s"(lp.Tin), "s"(lp.lda), "s"(lp.a_split), "s"(lp.a_gap));
+        const int ldw = p.ldw ? p.ldw : lp.K;
+        constexpr unsigned OOB = 0x80000000u;
+        // Addressing with the K position kept UNIFORM (scalar registers): a step's 16 k are one tap and one side of the A split for every thread
+        // (launch checks: Cin and a_split multiples of 16), so the per-step advance is scalar arithmetic, the column offset travels in the buffer
+        // instruction's scalar offset, and the per-thread part - row base + kq - only changes when the tap does (a uniform branch).  The first form
+        // (per-thread ci / tap, offsets rebuilt per load) cost the staging waves 580 clk of address VALU per step beside two MFMA waves per SIMD.
+        unsigned wfix[4], afix[2];                           // per-thread byte offsets (OOB: row outside the matrix / frame outside the sequence)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + lr + 64 * j;
+            avalid[j] = m < p.M;
+            const int mm = avalid[j] ? m : 0;
+            const int b = mm / p.Tout, t = mm - b * p.Tout + p.win_off;
+            atbase[j] = t * p.stride - p.pad;
+            arow_off[j] = (unsigned)((int64_t)b * lp.Tin * lp.lda);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + lr + 64 * j;
+            wfix[j] = n < p.N ? (unsigned)((int64_t)n * ldw + kq) * 4u : OOB;
+        }
+        int kb = 0, tap = 0, cib = 0;                        // uniform: first k of the step being requested, its tap, its first channel
+        const int nseq = (p.M + p.Tout - 1) / p.Tout;
+        const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)nseq * lp.Tin * lp.lda * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * ldw * 4), 0x00020000);
+        auto set_tap = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tin = atbase[j] + tap;
+                const bool ok = avalid[j] && tin >= 0 && tin < lp.Tin;
+                afix[j] = ok ? (arow_off[j] + (unsigned)(tin * lp.lda) + (unsigned)kq) * 4u : OOB;
+            }
+        };
+        set_tap();
+        // K is a multiple of 16 here (launch check), so no quad of a step is past K and the per-thread offsets are loop-invariant registers: no
+        // VALU at all between the loads of one step and the next.  The requests past the last step (the loop runs two sets ahead) re-read the
+        // last step instead of running off the matrix: the uniform position simply stops advancing.
+        auto fetch = [&](float4* ra, float4* rb) {
+            const int acol = __builtin_amdgcn_readfirstlane((cib + (cib >= lp.a_split ? lp.a_gap : 0)) * 4);
+            const int wcol = __builtin_amdgcn_readfirstlane(kb * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_rs, (int)afix[j], acol, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_rs, (int)wfix[j], wcol, 0));
+        };
+        auto advance = [&]() {
+            if (kb + WK < lp.K) {                                                            // uniform
+                kb += WK; cib += WK;
+                if (lp.taps > 1 && cib >= lp.Cin) { cib -= lp.Cin; ++tap; set_tap(); }
+            }
+        };
+        const int st_off = lr * WLDB + kq * 2;
+        auto stage = [&](const float4* ra, const float4* rb, int st) {
+            unsigned char* base = smem + st * WSTAGE + st_off;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const X3Split sa = x3_split(ra[j]);
+                unsigned char* ad = base + 64 * j * WLDB;
+                *reinterpret_cast<uint2*>(ad) = sa.hi; *reinterpret_cast<uint2*>(ad + WPA) = sa.mid; *reinterpret_cast<uint2*>(ad + 2 * WPA) = sa.lo;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const X3Split sb = x3_split(rb[j]);
+                unsigned char* bd = base + 3 * WPA + 64 * j * WLDB;
+                *reinterpret_cast<uint2*>(bd) = sb.hi; *reinterpret_cast<uint2*>(bd + WPB) = sb.mid; *reinterpret_cast<uint2*>(bd + 2 * WPB) = sb.lo;
+            }
+        };
+        // branch-free body, requests before the older sets are waited for (see the narrow kernel).  THREE register sets: the data staged in
+        // iteration ks (step ks+1) were requested in iteration ks-2 - two K steps (~3 500 clk) to land; with two sets (one step) the staging
+        // waves still waited ~400 clk per step for rows of A that come from HBM
+        float4 ra0[2], rb0[4], ra1[2], rb1[4], ra2[2], rb2[4];
+        fetch(ra0, rb0);
+        advance(); fetch(ra1, rb1);
+        advance(); fetch(ra2, rb2);
+        stage(ra0, rb0, 0);
+        __syncthreads();                                     // stage 0 = step 0
+        // every request of the prologue has landed before the loop is entered: with loads pending on the entry edge the wait-count pass merges
+        // them with the back edge's at the loop header and drains ALL outstanding loads (vmcnt(0)) once per trip
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define L2S_X3W_PRODUCE(KS_, RA_NEW, RB_NEW, RA_OLD, RB_OLD)                                                   \
+        X3_STAMP(KS_, 0);                                                                                      \
+        advance(); fetch(RA_NEW, RB_NEW);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        X3_STAMP(KS_, 4);                                                                                      \
+        if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); X3_STAMP(KS_, 1); }           \
+        stage(RA_OLD, RB_OLD, ((KS_) + 1) & 1);                                                                \
+        if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }                            \
+        X3_STAMP(KS_, 2);                                                                                      \
+        __syncthreads();                                                                                       \
+        X3_STAMP(KS_, 3);
+        for (int ks = 0; ks < nks; ks += 3) {
+            L2S_X3W_PRODUCE(ks, ra0, rb0, ra1, rb1)
+            if (ks + 1 >= nks) break;
+            L2S_X3W_PRODUCE(ks + 1, ra1, rb1, ra2, rb2)
+            if (ks + 2 >= nks) break;
+            L2S_X3W_PRODUCE(ks + 2, ra2, rb2, ra0, rb0)
+        }
+#undef L2S_X3W_PRODUCE
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i) __syncthreads();
+            __syncthreads();
+            store_rows(i);
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ consumers
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const unsigned char* a_rd = smem + (wm * 64 + li) * WLDB + lg * 16;
+        const unsigned char* b_rd = smem + 3 * WPA + (wn * 64 + li) * WLDB + lg * 16;
+        struct FA { bf16x8 h[2], m[2], l[2]; };
+        struct FB { bf16x8 h, m, l; };
+        auto read_a = [&](FA& f, int so) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned char* ap = a_rd + so + i * 32 * WLDB;
+                f.h[i] = *reinterpret_cast<const bf16x8*>(ap); f.m[i] = *reinterpret_cast<const bf16x8*>(ap + WPA); f.l[i] = *reinterpret_cast<const bf16x8*>(ap + 2 * WPA);
+            }
+        };
+        auto read_b = [&](FB& f, int so, int j) {
+            const unsigned char* bp = b_rd + so + j * 32 * WLDB;
+            f.h = *reinterpret_cast<const bf16x8*>(bp); f.m = *reinterpret_cast<const bf16x8*>(bp + WPB); f.l = *reinterpret_cast<const bf16x8*>(bp + 2 * WPB);
+        };
+        // smallest partial products first; the two accumulators of a half alternate so that no MFMA waits on its predecessor
+#define L2S_X3W_TERM(A_, B_, J_)                                                                              \
+        acc[0][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_, acc[0][J_], 0, 0, 0);                \
+        acc[1][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_, acc[1][J_], 0, 0, 0);
+#define L2S_X3W_MMA_HEAD(FA_, FB_, J_) { L2S_X3W_TERM(FA_.l, FB_.h, J_) }
+#define L2S_X3W_MMA_TAIL(FA_, FB_, J_) { L2S_X3W_TERM(FA_.h, FB_.l, J_) L2S_X3W_TERM(FA_.m, FB_.m, J_) L2S_X3W_TERM(FA_.m, FB_.h, J_) L2S_X3W_TERM(FA_.h, FB_.m, J_) L2S_X3W_TERM(FA_.h, FB_.h, J_) }
+        // the LDS reads of a half are issued AFTER its first two MFMAs: right behind the barrier every MFMA wave of the block starts from an empty
+        // pipe, and nine ds_read_b128 in front of the first MFMA were ~150 clk of that bubble per step
+#define L2S_X3W_STEP(KS_, FA_CUR, FA_NXT, SO_)                                                                 \
+        X3_STAMP(KS_, 0);                                                                                      \
+        L2S_X3W_MMA_HEAD(FA_CUR, fb0, 0)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        read_b(fb1, SO_, 1);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        L2S_X3W_MMA_TAIL(FA_CUR, fb0, 0)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        X3_STAMP(KS_, 1);                                                                                      \
+        __syncthreads();              /* this stage is read (fb1 has landed); the other one is written */      \
+        X3_STAMP(KS_, 2);                                                                                      \
+        L2S_X3W_MMA_HEAD(FA_CUR, fb1, 1)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        read_a(FA_NXT, WSTAGE - (SO_)); read_b(fb0, WSTAGE - (SO_), 0);   /* past the last step: unused */     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        L2S_X3W_MMA_TAIL(FA_CUR, fb1, 1)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        X3_STAMP(KS_, 3);
+        FA fa0, fa1;
+        FB fb0, fb1;
+        __syncthreads();                                     // stage 0 ready
+        read_a(fa0, 0); read_b(fb0, 0, 0);
+        int ks = 0;
+        for (; ks + 1 < nks; ks += 2) {                      // pairs of steps: no exit from the middle of the body (the accumulators would be copied at it)
+            L2S_X3W_STEP(ks, fa0, fa1, 0)
+            L2S_X3W_STEP(ks + 1, fa1, fa0, WSTAGE)
+        }
+        if (ks < nks) { L2S_X3W_STEP(ks, fa0, fa1, 0) }
+#undef L2S_X3W_STEP
+#undef L2S_X3W_MMA_HEAD
+#undef L2S_X3W_MMA_TAIL
+#undef L2S_X3W_TERM
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * WN + wn * 64 + j * 32 + li] = acc[i][j][r];
+            __syncthreads();
+            store_rows(i);
+        }
+    }
+}
+
 static bool x3_aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
 // true when every GEMM of the group can run on the split-bf16 kernel (float4-addressable operands, no batch-statistics pass) AND the
@@ -278,16 +554,30 @@ bool gemm_x3_eligible(const GemmBatch& b) {
                          (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= XK) &&
                          (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
         if (!ok4 || p.stats) return false;
-        if (p.x3 != 2 && (p.N < 96 || p.K < 1024)) return false;          // x3 == 2: forced (operator tests run every eligible shape)
+        if (!(p.x3 & 2) && (p.N < 96 || p.K < 1024)) return false;       // x3 bit 2: forced (operator tests run every eligible shape)
         const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);                    // rows of ONE batch of a grouped launch
         tiles += (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
     }
-    return tiles >= (b.count > 1 ? 256 : 100) || b.p[0].x3 == 2;
+    return tiles >= (b.count > 1 ? 256 : 100) || (b.p[0].x3 & 2);
 }
 
 static unsigned long long* g_x3_ts = nullptr;
 static int g_x3_stamp_block = 0;
 void gemm_x3_set_timeline(unsigned long long* ts, int block) { g_x3_ts = ts; g_x3_stamp_block = block; }
+
+// the wide tile pays when it wastes no columns (N a multiple of 256 - every Conv1d / Linear of this path that is eligible at all) and the launch
+// still has at least two tiles per CU; decided on the rows of ONE batch like the eligibility above, so grouping never changes a batch's kernel
+static bool x3_wide(const GemmBatch& b) {
+    if (b.p[0].x3 & 4) return false;                          // mode bit 4 (option "gemm_x3" = 5): the 128x128x32 tile everywhere
+    int64_t tiles = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const GemmP& p = b.p[i];
+        if (p.N % WN != 0 || p.K % WK != 0 || p.a_split % WK != 0 || (p.taps > 1 && p.Cin % WK != 0)) return false;
+        const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);
+        tiles += (int64_t)((m_unit + WM - 1) / WM) * (p.N / WN);
+    }
+    return tiles >= 64 || (b.p[0].x3 & 2);
+}
 
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP && gemm_x3_eligible(b), "split-bf16 gemm: group not eligible");
@@ -297,11 +587,26 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
         maxM = b.p[i].M > maxM ? b.p[i].M : maxM;
         maxN = b.p[i].N > maxN ? b.p[i].N : maxN;
     }
+    ProfScope ps(name, s);
+    if (x3_wide(b)) {
+        dim3 grid((maxN + WN - 1) / WN, (maxM + WM - 1) / WM, b.count);
+        constexpr int LDS_BYTES = 2 * WSTAGE;                 // 110 592
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        L2S_CHECK_HIP(attr);
+        if (g_x3_ts) {
+            static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            L2S_CHECK_HIP(attr_t);
+            hipLaunchKernelGGL(gemm_x3w_kernel<true>, grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
+        } else {
+            hipLaunchKernelGGL(gemm_x3w_kernel<false>, grid, dim3(WTHREADS), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
+        }
+        L2S_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     dim3 grid((maxN + XN - 1) / XN, (maxM + XM - 1) / XM, b.count);
     constexpr int LDS_BYTES = 2 * 6 * XPLANE;              // 122 880: two operand stages (one block per CU)
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     L2S_CHECK_HIP(attr);
-    ProfScope ps(name, s);
     if (g_x3_ts) {
         static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         L2S_CHECK_HIP(attr_t);

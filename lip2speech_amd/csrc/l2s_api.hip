@@ -1693,13 +1693,13 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 }
 int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                    int K, int act, int flags, void* stream) {
-    X3Scope x3scope((flags & 1) ? 2 : 0);
+    X3Scope x3scope((flags & 1) ? (3 | (flags & 4)) : 0);      // forced; flags bit 4: the narrow tile
     Bf16Scope bf16scope((flags & 2) ? 1 : 0);
     return l2s_op_gemm(A, Wt, scale, shift, actw, C, M, N, K, act, stream);
 }
 int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
                      int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream) {
-    X3Scope x3scope((flags & 1) ? 2 : 0);
+    X3Scope x3scope((flags & 1) ? (3 | (flags & 4)) : 0);      // forced; flags bit 4: the narrow tile
     Bf16Scope bf16scope((flags & 2) ? 1 : 0);
     return l2s_op_conv1d(X, Wp, scale, shift, actw, out, B, Tin, Cin, Cout, taps, stride, pad, act, stream);
 }

@@ -61,7 +61,7 @@ struct Options {
     int skinny_flat = 1;        // "skinny_flat": launches with several GEMM groups at >= 64 rows run per-group block shapes in one flat grid of at most one
                                 //   block per CU (the step's first phase), instead of one block shape for every group
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
-    int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible
+    int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible; 5 = its 128x128x32 tile only
     int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)
     int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
     int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
@@ -98,7 +98,8 @@ struct GemmP {
     const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
     int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
     int ldw;              // row stride of W in floats (0: K) - a K slice of a wider matrix (split-K)
-    int x3;               // 1: run on the split-bf16 kernel (gemm_x3.hip) when the whole launch group is eligible; set from gemm_x3_mode()
+    int x3;               // bit 1: run on the split-bf16 kernel (gemm_x3.hip) when the whole launch group is eligible; bit 2: whatever its size
+                          //   (operator tests); bit 4: the 128x128x32 tile only; set from gemm_x3_mode()
     int x3_group;         // batches sharing this launch (grouped inference): the size thresholds of the kernel choice look at M / x3_group,
                           //   so a batch meets the same kernels alone and in a group (results stay bit-identical)
     float* stats;         // training, batch-statistics BatchNorm: STATS PASS - nothing is stored; per-column sums of the raw product

@@ -60,6 +60,22 @@ def test_gemm_split_bf16_operator(M, N, K, act):
     assert e3 < 2e-5 and e3 <= 1.5 * e32 + 1e-7, (e3, e32)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(9600, 512, 2560, 3), (1000, 256, 1040, 0), (129, 768, 48, 1), (333, 512, 20, 0)])
+def test_gemm_split_bf16_tiles_agree(M, N, K, act):
+    """the 128x256x16 tile (eight MFMA waves; default where N is a multiple of 256) and the 128x128x32 tile accumulate every output in the same
+    order: bit-identical, ragged M and K (odd number of K steps, K tail of 4) included"""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K).cuda()
+    W = (torch.randn(N, K) / K ** 0.5).cuda()
+    sc, sh, aw = (torch.rand(N) + 0.5).cuda(), torch.randn(N).cuda(), (torch.rand(N) + 0.5).cuda()
+    wide = native.op_gemm(A, W, sc, sh, aw, act, x3=True)
+    narrow = native.op_gemm(A, W, sc, sh, aw, act, x3=True, x3_narrow=True)
+    assert torch.equal(wide, narrow)
+    ref = (A.double() @ W.double().t()) * sc.double() + sh.double()
+    ref = [ref, ref.relu(), ref * torch.sigmoid(ref), torch.sin(ref) * aw.double()][act]
+    assert pc.maxdiff(wide, ref) < 2e-5
+
+
 @pytest.mark.parametrize("B,T,Ci,Co,k,st,pad", [(32, 300, 512, 512, 5, 1, 2), (2, 29, 512, 512, 11, 1, 5), (3, 40, 80, 512, 5, 1, 2), (2, 29, 512, 512, 3, 3, 0)])
 def test_conv1d_split_bf16_operator(B, T, Ci, Co, k, st, pad):
     torch.manual_seed(T + k)
@@ -69,6 +85,7 @@ def test_conv1d_split_bf16_operator(B, T, Ci, Co, k, st, pad):
     out = native.op_conv1d(X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad, x3=True)
     ref = torch.nn.functional.conv1d(X.double().permute(0, 2, 1), Wt.double(), stride=st, padding=pad).permute(0, 2, 1)
     assert pc.maxdiff(out, ref) < 2e-5
+    assert torch.equal(out, native.op_conv1d(X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad, x3=True, x3_narrow=True))      # both tiles: same bits
 
 
 @pytest.mark.parametrize("M,N,K", [(9600, 512, 2560), (300, 200, 64), (130, 129, 36)])
