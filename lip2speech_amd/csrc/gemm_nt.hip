@@ -320,6 +320,20 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
     bool x3 = vec4;
     for (int i = 0; i < b.count; ++i) x3 = x3 && b.p[i].x3 != 0;
     if (x3 && gemm_x3_eligible(b)) return launch_gemm_x3(b, s, name);
+    if (x3 && b.count > 1) {
+        // a group with members that cannot run on the split-bf16 kernel (the k = 1 MultiHop convs: K = 512) used to keep ALL of it on the f32
+        // kernel; the members that can (per member, on one batch's rows: the same choice alone and in a group) now go there as their own launch
+        GemmBatch yes{}, no{};
+        for (int i = 0; i < b.count; ++i) {
+            GemmBatch one{}; one.p[0] = b.p[i]; one.p[0].x3 |= 2; one.count = 1;       // member-level test: shape only, no size threshold
+            if (gemm_x3_eligible(one) && b.p[i].K >= 1024 && b.p[i].N >= 96) yes.p[yes.count++] = b.p[i];
+            else no.p[no.count++] = b.p[i];
+        }
+        if (yes.count >= 1 && no.count >= 1 && gemm_x3_eligible(yes)) {
+            if (launch_gemm_x3(yes, s, name)) return 1;
+            return launch_gemm(no, s, name);
+        }
+    }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count);
     ProfScope ps(name, s);
     const bool bf16 = gemm_bf16_mode() != 0;                 // training, option "train_bf16": bf16 operands, fp32 accumulation

@@ -558,25 +558,29 @@ bool gemm_x3_eligible(const GemmBatch& b) {
         const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);                    // rows of ONE batch of a grouped launch
         tiles += (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
     }
-    return tiles >= (b.count > 1 ? 256 : 100) || (b.p[0].x3 & 2);
+    return tiles >= (b.count > 1 ? 150 : 100) || (b.p[0].x3 & 2);
 }
 
 static unsigned long long* g_x3_ts = nullptr;
 static int g_x3_stamp_block = 0;
 void gemm_x3_set_timeline(unsigned long long* ts, int block) { g_x3_ts = ts; g_x3_stamp_block = block; }
 
-// the wide tile pays when it wastes no columns (N a multiple of 256 - every Conv1d / Linear of this path that is eligible at all) and the launch
-// still has at least two tiles per CU; decided on the rows of ONE batch like the eligibility above, so grouping never changes a batch's kernel
+// Which tile: both give the same bits, so the choice is free per launch.  The wide tile needs N, K, Cin and the A split to fit its uniform K steps, and
+// it pays when the launch runs in fewer "rounds" of 256 blocks x tile time: a wide tile takes ~1.7x a narrow one for twice the work (2 250 against
+// 2 x 1 320 clk per 16 k), so 9600 x 512 (150 wide tiles, one round, against 300 narrow = two) wins and 7424 x 512 (116 against 232: one round each) loses;
+// grouped launches whose members differ in K (the MultiHop convs) have a longer tail with the longer tile and need a clearer margin.
 static bool x3_wide(const GemmBatch& b) {
-    if (b.p[0].x3 & 4) return false;                          // mode bit 4 (option "gemm_x3" = 5): the 128x128x32 tile everywhere
-    int64_t tiles = 0;
+    if (b.p[0].x3 & 4) return false;                          // mode bit 4 (option "gemm_x3" = 5, operator flag 4): the 128x128x32 tile everywhere
+    int64_t wide = 0, narrow = 0;
     for (int i = 0; i < b.count; ++i) {
         const GemmP& p = b.p[i];
         if (p.N % WN != 0 || p.K % WK != 0 || p.a_split % WK != 0 || (p.taps > 1 && p.Cin % WK != 0)) return false;
-        const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);
-        tiles += (int64_t)((m_unit + WM - 1) / WM) * (p.N / WN);
+        wide += (int64_t)((p.M + WM - 1) / WM) * (p.N / WN);
+        narrow += (int64_t)((p.M + XM - 1) / XM) * ((p.N + XN - 1) / XN);
     }
-    return tiles >= 64 || (b.p[0].x3 & 2);
+    if (b.p[0].x3 & 2) return true;                           // forced (operator tests): the wide tile wherever it fits
+    const double cost_w = (double)((wide + 255) / 256) * (b.count > 1 ? 2.0 : 1.7), cost_n = (double)((narrow + 255) / 256);
+    return cost_w < cost_n;
 }
 
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {

@@ -38,15 +38,16 @@ span = t[:, :nkt, :4].max()
 print(f"block {block}: stamped span of the K loop {span:.0f} ticks over {nkt} K tiles = {span / nkt:.0f} ticks per K tile")
 per = np.diff(c[:, :, 0], axis=1)                       # consumer tile period
 print(f"consumer K-tile period (ticks) median {np.median(per):.0f}, 10/90 % {np.percentile(per, 10):.0f} / {np.percentile(per, 90):.0f}")
-print("consumers (median ticks per tile):  24 MFMAs issued {:.0f} | barrier wait {:.0f} | next 24 issued {:.0f}".format(
+NM = 24 if NARROW else 12
+print(f"MFMA waves (median ticks per tile):  first {NM} MFMAs issued {{:.0f}} | barrier wait {{:.0f}} | next {NM} issued {{:.0f}}".format(
     np.median(c[:, 2:, 1] - c[:, 2:, 0]), np.median(c[:, 2:, 2] - c[:, 2:, 1]), np.median(c[:, 2:, 3] - c[:, 2:, 2])))
 pv = p[:, 2:nkt - 3]
-print("producers (median ticks per tile):  fetch issue + wait for the older set {:.0f} | split + LDS writes {:.0f} | barrier wait {:.0f}".format(
+print("staging waves (median ticks per tile):  fetch issue + wait for the older set {:.0f} | split + LDS writes {:.0f} | barrier wait {:.0f}".format(
     np.median(pv[:, :, 1] - pv[:, :, 0]), np.median(pv[:, :, 2] - pv[:, :, 1]), np.median(pv[:, :, 3] - pv[:, :, 2])))
 if not NARROW: print("producers: address arithmetic + 6 load requests {:.0f} | wait for the set requested two steps ago {:.0f}".format(
     np.median(pv[:, :, 4] - pv[:, :, 0]), np.median(pv[:, :, 1] - pv[:, :, 4])))
 if NARROW: print("producers: split VALU (older set landed -> all 16 splits in registers) {:.0f} | 24 ds_write_b64 + lgkmcnt(0) {:.0f}".format(
     np.median(pv[:, :, 4] - pv[:, :, 1]), np.median(pv[:, :, 2] - pv[:, :, 4])))
-print("first 12 K tiles, wave 0 (consumer) and wave 4 (producer), ticks since the block's first stamp:")
+print("first 12 K tiles, MFMA wave 0 (tile start / first half issued / past the barrier / second half issued) and the first staging wave (tile start / older set landed / stores done / past the barrier), ticks since the block's first stamp:")
 for kt in range(min(12, nkt)):
-    print(f"  kt {kt:2d}  consumer " + " ".join(f"{v:7.0f}" for v in c[0, kt]) + "   producer " + " ".join(f"{v:7.0f}" for v in p[0, kt]))
+    print(f"  kt {kt:2d}  MFMA wave " + " ".join(f"{v:7.0f}" for v in c[0, kt, :4]) + "   staging wave " + " ".join(f"{v:7.0f}" for v in p[0, kt, :4]))
