@@ -326,7 +326,10 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         GemmBatch yes{}, no{};
         for (int i = 0; i < b.count; ++i) {
             GemmBatch one{}; one.p[0] = b.p[i]; one.p[0].x3 |= 2; one.count = 1;       // member-level test: shape only, no size threshold
-            if (gemm_x3_eligible(one) && b.p[i].K >= 1024 && b.p[i].N >= 96) yes.p[yes.count++] = b.p[i];
+            GemmBatch own{}; own.p[0] = b.p[i]; own.count = 1;                         // with its own x3 mode: the N / K / rows-per-batch rules
+            GemmP& q = own.p[0];
+            const bool member_ok = gemm_x3_eligible(one) && q.N >= 96 && (q.K >= 1024 || (q.K >= 384 && (int64_t)((q.M / (q.x3_group > 1 ? q.x3_group : 1) + 127) / 128) * ((q.N + 127) / 128) >= 128));
+            if (member_ok) yes.p[yes.count++] = b.p[i];
             else no.p[no.count++] = b.p[i];
         }
         if (yes.count >= 1 && no.count >= 1 && gemm_x3_eligible(yes)) {

@@ -554,9 +554,12 @@ bool gemm_x3_eligible(const GemmBatch& b) {
                          (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= XK) &&
                          (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
         if (!ok4 || p.stats) return false;
-        if (!(p.x3 & 2) && (p.N < 96 || p.K < 1024)) return false;       // x3 bit 2: forced (operator tests run every eligible shape)
         const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);                    // rows of ONE batch of a grouped launch
-        tiles += (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
+        const int64_t t_unit = (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
+        // short K (the post-net's first layer: K = 400; conv_last: K = 464) only pays with many rows per batch: 9600 x 512 x 400 runs 42 us
+        // against 52 on the f32 kernel, 928 x 512 x 512 36 against 21 (tools/time_gemm_shapes.py)
+        if (!(p.x3 & 2) && (p.N < 96 || p.K < 384 || (p.K < 1024 && t_unit < 128))) return false;       // x3 bit 2: forced (operator tests run every eligible shape)
+        tiles += t_unit;
     }
     return tiles >= (b.count > 1 ? 150 : 100) || (b.p[0].x3 & 2);
 }
