@@ -10,6 +10,7 @@
 //  pool_norm_cat     : AvgPool(3x3) + L2 normalise + concatenation with the tiled speaker embedding
 //                      (video.py:81-85, model.py:52-55).
 #include "l2s_common.h"
+#include <type_traits>
 
 namespace l2s {
 
@@ -738,101 +739,78 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, 
     // phase 1: pw1 + BN + ReLU, in place
     su_gemm<typename Q::GM, LDA>(buf, p.w1f, p.s1, p.b1);
     SU_STAMP(3);
-    // phase 2: depthwise 3x3 (pad 1) + BN, in place.  From 116 channels per branch on, a lane takes TWO channels (8-byte LDS reads, float2
-    // FMAs): one pass over the pixels instead of two, half the reads / address arithmetic / border selects per value (6x6 unit 263 -> 236 us,
-    // 3x3 unit 287 -> 272 us at 256 clips).  With 58 channels one pass already covers them and the pair form only idles half the lanes
-    // (12x12 unit 370 -> 377 us): it keeps one channel per lane.  Per channel the arithmetic (tap order, fma chain) is the same in both forms.
+    // phase 2: depthwise 3x3 (pad 1) + BN, in place.  A wave takes whole pixel ROWS (row R = wave + 8*r over the block's F*H rows) and slides a 3x3
+    // window along x: every input value of the three rows is read from LDS ONCE (3 reads per output instead of 9), the x borders are compile-time
+    // (their taps are simply not issued), the y borders are two wave-uniform flags that zero the upper / lower tap weights.  Per output the FMA chain
+    // is the tap-ordered one of the pixel-per-wave form it replaces: a skipped or zero-weight tap adds exactly +-0 to an accumulator that is never -0,
+    // so the results are the same bits.  The CU is bound by VALU + MFMA issue over its two blocks (phase timelines: 16-byte input loads / output stores,
+    // a quarter of the instructions, cut the input phase from 5.9 to 3.3 us and only moved the wait - block lifetime 23.2 -> 23.0 us - at 10 more
+    // registers; not kept), and this phase was 1 100 VALU / LDS instructions per wave of ~36 per output.  From 116 channels per branch on a lane takes TWO
+    // channels (8-byte LDS reads, float2 FMAs); with 58 the pair form only idles half the lanes and a lane keeps one channel.
     constexpr bool PAIRS = HALF > 64;
-    if constexpr (PAIRS) {
-        typedef float su_f2 __attribute__((ext_vector_type(2)));
-        constexpr int CH2 = (HALF + 127) / 128;
-        static_assert(HALF % 2 == 0 && LDA % 2 == 0, "channel pairs");
-        su_f2 dv[CH2][PPW];
+    constexpr int NROW = F * H, RPW = (NROW + 7) / 8;
+    typedef float su_f2 __attribute__((ext_vector_type(2)));
+    using DV = std::conditional_t<PAIRS, su_f2, float>;
+    constexpr int DW = PAIRS ? 2 : 1;                         // channels per lane
+    constexpr int CHD = (HALF + 64 * DW - 1) / (64 * DW);     // channel passes
+    DV dv[CHD][RPW][H];
+    const DV zero = DV{};
 #pragma unroll
-        for (int jc = 0; jc < CH2; ++jc) {
-            const int c = min(2 * lane + 128 * jc, HALF - 2);
-            su_f2 wk[9];
+    for (int jc = 0; jc < CHD; ++jc) {
+        const int c = min(DW * lane + 64 * DW * jc, HALF - DW);
+        DV wk[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const su_f2*>(p.wd + t * HALF + c);
-            const su_f2 sd = *reinterpret_cast<const su_f2*>(p.sd + c), bd = *reinterpret_cast<const su_f2*>(p.bd + c);
-            const su_f2 zero2 = {0.f, 0.f};
+        for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const DV*>(p.wd + t * HALF + c);
+        const DV sd = *reinterpret_cast<const DV*>(p.sd + c), bd = *reinterpret_cast<const DV*>(p.bd + c);
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int m = wave + 8 * i;                   // wave-uniform
-                su_f2 acc = zero2;
-                if (m < Mv) {
-                    const int f = m / HH, q = m - f * HH;
-                    const int y = q / H, x = q - y * H;
-                    const float* rb = buf + (f * HH) * LDA + c;
-                    // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
-                    // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
+        for (int r = 0; r < RPW; ++r) {
+            const int R = wave + 8 * r;                       // wave-uniform
+            if (R * H < Mv) {
+                const int y = R % H;
+                const bool up = y > 0, dn = y < H - 1;
+                const float* rm = buf + (R * H) * LDA + c;    // this row; the rows above / below (or this one again, under zero weights)
+                const float* ru = rm - (up ? H * LDA : 0);
+                const float* rd = rm + (dn ? H * LDA : 0);
+                DV wu[3], wdn[3];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
+                for (int k = 0; k < 3; ++k) { wu[k] = up ? wk[k] : zero; wdn[k] = dn ? wk[6 + k] : zero; }
+                DV a0 = zero, a1 = zero, a2 = zero;
+                DV b0 = *reinterpret_cast<const DV*>(ru), b1 = *reinterpret_cast<const DV*>(rm), b2 = *reinterpret_cast<const DV*>(rd);
+                DV c0 = zero, c1 = zero, c2 = zero;
+                if constexpr (H > 1) { c0 = *reinterpret_cast<const DV*>(ru + LDA); c1 = *reinterpret_cast<const DV*>(rm + LDA); c2 = *reinterpret_cast<const DV*>(rd + LDA); }
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int yy = y + ky - 1, xx = x + kx - 1;
-                            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
-                            const su_f2 v = *reinterpret_cast<const su_f2*>(rb + (in ? yy * H + xx : q) * LDA);
-                            acc = __builtin_elementwise_fma(v, in ? wk[ky * 3 + kx] : zero2, acc);
-                        }
+                for (int x = 0; x < H; ++x) {
+                    DV acc = zero;
+                    if (x > 0) acc = __builtin_elementwise_fma(a0, wu[0], acc);
+                    acc = __builtin_elementwise_fma(b0, wu[1], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c0, wu[2], acc);
+                    if (x > 0) acc = __builtin_elementwise_fma(a1, wk[3], acc);
+                    acc = __builtin_elementwise_fma(b1, wk[4], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c1, wk[5], acc);
+                    if (x > 0) acc = __builtin_elementwise_fma(a2, wdn[0], acc);
+                    acc = __builtin_elementwise_fma(b2, wdn[1], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c2, wdn[2], acc);
+                    dv[jc][r][x] = acc * sd + bd;
+                    a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+                    if (x + 2 < H) {
+                        c0 = *reinterpret_cast<const DV*>(ru + (x + 2) * LDA); c1 = *reinterpret_cast<const DV*>(rm + (x + 2) * LDA);
+                        c2 = *reinterpret_cast<const DV*>(rd + (x + 2) * LDA);
                     }
                 }
-                dv[jc][i] = acc * sd + bd;
             }
         }
-        SU_STAMP(4);                                          // depthwise taps computed
-        __syncthreads();
+    }
+    SU_STAMP(4);                                          // depthwise taps computed
+    __syncthreads();
 #pragma unroll
-        for (int jc = 0; jc < CH2; ++jc) {
-            const int c = 2 * lane + 128 * jc;
+    for (int jc = 0; jc < CHD; ++jc) {
+        const int c = DW * lane + 64 * DW * jc;
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int m = wave + 8 * i;
-                if (m < Mv && c < HALF) *reinterpret_cast<su_f2*>(buf + m * LDA + c) = dv[jc][i];
-            }
-        }
-    } else {
-        constexpr int CH = Q::CH;
-        float dv[CH][PPW];
+        for (int r = 0; r < RPW; ++r) {
+            const int R = wave + 8 * r;
+            if (R * H < Mv && c < HALF) {
 #pragma unroll
-        for (int jc = 0; jc < CH; ++jc) {
-            const int c = min(lane + 64 * jc, HALF - 1);
-            float wk[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wk[t] = p.wd[t * HALF + c];
-            const float sd = p.sd[c], bd = p.bd[c];
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int m = wave + 8 * i;                   // wave-uniform
-                float acc = 0.f;
-                if (m < Mv) {
-                    const int f = m / HH, q = m - f * HH;
-                    const int y = q / H, x = q - y * H;
-                    const float* rb = buf + (f * HH) * LDA + c;
-                    // border taps are predicated, not branched around: tap weight 0 and a safe address (v * 0 adds exactly 0),
-                    // so the nine LDS reads of a pixel issue back to back instead of behind eighteen scalar branches
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int yy = y + ky - 1, xx = x + kx - 1;
-                            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;
-                            acc = fmaf(rb[(in ? yy * H + xx : q) * LDA], in ? wk[ky * 3 + kx] : 0.f, acc);
-                        }
-                    }
-                }
-                dv[jc][i] = acc * sd + bd;
-            }
-        }
-        SU_STAMP(4);                                          // depthwise taps computed
-        __syncthreads();
-#pragma unroll
-        for (int jc = 0; jc < CH; ++jc) {
-            const int c = lane + 64 * jc;
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int m = wave + 8 * i;
-                if (m < Mv && c < HALF) buf[m * LDA + c] = dv[jc][i];
+                for (int x = 0; x < H; ++x) *reinterpret_cast<DV*>(buf + (R * H + x) * LDA + c) = dv[jc][r][x];
             }
         }
     }
