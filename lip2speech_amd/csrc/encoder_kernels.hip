@@ -611,21 +611,9 @@ struct SuGemm {
 // operand and result. Work item = (column tile, group of G row tiles); the last group is shifted back so every item
 // has exactly G tiles (an overlapped tile is computed twice with identical results) - no data-dependent guards around
 // the MFMAs. One buffer instead of two is what lets two blocks share a CU.
-// the weight strip of a wave's FIRST work item, requested ahead of the phase that produces the GEMM's operand (su_gemm<.., PRE = true>): the L2
-// round trip (~1 us at the head of every pointwise conv) then runs under the input wait / the depthwise phase
-template <class GM>
-__device__ __forceinline__ void su_gemm_prefetch(const float* __restrict__ Wf, float4 (&b4)[GM::NC]) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nt = wave % GM::NT;                        // item = wave < 8 <= ITEMS for every geometry of this path (static_assert in the caller)
-    const float4* wb = reinterpret_cast<const float4*>(Wf) + nt * (GM::NC * 64) + lane;
-#pragma unroll
-    for (int c = 0; c < GM::NC; ++c) b4[c] = wb[c * 64];
-}
-
-template <class GM, int LDA, bool PRE = false>
+template <class GM, int LDA>
 __device__ __forceinline__ void su_gemm(float* __restrict__ buf, const float* __restrict__ Wf,
-                                        const float* __restrict__ scale, const float* __restrict__ shift, const float4* pre = nullptr) {
+                                        const float* __restrict__ scale, const float* __restrict__ shift) {
     constexpr int NC = GM::NC, G = GM::G, IT = GM::IT, NT = GM::NT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -643,7 +631,7 @@ __device__ __forceinline__ void su_gemm(float* __restrict__ buf, const float* __
             const float* ab = buf + (mt0 * 16 + li) * LDA + 4 * lg;
             float4 b4[NC];                               // the whole K strip of this column tile: one round trip to L2
 #pragma unroll
-            for (int c = 0; c < NC; ++c) b4[c] = (PRE && it == 0) ? pre[c] : wb[c * 64];
+            for (int c = 0; c < NC; ++c) b4[c] = wb[c * 64];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -725,10 +713,6 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, 
         for (int j = 0; j < CIT; ++j)
             xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
     }
-    static_assert(Q::GM::ITEMS >= 8, "every wave has a first work item (su_gemm_prefetch)");
-    constexpr bool PREW2 = Q::GM::NC <= 8;                // the second strip waits in registers across the depthwise phase: 16-32 of them, not 60
-    float4 wpre[Q::GM::NC];
-    if constexpr (PREW2) su_gemm_prefetch<typename Q::GM>(p.w1f, wpre);       // pw1's strip lands under the input wait
     // zero the K padding columns and the padded rows (the GEMMs read them; 0 * weight-padding must stay 0)
     if (KP > HALF) {
         for (int idx = tid; idx < ROWS * (KP - HALF); idx += 512) {
@@ -753,10 +737,8 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, 
     __syncthreads();
     SU_STAMP(2);
     // phase 1: pw1 + BN + ReLU, in place
-    if constexpr (PREW2) su_gemm<typename Q::GM, LDA, true>(buf, p.w1f, p.s1, p.b1, wpre);
-    else su_gemm<typename Q::GM, LDA>(buf, p.w1f, p.s1, p.b1);
+    su_gemm<typename Q::GM, LDA>(buf, p.w1f, p.s1, p.b1);
     SU_STAMP(3);
-    if constexpr (PREW2) su_gemm_prefetch<typename Q::GM>(p.w2f, wpre);       // pw2's strip lands under the depthwise phase
     // phase 2: depthwise 3x3 (pad 1) + BN, in place.  A wave takes whole pixel ROWS (row R = wave + 8*r over the block's F*H rows) and slides a 3x3
     // window along x: every input value of the three rows is read from LDS ONCE (3 reads per output instead of 9), the x borders are compile-time
     // (their taps are simply not issued), the y borders are two wave-uniform flags that zero the upper / lower tap weights.  Per output the FMA chain
@@ -835,8 +817,7 @@ __global__ __launch_bounds__(512, 4) void shuffle_s1_kernel(const ShuffleS1P p, 
     __syncthreads();
     SU_STAMP(5);
     // phase 3: pw2 + BN + ReLU, in place
-    if constexpr (PREW2) su_gemm<typename Q::GM, LDA, true>(buf, p.w2f, p.s2, p.b2, wpre);
-    else su_gemm<typename Q::GM, LDA>(buf, p.w2f, p.s2, p.b2);
+    su_gemm<typename Q::GM, LDA>(buf, p.w2f, p.s2, p.b2);
     SU_STAMP(6);
     // phase 4: channel_shuffle store: out[2k] = x1[k] (register), out[2k+1] = branch[k] (LDS) as one 8-byte store
 #pragma unroll
