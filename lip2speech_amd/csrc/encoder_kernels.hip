@@ -961,8 +961,9 @@ __device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* _
     }
 }
 
-template <int H, int CIN, int HALF, int RO>
-__global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) {
+#define S2_STAMP(k) do { if (TIMED && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 10 + (k)] = wall_clock64(); } while (0)
+template <int H, int CIN, int HALF, int RO, bool TIMED>
+__global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p, unsigned long long* __restrict__ ts) {
     using Q = S2Geo<H, CIN, HALF, RO>;
     constexpr int HO = Q::HO, KIN = Q::KIN, KH = Q::KH, LDA = Q::LDA, MTI = Q::MTI, MTO = Q::MTO, CIN4 = CIN / 4;
     extern __shared__ __attribute__((aligned(16))) float su_smem[];
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) 
     float* X = su_smem;
     float* D1 = X + MTI * 16 * LDA;
     float* D2 = D1 + MTO * 16 * LDA;
+    S2_STAMP(0);
 
     // the tile's rows inside the frame are one contiguous run of (pixel, channel) floats in HBM: float4 loads, LDS row per pixel.
     // Tile rows outside the frame are never written and never read by the depthwise taps; the GEMM turns them into garbage
@@ -984,9 +986,22 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) 
     const int n4 = (iy_hi - iy_lo) * (H * CIN4);
     const float4* src4 = reinterpret_cast<const float4*>(p.x + ((int64_t)f * H + iy_lo) * (H * CIN));
     float* xt = X + (iy_lo - iy0) * (H * LDA);
-    for (int idx = tid; idx < n4; idx += 512) {
-        const int px = idx / CIN4, c4 = idx - px * CIN4;
-        *reinterpret_cast<float4*>(xt + px * LDA + 4 * c4) = src4[idx];
+    // every request before the first LDS write: as a rolled load -> store loop this was one memory round trip per trip (stamped: 6.4 us of a 26 us
+    // block at stage 3, four trips)
+    constexpr int NLD = (Q::RIN * H * CIN4 + 511) / 512;
+    float4 xin[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        xin[i] = idx < n4 ? src4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        if (idx < n4) {
+            const int px = idx / CIN4, c4 = idx - px * CIN4;
+            *reinterpret_cast<float4*>(xt + px * LDA + 4 * c4) = xin[i];
+        }
     }
     // zero the K padding columns (0 * weight padding must stay 0, and LDS garbage may be NaN)
     if (KIN > CIN) {
@@ -1001,17 +1016,24 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) 
             D2[m * LDA + k] = 0.f;
         }
     }
+    S2_STAMP(1);
     __syncthreads();
+    S2_STAMP(2);
     // banch1: depthwise s2 + BN of x -> D1 (must read x before pw1 overwrites it in place)
     su_dw_s2<H, HO, LDA, CIN>(X, D1, iy0, outv, p.wd1, p.sd1, p.bd1);
+    S2_STAMP(3);
     // banch2: pw1 + BN + ReLU at full resolution, in place (its first barrier also orders the D1 reads of x before the overwrite)
     su_gemm<typename Q::G1, LDA>(X, p.w1f, p.s1, p.b1);
+    S2_STAMP(4);
     // banch2: depthwise s2 + BN -> D2
     su_dw_s2<H, HO, LDA, HALF>(X, D2, iy0, outv, p.wd, p.sd, p.bd);
     __syncthreads();
+    S2_STAMP(5);
     // the two output-resolution pointwise convs + BN + ReLU, in place
     su_gemm<typename Q::G2, LDA>(D1, p.wb1f, p.sb1, p.bb1);
+    S2_STAMP(6);
     su_gemm<typename Q::G3, LDA>(D2, p.w2f, p.s2, p.b2);
+    S2_STAMP(7);
     // channel_shuffle store: out[2k] = banch1[k], out[2k+1] = banch2[k]
     float* ob = p.out + ((int64_t)f * HO + oy0) * (HO * 2 * HALF);
     for (int m = wave; m < outv; m += 8) {
@@ -1026,6 +1048,7 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p) 
             }
         }
     }
+    if (TIMED) { __builtin_amdgcn_s_waitcnt(0); S2_STAMP(8); }
 }
 
 template <int H, int CIN, int HALF, int RO>
@@ -1034,11 +1057,15 @@ static int launch_s2_inst(const ShuffleS2P& p, hipStream_t s) {
     static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO>),
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
         attr_set = true;
     }
-    hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p);
+    // measurement hook: l2s_op_fused_unit_timeline(ts, -H) stamps the stride-2 unit whose INPUT is H x H
+    if (g_su_ts && g_su_ts_h == -H) hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO, true>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, g_su_ts);
+    else hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO, false>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 
