@@ -302,10 +302,12 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
  * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
 int l2s_op_skinny_timeline(void* ts_dev);
 /* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
-   ([wave][96 K tiles][4 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
+   ([12 waves][96 K tiles][8 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block);
 /* measurement: the same for the fused stride-1 ShuffleNet units of spatial size h (12, 6 or 3; the last such launch leaves its stamps) - 10 x 64-bit words per block to ts_dev[block*10 ..]: 8 stamps (entry,
- * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID */
+ * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID.  h = -24 / -12 / -6: the
+ * stride-2 unit whose INPUT map is that size (9 stamps: entry, input issued, after the barrier, banch1 depthwise, banch2 pw1, banch2 depthwise, banch1 pw,
+ * banch2 pw2, stores drained; block = frame * strips + strip).  ([wave][96 K tiles][8 slots] for the GEMM hook above.) */
 int l2s_op_fused_unit_timeline(void* ts_dev, int h);
 /* measurement: n back-to-back launches of the decode step's attention kernel alone on the state of l2s_decoder_prologue (zero queries): whether a
  * clip's K / V survive in its XCD's L2 between launches when nothing else runs in between (tools/attn_l2_probe.py; workspace: l2s_workspace_bytes) */
