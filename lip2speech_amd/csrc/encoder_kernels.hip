@@ -410,6 +410,234 @@ __global__ __launch_bounds__(256, 3) void frontend3d_x3_kernel(const FrontendW w
     }
 }
 
+// ------------------------------------------------------------------------------------------------ frontend, two output frames per block
+// The same operator with the temporal reuse a Conv3d offers: input frame tau feeds output frame t through tap kt = tau - t + 2, so a block that
+// produces TWO consecutive output frames (t0, t0 + 1) stages every input slab ONCE for both (6 slabs per input channel instead of 2 x 5) and lets
+// their 2 x 24 output channels share the N axis: 48 = three 16-wide tiles of v_mfma_f32_16x16x32_bf16, exactly - where one frame's 24 channels
+// pad a 32-wide tile by a third.  K step = 32 = four kernel rows x 8 column slots (rows 0-3, then rows 4-6 + the zero row).  Per input channel:
+// 16 column tiles (edge slabs carry one frame: two tiles) where 15 is ideal; padded MFMA work 1.88x -> 1.5x of the algorithm.
+// Column q of the N axis = (output frame o = q / 24, channel q % 24); the weight operand of a slab is assembled in LDS from the two temporal taps
+// it serves - rows taken straight from the packed planes of frontend3d_x3_kernel ([slab][4 steps of two kernel rows][3 planes][32 co][48-byte
+// rows]: kernel row r = 2 s' + half is the 16-byte half of step s'), an absent tap as zero rows.  120 accumulator registers: two blocks per CU.
+// Accumulation order per output differs from the one-frame kernel only inside the MFMA (32 k per instruction instead of 16): rounding-level.
+template <int HW>
+__global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
+    constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
+    constexpr int P = FE_CR * Wc;                    // conv pixels per strip
+    constexpr int PT = (P + 15) / 16;                // 16-pixel MFMA row tiles
+    constexpr int TPW = (PT + 3) / 4;                // tiles per wave
+    constexpr int XLD = FxGeom<HW>::XLD, PLANE = FxGeom<HW>::PLANE;
+    constexpr int XS = 3 * PLANE;                    // bytes: input planes
+    constexpr int WROW = 48, WSP = 24 * WROW;        // weight row; bytes per (step, plane) of one output frame: 24 channel rows
+    constexpr int WSO = 12 * WSP;                    // bytes per output frame: 4 steps x 3 planes
+    constexpr int WS = 2 * WSO;                      // 27 648
+    constexpr int CS = P * (FE_CO / 2) * 4;          // conv tile of half the channels of one output frame (aliases the operand area)
+    constexpr int SMEM = (XS + 2 * WS) > CS ? (XS + 2 * WS) : CS;     // two weight buffers: 76.8 KB, two blocks per CU
+    constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
+    constexpr int NWU = WS / 16, NWC = NWU / 64;                    // weight uint4 per slab; 1-KB pieces of the weight operand
+    static_assert(NWU % 64 == 0, "the weight operand is a whole number of wave-wide 16-byte pieces");
+    constexpr int SRC_SP = 32 * WROW / 16;           // uint4 per (step, plane) in the packed source (32 channel rows)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Xs = smem;
+    unsigned char* const Ws0 = smem + XS;
+
+    const int NPAIR = (T + 1) / 2;
+    const int bg = blockIdx.y / NPAIR, t0 = 2 * (blockIdx.y - bg * NPAIR);
+    const bool has1 = t0 + 1 < T;                    // block-uniform
+    const int grp = bg / vsrc.per, b = bg - grp * vsrc.per;
+    const float* __restrict__ video = vsrc.p[grp];
+    const int p0 = blockIdx.x * FE_PR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, kg = lane >> 4;
+
+    for (int i = tid; i < XS / 16; i += 256) reinterpret_cast<uint4*>(Xs)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    int base[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        int p = (wave + 4 * j) * 16 + li;
+        p = p < P ? p : P - 1;
+        const int lr = p / Wc, c = p - lr * Wc;
+        base[j] = ((2 * lr + kg) * XLD + 2 * c) * 2;
+    }
+    // weight operand of column tile nt: column q = 16 nt + li -> (frame o, channel ch); this lane's kernel row inside a K step is kg
+    int wof[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int q = nt * 16 + li, o = q >= FE_CO ? 1 : 0, ch = q - FE_CO * o;
+        wof[nt] = o * WSO + (kg >> 1) * (3 * WSP) + ch * WROW + (kg & 1) * 16;
+    }
+    f32x4 acc[TPW][3];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[j][nt] = {0.f, 0.f, 0.f, 0.f};
+
+    const int gy0 = 4 * p0 - 5;
+    // slab sl = ci * 6 + d: input frame tau = t0 - 2 + d; frame t0 takes it through tap d (d <= 4), frame t0 + 1 through tap d - 1 (d >= 1)
+    auto valid = [&](int sl) { const int d = sl % 6, tau = t0 - 2 + d; return tau >= 0 && tau < T && (d <= 4 || has1); };
+    auto next_valid = [&](int sl) { while (sl < 18 && !valid(sl)) ++sl; return sl; };
+
+    float4 rin[NLD];
+    auto fetch = [&](int sl) {
+        const int ci = sl / 6, d = sl - ci * 6;
+        const float* src = video + ((int64_t)(b * 3 + ci) * T + (t0 - 2 + d)) * (H * W);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            const int row = i / (W / 4), x4 = i - row * (W / 4);
+            const int gy = gy0 + row;
+            rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
+        }
+    };
+    // the weight operand of slab sl, straight into LDS buffer `buf` (global_load_lds: a wave's 64 lanes fill one contiguous 1-KB piece; no staging
+    // registers, no ds_write pass) - issued at the head of the PREVIOUS slab's MFMA phase, landed by the barrier that ends it.  A frame the slab does
+    // not feed gets zero rows by ordinary stores.
+    auto dma_weights = [&](int sl, int buf) {
+        const int ci = sl / 6, d = sl - ci * 6;
+        const uint4* w3 = reinterpret_cast<const uint4*>(w.w3);
+        unsigned char* const Wd = Ws0 + buf * WS;
+        for (int c = wave; c < NWC; c += 4) {                                // wave-uniform piece index
+            const int i = c * 64 + lane;
+            const int o = i >= NWU / 2 ? 1 : 0, r = i - o * (NWU / 2);
+            const int sp = r / (WSP / 16), u = r - sp * (WSP / 16);
+            const int kt = d - o;                                             // the tap through which frame t0 + o sees this input frame
+            const bool on = kt >= 0 && kt <= 4 && (o == 0 || has1);
+            if (on) {
+                const uint4* src = w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Wd + c * 1024), 16, 0, 0);
+            } else {
+                reinterpret_cast<uint4*>(Wd)[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int i = tid + 256 * q;
+            if (i < (FE_XROWS - 1) * (W / 4)) {
+                const int row = i / (W / 4), x4 = i - row * (W / 4);
+                unsigned char* dd = Xs + (row * XLD + 4 + 4 * x4) * 2;
+                uint2 hi, mid, lo;
+                fx_split4(rin[q], hi, mid, lo);
+                *reinterpret_cast<uint2*>(dd) = hi; *reinterpret_cast<uint2*>(dd + PLANE) = mid; *reinterpret_cast<uint2*>(dd + 2 * PLANE) = lo;
+            }
+        }
+    };
+
+    int sl = next_valid(0), nslab = 0;
+    if (sl < 18) { fetch(sl); dma_weights(sl, 0); }
+    while (sl < 18) {
+        __syncthreads();                             // previous slab consumed; its successor's frame rows (registers) and weights (LDS) have landed
+        stage();
+        const int d = sl % 6;
+        const bool on0 = d <= 4, on1 = d >= 1 && has1;       // block-uniform: which column tiles carry weights (tile 1 always does)
+        const int nxt = next_valid(sl + 1);
+        __syncthreads();
+        if (nxt < 18) { fetch(nxt); dma_weights(nxt, (nslab + 1) & 1); }     // both land under this slab's MFMAs
+        const unsigned char* const Ws = Ws0 + (nslab & 1) * WS;
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            fx_bf16x8 bh[3], bm[3], bl[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const unsigned char* wp = Ws + wof[nt] + S * (2 * 3 * WSP);
+                bh[nt] = *reinterpret_cast<const fx_bf16x8*>(wp);
+                bm[nt] = *reinterpret_cast<const fx_bf16x8*>(wp + WSP);
+                bl[nt] = *reinterpret_cast<const fx_bf16x8*>(wp + 2 * WSP);
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (wave + 4 * j < PT) {             // wave-uniform
+                    const unsigned* ap = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2));
+                    const unsigned* am_ = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2) + PLANE);
+                    const unsigned* al_ = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2) + 2 * PLANE);
+                    const fx_bf16x8 ah = __builtin_bit_cast(fx_bf16x8, make_uint4(ap[0], ap[1], ap[2], ap[3]));
+                    const fx_bf16x8 am = __builtin_bit_cast(fx_bf16x8, make_uint4(am_[0], am_[1], am_[2], am_[3]));
+                    const fx_bf16x8 al = __builtin_bit_cast(fx_bf16x8, make_uint4(al_[0], al_[1], al_[2], al_[3]));
+                    // one column tile after the other, its six partial products smallest first; the frame a slab does not feed is skipped under a
+                    // block-uniform branch.  Tried: the three slab shapes (both frames / first only / second only) as three straight-line code paths with
+                    // the terms interleaved across tiles - 213 spilled registers, 3.8 ms per 128 clips; all three tiles always, interleaved - no
+                    // spills, 12 % more MFMA work: 2.32 ms against this form's 2.13
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        if ((nt == 0 && !on0) || (nt == 2 && !on1)) continue;       // block-uniform
+                        f32x4 a = acc[j][nt];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], a, 0, 0, 0);
+                        acc[j][nt] = a;
+                    }
+                }
+            }
+        }
+        sl = nxt; ++nslab;
+    }
+    __syncthreads();
+
+    // BN + PReLU -> conv tile Cs[pixel][12] -> 3x3 / stride 2 / pad 1 max pool -> channel-last output, twelve channels of one output frame at a time
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CH = FE_CO / 2;
+    float sc[3], sh[3], slp[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int q = nt * 16 + li, ch = q >= FE_CO ? q - FE_CO : q;
+        sc[nt] = w.scale[ch]; sh[nt] = w.shift[ch]; slp[nt] = w.slope[ch];
+    }
+    for (int pass = 0; pass < (has1 ? 4 : 2); ++pass) {
+        const int o = pass >> 1, half = pass & 1;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int q = nt * 16 + li, qo = q >= FE_CO ? 1 : 0, ch = q - FE_CO * qo;
+            if (qo == o && ch >= half * CH && ch < (half + 1) * CH) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    if (wave + 4 * j < PT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int p = (wave + 4 * j) * 16 + 4 * kg + r;
+                            if (p < P) {
+                                float v = acc[j][nt][r] * sc[nt] + sh[nt];
+                                v = v >= 0.f ? v : slp[nt] * v;
+                                Cs[p * CH + (ch - half * CH)] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int f = bg * T + t0 + o;
+        for (int i = tid; i < FE_PR * Wp * CH; i += 256) {
+            const int ch = i % CH;
+            const int pw = (i / CH) % Wp;
+            const int prl = i / (CH * Wp);
+            const int pr = p0 + prl;
+            if (pr >= Hp) continue;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr) {
+                const int crow = 2 * pr - 1 + dr;
+                if (crow < 0 || crow >= Hc) continue;
+                const int lrow = 2 * prl + dr;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int cc = 2 * pw + dc;
+                    if (cc < 0 || cc >= Wc) continue;
+                    m = fmaxf(m, Cs[(lrow * Wc + cc) * CH + ch]);
+                }
+            }
+            out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + half * CH + ch] = m;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
     L2S_REQUIRE(video.per >= 1 && (B + video.per - 1) / video.per <= MAX_GROUP, "too many frame tensors in one launch");
@@ -421,6 +649,10 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
     if (!zout && w.w1) {                       // the bf16 leg (option "infer_bf16"): one bf16 plane
         if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96, 1>), grid, dim3(256), 0, s, w, video, T, out);
         else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out);
+    } else if (!zout && w.w3 && w.pair) {      // inference on the split-bf16 matrix path, two output frames per block (option "frontend_x3" = 2)
+        dim3 gp((Hp + FE_PR - 1) / FE_PR, B * ((T + 1) / 2));
+        if (H == 96) hipLaunchKernelGGL((frontend3d_x3p_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
+        else hipLaunchKernelGGL((frontend3d_x3p_kernel<88>), gp, dim3(256), 0, s, w, video, T, out);
     } else if (!zout && w.w3) {                // inference on the split-bf16 matrix path (option "frontend_x3")
         if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96, 3>), grid, dim3(256), 0, s, w, video, T, out);
         else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 3>), grid, dim3(256), 0, s, w, video, T, out);

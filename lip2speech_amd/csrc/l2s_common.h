@@ -62,7 +62,8 @@ struct Options {
                                 //   block per CU (the step's first phase), instead of one block shape for every group
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible; 5 = its 128x128x32 tile only
-    int frontend_x3 = 1;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel)
+    int frontend_x3 = 2;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel); 2 (default below): its
+                                //   two-output-frames-per-block form (frontend3d_x3p_kernel)
     int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
     int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
                                 //   voice tower with bf16 operands (fp32 accumulation); the recurrent loops, the fused ShuffleNet units and all statistics stay fp32
@@ -212,6 +213,7 @@ struct FrontendW {          // device pointers into the weight blob
     const float* slope;     // [24] PReLU
     const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows]
                             //   (null: f32 MFMA kernel)
+    int pair = 0;           // with w3: two output frames per block (frontend3d_x3p_kernel) - set by the callers from option "frontend_x3" == 2
     const float* w1;        // the same as ONE plane rounded to nearest even: [15 slabs][4 steps][32 co][16 taps, 48-byte rows] (set by the callers
                             //   of launch_frontend only for a model with "infer_bf16"; takes precedence over w3)
 };

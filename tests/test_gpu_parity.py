@@ -113,12 +113,25 @@ def test_frontend_kernel_bf16_leg(synth_sd, hw, T):
     assert pc.maxdiff(out, orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)) > 1e-4
 
 
-@pytest.mark.parametrize("hw,T", [(96, 4), (88, 3), (96, 1)])
+@pytest.mark.parametrize("hw,T", [(96, 4), (88, 3), (96, 1), (96, 7)])
 def test_frontend_kernel(nm, synth_sd, hw, T):
-    v = synth.synth_video(1, T, hw, hw, tag=f"fe{hw}")
+    """default: the two-output-frames-per-block split-bf16 kernel (odd T: the last block carries one frame; T = 1: every temporal tap but the
+    centre one is padding)"""
+    v = synth.synth_video(2, T, hw, hw, tag=f"fe{hw}")
     out = nm.op_frontend(v.cuda())
     ref = orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)
     assert pc.maxdiff(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("x3", [1, 0])
+def test_frontend_kernel_other_forms(synth_sd, nm, x3):
+    """option frontend_x3 = 1: one output frame per block (32-wide tiles); 0: the f32 MFMA kernel.  Both against the oracle and against the default form."""
+    own = pc.fresh_native_model(synth_sd, frontend_x3=x3)
+    v = synth.synth_video(2, 5, 96, 96, tag="fe_forms")
+    out = own.op_frontend(v.cuda())
+    assert pc.maxdiff(out, orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)) < 2e-5
+    d = pc.maxdiff(out, nm.op_frontend(v.cuda()))
+    assert 0 < d < 5e-5                                      # another kernel really ran: rounding-level differences, not zero
 
 
 def test_encoder_matches_reference_golden(nm):
@@ -316,6 +329,7 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     ({"use_graph": 1, "fold_step_weights": 0}, False),
     ({"hoist_vproj": 1}, False), ({"hoist_vproj": 0}, False),      # attention_proj on the values (K = 1280 layer 0) / on a @ v through W_ih W_ap (K = 1536)
     ({"skinny_flat": 0}, True),            # uniform first-phase grid
+    ({"frontend_x3": 1}, False), ({"frontend_x3": 0}, False),      # front-end conv: one output frame per block / the f32 MFMA kernel
     ({"skinny_rc_jb": 28}, False),         # the straight-line blocks on eight waves (they do not sum u in the loader: layer 0 on K = 1280, other bits)
 ])
 def test_runtime_options_keep_parity(synth_sd, nm, opts, exact):
