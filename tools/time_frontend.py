@@ -1,4 +1,5 @@
-"""Front-end conv kernel: split-bf16 path vs f32 MFMA path, time per batch and difference."""
+"""Front-end conv kernel: the split-bf16 path in both forms (two output frames per block = option frontend_x3 2, default; one frame per block = 1) vs the
+f32 MFMA path (0), time per batch and difference."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
@@ -6,12 +7,12 @@ sd = synth.synth_state_dict()
 tens = {k: v.cuda() for k, v in sd.items()}
 def mk(x3):
     nm = native.NativeModel(); nm.set_option("frontend_x3", x3); nm.load(tens, list(sd.keys())); return nm
-a, b = mk(1), mk(0)
+a, a1, b = mk(2), mk(1), mk(0)
 for B in (32, 128):
     v = synth.synth_video(32, 29, tag="bench").cuda().repeat(B // 32, 1, 1, 1, 1)
     oa, ob = a.op_frontend(v), b.op_frontend(v)
     print(f"B={B}: max|x3 - f32| = {(oa-ob).abs().max().item():.3e}  (|out| max {ob.abs().max().item():.2f})")
-    for name, nm in (("x3 ", a), ("f32", b)):
+    for name, nm in (("x3, two frames per block", a), ("x3, one frame per block ", a1), ("f32                     ", b)):
         for _ in range(3): nm.op_frontend(v)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): nm.op_frontend(v)
