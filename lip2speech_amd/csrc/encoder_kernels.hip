@@ -479,26 +479,28 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
     auto next_valid = [&](int sl) { while (sl < 18 && !valid(sl)) ++sl; return sl; };
 
     float4 rin[NLD];
-    auto fetch = [&](int sl) {
+    auto fetch_piece = [&](int sl, int q) {
         const int ci = sl / 6, d = sl - ci * 6;
         const float* src = video + ((int64_t)(b * 3 + ci) * T + (t0 - 2 + d)) * (H * W);
+        const int i = tid + 256 * q;
+        const int row = i / (W / 4), x4 = i - row * (W / 4);
+        const int gy = gy0 + row;
+        rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
+    };
+    auto fetch = [&](int sl) {
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int i = tid + 256 * q;
-            const int row = i / (W / 4), x4 = i - row * (W / 4);
-            const int gy = gy0 + row;
-            rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
-        }
+        for (int q = 0; q < NLD; ++q) fetch_piece(sl, q);
     };
     // the weight operand of slab sl, straight into LDS buffer `buf` (global_load_lds: a wave's 64 lanes fill one contiguous 1-KB piece; no staging
     // registers, no ds_write pass) - issued at the head of the PREVIOUS slab's MFMA phase, landed by the barrier that ends it.  A frame the slab does
     // not feed gets zero rows by ordinary stores.
-    auto dma_weights = [&](int sl, int buf) {
-        const int ci = sl / 6, d = sl - ci * 6;
-        const uint4* w3 = reinterpret_cast<const uint4*>(w.w3);
-        unsigned char* const Wd = Ws0 + buf * WS;
-        for (int c = wave; c < NWC; c += 4) {                                // wave-uniform piece index
+    auto dma_piece = [&](int sl, int buf, int kp) {                          // piece c = wave + 4 kp of the NWC 1-KB pieces
+        const int c = wave + 4 * kp;
+        if (c < NWC) {                                                       // wave-uniform
+            const int ci = sl / 6, d = sl - ci * 6;
+            const uint4* w3 = reinterpret_cast<const uint4*>(w.w3);
+            unsigned char* const Wd = Ws0 + buf * WS;
             const int i = c * 64 + lane;
             const int o = i >= NWU / 2 ? 1 : 0, r = i - o * (NWU / 2);
             const int sp = r / (WSP / 16), u = r - sp * (WSP / 16);
@@ -512,6 +514,11 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
                 reinterpret_cast<uint4*>(Wd)[i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
+    };
+    constexpr int NDP = (NWC + 3) / 4;                                       // pieces per wave
+    auto dma_weights = [&](int sl, int buf) {
+#pragma unroll
+        for (int kp = 0; kp < NDP; ++kp) dma_piece(sl, buf, kp);
     };
     auto stage = [&]() {
 #pragma unroll
@@ -536,7 +543,10 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
         const bool on0 = d <= 4, on1 = d >= 1 && has1;       // block-uniform: which column tiles carry weights (tile 1 always does)
         const int nxt = next_valid(sl + 1);
         __syncthreads();
-        if (nxt < 18) { fetch(nxt); dma_weights(nxt, (nslab + 1) & 1); }     // both land under this slab's MFMAs
+        // the next slab's weight pieces and frame rows are requested BETWEEN this slab's pixel tiles (one request per tile): a
+        // request costs the wave 60-100 clk to issue, and ten of them in front of the first MFMA left the pipe idle that long per slab
+        const bool more = nxt < 18;
+        static_assert(NDP + NLD <= 2 * TPW, "one request per pixel tile");
         const unsigned char* const Ws = Ws0 + (nslab & 1) * WS;
 #pragma unroll
         for (int S = 0; S < 2; ++S) {
@@ -550,6 +560,11 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
             }
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
+                if (more) {
+                    const int pos = S * TPW + j;                              // compile-time
+                    if (pos < NDP) dma_piece(nxt, (nslab + 1) & 1, pos);
+                    else if (pos < NDP + NLD) fetch_piece(nxt, pos - NDP);
+                }
                 if (wave + 4 * j < PT) {             // wave-uniform
                     const unsigned* ap = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2));
                     const unsigned* am_ = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2) + PLANE);
