@@ -325,11 +325,7 @@ int launch_gemm(const GemmBatch& b, hipStream_t s, const char* name) {
         // kernel; the members that can (per member, on one batch's rows: the same choice alone and in a group) now go there as their own launch
         GemmBatch yes{}, no{};
         for (int i = 0; i < b.count; ++i) {
-            GemmBatch one{}; one.p[0] = b.p[i]; one.p[0].x3 |= 2; one.count = 1;       // member-level test: shape only, no size threshold
-            GemmBatch own{}; own.p[0] = b.p[i]; own.count = 1;                         // with its own x3 mode: the N / K / rows-per-batch rules
-            GemmP& q = own.p[0];
-            const bool member_ok = gemm_x3_eligible(one) && q.N >= 96 && (q.K >= 1024 || (q.K >= 384 && (int64_t)((q.M / (q.x3_group > 1 ? q.x3_group : 1) + 127) / 128) * ((q.N + 127) / 128) >= 128));
-            if (member_ok) yes.p[yes.count++] = b.p[i];
+            if (gemm_x3_member_ok(b.p[i])) yes.p[yes.count++] = b.p[i];
             else no.p[no.count++] = b.p[i];
         }
         if (yes.count >= 1 && no.count >= 1 && gemm_x3_eligible(yes)) {

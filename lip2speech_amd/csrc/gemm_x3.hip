@@ -541,25 +541,32 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
 
 static bool x3_aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
-// true when every GEMM of the group can run on the split-bf16 kernel (float4-addressable operands, no batch-statistics pass) AND the
-// launch is large enough to win: the kernel keeps one 128x128 tile per CU and is bound by the operand bytes a CU can pull per MFMA cycle
-// (~10 B/clk/CU under load, measured), so it only pays with at least one full round of tiles and long K; measured on MI355X
-// (tools/time_gemm_x3.py, f32 kernel -> this one): 38400x512x2560 846 -> 602 us (167 TFLOP/s, above the 157 TFLOP/s f32 matrix peak),
-// 9600x512x2560 267 -> 216 us, 3712x4096x1024 278 -> 210 us; 3712x512x5632 (116 tiles) 218 -> 200 us; 928x512x5632 (32 tiles) and K = 400 lose.
+// A group runs on the split-bf16 kernel when every member can (below) AND the launch is large enough to fill the chip: at least one full round of tiles
+// of ONE batch's rows.  Measured on MI355X (tools/time_gemm_x3.py, time_conv_x3.py, time_gemm_shapes.py; f32 kernel -> this one, round 3): 76800x512x2560
+// 1 640 -> 990 us (204 TFLOP/s; the f32 matrix peak is 157), 9600x512x2560 233 -> 142 us, 7424x512x5632 383 -> 223 us; 928x512x2560 (32 tiles) loses.
+// one member of a launch: operands the kernel can address (float4, no batch-statistics pass) and a shape it wins on - judged on the rows of ONE
+// batch of a grouped launch, so a batch meets the same kernel alone and in a group
+bool gemm_x3_member_ok(const GemmP& p) {
+    const bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && x3_aligned16(p.A) && x3_aligned16(p.W) &&
+                     (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= XK) &&
+                     (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
+    if (!ok4 || p.stats) return false;
+    if (p.x3 & 2) return true;                                 // forced (operator tests run every addressable shape)
+    const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);
+    const int64_t t_unit = (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
+    // short K (the post-net's first layer: K = 400; conv_last: K = 464) only pays with many rows per batch: 9600 x 512 x 400 runs 42 us against 52 on
+    // the f32 kernel, 928 x 512 x 512 36 against 21; narrow outputs (the post-net's last layer: N = 80, five eighths of a 128-wide tile) likewise:
+    // 76800 x 80 x 2560 runs 320 us against 490 (tools/time_gemm_shapes.py)
+    return p.N >= 64 && (p.N >= 96 || t_unit >= 64) && p.K >= 384 && (p.K >= 1024 || t_unit >= 128);
+}
+
 bool gemm_x3_eligible(const GemmBatch& b) {
     int64_t tiles = 0;
     for (int i = 0; i < b.count; ++i) {
         const GemmP& p = b.p[i];
-        const bool ok4 = p.vec == 4 && (p.K % 4 == 0) && (p.Cin % 4 == 0) && (p.lda % 4 == 0) && x3_aligned16(p.A) && x3_aligned16(p.W) &&
-                         (p.a_split % 4 == 0) && (p.a_gap % 4 == 0) && (p.taps == 1 || p.Cin >= XK) &&
-                         (int64_t)((p.M + p.Tout - 1) / p.Tout) * p.Tin * p.lda * 4 < (1ll << 31) && (int64_t)p.N * (p.ldw ? p.ldw : p.K) * 4 < (1ll << 31);
-        if (!ok4 || p.stats) return false;
+        if (!gemm_x3_member_ok(p)) return false;
         const int m_unit = p.M / (p.x3_group > 1 ? p.x3_group : 1);                    // rows of ONE batch of a grouped launch
-        const int64_t t_unit = (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
-        // short K (the post-net's first layer: K = 400; conv_last: K = 464) only pays with many rows per batch: 9600 x 512 x 400 runs 42 us
-        // against 52 on the f32 kernel, 928 x 512 x 512 36 against 21 (tools/time_gemm_shapes.py)
-        if (!(p.x3 & 2) && (p.N < 96 || p.K < 384 || (p.K < 1024 && t_unit < 128))) return false;       // x3 bit 2: forced (operator tests run every eligible shape)
-        tiles += t_unit;
+        tiles += (int64_t)((m_unit + XM - 1) / XM) * ((p.N + XN - 1) / XN);
     }
     return tiles >= (b.count > 1 ? 150 : 100) || (b.p[0].x3 & 2);
 }

@@ -128,6 +128,7 @@ struct X3Group { int prev; explicit X3Group(int g) : prev(gemm_x3_group()) { gem
 int& gemm_bf16_mode();
 struct Bf16Scope { int prev; explicit Bf16Scope(int on) : prev(gemm_bf16_mode()) { gemm_bf16_mode() = on; } ~Bf16Scope() { gemm_bf16_mode() = prev; } };
 bool gemm_x3_eligible(const GemmBatch& b);
+bool gemm_x3_member_ok(const GemmP& p);               // one member's operands and shape (no launch-size threshold)
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name);
 void gemm_x3_set_timeline(unsigned long long* ts, int block);      // non-null: launch the stamped measurement build (tools/gemm_x3_timeline.py)
 // split-K for plain GEMMs whose 64x64 tiles are too few to fill the chip (M <= 128 rows in the content path, the B-row Linears):

@@ -6,7 +6,8 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-for name, (M, N, K) in {"postnet first layer, 1 batch": (9600, 512, 400), "postnet first layer, 8 batches": (76800, 512, 400),
+for name, (M, N, K) in {"postnet last layer, 1 batch": (9600, 80, 2560), "postnet last layer, 8 batches": (76800, 80, 2560),
+                        "postnet first layer, 1 batch": (9600, 512, 400), "postnet first layer, 8 batches": (76800, 512, 400),
                         "conv_last, 1 batch": (8352, 1024, 464), "conv_last, 8 batches": (66816, 1024, 464),
                         "bottleneck, 1 batch": (928, 512, 2560), "bottleneck, 8 batches": (7424, 512, 2560),
                         "enc_proj, 1 batch": (928, 512, 1024), "enc_proj, 8": (7424, 512, 1024),
