@@ -259,7 +259,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
     // at a time: every accumulator element is addressed with compile-time indices (a rolled loop over them would put all 64 in scratch
     // memory), the rolled store loop that follows - all eight waves - reads LDS, runs the fused epilogue once per element and writes rows
     // of 128 consecutive columns.  C/D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    float* const ct = reinterpret_cast<float*>(smem);          // [64][128]; the operand stages are dead (barrier at the loop end)
+    constexpr int CTLD = XN + 1;                               // odd pitch: rows and columns of the tile are both conflict-free to walk
+    float* const ct = reinterpret_cast<float*>(smem);          // [64][129]; the operand stages are dead (barrier at the loop end)
     const GemmP pl = p;                                        // epilogue parameters in SGPRs: through the kernarg reference the rolled loop
                                                                // below re-fetches them with scalar loads on every iteration
 #pragma unroll
@@ -270,9 +271,21 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * XN + wn * 64 + j * 32 + li] = acc[i][j][r];
+                    ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * CTLD + wn * 64 + j * 32 + li] = acc[i][j][r];
         }
         __syncthreads();
+        if (pl.c_tr_T > 0) {
+            // channel-first store (the post-net's last layer: out[(b, n, t)]): lanes run along the ROWS, so a wave writes 32 + 32 consecutive frames of
+            // one channel (128-byte runs) instead of 64 channels 4 T bytes apart; the odd row pitch of the tile keeps the column reads conflict-free
+            const int q = tid & 63, row = m0 + (q >> 5) * 64 + i * 32 + (q & 31);
+            if (row < pl.M) {
+                for (int cl = tid >> 6; cl < XN; cl += 8) {
+                    const int col = n0 + cl;
+                    if (col < pl.N) gemm_store(pl, row, col, ct[q * CTLD + cl], pl.scale ? pl.scale[col] : 1.0f, pl.shift ? pl.shift[col] : 0.0f);
+                }
+            }
+            continue;
+        }
         const int cl = tid & 127, col = n0 + cl;
         if (col < pl.N) {
             const float sc = pl.scale ? pl.scale[col] : 1.0f;
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const GemmBatch batch, 
 #pragma unroll 4
             for (int q = tid >> 7; q < 64; q += 4) {              // local row q: wave-row q >> 5, row q & 31 of sub-tile i
                 const int row = m0 + (q >> 5) * 64 + i * 32 + (q & 31);
-                if (row < pl.M) gemm_store(pl, row, col, ct[q * XN + cl], sc, sh);
+                if (row < pl.M) gemm_store(pl, row, col, ct[q * CTLD + cl], sc, sh);
             }
         }
     }
