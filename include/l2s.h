@@ -301,6 +301,9 @@ int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, c
  * writes 8 x 64-bit 100 MHz wall-clock stamps (entry, parameters in SGPRs, loads issued, first operands landed, MFMAs done, after the
  * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
 int l2s_op_skinny_timeline(void* ts_dev);
+/* the same for the attention blocks of the step's second launch: 8 x uint64 per block (entry, requests issued, q visible, logits, after the barrier,
+   weights visible, stored) of the 100 MHz wall clock.  tools/attn_timeline.py */
+int l2s_op_attn_timeline(void* ts_dev);
 /* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
    ([12 waves][96 K tiles][8 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block);

@@ -1815,6 +1815,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
     for (int i = 0; i < n_launches; ++i) {
         AttnP at{};
         at.q = q; at.ldq = 512; at.k = state + sl.k; at.v = state + sl.v; at.tau = w.tau; at.av_frag = av;
+        if (m->opt.hoist_vproj && w.vproj.W) at.vp = state + sl.vp;      // the production form: 256 value columns
         at.attn_out = nullptr; at.ld_attn_b = 0; at.attn_logits = 0;
         at.qc = qc; at.ldqc = 256; at.ckey = state + sl.ckey; at.cval = state + sl.cval; at.tau_c = w.tau_c; at.cc_frag = cc;
         at.B = B; at.T = T; at.m = sl.m;
@@ -1825,6 +1826,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
     return 0;
 }
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
+int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block) { gemm_x3_set_timeline((unsigned long long*)ts_dev, block); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
 

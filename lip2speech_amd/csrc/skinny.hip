@@ -368,13 +368,15 @@ struct StepB {
 };
 
 constexpr int ATT_PRE2_MAXC = 2;      // prenet layer 2: K = 256 = 16 * 8 waves * 2 chunks
+template <bool VL>
 __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
-    __shared__ __attribute__((aligned(16))) float sm[ATT_SM_FLOATS > SK_RED_FLOATS ? ATT_SM_FLOATS : SK_RED_FLOATS];
+    constexpr int SMF = ATT_SM_FLOATS + (VL ? ATT_VLDS_FLOATS : 0);
+    __shared__ __attribute__((aligned(16))) float sm[SMF > SK_RED_FLOATS ? SMF : SK_RED_FLOATS];
     const int nb = sb.at.B, ptiles = sb.pre2_tiles;
     L2S_PIN_S("s"(nb), "s"(ptiles));
     const int bid = blockIdx.x;
     if (bid < nb) {
-        attention_block(sb.at, bid, sm);
+        attention_block<false, false, VL>(sb.at, bid, sm);
     } else if (bid < 2 * nb) {
         content_block(sb.at, bid - nb, sm);
     } else {
@@ -383,6 +385,23 @@ __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
         skinny_block<false, ATT_PRE2_MAXC>(sb.pre2, tile, mt, sm);       // K = 256: the 12-chunk instance would set this kernel's VGPR count
     }
 }
+
+// measurement build (tools/attn_timeline.py): thread 0 of every attention block stamps the 100 MHz wall clock at seven points
+__global__ __launch_bounds__(512) void step_attn_timed_kernel(const StepB sb, unsigned long long* ts) {
+    __shared__ __attribute__((aligned(16))) float sm[(ATT_SM_FLOATS + ATT_VLDS_FLOATS) > SK_RED_FLOATS ? (ATT_SM_FLOATS + ATT_VLDS_FLOATS) : SK_RED_FLOATS];
+    const int nb = sb.at.B, ptiles = sb.pre2_tiles;
+    const int bid = blockIdx.x;
+    if (bid < nb) {
+        attention_block<false, true, true>(sb.at, bid, sm, nullptr, ts);
+    } else if (bid < 2 * nb) {
+        content_block(sb.at, bid - nb, sm);
+    } else {
+        const int j = bid - 2 * nb;
+        skinny_block<false, ATT_PRE2_MAXC>(sb.pre2, j % ptiles, j / ptiles, sm);
+    }
+}
+static unsigned long long* g_attn_ts = nullptr;
+void attn_set_timeline(unsigned long long* ts) { g_attn_ts = ts; }
 
 int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s) {
     L2S_REQUIRE(at.T <= ATT_MAXT && at.m <= 16, "attention sizes");
@@ -393,7 +412,10 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     sb.pre2_tiles = pre2_tiles;
     sb.mts = (at.B + 15) / 16;
     ProfScope ps("step_attention_prenet2", s);
-    hipLaunchKernelGGL(step_attn_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    const bool vl = at.vp != nullptr && at.T <= 32;        // projected values of a short clip: fetched as 16-byte rows through LDS
+    if (g_attn_ts && vl) hipLaunchKernelGGL(step_attn_timed_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb, g_attn_ts);
+    else if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    else hipLaunchKernelGGL(step_attn_kernel<false>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }

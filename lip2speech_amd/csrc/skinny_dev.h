@@ -764,6 +764,7 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 
 constexpr int ATT_MAXT = 320;
 constexpr int ATT_SM_FLOATS = 512 + ATT_MAXT + 16 + 16;
+constexpr int ATT_VLDS_FLOATS = 32 * 256;            // a clip's projected values V' (<= 32 frames x 256) staged through LDS (attention_block<.., VLDS>)
 
 __device__ __forceinline__ float block_max8(float x, float* scratch) {
     x = wave_max_f(x);
@@ -786,8 +787,14 @@ __device__ __forceinline__ float block_sum8(float x, float* scratch) {
 // 512 threads (8 waves) per batch row.  Every global operand of the block (q, this wave's k rows, this thread's v
 // column) has an address known at launch, so all loads are issued before the first dependent instruction: one memory
 // round trip instead of five serialized ones.
-template <bool TRAIN = false>
-__device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm, const AttnTrain* tr = nullptr) {
+#define L2S_ATT_STAMP(k) do { if constexpr (TIMED) { if (threadIdx.x == 0) ats[blockIdx.x * 8 + (k)] = wall_clock64(); } } while (0)
+// VLDS (the inference step kernel; needs ATT_SM_FLOATS + ATT_VLDS_FLOATS of shared memory): with the projected values (256 columns) and T <= 32 the
+// block's threads fetch V' as 16-byte rows - four requests per thread instead of 29 one-column dword requests for half of them - and pass it through
+// LDS; a@V' then reads its column from there, t ascending as before (same bits).  The stamped build showed the 38 requests of a thread taking 2.1 us
+// to ISSUE (~60 clk each), 40 % of the block's lifetime.
+template <bool TRAIN = false, bool TIMED = false, bool VLDS = false>
+__device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm, const AttnTrain* tr = nullptr, unsigned long long* ats = nullptr) {
+    L2S_ATT_STAMP(0);
     float* qs = sm;                  // 512
     float* sc = sm + 512;            // ATT_MAXT
     float* scratch = sc + ATT_MAXT;  // 16
@@ -807,20 +814,44 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     const float qv = pq[(int64_t)b * ldq + tid];
     const float tau = ptau[0];
     float4 k0[4], k1[4];
+    if constexpr (VLDS) {
+        // buffer loads: one scalar descriptor per clip, the frame as a scalar byte offset, one per-lane offset for all eight requests - no 64-bit address
+        // per request (the flat form kept ~20 registers of addresses alive and the block at 102: two blocks per CU, the launch's 768 blocks in 1.5 rounds);
+        // frames past T read zero through the descriptor's byte count
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk + (int64_t)b * T * 512), 0, T * 2048, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int t = wave + 8 * r;
-        if (t < T) {
-            k0[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
-            k1[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+        for (int r = 0; r < 4; ++r) {
+            const int so = __builtin_amdgcn_readfirstlane((wave + 8 * r) * 2048);
+            k0[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, lane * 32, so, 0));
+            k1[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, lane * 32, so + 16, 0));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = wave + 8 * r;
+            if (t < T) {
+                k0[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512);
+                k1[r] = *reinterpret_cast<const float4*>(kb + (int64_t)t * 512 + 4);
+            }
         }
     }
-    float vv[32];
+    constexpr bool vlds = VLDS;                               // the launch picks the instance: VLDS only with projected values and T <= 32
+    float* const vs = sm + ATT_SM_FLOATS;
+    float vv[vlds ? 1 : 32];
+    float4 vq[vlds ? 4 : 1];
+    if constexpr (vlds) {
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pv + (int64_t)b * T * 256), 0, T * 1024, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < 32; ++e) vv[e] = (vlane && e < T) ? vb[(int64_t)e * vcols] : 0.f;
+        for (int i = 0; i < 4; ++i) vq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, tid * 16, 8192 * i, 0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) vv[e] = (vlane && e < T) ? vb[(int64_t)e * vcols] : 0.f;
+    }
+    L2S_ATT_STAMP(1);               // every request issued
     // ---- logits
     qs[tid] = qv * tau;
     __syncthreads();
+    L2S_ATT_STAMP(2);               // q landed, visible to the block
     float qq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qq[e] = qs[lane * 8 + e];
@@ -842,9 +873,27 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
         d = wave_sum_d(d);
         if (lane == 0) sc[t] = (float)d;
     }
+    if constexpr (vlds) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int idx = tid + 512 * i; if (idx < T * 64) reinterpret_cast<float4*>(vs)[idx] = vq[i]; }
+    }
+    L2S_ATT_STAMP(3);               // this wave's logits (its k rows have landed)
     __syncthreads();
+    L2S_ATT_STAMP(4);
     // ---- softmax over T
-    if (T <= 64) {
+    static_assert(!(VLDS && TRAIN), "the LDS-staged form is the inference step's");
+    float awr = 0.f;                                 // VLDS form: this lane's attention weight (lane = frame), computed by EVERY wave
+    if constexpr (VLDS) {
+        // T <= 32: each wave runs the 29-lane softmax itself (same shuffles, same bits in every wave) and keeps the weights in a register - no LDS
+        // round trip and no third block barrier; a@V' below broadcasts weight e with v_readlane
+        const bool on = lane < T;
+        const float x = on ? sc[lane] : -INFINITY;
+        const float mx = wave_max_f(x);
+        const float ex = on ? expf(x - mx) : 0.f;
+        const float tot = wave_sum_f(ex);
+        awr = on ? ex / tot : 0.f;
+        if (wave == 0 && on && pattn) pattn[(int64_t)b * ld_attn + lane] = logits ? x : awr;
+    } else if (T <= 64) {
         // one wave, shuffles only (LRW: T = 29): one block barrier instead of five
         if (wave == 0) {
             const bool on = lane < T;
@@ -875,11 +924,25 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
         }
         __syncthreads();
     }
+    L2S_ATT_STAMP(5);               // attention weights visible
     // ---- av = a @ v : one column per thread, t ascending
     float acc = 0.f;
+    if constexpr (vlds) {
+        const float* vc = vs + (tid & 255);
 #pragma unroll
-    for (int e = 0; e < 32; ++e)
-        if (e < T) acc = fmaf(sc[e], vv[e], acc);
+        for (int h = 0; h < 2; ++h) {                                         // sixteen unconditional reads in flight at a time (a guarded read per frame serialises them)
+            float vl[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vl[e] = vc[(16 * h + e < T ? 16 * h + e : 0) * 256];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (16 * h + e < T) acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, awr), 16 * h + e)), vl[e], acc);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if (e < T) acc = fmaf(sc[e], vv[e], acc);
+    }
     for (int t0 = 32; t0 < T; t0 += 16) {
         float v2[16];
 #pragma unroll
@@ -890,6 +953,7 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     }
     if (vlane) pav[frag16_index(b, tid, vcols)] = acc;
     if constexpr (TRAIN) { if (tr->av_plain) tr->av_plain[(int64_t)b * 512 + tid] = acc; }
+    if constexpr (TIMED) { __builtin_amdgcn_s_waitcnt(0); L2S_ATT_STAMP(6); }
 }
 
 // Content.forward (decoder.py:262-271) for one batch row: alpha = softmax_m(SiLU(..)*tau_c . key), cc = alpha @ value
