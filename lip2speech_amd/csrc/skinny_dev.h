@@ -536,43 +536,47 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- operand streams: one base pointer per (segment, row tile) and per column tile; everything per chunk is a compile-time offset
-    // (tiles past the end of the group / batch are computed on the last valid tile's operands and dropped in the epilogue)
-    const float4* wb[CT];
+    // ---- operand streams: BUFFER loads - one scalar descriptor per stream (weights, the four K segments, the second source of segment 1), one 32-bit
+    // per-lane offset per (segment, row tile) and per column tile, and the chunk as a compile-time SCALAR offset.  The flat form (a 64-bit base
+    // pointer per stream in VGPRs plus a 64-bit add per request whose chunk offset does not fit the 12-bit immediate) took the wave ~100 clk per
+    // request to issue: 1.1 us for the first 24 of an LSTM block, on the launch's critical path (the attention block's stamps showed the same,
+    // 2.1 -> 0.6 us).  (Tiles past the end of the group / batch are computed on the last valid tile's operands and dropped in the epilogue.)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa3), 0, 0x7fffffff, 0x00020000);
+    int wo[CT];
 #pragma unroll
-    for (int i = 0; i < CT; ++i) wb[i] = reinterpret_cast<const float4*>(W) + ((int64_t)min(tp * CT + i, ntiles - 1) * NC + wave) * 64 + lane;
-    const float4* ab[4][RT];
+    for (int i = 0; i < CT; ++i) wo[i] = ((min(tp * CT + i, ntiles - 1) * NC + wave) * 64 + lane) * 16;
+    int ao[4][RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        const int64_t rt = min(mg * RT + r, mts - 1);
-        ab[0][r] = reinterpret_cast<const float4*>(sa0) + (rt * LAY::n0 + wave) * 64 + lane;
-        ab[1][r] = reinterpret_cast<const float4*>(sa1) + (rt * LAY::n1 + wave) * 64 + lane;
-        ab[2][r] = reinterpret_cast<const float4*>(sa2) + (rt * LAY::n2 + wave) * 64 + lane;
-        ab[3][r] = reinterpret_cast<const float4*>(sa3) + (rt * LAY::n3 + wave) * 64 + lane;
+        const int rt = min(mg * RT + r, mts - 1);
+        ao[0][r] = ((rt * LAY::n0 + wave) * 64 + lane) * 16;
+        ao[1][r] = ((rt * LAY::n1 + wave) * 64 + lane) * 16;
+        ao[2][r] = ((rt * LAY::n2 + wave) * 64 + lane) * 16;
+        ao[3][r] = ((rt * LAY::n3 + wave) * 64 + lane) * 16;
     }
     // the slots of segment 1 when it has a second source (LAY::SUM1): its fragments travel beside the first source's and are added right before the MFMAs
     constexpr int NS1 = LAY::SUM1 ? (LAY::n1 / SK_WAVES) * VW : 1;          // slots whose chunk lies in segment 1 (first slot: FS1)
     constexpr int FS1 = (E0 / SK_WAVES) * VW;
-    const float4* ab2[RT];
-    if constexpr (LAY::SUM1) {
-        const float* const s1b = p.a_sum;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) ab2[r] = reinterpret_cast<const float4*>(s1b) + ((int64_t)min(mg * RT + r, mts - 1) * LAY::n1 + wave) * 64 + lane;
-    }
+    const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LAY::SUM1 ? p.a_sum : W), 0, 0x7fffffff, 0x00020000);
     float4 a[TC][RT], w[TC][CT], a2[NS1][RT];
     auto load_chunk = [&](auto jc) {          // slot t: K slice h = t % VW (wave + NW * h), its j-th chunk (j = t / VW)
         constexpr int t_ = decltype(jc)::value, j = t_;
         constexpr int cj = SK_WAVES * (t_ / VW) + NW * (t_ % VW);
         constexpr int sg = cj >= E2 ? 3 : cj >= E1 ? 2 : cj >= E0 ? 1 : 0;
         constexpr int off = cj - (sg == 3 ? E2 : sg == 2 ? E1 : sg == 1 ? E0 : 0);
+        const __amdgpu_buffer_rsrc_t rs = sg == 3 ? rs_a3 : sg == 2 ? rs_a2 : sg == 1 ? rs_a1 : rs_a0;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) a[j][r] = ab[sg][r][off * 64];
+        for (int r = 0; r < RT; ++r) a[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ao[sg][r], off * 1024, 0));
         if constexpr (LAY::SUM1 && sg == 1) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) a2[j - FS1][r] = ab2[r][off * 64];
+            for (int r = 0; r < RT; ++r) a2[j - FS1][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_s1, ao[1][r], off * 1024, 0));
         }
 #pragma unroll
-        for (int i = 0; i < CT; ++i) w[j][i] = wb[i][cj * 64];
+        for (int i = 0; i < CT; ++i) w[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo[i], cj * 1024, 0));
     };
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, PRE>([&](auto jc) { load_chunk(jc); });
