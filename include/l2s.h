@@ -304,6 +304,9 @@ int l2s_op_skinny_timeline(void* ts_dev);
 /* the same for the attention blocks of the step's second launch: 8 x uint64 per block (entry, requests issued, q visible, logits, after the barrier,
    weights visible, stored) of the 100 MHz wall clock.  tools/attn_timeline.py */
 int l2s_op_attn_timeline(void* ts_dev);
+/* and for the step's first launch (the flat grid of per-group block shapes, at >= 128 rows): 8 stamps per block as for l2s_op_skinny_timeline; the last
+   such launch leaves its stamps.  tools/flat_timeline.py */
+int l2s_op_flat_timeline(void* ts_dev);
 /* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
    ([12 waves][96 K tiles][8 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block);

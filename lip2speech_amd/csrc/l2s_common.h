@@ -325,6 +325,7 @@ struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o = Options());
 bool skinny_sum_supported(const Options& o);           // launches with SkinnyP::a_sum need the straight-line four-wave blocks: default operand batching, no stamped build
 void attn_set_timeline(unsigned long long* ts);        // non-null: the stamped attention kernel (tools/attn_timeline.py)
+void skinny_set_flat_timeline(unsigned long long* ts);   // non-null: the stamped build of the step's flat first phase (tools/flat_timeline.py)
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
 int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);

@@ -180,8 +180,8 @@ struct SkinnyFlat {
 };
 // One instance per pair of shapes (S8 for the K <= 1024 groups, S4 for the K <= 512 groups; RT * 10 + CT): an instance that carries every
 // shape is 60 KB of code and pays ~2.5 us of instruction fetch per launch.
-template <int S8, int S4, int STATIC = 0>
-__global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void skinny_flat_kernel(const SkinnyBatch batch, const SkinnyFlat fl, int mts) {
+template <int S8, int S4, int STATIC = 0, bool TIMED = false>
+__global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void skinny_flat_kernel(const SkinnyBatch batch, const SkinnyFlat fl, int mts, unsigned long long* ts = nullptr) {
     constexpr int R8 = S8 / 10, C8 = S8 % 10, R4 = S4 / 10, C4 = S4 % 10;
     constexpr int RED = SkRc<R8, C8>::RED_FLOATS > SkRc<R4, C4>::RED_FLOATS ? SkRc<R8, C8>::RED_FLOATS : SkRc<R4, C4>::RED_FLOATS;
     __shared__ float red[RED];
@@ -197,8 +197,9 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
         if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
         else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
     } else if constexpr (STATIC == 1) {      // the same on eight waves
-        if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 8, false>(p, tp, mg, red, batch.ntiles[g], mts);
-        else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false>(p, tp, mg, red, batch.ntiles[g], mts);
+        unsigned long long* const tb = TIMED ? ts + (int64_t)b * 8 : nullptr;       // measurement build (l2s_op_flat_timeline): 8 stamps per block
+        if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 8, false, TIMED>(p, tp, mg, red, batch.ntiles[g], mts, tb);
+        else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false, TIMED>(p, tp, mg, red, batch.ntiles[g], mts, tb);
     } else {
         if (fl.wide[k]) skinny_block_rc<R8, C8, 8, 2>(p, tp, mg, red, batch.ntiles[g], mts);
         else skinny_block_rc<R4, C4, 4, 2>(p, tp, mg, red, batch.ntiles[g], mts);
@@ -242,11 +243,16 @@ static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl) {
     for (int k = n; k <= SKINNY_MAX_GROUP; ++k) fl.first[k] = pos;
     return best8 * 100 + best4;
 }
+static unsigned long long* g_flat_ts = nullptr;
+void skinny_set_flat_timeline(unsigned long long* ts) { g_flat_ts = ts; }
 template <int S8, int S4>
 static void launch_flat(const SkinnyBatch& bl, const SkinnyFlat& fl, int mts, hipStream_t s, int stat) {
-    if (stat == 2) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 2>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(256), 0, s, bl, fl, mts);
-    else if (stat == 1) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
-    else hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 0>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts);
+    if (g_flat_ts && stat == 1) {
+        if constexpr (S8 == 22 && S4 == 42) { hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1, true>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, g_flat_ts); return; }
+    }
+    if (stat == 2) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 2>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(256), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
+    else if (stat == 1) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 0>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
 }
 
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
