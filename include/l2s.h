@@ -342,6 +342,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  * accumulators are guarded - only changing an option of a model WHILE other threads run batches on it is the caller's race.
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
+ *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows: 1 = at up to
+ *                            128 rows per launch, 2 = always, 0 = never (one-column loads, 120 registers); same bits
  *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path: 2 = two consecutive output
  *                            frames per block (every input frame staged once for both, their 2 x 24 channels as three 16-wide MFMA tiles), 1 = one frame per
  *                            block (32-wide tiles), 0 = f32 MFMA kernel

@@ -28,7 +28,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
         {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
@@ -1217,7 +1217,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             pr.seg[0] = {d.p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE;
             if (fold) { pr.epi = SK_FRAG; pr.out = d.p2f; pr.ldo = 256; }
             else { pr.epi = SK_PLAIN; pr.out = d.p2; pr.ldo = 256; }
-            if (launch_step_attn(at, pr, w.pre2.tiles, s)) return 1;
+            if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds)) return 1;
         }
         if (!fold) {   // phase C: u = prenet + attention_proj(a @ v)
             SkinnyBatch sb{};
@@ -1821,7 +1821,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
         at.B = B; at.T = T; at.m = sl.m;
         SkinnyP pr = sk_base(w.pre2, B);
         pr.seg[0] = {p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE; pr.epi = SK_FRAG; pr.out = p2f; pr.ldo = 256;
-        if (launch_step_attn(at, pr, w.pre2.tiles, s)) return 1;
+        if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds)) return 1;
     }
     return 0;
 }

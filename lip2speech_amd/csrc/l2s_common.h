@@ -54,6 +54,8 @@ struct Options {
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
+    int attn_lds = 1;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
+                                //   1 = at up to 128 rows per launch, 2 = always, 0 = never
     int hoist_vproj = 2;        // "hoist_vproj": the phase-merged step reads o = a @ V' with V' = V W_ap^T + b_ap computed once in the prologue: 2 = LSTM0 on
                                 //   [content | prenet + o | h0] (K = 1024, the sum formed by the operand loader: the reference's own u = prenet + o), 1 = on
                                 //   [content | prenet | o | h0] through a second copy of W_ih's u columns (K = 1280; every block form), 0 = a @ v through the
@@ -347,7 +349,7 @@ struct AttnP {
     int B, T, m;
 };
 // attention role + second prenet layer in one grid (skinny.hip)
-int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s);
+int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values = 1);
 // adaptive average pooling of up to 5 channel-last maps into a concatenated (B, m, nmaps*C) buffer
 struct PoolCatP { const float* x[5]; int L[5]; int ld[5]; int nmaps; int B, m, C; float* out; };
 int launch_pool_cat(const PoolCatP& p, hipStream_t s);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512) void step_attn_timed_kernel(const StepB sb, un
 static unsigned long long* g_attn_ts = nullptr;
 void attn_set_timeline(unsigned long long* ts) { g_attn_ts = ts; }
 
-int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s) {
+int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values) {
     L2S_REQUIRE(at.T <= ATT_MAXT && at.m <= 16, "attention sizes");
     L2S_REQUIRE(pre2.K <= 16 * SK_WAVES * ATT_PRE2_MAXC, "prenet layer 2 is a 256-wide layer");
     StepB sb;
@@ -418,7 +418,9 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     sb.pre2_tiles = pre2_tiles;
     sb.mts = (at.B + 15) / 16;
     ProfScope ps("step_attention_prenet2", s);
-    const bool vl = at.vp != nullptr && at.T <= 32;        // projected values of a short clip: fetched as 16-byte rows through LDS
+    // projected values of a short clip fetched as 16-byte rows through LDS (attention_block<.., VLDS>): faster alone and at up to 128 rows per launch
+    // (32 rows: 8.64 against 8.85 us inside the step), not at 256 (11.2 against 10.6 us event-bracketed, the pass 0.06 ms longer): option 1 = by rows, 2 = always
+    const bool vl = lds_values && (lds_values >= 2 || at.B <= 128) && at.vp != nullptr && at.T <= 32;
     if (g_attn_ts && vl) hipLaunchKernelGGL(step_attn_timed_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb, g_attn_ts);
     else if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     else hipLaunchKernelGGL(step_attn_kernel<false>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);

@@ -330,6 +330,7 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     ({"hoist_vproj": 1}, False), ({"hoist_vproj": 0}, False),      # attention_proj on the values (K = 1280 layer 0) / on a @ v through W_ih W_ap (K = 1536)
     ({"skinny_flat": 0}, True),            # uniform first-phase grid
     ({"frontend_x3": 1}, False), ({"frontend_x3": 0}, False),      # front-end conv: one output frame per block / the f32 MFMA kernel
+    ({"attn_lds": 0}, True), ({"attn_lds": 2}, True),              # attention blocks: one-column value loads / values through LDS (the default picks by rows)
     ({"skinny_rc_jb": 28}, False),         # the straight-line blocks on eight waves (they do not sum u in the loader: layer 0 on K = 1280, other bits)
 ])
 def test_runtime_options_keep_parity(synth_sd, nm, opts, exact):
