@@ -44,6 +44,7 @@ from lip2speech_amd import native, synth  # noqa: E402
 
 B, T, HW, S = 32, 29, 96, 300
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (same guide); the split-bf16 kernels issue SIX bf16 products per fp32 product
 HBM_PEAK_GBS = 8000.0
 
 
@@ -74,7 +75,7 @@ def kernel_model(name, rows=B):
 
 def executed_flops(name, rows=B):
     """FLOPs the launch really issues where they differ from the algorithmic count (phase-merged weights)."""
-    return {"step_lstm_cell": 2 * rows * 2048 * (1280 + 1024) / 2}.get(name)      # layer 0 runs K = 1280: [content | prenet | a.V' | h0] (option hoist_vproj)
+    return {"step_lstm_cell": 2 * rows * 2048 * (1024 + 1024) / 2}.get(name)      # both layers run K = 1024 (layer 0 on [content | prenet + a.V' | h0], option hoist_vproj = 2)
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -462,8 +463,14 @@ def main():
             if ex and roof["bound"] == "mfma":
                 roof["executed_flops"] = ex
                 roof["frac_executed"] = ex / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
-                roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj) / measured "
-                                "duration / peak; frac_executed counts the K=1280 products the phase-merged layer 0 really runs")
+                roof["pipe"] = ("bf16 matrix cores through the exact three-way split (option lstm_x3, default): fp32 operands, six bf16 MFMAs per pair of "
+                                "fp32 K-chunks, fp32 accumulation; peak above is the FP32 matrix peak - the data's dtype")
+                roof["executed_bf16_flops"] = 6 * ex
+                roof["frac_bf16_pipe"] = 6 * ex / avg_s / 1e12 / BF16_MFMA_PEAK_TFLOPS
+                roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj, which the value "
+                                "projection hoisted into the prologue no longer executes per step) / measured duration / fp32 matrix peak; frac_executed "
+                                "counts the fp32-equivalent products the launch runs, frac_bf16_pipe the six bf16 products per fp32 product against the "
+                                "dense bf16 peak")
         # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
         # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None

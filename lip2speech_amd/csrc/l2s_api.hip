@@ -28,7 +28,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
         {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
@@ -569,6 +569,20 @@ static int pack_host(l2s_model* m, Packer& P, bool& want_enc, bool& want_dec, bo
 
 static int build_refresh_map(l2s_model* m, const Packer& P, hipStream_t stream);
 
+// bf16 planes of the two decoder LSTM weights (layer 0 in its unmerged [content | u | h0] form, layer 1) for the split-bf16 LSTM blocks: derived on the
+// device from the packed fp32 fragments, after every pack and every device-side refresh
+static int derive_lstm_planes(l2s_model* m, hipStream_t s) {
+    Weights& w = m->w;
+    w.lstm0.W3 = nullptr; w.lstm1.W3 = nullptr;
+    if (!m->has_dec || !w.lstm0.W || !w.lstm1.W || w.lstm0.K % 256 || w.lstm1.K % 256) return 0;
+    const int64_t b0 = (int64_t)w.lstm0.tiles * w.lstm0.K * 96, b1 = (int64_t)w.lstm1.tiles * w.lstm1.K * 96;      // 16 columns x K x 6 bytes per tile
+    if (!m->lstm_planes) L2S_CHECK_HIP(hipMalloc(&m->lstm_planes, b0 + b1));
+    char* base = reinterpret_cast<char*>(m->lstm_planes);
+    if (launch_skx_planes(w.lstm0.W, w.lstm0.tiles, w.lstm0.K, base, s) || launch_skx_planes(w.lstm1.W, w.lstm1.tiles, w.lstm1.K, base + b0, s)) return 1;
+    w.lstm0.W3 = base; w.lstm1.W3 = base + b0;
+    return 0;
+}
+
 static int pack_model(l2s_model* m, hipStream_t stream) {
     Packer P{m};
     bool want_enc = false, want_dec = false, want_spk = false;
@@ -589,6 +603,8 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     m->has_enc = want_enc;
     m->has_dec = want_dec;
     m->has_spk = want_spk;
+    if (m->lstm_planes) { (void)hipFree(m->lstm_planes); m->lstm_planes = nullptr; }
+    if (derive_lstm_planes(m, stream)) return 1;
     return 0;
 }
 
@@ -806,6 +822,7 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
                            reinterpret_cast<uint16_t*>(const_cast<float*>(m->w.fe.w3)), reinterpret_cast<uint16_t*>(const_cast<float*>(m->w.fe.w1)));
         L2S_CHECK_HIP(hipGetLastError());
     }
+    if (m->lstm_planes && derive_lstm_planes(m, s)) return 1;      // the LSTM weights' bf16 planes are splits of the old weights too
     m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are products of the old parameters ...
     if (remerge_step_weights(m, s)) return 1;      // ... rebuilt here when the decoder's tensors are bound (then the 4-launch step stays valid)
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -961,7 +978,7 @@ static GemmP conv_gemm(const float* X, int lda, int B, int Tin, int Cin, const C
 
 static SkinnyP sk_base(const SkW& sw, int B) {
     SkinnyP p{};
-    p.W = sw.W; p.bias = sw.bias; p.actw = sw.actw;
+    p.W = sw.W; p.W3 = sw.W3; p.bias = sw.bias; p.actw = sw.actw;
     p.B = B; p.N = sw.N; p.K = sw.K;
     p.act = ACT_NONE; p.epi = SK_PLAIN;
     return p;
@@ -1426,6 +1443,7 @@ int l2s_model_destroy(l2s_model* m) {
     if (m->r_idx) (void)hipFree(m->r_idx);
     if (m->r_tables) (void)hipFree(m->r_tables);
     if (m->merge_scratch) (void)hipFree(m->merge_scratch);
+    if (m->lstm_planes) (void)hipFree(m->lstm_planes);
     delete m;
     return 0;
 }

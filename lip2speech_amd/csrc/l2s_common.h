@@ -54,6 +54,8 @@ struct Options {
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
+    int lstm_x3 = 2;            // "lstm_x3": the decode step's LSTM launches on the bf16 matrix cores (exact three-way split, pre-split weight planes): 2 = eight-wave
+                                //   blocks (default), 1 = four-wave blocks (same bits), 0 = the f32 MFMA form
     int attn_lds = 1;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
                                 //   1 = at up to 128 rows per launch, 2 = always, 0 = never
     int hoist_vproj = 2;        // "hoist_vproj": the phase-merged step reads o = a @ V' with V' = V W_ap^T + b_ap computed once in the prologue: 2 = LSTM0 on
@@ -294,6 +296,8 @@ struct SkinnyP {
                            //   (the decode step's u = prenet + attention_proj(a @ v), decoder.py:421; straight-line four-wave blocks only)
     int layout;            // set by launch_skinny: index of a compile-time segment layout the kernel has an instance for (0 = general path)
     const float* W;        // packed frag16 of the [Npad][K] weight, K = sum of segments
+    const void* W3;        // optional: the same weight as three bf16 planes for the split-bf16 LSTM blocks ([tile][K slice 8][chunk pair][plane][lane] 16 B;
+                           //   skx_planes_kernel); with it and option "lstm_x3" the launch runs on the bf16 matrix cores
     const float* bias;     // [Npad] (permuted order for SK_LSTM)
     const float* actw;     // [N] psine weights
     const float* add;      // optional plain [B][ld_add] added after activation (SK_PLAIN/SK_FRAG)
@@ -325,6 +329,7 @@ struct SkinnyP {
 constexpr int SKINNY_MAX_GROUP = 4;
 struct SkinnyBatch { SkinnyP p[SKINNY_MAX_GROUP]; int ntiles[SKINNY_MAX_GROUP]; int count; };
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o = Options());
+int launch_skx_planes(const float* Wf, int ntiles, int K, void* out, hipStream_t s);      // bf16 planes of a packed LSTM weight (SkinnyP::W3): ntiles * K * 16 * 6 bytes
 bool skinny_sum_supported(const Options& o);           // launches with SkinnyP::a_sum need the straight-line four-wave blocks: default operand batching, no stamped build
 void attn_set_timeline(unsigned long long* ts);        // non-null: the stamped attention kernel (tools/attn_timeline.py)
 void skinny_set_flat_timeline(unsigned long long* ts);   // non-null: the stamped build of the step's flat first phase (tools/flat_timeline.py)

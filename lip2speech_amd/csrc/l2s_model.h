@@ -39,7 +39,7 @@ struct UnitW {
     const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // fused units: frag16 [pad16(half)][K]; kpad = pad16(half)
     const float* b1_frag = nullptr; int kin = 0;                                      // stride-2 units: banch1 pw, and pw1, have K = kin = pad16(cin)
 };
-struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; };
+struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; const void* W3 = nullptr; };      // W3: bf16 planes (split-bf16 LSTM blocks)
 
 struct Weights {
     FrontendW fe;
@@ -102,6 +102,8 @@ struct l2s_model {
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
     bool planes_valid = true;                                 // the front-end's bf16 operand planes (w3 / w1) match the current parameters
     float* merge_scratch = nullptr;                           // device: the two products of the device-side re-merge (l2s_train_refresh_weights)
+    void* lstm_planes = nullptr;                              // device: bf16 planes of the decoder LSTM weights (split-bf16 LSTM blocks, option "lstm_x3"); rebuilt
+                                                              //   from the packed fp32 fragments after every pack / device-side refresh
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics
     bool bn_batch = false; float bn_momentum = 0.1f;
     const float* canon(const std::string& key) const { auto it = bound.find(key); return it == bound.end() ? nullptr : it->second.first; }

@@ -83,9 +83,59 @@ __global__ __launch_bounds__(256, 1) void skinny_rc4_kernel(const SkinnyBatch ba
     const int g = blockIdx.z;
     skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, IS_LSTM, false, 4>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
 }
+// the same LSTM blocks on the bf16 matrix cores (skinny_block_rcs<..., X3>): every group of the launch carries pre-split weight planes (SkinnyP::W3)
+template <int RT, int CT, int LAYID, int DEPTH>
+__global__ __launch_bounds__(256, 1) void skinny_rc4x_kernel(const SkinnyBatch batch, int mts) {
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 4, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
+template <int RT, int CT, int LAYID, int DEPTH>
+__global__ __launch_bounds__(512, 1) void skinny_rc8x_kernel(const SkinnyBatch batch, int mts) {      // the same on eight waves: the two waves of a SIMD alternate split VALU and MFMAs
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 8, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
+// weight planes of the split-bf16 LSTM blocks from the packed fp32 fragments ([tile][chunk][lane] float4): chunk pair ip of K slice s = chunks
+// (s + 16 ip, s + 16 ip + 8); out[tile][s][ip][plane][lane] = 8 bf16 (the lane's quad of the first chunk, then of the second)
+__global__ __launch_bounds__(256) void skx_planes_kernel(const float4* __restrict__ Wf, int ntiles, int NC, uint4* __restrict__ out) {
+    const int NPI = NC / 16;
+    const int64_t total = (int64_t)ntiles * 8 * NPI * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int ip = (int)(r % NPI); r /= NPI;
+        const int sl = (int)(r & 7);
+        const int64_t tile = r >> 3;
+        const float4 f0 = Wf[(tile * NC + sl + 16 * ip) * 64 + lane], f1 = Wf[(tile * NC + sl + 16 * ip + 8) * 64 + lane];
+        uint2 h0, m0, l0, h1, m1, l1;
+        skx_split4(f0, h0, m0, l0); skx_split4(f1, h1, m1, l1);
+        uint4* o = out + (((tile * 8 + sl) * NPI + ip) * 3) * 64 + lane;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y); o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y); o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+int launch_skx_planes(const float* Wf, int ntiles, int K, void* out, hipStream_t s) {
+    L2S_REQUIRE(Wf && out && K % 256 == 0, "split-bf16 LSTM planes: K must be a multiple of 256 (whole chunk pairs per slice)");
+    const int64_t total = (int64_t)ntiles * 8 * (K / 256) * 64;
+    hipLaunchKernelGGL(skx_planes_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, reinterpret_cast<const float4*>(Wf), ntiles, K / 16,
+                       reinterpret_cast<uint4*>(out));
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int RT, int CT, int DEPTH>
-static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s) {
+static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s, int x3 = 0) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(256);
+    if (kind == 2 && x3 == 2 && (lay == 2 || lay == 6)) {
+        if (lay == 2) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 2, DEPTH>), grid, dim3(512), 0, s, bl, mts);
+        else hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 6, DEPTH>), grid, dim3(512), 0, s, bl, mts);
+        return true;
+    }
+    if (kind == 2 && x3 && (lay == 2 || lay == 6)) {
+        if (lay == 2) hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 2, DEPTH>), grid, blk, 0, s, bl, mts);
+        else hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 6, DEPTH>), grid, blk, 0, s, bl, mts);
+        return true;
+    }
     if (kind == 2) {
         if (lay == 1) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 1, DEPTH, true>), grid, blk, 0, s, bl, mts);
         else if (lay == 2) hipLaunchKernelGGL((skinny_rc4_kernel<RT, CT, 2, DEPTH, true>), grid, blk, 0, s, bl, mts);
@@ -101,11 +151,11 @@ static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
     return true;
 }
 // measurement build of the 4x2 LSTM form: thread 0 of every block stamps its phases (8 x 64-bit per block, tools/skinny_timeline.py ROWS=256)
-template <int LAYID>
+template <int LAYID, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void skinny_rcs_timed_kernel(const SkinnyBatch batch, int mts, unsigned long long* ts) {
     __shared__ float red[SkRc<4, 2>::RED_FLOATS];
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, 4>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
+    skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, 4, X3>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
 }
 // lay: the K layout every group shares; kind: 2 = every group is an LSTM cell, 1 = none is
 template <int RT, int CT, int DEPTH>
@@ -126,7 +176,7 @@ static bool launch_rcs(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
 }
 
 template <int RT, int CT>
-static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb, int lay, int kind) {
+static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStream_t s, int rc_jb, int lay, int kind, int x3 = 0) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(512);
     // every group in one of the decode step's K layouts and no forced batching: the straight-line form (exact waits, DEPTH - 1 chunks in flight
     // under every chunk's MFMAs)
@@ -135,7 +185,7 @@ static void launch_rc(const SkinnyBatch& bl, int cls, int maxt, int mts, hipStre
     // waves of a SIMD do not share the matrix pipe evenly: the older one runs ahead, the younger follows in its shadow and finishes ~4 us later,
     // alone (stamped build, tools/skinny_timeline.py ROWS=256: block lifetime 14.3 us, kernel span 19.4 us at K = 1024); with one wave per SIMD the
     // pipe is 90 % busy through the K loop and every block ends within 0.2 us of the others (span 12.4 us).  Same bits.
-    if (rc_jb == 0 && lay && launch_rc4<RT, CT, 4>(bl, lay, kind, maxt, mts, s)) return;
+    if (rc_jb == 0 && lay && launch_rc4<RT, CT, 4>(bl, lay, kind, maxt, mts, s, x3)) return;
     if (rc_jb == 28 && lay && launch_rcs<RT, CT, (RT * CT >= 8 ? 4 : 6)>(bl, lay, kind, maxt, mts, s)) return;      // the same straight-line form on eight waves
     if constexpr (RT * CT >= 8) {
         // the 4x2 form holds 6 fragments per chunk and runs alone on its CU.  Default ("skinny_rc_jb" = 0): one-chunk operand batches, four in
@@ -316,6 +366,8 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     int n_lstm = 0;
     for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
     const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
+    int x3 = (o.rc_jb == 0 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 6)) ? o.lstm_x3 : 0;      // LSTM launches on the bf16 matrix cores (1: four waves, 2: eight)
+    for (int i = 0; i < bl.count; ++i) if (!bl.p[i].W3) x3 = 0;
     // several groups, >= 128 rows (below that the 1x1 / 2x1 uniform grids with two blocks per CU are faster, tools/time_step_phases.py): per-group
     // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
     if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024 && rc_kind == 1) {      // a forced block shape wins; LSTM groups (the BiLSTM's two directions) keep the uniform grid of four-wave blocks
@@ -343,13 +395,14 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
+        else if (x3) hipLaunchKernelGGL((skinny_rcs_timed_kernel<2, true>), grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
         else hipLaunchKernelGGL(skinny_rcs_timed_kernel<2>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
     }
     else if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
-    else if (shape == 11 && o.rc_jb == 0 && rc_lay && rc_kind && launch_rc4<1, 1, 4>(bl, rc_lay, rc_kind, maxt, mts, s)) {}      // 16 x 16 tiles, four waves
-    else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
-    else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
-    else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind);
+    else if (shape == 11 && o.rc_jb == 0 && rc_lay && rc_kind && launch_rc4<1, 1, 4>(bl, rc_lay, rc_kind, maxt, mts, s, x3)) {}      // 16 x 16 tiles, four waves
+    else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
+    else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
+    else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
     else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8 && o.skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);

@@ -520,9 +520,39 @@ __device__ __forceinline__ void skinny_block_rc(const SkinnyP& p, int tp, int mg
 // NW = real waves of the block: 8, or 4 (one per SIMD: no partner on the matrix pipe, 512 VGPRs per lane - room for many chunks in flight); with 4
 // every wave plays TWO of the eight K slices (w and w + 4) with their own accumulators, so the partial sums that reach the reduction - and
 // every output bit - are the eight-wave block's.
-template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES>
+// X3 (LSTM launches of the decode step, option "lstm_x3"): the products run on the BF16 matrix cores by the exact three-way split of the dense kernels
+// (x = hi + mid + lo, six partial products per pair).  A K step is a PAIR of a slice's chunks (32 k): the activations' two fp32 quads are split by the
+// wave that loaded them (44 VALU per row tile), the weights arrive pre-split (SkinnyP::W3: [tile][slice][pair][plane][lane] 16 bytes, made from the packed
+// fp32 fragments by skx_planes_kernel) - six v_mfma_f32_16x16x32_bf16 (96 clk) where the f32 form needs eight v_mfma_f32_16x16x4_f32 (256 clk).  The
+// K-slice structure, the even / odd accumulators (now per pair), the reduction order and the epilogue are unchanged; per output the arithmetic is the same
+// whatever the block shape or grouping, and differs from the f32 form by rounding-level amounts like every split-bf16 kernel of this path.
+typedef __bf16 skx_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void skx_split4(const float4& v, uint2& hi, uint2& mid, uint2& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned xb = __float_as_uint(f[e]);
+        const float r1 = f[e] - __uint_as_float(xb & 0xFFFF0000u);                          // exact
+        const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);           // exact, <= 8 significant bits
+        h[e] = xb; m[e] = __float_as_uint(r1); l[e] = __float_as_uint(r2);
+    }
+    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+__device__ __forceinline__ void skx_split8(const float4& a, const float4& b, skx_bf16x8& hi, skx_bf16x8& mid, skx_bf16x8& lo) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    skx_split4(a, h0, m0, l0); skx_split4(b, h1, m1, l1);
+    hi = __builtin_bit_cast(skx_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    mid = __builtin_bit_cast(skx_bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+    lo = __builtin_bit_cast(skx_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false>
 __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr) {
     static_assert(NW == 8 || NW == 4, "eight waves, or four that each play two");
+    static_assert(!X3 || (IS_LSTM && (LAY::NC / SK_WAVES) % 2 == 0), "the split-bf16 form: LSTM blocks, whole chunk pairs per slice");
     constexpr int VW = SK_WAVES / NW, NH = NW / 4;       // K slices per real wave; 256-thread epilogue teams
     L2S_STAMP(0);
     static_assert(LAY::STATIC && LAY::NC % SK_WAVES == 0, "static layout, every wave the same number of chunks");
@@ -562,7 +592,13 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     constexpr int NS1 = LAY::SUM1 ? (LAY::n1 / SK_WAVES) * VW : 1;          // slots whose chunk lies in segment 1 (first slot: FS1)
     constexpr int FS1 = (E0 / SK_WAVES) * VW;
     const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LAY::SUM1 ? p.a_sum : W), 0, 0x7fffffff, 0x00020000);
-    float4 a[TC][RT], w[TC][CT], a2[NS1][RT];
+    constexpr int NPI = MAXC / 2;                                           // chunk pairs per K slice (X3)
+    const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(X3 ? p.W3 : (const void*)W), 0, 0x7fffffff, 0x00020000);
+    int wo3[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wo3[i] = (((min(tp * CT + i, ntiles - 1) * SK_WAVES + wave) * NPI * 3) * 64 + lane) * 16;
+    float4 a[TC][RT], w[X3 ? 1 : TC][CT], a2[NS1][RT];
+    uint4 w3[X3 ? TC / 2 : 1][CT][3];
     auto load_chunk = [&](auto jc) {          // slot t: K slice h = t % VW (wave + NW * h), its j-th chunk (j = t / VW)
         constexpr int t_ = decltype(jc)::value, j = t_;
         constexpr int cj = SK_WAVES * (t_ / VW) + NW * (t_ % VW);
@@ -575,8 +611,19 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
 #pragma unroll
             for (int r = 0; r < RT; ++r) a2[j - FS1][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_s1, ao[1][r], off * 1024, 0));
         }
+        if constexpr (X3) {
+            if constexpr ((t_ / VW) % 2 == 0) {       // the first chunk of a pair brings the pair's three weight planes
+                constexpr int ip = (t_ / VW) / 2, hs = t_ % VW;
 #pragma unroll
-        for (int i = 0; i < CT; ++i) w[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo[i], cj * 1024, 0));
+                for (int i = 0; i < CT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        w3[ip * VW + hs][i][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, wo3[i], ((hs * NW * NPI + ip) * 3 + pl) * 1024, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CT; ++i) w[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo[i], cj * 1024, 0));
+        }
     };
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, PRE>([&](auto jc) { load_chunk(jc); });
@@ -658,6 +705,21 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
                     a[j][r].x += a2[j - FS1][r].x; a[j][r].y += a2[j - FS1][r].y; a[j][r].z += a2[j - FS1][r].z; a[j][r].w += a2[j - FS1][r].w;
                 }
             }
+            if constexpr (X3) {
+                if constexpr ((j / VW) % 2 == 1) {   // the second chunk of a pair: both quads are here (and summed): split, six partial products per tile pair
+                    constexpr int ip = (j / VW) / 2, px = ip & 1, ws = ip * VW + hh;
+                    skx_bf16x8 ah[RT], am[RT], al[RT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) skx_split8(a[j - VW][r], a[j][r], ah[r], am[r], al[r]);
+                    // smallest partial products first; tile-major inside a term, so that an accumulator's next MFMA is NT instructions away
+#define L2S_SKX_TERM(A_, PL_)                                                                                                              \
+                    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                                         \
+                        _Pragma("unroll") for (int i = 0; i < CT; ++i)                                                                     \
+                            acc[r * CT + i][px][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[r], __builtin_bit_cast(skx_bf16x8, w3[ws][i][PL_]), acc[r * CT + i][px][hh], 0, 0, 0);
+                    L2S_SKX_TERM(al, 0) L2S_SKX_TERM(ah, 2) L2S_SKX_TERM(am, 1) L2S_SKX_TERM(am, 0) L2S_SKX_TERM(ah, 1) L2S_SKX_TERM(ah, 0)
+#undef L2S_SKX_TERM
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -668,6 +730,7 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
                         const float wv = e == 0 ? w[j][i].x : e == 1 ? w[j][i].y : e == 2 ? w[j][i].z : w[j][i].w;
                         acc[r * CT + i][par][hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc[r * CT + i][par][hh], 0, 0, 0);
                     }
+            }
         }
         if constexpr (j + PRE < TC) {                // the registers of this chunk are free again: request the chunk DEPTH ahead
             __builtin_amdgcn_sched_barrier(0);

@@ -330,6 +330,7 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     ({"hoist_vproj": 1}, False), ({"hoist_vproj": 0}, False),      # attention_proj on the values (K = 1280 layer 0) / on a @ v through W_ih W_ap (K = 1536)
     ({"skinny_flat": 0}, True),            # uniform first-phase grid
     ({"frontend_x3": 1}, False), ({"frontend_x3": 0}, False),      # front-end conv: one output frame per block / the f32 MFMA kernel
+    ({"lstm_x3": 0}, False), ({"lstm_x3": 1}, True),               # LSTM launches on the f32 matrix pipe / the four-wave split-bf16 form
     ({"attn_lds": 0}, True), ({"attn_lds": 2}, True),              # attention blocks: one-column value loads / values through LDS (the default picks by rows)
     ({"skinny_rc_jb": 28}, False),         # the straight-line blocks on eight waves (they do not sum u in the loader: layer 0 on K = 1280, other bits)
 ])
@@ -672,10 +673,21 @@ def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
     # and the forced block shapes agree with each other (options are per model: this handle only).  The general block forms ("skinny_rc_jb" != 0)
     # cannot sum u = prenet + o in the loader, so LSTM layer 0 runs on [content | prenet | o | h0] (hoist_vproj = 1: another, equally valid, order of
     # additions): every form is compared on THAT layout - bit for bit among themselves - and the default layout against the single-batch calls above
+    # first the split-bf16 LSTM blocks (default, "lstm_x3" = 2: eight waves) in every block shape, and their four-wave form: same bits as the default
+    xown = pc.fresh_native_model(synth_sd)
+    for x3 in (2, 1):
+        xown.set_option("lstm_x3", x3)
+        for shape in (0, 11, 21, 22, 42):
+            xown.set_option("skinny_rc", shape)
+            alt = xown.inference_multi(batches, S=S, want_attn=True)
+            for a, w in zip(alt, want):
+                assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[2], w[2]), (x3, shape)
+    # the f32 block forms among themselves ("lstm_x3" = 0)
     own = pc.fresh_native_model(synth_sd)
+    own.set_option("lstm_x3", 0)
     own.set_option("hoist_vproj", 1)
     want = [tuple(t.clone() for t in own.inference(*b, S=S, want_attn=True)) for b in batches]
-    assert all(pc.maxdiff(w[0], g[0]) < 1e-4 for w, g in zip(want, got))      # the two layouts agree to rounding
+    assert all(pc.maxdiff(w[0], g[0]) < 1e-4 for w, g in zip(want, got))      # the layouts / matrix pipes agree to rounding
     for shape in (11, 21, 22, 42):
         own.set_option("skinny_rc", shape)
         for jb in (0, 2, 4, 15):

@@ -4,7 +4,9 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
-nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+nm = native.NativeModel()
+if os.environ.get("X3"): nm.set_option("lstm_x3", 1)          # the split-bf16 LSTM blocks
+nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
 B = int(os.environ.get("ROWS", "32"))      # ROWS=256: the straight-line 4x2 form (skinny_block_rcs), one block per CU
 L = native.lib()
 ts = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
