@@ -342,6 +342,10 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  * accumulators are guarded - only changing an option of a model WHILE other threads run batches on it is the caller's race.
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
+ *   "lstm_x3"           (2)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
+ *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
+ *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks (same bits), 0 = f32 MFMAs
+ *                            (other bits, rounding-level)
  *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows: 1 = at up to
  *                            128 rows per launch, 2 = always, 0 = never (one-column loads, 120 registers); same bits
  *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path: 2 = two consecutive output
