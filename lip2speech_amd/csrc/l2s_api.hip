@@ -573,13 +573,22 @@ static int build_refresh_map(l2s_model* m, const Packer& P, hipStream_t stream);
 // device from the packed fp32 fragments, after every pack and every device-side refresh
 static int derive_lstm_planes(l2s_model* m, hipStream_t s) {
     Weights& w = m->w;
-    w.lstm0.W3 = nullptr; w.lstm1.W3 = nullptr;
-    if (!m->has_dec || !w.lstm0.W || !w.lstm1.W || w.lstm0.K % 256 || w.lstm1.K % 256) return 0;
-    const int64_t b0 = (int64_t)w.lstm0.tiles * w.lstm0.K * 96, b1 = (int64_t)w.lstm1.tiles * w.lstm1.K * 96;      // 16 columns x K x 6 bytes per tile
-    if (!m->lstm_planes) L2S_CHECK_HIP(hipMalloc(&m->lstm_planes, b0 + b1));
+    SkW* const sk[4] = {&w.lstm0, &w.lstm1, &w.whh[0], &w.whh[1]};          // decoder layers 0 (unmerged [content | u | h0]) and 1, the BiLSTM's two directions
+    for (SkW* k : sk) k->W3 = nullptr;
+    if (!m->has_dec) return 0;
+    int64_t bytes[4], total = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!sk[i]->W || sk[i]->K % 256) return 0;
+        bytes[i] = (int64_t)sk[i]->tiles * sk[i]->K * 96;                    // 16 columns x K x 6 bytes per tile
+        total += bytes[i];
+    }
+    if (!m->lstm_planes) L2S_CHECK_HIP(hipMalloc(&m->lstm_planes, total));
     char* base = reinterpret_cast<char*>(m->lstm_planes);
-    if (launch_skx_planes(w.lstm0.W, w.lstm0.tiles, w.lstm0.K, base, s) || launch_skx_planes(w.lstm1.W, w.lstm1.tiles, w.lstm1.K, base + b0, s)) return 1;
-    w.lstm0.W3 = base; w.lstm1.W3 = base + b0;
+    for (int i = 0; i < 4; ++i) {
+        if (launch_skx_planes(sk[i]->W, sk[i]->tiles, sk[i]->K, base, s)) return 1;
+        sk[i]->W3 = base;
+        base += bytes[i];
+    }
     return 0;
 }
 

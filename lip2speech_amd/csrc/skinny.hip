@@ -126,13 +126,15 @@ int launch_skx_planes(const float* Wf, int ntiles, int K, void* out, hipStream_t
 template <int RT, int CT, int DEPTH>
 static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s, int x3 = 0) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(256);
-    if (kind == 2 && x3 == 2 && (lay == 2 || lay == 6)) {
-        if (lay == 2) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 2, DEPTH>), grid, dim3(512), 0, s, bl, mts);
+    if (kind == 2 && x3 == 2 && (lay == 1 || lay == 2 || lay == 6)) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 1, DEPTH>), grid, dim3(512), 0, s, bl, mts);      // the BiLSTM recurrence (K = 512)
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 2, DEPTH>), grid, dim3(512), 0, s, bl, mts);
         else hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 6, DEPTH>), grid, dim3(512), 0, s, bl, mts);
         return true;
     }
-    if (kind == 2 && x3 && (lay == 2 || lay == 6)) {
-        if (lay == 2) hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 2, DEPTH>), grid, blk, 0, s, bl, mts);
+    if (kind == 2 && x3 && (lay == 1 || lay == 2 || lay == 6)) {
+        if (lay == 1) hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 1, DEPTH>), grid, blk, 0, s, bl, mts);
+        else if (lay == 2) hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 2, DEPTH>), grid, blk, 0, s, bl, mts);
         else hipLaunchKernelGGL((skinny_rc4x_kernel<RT, CT, 6, DEPTH>), grid, blk, 0, s, bl, mts);
         return true;
     }
@@ -366,7 +368,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     int n_lstm = 0;
     for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
     const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
-    int x3 = (o.rc_jb == 0 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 6)) ? o.lstm_x3 : 0;      // LSTM launches on the bf16 matrix cores (1: four waves, 2: eight)
+    int x3 = (o.rc_jb == 0 && rc_kind == 2 && (rc_lay == 1 || rc_lay == 2 || rc_lay == 6)) ? o.lstm_x3 : 0;      // LSTM launches on the bf16 matrix cores (1: four waves, 2: eight)
     for (int i = 0; i < bl.count; ++i) if (!bl.p[i].W3) x3 = 0;
     // several groups, >= 128 rows (below that the 1x1 / 2x1 uniform grids with two blocks per CU are faster, tools/time_step_phases.py): per-group
     // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
