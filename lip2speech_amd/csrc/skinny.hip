@@ -153,11 +153,11 @@ static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
     return true;
 }
 // measurement build of the 4x2 LSTM form: thread 0 of every block stamps its phases (8 x 64-bit per block, tools/skinny_timeline.py ROWS=256)
-template <int LAYID, bool X3 = false>
-__global__ __launch_bounds__(256, 1) void skinny_rcs_timed_kernel(const SkinnyBatch batch, int mts, unsigned long long* ts) {
+template <int LAYID, bool X3 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void skinny_rcs_timed_kernel(const SkinnyBatch batch, int mts, unsigned long long* ts) {
     __shared__ float red[SkRc<4, 2>::RED_FLOATS];
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, 4, X3>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
+    skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, NW, X3>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
 }
 // lay: the K layout every group shares; kind: 2 = every group is an LSTM cell, 1 = none is
 template <int RT, int CT, int DEPTH>
@@ -397,6 +397,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
+        else if (x3 == 2) hipLaunchKernelGGL((skinny_rcs_timed_kernel<2, true, 8>), grid, dim3(512), 0, s, bl, mts, g_skinny_ts);
         else if (x3) hipLaunchKernelGGL((skinny_rcs_timed_kernel<2, true>), grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
         else hipLaunchKernelGGL(skinny_rcs_timed_kernel<2>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
     }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
 nm = native.NativeModel()
-if os.environ.get("X3"): nm.set_option("lstm_x3", 1)          # the split-bf16 LSTM blocks
+nm.set_option("lstm_x3", int(os.environ.get("X3", "2")))      # 2 (default): split-bf16 LSTM blocks on eight waves, 1: on four, 0: the f32 MFMA form
 nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
 B = int(os.environ.get("ROWS", "32"))      # ROWS=256: the straight-line 4x2 form (skinny_block_rcs), one block per CU
 L = native.lib()
