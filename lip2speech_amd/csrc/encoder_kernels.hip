@@ -426,7 +426,11 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
     constexpr int P = FE_CR * Wc;                    // conv pixels per strip
     constexpr int PT = (P + 15) / 16;                // 16-pixel MFMA row tiles
     constexpr int TPW = (PT + 3) / 4;                // tiles per wave
-    constexpr int XLD = FxGeom<HW>::XLD, PLANE = FxGeom<HW>::PLANE;
+    // input row pitch 112 bf16 = 56 dwords: the A operand is read with ds_read2_b32 (32 banks, lanes 0-31 and 32-63 as groups), a group holds the 16
+    // pixels of TWO k-groups - placed two input rows apart (112 dwords = 16 mod 32) they cover the 32 banks exactly; one row apart (24 mod 32) eight banks
+    // were hit twice and every operand read cost double (SQ_LDS_BANK_CONFLICT: 24 % of the kernel's CU cycles)
+    constexpr int XLD = 112, PLANE = FE_XROWS * XLD * 2;
+    static_assert(XLD >= W + 8 && (XLD / 2) % 32 == 24, "row pitch");
     constexpr int XS = 3 * PLANE;                    // bytes: input planes
     constexpr int WROW = 48, WSP = 24 * WROW;        // weight row; bytes per (step, plane) of one output frame: 24 channel rows
     constexpr int WSO = 12 * WSP;                    // bytes per output frame: 4 steps x 3 planes
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
     const int p0 = blockIdx.x * FE_PR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, kg = lane >> 4;
+    const int kr = ((kg & 1) << 1) | (kg >> 1);       // kernel row (of the four of a K step) this lane's k-group carries: k-groups 0,1,2,3 = rows 0,2,1,3
 
     for (int i = tid; i < XS / 16; i += 256) reinterpret_cast<uint4*>(Xs)[i] = make_uint4(0u, 0u, 0u, 0u);
 
@@ -458,14 +463,14 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
         int p = (wave + 4 * j) * 16 + li;
         p = p < P ? p : P - 1;
         const int lr = p / Wc, c = p - lr * Wc;
-        base[j] = ((2 * lr + kg) * XLD + 2 * c) * 2;
+        base[j] = ((2 * lr + kr) * XLD + 2 * c) * 2;
     }
-    // weight operand of column tile nt: column q = 16 nt + li -> (frame o, channel ch); this lane's kernel row inside a K step is kg
+    // weight operand of column tile nt: column q = 16 nt + li -> (frame o, channel ch); this lane's kernel row inside a K step is kr
     int wof[3];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
         const int q = nt * 16 + li, o = q >= FE_CO ? 1 : 0, ch = q - FE_CO * o;
-        wof[nt] = o * WSO + (kg >> 1) * (3 * WSP) + ch * WROW + (kg & 1) * 16;
+        wof[nt] = o * WSO + (kr >> 1) * (3 * WSP) + ch * WROW + (kr & 1) * 16;
     }
     f32x4 acc[TPW][3];
 #pragma unroll
@@ -493,8 +498,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
         for (int q = 0; q < NLD; ++q) fetch_piece(sl, q);
     };
     // the weight operand of slab sl, straight into LDS buffer `buf` (global_load_lds: a wave's 64 lanes fill one contiguous 1-KB piece; no staging
-    // registers, no ds_write pass) - issued at the head of the PREVIOUS slab's MFMA phase, landed by the barrier that ends it.  A frame the slab does
-    // not feed gets zero rows by ordinary stores.
+    // registers, no ds_write pass) - issued at the head of the PREVIOUS slab's MFMA phase, landed by the barrier that ends it.
     auto dma_piece = [&](int sl, int buf, int kp) {                          // piece c = wave + 4 kp of the NWC 1-KB pieces
         const int c = wave + 4 * kp;
         if (c < NWC) {                                                       // wave-uniform
@@ -506,13 +510,12 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
             const int sp = r / (WSP / 16), u = r - sp * (WSP / 16);
             const int kt = d - o;                                             // the tap through which frame t0 + o sees this input frame
             const bool on = kt >= 0 && kt <= 4 && (o == 0 || has1);
-            if (on) {
-                const uint4* src = w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + u;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Wd + c * 1024), 16, 0, 0);
-            } else {
-                reinterpret_cast<uint4*>(Wd)[i] = make_uint4(0u, 0u, 0u, 0u);
-            }
+            // a frame the slab does not feed takes its rows from a zero chunk of the packed planes (output-channel row 24 of 32 is padding: zeros) -
+            // as ordinary zero stores those lanes cost an s_waitcnt vmcnt(0) each (a store to LDS behind a pending LDS-DMA), i.e. a full drain of
+            // the requests in flight in the middle of the MFMA phase of every edge slab
+            const uint4* src = on ? w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + u : w3 + (24 * WROW) / 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Wd + c * 1024), 16, 0, 0);
         }
     };
     constexpr int NDP = (NWC + 3) / 4;                                       // pieces per wave

@@ -216,7 +216,8 @@ struct FrontendW {          // device pointers into the weight blob
     const float* scale;     // [24] BN scale
     const float* shift;     // [24]
     const float* slope;     // [24] PReLU
-    const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows]
+    const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows];
+                            //   channel rows 24-31 are zeros (frontend3d_x3p_kernel takes the zero rows of an absent frame from row 24)
                             //   (null: f32 MFMA kernel)
     int pair = 0;           // with w3: two output frames per block (frontend3d_x3p_kernel) - set by the callers from option "frontend_x3" == 2
     const float* w1;        // the same as ONE plane rounded to nearest even: [15 slabs][4 steps][32 co][16 taps, 48-byte rows] (set by the callers

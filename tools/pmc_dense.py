@@ -1,0 +1,11 @@
+"""The encoder of one grouped pass at 256 clips (front-end conv, ShuffleNet trunk units, conv_last), for
+rocprofv3 --pmc / --kernel-trace passes (tools/pmc_dense_kernels.sh)."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from lip2speech_amd import native, synth
+ROWS = int(os.environ.get("ROWS", 256))
+sd = synth.synth_state_dict()
+nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+video = torch.cat([synth.synth_video(32, 29, tag=f"b{i}") for i in range(ROWS // 32)]).cuda()
+nm.encoder_fwd(video)
+torch.cuda.synchronize()
