@@ -549,6 +549,12 @@ __device__ __forceinline__ void skx_split8(const float4& a, const float4& b, skx
     lo = __builtin_bit_cast(skx_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
 
+// Where element (row, col) of partial tile `slot` sits in the reduction buffer of skinny_block_rcs: 256 floats per tile, no padding, row r at
+// 16 * (r ^ bit 2 of r) with its columns XORed by bits 1-2 of r.  Both sides go through LDS as 32-bit accesses (32 banks, 32-lane groups): the
+// MFMA D layout writes rows R and R + 4 from one group (they land in opposite 16-bank halves), the cell threads read rows 0-7 x the four columns
+// {4u + g} (four rows per half, their low column bits made distinct by the XOR) - neither side shares a bank.  The [16][17] layout cost every
+// write and every gate read a second LDS cycle (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the LSTM launches).
+__device__ __forceinline__ int sk_red_idx(int slot, int row, int col) { return slot * 256 + ((row ^ ((row >> 2) & 1)) << 4) + (col ^ ((row >> 1) & 3)); }
 template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false>
 __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr) {
     static_assert(NW == 8 || NW == 4, "eight waves, or four that each play two");
@@ -749,7 +755,7 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
 #pragma unroll
             for (int q = 0; q < NT; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(((wave + NW * h) * NT + q) * 16 + rb + r) * 17 + col] = acc[q][0][h][r] + acc[q][1][h][r];
+                for (int r = 0; r < 4; ++r) red[sk_red_idx((wave + NW * h) * NT + q, rb + r, col)] = acc[q][0][h][r] + acc[q][1][h][r];
     }
     __syncthreads();
     L2S_STAMP(5);
@@ -762,7 +768,7 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
             if (t >= ntiles || rt >= mts) continue;
             float v = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q) * 16 + e_row) * 17 + e_col];
+            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[sk_red_idx(wv * NT + q, e_row, e_col)];
             v += pf_bias[n];
             const int b = rt * 16 + e_row, np = t * 16 + e_col;
             if (b >= nB) continue;
@@ -796,7 +802,7 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         for (int g = 0; g < 4; ++g) {
             float v = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[((wv * NT + q2) * 16 + r2) * 17 + 4 * u2 + g];
+            for (int wv = 0; wv < SK_WAVES; ++wv) v += red[sk_red_idx(wv * NT + q2, r2, 4 * u2 + g)];
             v += pf_gb[cr][g];
             v += pf_gp[cr][g];
             g4[g] = v;
