@@ -432,11 +432,12 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
     constexpr int XLD = 112, PLANE = FE_XROWS * XLD * 2;
     static_assert(XLD >= W + 8 && (XLD / 2) % 32 == 24, "row pitch");
     constexpr int XS = 3 * PLANE;                    // bytes: input planes
-    constexpr int WROW = 48, WSP = 24 * WROW;        // weight row; bytes per (step, plane) of one output frame: 24 channel rows
+    constexpr int WROW = 48, LROW = 32;              // weight row in the packed planes (16 bf16 + pad) and in LDS (no pad: a third fewer DMA pieces)
+    constexpr int WSP = 24 * LROW;                   // bytes per (step, plane) of one output frame: 24 channel rows
     constexpr int WSO = 12 * WSP;                    // bytes per output frame: 4 steps x 3 planes
-    constexpr int WS = 2 * WSO;                      // 27 648
+    constexpr int WS = 2 * WSO;                      // 18 432
     constexpr int CS = P * (FE_CO / 2) * 4;          // conv tile of half the channels of one output frame (aliases the operand area)
-    constexpr int SMEM = (XS + 2 * WS) > CS ? (XS + 2 * WS) : CS;     // two weight buffers: 76.8 KB, two blocks per CU
+    constexpr int SMEM = (XS + 2 * WS) > CS ? (XS + 2 * WS) : CS;     // two weight buffers: 58.4 KB, two blocks per CU
     constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
     constexpr int NWU = WS / 16, NWC = NWU / 64;                    // weight uint4 per slab; 1-KB pieces of the weight operand
     static_assert(NWU % 64 == 0, "the weight operand is a whole number of wave-wide 16-byte pieces");
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
         const int q = nt * 16 + li, o = q >= FE_CO ? 1 : 0, ch = q - FE_CO * o;
-        wof[nt] = o * WSO + (kr >> 1) * (3 * WSP) + ch * WROW + (kr & 1) * 16;
+        wof[nt] = o * WSO + (kr >> 1) * (3 * WSP) + ch * LROW + (kr & 1) * 16;
     }
     f32x4 acc[TPW][3];
 #pragma unroll
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
             // a frame the slab does not feed takes its rows from a zero chunk of the packed planes (output-channel row 24 of 32 is padding: zeros) -
             // as ordinary zero stores those lanes cost an s_waitcnt vmcnt(0) each (a store to LDS behind a pending LDS-DMA), i.e. a full drain of
             // the requests in flight in the middle of the MFMA phase of every edge slab
-            const uint4* src = on ? w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + u : w3 + (24 * WROW) / 16;
+            const uint4* src = on ? w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + (u >> 1) * (WROW / 16) + (u & 1) : w3 + (24 * WROW) / 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Wd + c * 1024), 16, 0, 0);
         }
