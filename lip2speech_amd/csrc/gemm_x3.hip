@@ -315,8 +315,12 @@ constexpr int WLDB = 48;                         // bytes per LDS row (16 bf16 +
 constexpr int WPA = WM * WLDB, WPB = WN * WLDB;  // bytes per plane
 constexpr int WSTAGE = 3 * WPA + 3 * WPB;        // 55 296
 constexpr int WTHREADS = 768;
+// with the weight operand by LDS-DMA from pre-split planes (GemmP::W3): B rows of 32 bytes, no pad - the DMA's per-lane source address swaps the two
+// 16-byte halves of rows 8-15 (mod 16), which makes the consumers' ds_read_b128 lane groups conflict-free without it
+constexpr int WLDBD = 32, WPBD = WN * WLDBD;     // 8 192 bytes per plane
+constexpr int WSTAGED = 3 * WPA + 3 * WPBD;      // 43 008
 
-template <bool TIMED>
+template <bool TIMED, bool DMAW>
 __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batch, unsigned long long* __restrict__ ts, int stamp_block) {
     const GemmP& p = batch.p[blockIdx.z];
     const bool stamp_on = TIMED && (int)(blockIdx.y * gridDim.x + blockIdx.x) == stamp_block && blockIdx.z == 0;
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
     const int nks = (p.K + WK - 1) / WK;
     const int wm = (wave >> 2) & 1, wn = wave & 3;
     const int li = lane & 31, lg = lane >> 5;
+    constexpr int STG = DMAW ? WSTAGED : WSTAGE;     // bytes per stage
 
     // the accumulators leave through LDS, one 32-row sub-tile of both wave rows (64 rows x 256 columns, 64 KB) at a time; all twelve waves run
     // the fused epilogue over it (rows of 256 consecutive columns).  The accumulators are declared in the consumer branch only: live across the
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         // (launch checks: Cin and a_split multiples of 16), so the per-step advance is scalar arithmetic, the column offset travels in the buffer
         // instruction's scalar offset, and the per-thread part - row base + kq - only changes when the tap does (a uniform branch).  The first form
         // (per-thread ci / tap, offsets rebuilt per load) cost the staging waves 580 clk of address VALU per step beside two MFMA waves per SIMD.
-        unsigned wfix[4], afix[2];                           // per-thread byte offsets (OOB: row outside the matrix / frame outside the sequence)
+        unsigned wfix[DMAW ? 1 : 4], afix[2];                           // per-thread byte offsets (OOB: row outside the matrix / frame outside the sequence)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = m0 + lr + 64 * j;
@@ -384,15 +389,32 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
             atbase[j] = t * p.stride - p.pad;
             arow_off[j] = (unsigned)((int64_t)b * lp.Tin * lp.lda);
         }
+        if constexpr (!DMAW) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + lr + 64 * j;
-            wfix[j] = n < p.N ? (unsigned)((int64_t)n * ldw + kq) * 4u : OOB;
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + lr + 64 * j;
+                wfix[j] = n < p.N ? (unsigned)((int64_t)n * ldw + kq) * 4u : OOB;
+            }
         }
         int kb = 0, tap = 0, cib = 0;                        // uniform: first k of the step being requested, its tap, its first channel
         const int nseq = (p.M + p.Tout - 1) / p.Tout;
         const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)nseq * lp.Tin * lp.lda * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * ldw * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw_rs = DMAW ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W3), 0, (int)((int64_t)p.N * lp.K * 6), 0x00020000)
+                                                  : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((int64_t)p.N * ldw * 4), 0x00020000);
+        // LDS-DMA of the weight planes of K step `ks` into stage `st`: 3 planes x 256 rows x 32 bytes = 24 contiguous 1-KB pieces (a piece = 32 rows of
+        // one plane), six per staging wave; lane l fills 16-byte chunk l of its piece = (row l >> 1, half l & 1), reading the half the swizzle puts there
+        const unsigned dma_lane = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
+        auto dma_b = [&](int ks, int st) {
+            if (ks < nks) {                                                                  // uniform
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int q = (wave - 8) * 6 + e, pl = q >> 3, sub = q & 7;
+                    const int soff = __builtin_amdgcn_readfirstlane((int)((((int64_t)ks * 3 + pl) * p.N + n0 + sub * 32) * 32));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_rs, (__attribute__((address_space(3))) void*)(smem + st * STG + 3 * WPA + pl * WPBD + sub * 1024), 16,
+                                                             (int)dma_lane, soff, 0, 0);
+                }
+            }
+        };
         auto set_tap = [&]() {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -411,9 +433,11 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_rs, (int)afix[j], acol, 0));
+            if constexpr (!DMAW) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_rs, (int)wfix[j], wcol, 0));
+                for (int j = 0; j < 4; ++j)
+                    rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_rs, (int)wfix[j], wcol, 0));
+            }
         };
         auto advance = [&]() {
             if (kb + WK < lp.K) {                                                            // uniform
@@ -423,34 +447,39 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         };
         const int st_off = lr * WLDB + kq * 2;
         auto stage = [&](const float4* ra, const float4* rb, int st) {
-            unsigned char* base = smem + st * WSTAGE + st_off;
+            unsigned char* base = smem + st * STG + st_off;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const X3Split sa = x3_split(ra[j]);
                 unsigned char* ad = base + 64 * j * WLDB;
                 *reinterpret_cast<uint2*>(ad) = sa.hi; *reinterpret_cast<uint2*>(ad + WPA) = sa.mid; *reinterpret_cast<uint2*>(ad + 2 * WPA) = sa.lo;
             }
+            if constexpr (!DMAW) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const X3Split sb = x3_split(rb[j]);
-                unsigned char* bd = base + 3 * WPA + 64 * j * WLDB;
-                *reinterpret_cast<uint2*>(bd) = sb.hi; *reinterpret_cast<uint2*>(bd + WPB) = sb.mid; *reinterpret_cast<uint2*>(bd + 2 * WPB) = sb.lo;
+                for (int j = 0; j < 4; ++j) {
+                    const X3Split sb = x3_split(rb[j]);
+                    unsigned char* bd = base + 3 * WPA + 64 * j * WLDB;
+                    *reinterpret_cast<uint2*>(bd) = sb.hi; *reinterpret_cast<uint2*>(bd + WPB) = sb.mid; *reinterpret_cast<uint2*>(bd + 2 * WPB) = sb.lo;
+                }
             }
         };
         // branch-free body, requests before the older sets are waited for (see the narrow kernel).  THREE register sets: the data staged in
         // iteration ks (step ks+1) were requested in iteration ks-2 - two K steps (~3 500 clk) to land; with two sets (one step) the staging
         // waves still waited ~400 clk per step for rows of A that come from HBM
-        float4 ra0[2], rb0[4], ra1[2], rb1[4], ra2[2], rb2[4];
+        float4 ra0[2], rb0[DMAW ? 1 : 4], ra1[2], rb1[DMAW ? 1 : 4], ra2[2], rb2[DMAW ? 1 : 4];
+        if constexpr (DMAW) dma_b(0, 0);
         fetch(ra0, rb0);
         advance(); fetch(ra1, rb1);
         advance(); fetch(ra2, rb2);
         stage(ra0, rb0, 0);
+        if constexpr (DMAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage 0's weight planes have landed before the barrier publishes it
         __syncthreads();                                     // stage 0 = step 0
         // every request of the prologue has landed before the loop is entered: with loads pending on the entry edge the wait-count pass merges
         // them with the back edge's at the loop header and drains ALL outstanding loads (vmcnt(0)) once per trip
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define L2S_X3W_PRODUCE(KS_, RA_NEW, RB_NEW, RA_OLD, RB_OLD)                                                   \
         X3_STAMP(KS_, 0);                                                                                      \
+        if constexpr (DMAW) dma_b((KS_) + 1, ((KS_) + 1) & 1);   /* that stage was last read in step KS_ - 1 */  \
         advance(); fetch(RA_NEW, RB_NEW);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         X3_STAMP(KS_, 4);                                                                                      \
@@ -458,6 +487,8 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         stage(RA_OLD, RB_OLD, ((KS_) + 1) & 1);                                                                \
         if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }                            \
         X3_STAMP(KS_, 2);                                                                                      \
+        /* all but the two newest requests (this step's activation rows) are back: the DMA pieces of step KS_ + 1 have landed */ \
+        if constexpr (DMAW) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                   \
         __syncthreads();                                                                                       \
         X3_STAMP(KS_, 3);
         for (int ks = 0; ks < nks; ks += 3) {
@@ -484,7 +515,9 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const unsigned char* a_rd = smem + (wm * 64 + li) * WLDB + lg * 16;
-        const unsigned char* b_rd = smem + 3 * WPA + (wn * 64 + li) * WLDB + lg * 16;
+        const unsigned char* b_rd = DMAW ? smem + 3 * WPA + (wn * 64 + li) * WLDBD + ((lg ^ ((li >> 3) & 1)) * 16)
+                                         : smem + 3 * WPA + (wn * 64 + li) * WLDB + lg * 16;
+        constexpr int BROW = DMAW ? WLDBD : WLDB, BPL = DMAW ? WPBD : WPB;
         struct FA { bf16x8 h[2], m[2], l[2]; };
         struct FB { bf16x8 h, m, l; };
         auto read_a = [&](FA& f, int so) {
@@ -495,8 +528,8 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
             }
         };
         auto read_b = [&](FB& f, int so, int j) {
-            const unsigned char* bp = b_rd + so + j * 32 * WLDB;
-            f.h = *reinterpret_cast<const bf16x8*>(bp); f.m = *reinterpret_cast<const bf16x8*>(bp + WPB); f.l = *reinterpret_cast<const bf16x8*>(bp + 2 * WPB);
+            const unsigned char* bp = b_rd + so + j * 32 * BROW;
+            f.h = *reinterpret_cast<const bf16x8*>(bp); f.m = *reinterpret_cast<const bf16x8*>(bp + BPL); f.l = *reinterpret_cast<const bf16x8*>(bp + 2 * BPL);
         };
         // smallest partial products first; the two accumulators of a half alternate so that no MFMA waits on its predecessor
 #define L2S_X3W_TERM(A_, B_, J_)                                                                              \
@@ -519,7 +552,7 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         X3_STAMP(KS_, 2);                                                                                      \
         L2S_X3W_MMA_HEAD(FA_CUR, fb1, 1)                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        read_a(FA_NXT, WSTAGE - (SO_)); read_b(fb0, WSTAGE - (SO_), 0);   /* past the last step: unused */     \
+        read_a(FA_NXT, STG - (SO_)); read_b(fb0, STG - (SO_), 0);         /* past the last step: unused */     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         L2S_X3W_MMA_TAIL(FA_CUR, fb1, 1)                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -531,7 +564,7 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         int ks = 0;
         for (; ks + 1 < nks; ks += 2) {                      // pairs of steps: no exit from the middle of the body (the accumulators would be copied at it)
             L2S_X3W_STEP(ks, fa0, fa1, 0)
-            L2S_X3W_STEP(ks + 1, fa1, fa0, WSTAGE)
+            L2S_X3W_STEP(ks + 1, fa1, fa0, STG)
         }
         if (ks < nks) { L2S_X3W_STEP(ks, fa0, fa1, 0) }
 #undef L2S_X3W_STEP
@@ -606,6 +639,28 @@ static bool x3_wide(const GemmBatch& b) {
     return cost_w < cost_n;
 }
 
+// W [N][K] (K contiguous) -> its split-bf16 planes [K / 16][3 planes][N][16 k], the layout gemm_x3w_kernel<., true> fetches by LDS-DMA (a K step of one
+// plane = N rows of 32 bytes); the same truncation split the staging waves apply, so both forms of the kernel multiply the same operand bits
+__global__ __launch_bounds__(256) void gemm_planes_kernel(const float* __restrict__ W, int N, int K, unsigned char* __restrict__ planes) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kq4 = K / 4;
+    if (idx >= (int64_t)N * kq4) return;
+    const int n = (int)(idx / kq4), k = 4 * (int)(idx - (int64_t)n * kq4);
+    const X3Split sp = x3_split(*reinterpret_cast<const float4*>(W + (int64_t)n * K + k));
+    const int64_t step = (int64_t)(k >> 4) * 3 * N;
+    unsigned char* d = planes + ((step + n) * 16 + (k & 15)) * 2;
+    *reinterpret_cast<uint2*>(d) = sp.hi;
+    *reinterpret_cast<uint2*>(d + (int64_t)N * 32) = sp.mid;
+    *reinterpret_cast<uint2*>(d + (int64_t)N * 64) = sp.lo;
+}
+int launch_gemm_planes(const float* W, int N, int K, void* planes, hipStream_t s) {
+    L2S_REQUIRE(W && planes && N % WN == 0 && K % WK == 0, "gemm planes: N a multiple of 256, K of 16");
+    const int64_t n = (int64_t)N * (K / 4);
+    hipLaunchKernelGGL(gemm_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, N, K, reinterpret_cast<unsigned char*>(planes));
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     L2S_REQUIRE(b.count >= 1 && b.count <= GEMM_MAX_GROUP && gemm_x3_eligible(b), "split-bf16 gemm: group not eligible");
     int maxM = 0, maxN = 0;
@@ -618,14 +673,21 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     if (x3_wide(b)) {
         dim3 grid((maxN + WN - 1) / WN, (maxM + WM - 1) / WM, b.count);
         constexpr int LDS_BYTES = 2 * WSTAGE;                 // 110 592
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        constexpr int LDS_BYTES_D = 2 * WSTAGED;              // 86 016 (the epilogue's 64-row sub-tile needs 65 536)
+        bool dma = !g_x3_ts;
+        for (int i = 0; i < b.count; ++i) dma = dma && b.p[i].W3 && b.p[i].ldw == 0;      // every member brings pre-split weight planes
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         L2S_CHECK_HIP(attr);
+        static const hipError_t attr_d = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_D);
+        L2S_CHECK_HIP(attr_d);
         if (g_x3_ts) {
-            static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             L2S_CHECK_HIP(attr_t);
-            hipLaunchKernelGGL(gemm_x3w_kernel<true>, grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
+            hipLaunchKernelGGL((gemm_x3w_kernel<true, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
+        } else if (dma) {
+            hipLaunchKernelGGL((gemm_x3w_kernel<false, true>), grid, dim3(WTHREADS), LDS_BYTES_D, s, b, (unsigned long long*)nullptr, 0);
         } else {
-            hipLaunchKernelGGL(gemm_x3w_kernel<false>, grid, dim3(WTHREADS), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
+            hipLaunchKernelGGL((gemm_x3w_kernel<false, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
         }
         L2S_CHECK_HIP(hipGetLastError());
         return 0;

@@ -28,7 +28,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
         {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3}, {"gemm_x3_dma", &Options::gemm_x3_dma},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
         {"infer_bf16", &Options::infer_bf16}};
     for (auto& t : table)
@@ -592,6 +592,25 @@ static int derive_lstm_planes(l2s_model* m, hipStream_t s) {
     return 0;
 }
 
+// bf16 planes of the post-net's Conv1d weights (layers 0-3: N = 512, K = 5 x Cin) for the split-bf16 GEMM's LDS-DMA weight operand: derived on the device
+// from the packed fp32 [N][K] matrices, after every pack and every device-side refresh
+static int derive_gemm_planes(l2s_model* m, hipStream_t s) {
+    Weights& w = m->w;
+    for (int i = 0; i < 5; ++i) w.post[i].W3 = nullptr;
+    if (!m->has_dec) return 0;
+    const int Ks[4] = {5 * NM, 5 * 512, 5 * 512, 5 * 512};
+    int64_t total = 0;
+    for (int i = 0; i < 4; ++i) { if (!w.post[i].W) return 0; total += (int64_t)512 * Ks[i] * 6; }
+    if (!m->gemm_planes) L2S_CHECK_HIP(hipMalloc(&m->gemm_planes, total));
+    char* base = reinterpret_cast<char*>(m->gemm_planes);
+    for (int i = 0; i < 4; ++i) {
+        if (launch_gemm_planes(w.post[i].W, 512, Ks[i], base, s)) return 1;
+        w.post[i].W3 = base;
+        base += (int64_t)512 * Ks[i] * 6;
+    }
+    return 0;
+}
+
 static int pack_model(l2s_model* m, hipStream_t stream) {
     Packer P{m};
     bool want_enc = false, want_dec = false, want_spk = false;
@@ -614,6 +633,8 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     m->has_spk = want_spk;
     if (m->lstm_planes) { (void)hipFree(m->lstm_planes); m->lstm_planes = nullptr; }
     if (derive_lstm_planes(m, stream)) return 1;
+    if (m->gemm_planes) { (void)hipFree(m->gemm_planes); m->gemm_planes = nullptr; }
+    if (derive_gemm_planes(m, stream)) return 1;
     return 0;
 }
 
@@ -832,6 +853,7 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
         L2S_CHECK_HIP(hipGetLastError());
     }
     if (m->lstm_planes && derive_lstm_planes(m, s)) return 1;      // the LSTM weights' bf16 planes are splits of the old weights too
+    if (m->gemm_planes && derive_gemm_planes(m, s)) return 1;
     m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are products of the old parameters ...
     if (remerge_step_weights(m, s)) return 1;      // ... rebuilt here when the decoder's tensors are bound (then the 4-launch step stays valid)
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -982,6 +1004,7 @@ static GemmP conv_gemm(const float* X, int lda, int B, int Tin, int Cin, const C
     GemmP p = gemm_plain(X, lda, c.W, out, ldc, B * Tout, Cout, taps * Cin);
     p.Tout = Tout; p.Tin = Tin; p.taps = taps; p.stride = stride; p.pad = pad; p.Cin = Cin;
     p.scale = c.scale; p.shift = c.shift; p.actw = c.actw; p.act = act;
+    p.W3 = c.W3;
     return p;
 }
 
@@ -1332,7 +1355,7 @@ static int postnet_alloc(Bump& bp, int B, int S, PostBufs& pb) {
 
 // One post-net layer (decoder.py:143-156) over the frames [t0, t1) of every sequence; layer 0..4.
 // Layer i reads buffer i (mel for i = 0) and writes buffer i+1 (mel_post, channel-first, for i = 4).
-static int postnet_layer(const Weights& w, int layer, const float* mel, const PostBufs& pb, float* mel_post, int B, int S, int t0, int t1, hipStream_t s) {
+static int postnet_layer(const Weights& w, int layer, const float* mel, const PostBufs& pb, float* mel_post, int B, int S, int t0, int t1, hipStream_t s, bool dma_weights) {
     if (t1 <= t0) return 0;
     float* const* bufs = pb.x;
     const float* in = layer == 0 ? mel : bufs[layer - 1];
@@ -1342,6 +1365,7 @@ static int postnet_layer(const Weights& w, int layer, const float* mel, const Po
     p.M = B * (t1 - t0); p.Tout = t1 - t0; p.win_T = S; p.win_off = t0;
     if (layer >= 1 && layer <= 3) { p.R1 = in; p.ldr1 = 512; p.r1_mod = 0; }
     if (layer == 4) { p.R1 = mel; p.ldr1 = NM; p.r1_mod = 0; p.c_tr_T = S; }
+    if (!dma_weights) p.W3 = nullptr;
     return launch_gemm1(p, s, "postnet_conv_gemm");
 }
 
@@ -1353,7 +1377,7 @@ static int postnet_run(l2s_model* m, const float* mel, int B, int S, float* mel_
     PostBufs pb;
     L2S_REQUIRE(postnet_alloc(bp, B, S, pb) == 0, "postnet workspace too small");
     for (int layer = 0; layer < 5; ++layer)
-        if (postnet_layer(w, layer, mel, pb, mel_post, B, S, 0, S, s)) return 1;
+        if (postnet_layer(w, layer, mel, pb, mel_post, B, S, 0, S, s, m->opt.gemm_x3_dma != 0)) return 1;
     if (mel_cf && launch_transpose_bsc(mel, B, S, NM, mel_cf, s)) return 1;
     return 0;
 }
@@ -1453,6 +1477,7 @@ int l2s_model_destroy(l2s_model* m) {
     if (m->r_tables) (void)hipFree(m->r_tables);
     if (m->merge_scratch) (void)hipFree(m->merge_scratch);
     if (m->lstm_planes) (void)hipFree(m->lstm_planes);
+    if (m->gemm_planes) (void)hipFree(m->gemm_planes);
     delete m;
     return 0;
 }
@@ -1594,7 +1619,7 @@ static int path_run(l2s_model* m, const FrameSrc& video, const float* emb, const
             L2S_CHECK_HIP(hipStreamWaitEvent(m->side, ev, 0));
             for (int layer = 0; layer < 5; ++layer) {
                 const int end = n == S ? S : std::max(done[layer], n - 2 * (layer + 1));
-                if (postnet_layer(m->w, layer, mel, pb, o.mel_post, B, S, done[layer], end, m->side)) return 1;
+                if (postnet_layer(m->w, layer, mel, pb, o.mel_post, B, S, done[layer], end, m->side, m->opt.gemm_x3_dma != 0)) return 1;
                 done[layer] = end;
             }
             return 0;

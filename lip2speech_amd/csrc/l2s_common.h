@@ -54,6 +54,7 @@ struct Options {
     int skinny_split8 = 1;      // "skinny_split8": the same for the K <= 1024 instance
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
+    int gemm_x3_dma = 1;        // "gemm_x3_dma": constant Conv1d / Linear weights of the split-bf16 GEMMs as pre-split planes fetched by LDS-DMA (ConvW::W3)
     int lstm_x3 = 2;            // "lstm_x3": the decode step's LSTM launches on the bf16 matrix cores (exact three-way split, pre-split weight planes): 2 = eight-wave
                                 //   blocks (default), 1 = four-wave blocks (same bits), 0 = the f32 MFMA form
     int attn_lds = 1;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
@@ -103,6 +104,8 @@ struct GemmP {
     const float* mask;    // training: dropout multiplier mask[m*ldmask + n], applied after activation and addends
     int ldmask, mask_pre; //   (mask_pre: after the activation, before the addends)
     int ldw;              // row stride of W in floats (0: K) - a K slice of a wider matrix (split-K)
+    const void* W3;       // W as pre-split bf16 planes [K / 16][3 planes][N][16 k] (launch_gemm_planes; N % 256 == 0, K % 16 == 0, ldw == 0) or null: the
+                          //   128x256x16 split-bf16 tile then brings its weight operand in by LDS-DMA instead of load + split + ds_write
     int x3;               // bit 1: run on the split-bf16 kernel (gemm_x3.hip) when the whole launch group is eligible; bit 2: whatever its size
                           //   (operator tests); bit 4: the 128x128x32 tile only; set from gemm_x3_mode()
     int x3_group;         // batches sharing this launch (grouped inference): the size thresholds of the kernel choice look at M / x3_group,
@@ -133,6 +136,7 @@ int& gemm_bf16_mode();
 struct Bf16Scope { int prev; explicit Bf16Scope(int on) : prev(gemm_bf16_mode()) { gemm_bf16_mode() = on; } ~Bf16Scope() { gemm_bf16_mode() = prev; } };
 bool gemm_x3_eligible(const GemmBatch& b);
 bool gemm_x3_member_ok(const GemmP& p);               // one member's operands and shape (no launch-size threshold)
+int launch_gemm_planes(const float* W, int N, int K, void* planes, hipStream_t s);      // planes: N * K * 6 bytes
 int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name);
 void gemm_x3_set_timeline(unsigned long long* ts, int block);      // non-null: launch the stamped measurement build (tools/gemm_x3_timeline.py)
 // split-K for plain GEMMs whose 64x64 tiles are too few to fill the chip (M <= 128 rows in the content path, the B-row Linears):

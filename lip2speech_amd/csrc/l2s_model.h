@@ -29,7 +29,8 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 static inline int pad16(int b) { return (b + 15) & ~15; }
 
 // ------------------------------------------------------------------------------------------------ model
-struct ConvW { const float* W = nullptr; const float* scale = nullptr; const float* shift = nullptr; const float* actw = nullptr; };
+struct ConvW { const float* W = nullptr; const float* scale = nullptr; const float* shift = nullptr; const float* actw = nullptr;
+               const void* W3 = nullptr; };      // W3: W as pre-split bf16 planes (GemmP::W3), derived on the device (derive_gemm_planes)
 struct DwW { const float* w9 = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
 struct UnitW {
     bool stride2 = false;
@@ -102,6 +103,7 @@ struct l2s_model {
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
     bool planes_valid = true;                                 // the front-end's bf16 operand planes (w3 / w1) match the current parameters
     float* merge_scratch = nullptr;                           // device: the two products of the device-side re-merge (l2s_train_refresh_weights)
+    void* gemm_planes = nullptr;                              // device: bf16 planes of the post-net's Conv1d weights (option "gemm_x3_dma"); rebuilt like lstm_planes
     void* lstm_planes = nullptr;                              // device: bf16 planes of the decoder LSTM weights (split-bf16 LSTM blocks, option "lstm_x3"); rebuilt
                                                               //   from the packed fp32 fragments after every pack / device-side refresh
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics

@@ -355,6 +355,40 @@ def test_runtime_options_keep_parity(synth_sd, nm, opts, exact):
     assert pc.maxdiff(out[1], gf["mel_post"]) < MEL_TOL
 
 
+@pytest.mark.parametrize("B,S", [(32, 300), (256, 77), (40, 123)])
+def test_postnet_weight_planes_by_dma_same_bits(synth_sd, nm, B, S):
+    """The post-net's Conv1d weights as pre-split bf16 planes fetched by LDS-DMA (option "gemm_x3_dma", default) against the staging waves' own load +
+    split + store of the fp32 weights: the same operand bits, so the same output bits - at sizes that run the 128x256x16 split-bf16 tile (K = 400 with
+    an odd number of K steps and K = 2560), and after a device-side weight refresh (the planes are re-derived with the other derived weights)."""
+    torch.manual_seed(3)
+    mel = torch.randn(B, S, 80, device="cuda")
+    off = pc.fresh_native_model(synth_sd, gemm_x3_dma=0)
+    a, _ = nm.postnet(mel)
+    b, _ = off.postnet(mel)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    nm.set_option("gemm_x3_dma", 0)                       # the switch is read at launch time
+    try:
+        c, _ = nm.postnet(mel)
+    finally:
+        nm.set_option("gemm_x3_dma", 1)
+    assert torch.equal(a, c)
+    if B == 32:
+        # bound weights changed in place, then the device-side refresh: both forms must follow the new weights (stale planes would keep the old output)
+        outs = []
+        for v_ in (1, 0):
+            m_ = native.NativeModel()
+            m_.set_option("refresh_map", 1); m_.set_option("gemm_x3_dma", v_)
+            m_.load({k: v.cuda() for k, v in synth_sd.items()}, list(synth_sd.keys()))
+            params = {k: v.cuda().clone() for k, v in synth_sd.items() if v.is_floating_point()}
+            m_.train_bind(params, {})
+            for k in params:
+                if k.startswith("decoder.postnet.convolutions.") and k.endswith("conv.weight"):
+                    params[k].mul_(1.25)
+            m_.train_refresh_weights()
+            outs.append(m_.postnet(mel)[0])
+        assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], a)
+
+
 def test_options_are_per_model(synth_sd, nm):
     """`l2s_set_option` only changes the defaults of models created later; a model's own switches do not leak into another model."""
     a = pc.fresh_native_model(synth_sd, fold_step_weights=0)
