@@ -279,7 +279,8 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
 /* the same two operators with flags: bit 0 = run on the split-bf16 kernel (fp32 operands split into 3 bf16 planes, six bf16 MFMAs per
  * K step; eligible shapes only - otherwise the f32 kernel runs); bit 1 = bf16 operands (round to nearest even on the way into LDS, one
  * bf16 MFMA per K step, fp32 accumulation); bit 2 (with bit 0) = the split-bf16 kernel's 128x128x32 tile instead of its default 128x256x16 one
- * (same bits out; kept for A/B timing) */
+ * (same bits out; kept for A/B timing); bit 3 (with bit 0) = the weight operand as pre-split bf16 planes fetched by LDS-DMA - what a model with
+ * "gemm_x3_dma" runs in its post-net - derived per call into scratch memory the library owns (N % 256 == 0, K % 16 == 0, else ignored; same bits out) */
 int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                    int K, int act, int flags, void* stream);
 int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(WTHREADS) void gemm_x3w_kernel(const GemmBatch batc
         advance(); fetch(RA_NEW, RB_NEW);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         X3_STAMP(KS_, 4);                                                                                      \
-        if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); X3_STAMP(KS_, 1); }           \
+        if constexpr (TIMED) { if constexpr (DMAW) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); X3_STAMP(KS_, 1); } \
         stage(RA_OLD, RB_OLD, ((KS_) + 1) & 1);                                                                \
         if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }                            \
         X3_STAMP(KS_, 2);                                                                                      \
@@ -674,7 +674,7 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
         dim3 grid((maxN + WN - 1) / WN, (maxM + WM - 1) / WM, b.count);
         constexpr int LDS_BYTES = 2 * WSTAGE;                 // 110 592
         constexpr int LDS_BYTES_D = 2 * WSTAGED;              // 86 016 (the epilogue's 64-row sub-tile needs 65 536)
-        bool dma = !g_x3_ts;
+        bool dma = true;
         for (int i = 0; i < b.count; ++i) dma = dma && b.p[i].W3 && b.p[i].ldw == 0;      // every member brings pre-split weight planes
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         L2S_CHECK_HIP(attr);
@@ -683,7 +683,10 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
         if (g_x3_ts) {
             static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             L2S_CHECK_HIP(attr_t);
-            hipLaunchKernelGGL((gemm_x3w_kernel<true, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
+            static const hipError_t attr_td = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_D);
+            L2S_CHECK_HIP(attr_td);
+            if (dma) hipLaunchKernelGGL((gemm_x3w_kernel<true, true>), grid, dim3(WTHREADS), LDS_BYTES_D, s, b, g_x3_ts, g_x3_stamp_block);
+            else hipLaunchKernelGGL((gemm_x3w_kernel<true, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
         } else if (dma) {
             hipLaunchKernelGGL((gemm_x3w_kernel<false, true>), grid, dim3(WTHREADS), LDS_BYTES_D, s, b, (unsigned long long*)nullptr, 0);
         } else {

@@ -1744,17 +1744,39 @@ int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const flo
     GemmP p = conv_gemm(X, Cin, B, Tin, Cin, c, Cout, taps, stride, pad, out, Cout, act);
     return launch_gemm1(p, (hipStream_t)stream, "op_conv1d");
 }
+// flags bit 8 of the two operators below: the weight operand as pre-split bf16 planes fetched by LDS-DMA (GemmP::W3; needs N % 256 == 0 and
+// K % 16 == 0, ignored otherwise) - derived per call into a scratch buffer the library owns (operator tests and tools; the model paths keep their own)
+static void* g_op_planes = nullptr;
+static int64_t g_op_planes_bytes = 0;
+static std::mutex g_op_planes_mu;
+static const void* op_planes(const float* W, int N, int K, hipStream_t s) {
+    if (N % 256 || K % 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_op_planes_mu);
+    const int64_t need = (int64_t)N * K * 6;
+    if (need > g_op_planes_bytes) {
+        if (g_op_planes) { (void)hipDeviceSynchronize(); (void)hipFree(g_op_planes); g_op_planes = nullptr; g_op_planes_bytes = 0; }
+        if (hipMalloc(&g_op_planes, need) != hipSuccess) { g_op_planes = nullptr; return nullptr; }
+        g_op_planes_bytes = need;
+    }
+    return launch_gemm_planes(W, N, K, g_op_planes, s) ? nullptr : g_op_planes;
+}
 int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                    int K, int act, int flags, void* stream) {
     X3Scope x3scope((flags & 1) ? (3 | (flags & 4)) : 0);      // forced; flags bit 4: the narrow tile
     Bf16Scope bf16scope((flags & 2) ? 1 : 0);
-    return l2s_op_gemm(A, Wt, scale, shift, actw, C, M, N, K, act, stream);
+    GemmP p = gemm_plain(A, K, Wt, C, N, M, N, K);
+    p.scale = scale; p.shift = shift; p.actw = actw; p.act = act;
+    if (flags & 8) p.W3 = op_planes(Wt, N, K, (hipStream_t)stream);
+    return launch_gemm1(p, (hipStream_t)stream, "op_gemm");
 }
 int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
                      int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream) {
     X3Scope x3scope((flags & 1) ? (3 | (flags & 4)) : 0);      // forced; flags bit 4: the narrow tile
     Bf16Scope bf16scope((flags & 2) ? 1 : 0);
-    return l2s_op_conv1d(X, Wp, scale, shift, actw, out, B, Tin, Cin, Cout, taps, stride, pad, act, stream);
+    ConvW c; c.W = Wp; c.scale = scale; c.shift = shift; c.actw = actw;
+    if (flags & 8) c.W3 = op_planes(Wp, Cout, taps * Cin, (hipStream_t)stream);
+    GemmP p = conv_gemm(X, Cin, B, Tin, Cin, c, Cout, taps, stride, pad, out, Cout, act);
+    return launch_gemm1(p, (hipStream_t)stream, "op_conv1d");
 }
 int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
                       int stride, int pad, void* stream) {

@@ -566,16 +566,18 @@ def state_field(state: torch.Tensor, B: int, T: int, field: int, shape) -> torch
     return state[off:off + n].view(*shape)
 
 
-def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0, x3: bool = False, bf16: bool = False, x3_narrow: bool = False) -> torch.Tensor:
+def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0, x3: bool = False, bf16: bool = False, x3_narrow: bool = False,
+            x3_dma: bool = False) -> torch.Tensor:
     A, Wt = _f32(A), _f32(Wt)
     M, K = A.shape
     N = Wt.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    check(lib().l2s_op_gemm_ex(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0), _stream()))
+    check(lib().l2s_op_gemm_ex(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0) | (8 if x3_dma else 0), _stream()))
     return C
 
 
-def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0, act: int = 0, x3: bool = False, bf16: bool = False, x3_narrow: bool = False) -> torch.Tensor:
+def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0, act: int = 0, x3: bool = False, bf16: bool = False, x3_narrow: bool = False,
+              x3_dma: bool = False) -> torch.Tensor:
     """X (B,Tin,Cin) channel-last, Wp (Cout, taps*Cin) tap-major."""
     X, Wp = _f32(X), _f32(Wp)
     B, Tin, Cin = X.shape
@@ -583,7 +585,7 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
     Tout = (Tin + 2 * pad - taps) // stride + 1
     out = torch.empty(B, Tout, Cout, dtype=torch.float32, device=X.device)
     check(lib().l2s_op_conv1d_ex(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
-                                 taps, stride, pad, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0), _stream()))
+                                 taps, stride, pad, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0) | (8 if x3_dma else 0), _stream()))
     return out
 
 

@@ -71,6 +71,7 @@ def test_gemm_split_bf16_tiles_agree(M, N, K, act):
     wide = native.op_gemm(A, W, sc, sh, aw, act, x3=True)
     narrow = native.op_gemm(A, W, sc, sh, aw, act, x3=True, x3_narrow=True)
     assert torch.equal(wide, narrow)
+    assert torch.equal(wide, native.op_gemm(A, W, sc, sh, aw, act, x3=True, x3_dma=True))      # weight planes by LDS-DMA (flags bit 8; wide tile only): same bits
     ref = (A.double() @ W.double().t()) * sc.double() + sh.double()
     ref = [ref, ref.relu(), ref * torch.sigmoid(ref), torch.sin(ref) * aw.double()][act]
     assert pc.maxdiff(wide, ref) < 2e-5
@@ -86,6 +87,7 @@ def test_conv1d_split_bf16_operator(B, T, Ci, Co, k, st, pad):
     ref = torch.nn.functional.conv1d(X.double().permute(0, 2, 1), Wt.double(), stride=st, padding=pad).permute(0, 2, 1)
     assert pc.maxdiff(out, ref) < 2e-5
     assert torch.equal(out, native.op_conv1d(X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad, x3=True, x3_narrow=True))      # both tiles: same bits
+    assert torch.equal(out, native.op_conv1d(X.cuda(), Wp.cuda(), taps=k, stride=st, pad=pad, x3=True, x3_dma=True))         # and with the weights by LDS-DMA
 
 
 @pytest.mark.parametrize("M,N,K", [(9600, 512, 2560), (300, 200, 64), (130, 129, 36)])

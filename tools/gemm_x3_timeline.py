@@ -7,25 +7,26 @@ import numpy as np, torch
 from lip2speech_amd import native
 
 NARROW = "narrow" in sys.argv                            # the 128x128x32 tile (4 + 4 waves, stamps per K tile of 32); default: 128x256x16 (8 + 4 waves, per K step of 16)
-args = [a for a in sys.argv[1:] if a != "narrow"]
+DMA = "dma" in sys.argv                                  # the wide tile with its weight operand by LDS-DMA (flags bit 8)
+args = [a for a in sys.argv[1:] if a not in ("narrow", "dma")]
 M, N, K = (int(a) for a in args[0:3]) if len(args) >= 3 else (38400, 512, 2560)
 block = int(args[3]) if len(args) > 3 else 0
 NC = 4 if NARROW else 8                                  # consumer waves
 KT = 32 if NARROW else 16
 L = native.lib()
 A = torch.randn(M, K, device="cuda"); Wt = torch.randn(N, K, device="cuda")
-for _ in range(3): native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW)
+for _ in range(3): native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW, x3_dma=DMA)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10): native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW)
+for _ in range(10): native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW, x3_dma=DMA)
 e1.record(); torch.cuda.synchronize()
 print(f"{M}x{N}x{K} ({'128x128x32 tile' if NARROW else '128x256x16 tile'}): production kernel {e0.elapsed_time(e1) * 100:.1f} us per launch")
 ts = torch.zeros(12 * 96 * 8, dtype=torch.int64, device="cuda")
 native.check(L.l2s_op_gemm_x3_timeline(ts.data_ptr(), block))
-native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW); torch.cuda.synchronize()
+native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW, x3_dma=DMA); torch.cuda.synchronize()
 ts.zero_()
-e0.record(); native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW); e1.record(); torch.cuda.synchronize()
+e0.record(); native.op_gemm(A, Wt, x3=True, x3_narrow=NARROW, x3_dma=DMA); e1.record(); torch.cuda.synchronize()
 native.check(L.l2s_op_gemm_x3_timeline(None, 0))
 print(f"stamped kernel {e0.elapsed_time(e1) * 1e3:.1f} us")
 t = ts.cpu().numpy().reshape(12, 96, 8)[:NC + 4].astype(np.float64)
