@@ -343,8 +343,9 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  * accumulators are guarded - only changing an option of a model WHILE other threads run batches on it is the caller's race.
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
  *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
- *   "gemm_x3_dma"       (1)  the post-net's Conv1d weights reach the split-bf16 kernel's 128x256x16 tile as pre-split bf16 planes (derived on the device at
- *                            load / refresh, 6 bytes per weight) by LDS-DMA instead of load + split + LDS store in its staging waves; same bits; 0 = off
+ *   "gemm_x3_dma"       (1)  the constant weights that meet the split-bf16 kernel's 128x256x16 tile (post-net layers 0-3, BiLSTM input matrix, conv_last) reach
+ *                            it as pre-split bf16 planes (derived on the device at load / refresh, 6 bytes per weight) by LDS-DMA instead of load + split +
+ *                            LDS store in its staging waves; same bits; 0 = off
  *   "lstm_x3"           (2)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
  *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
  *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks (same bits), 0 = f32 MFMAs

@@ -592,21 +592,30 @@ static int derive_lstm_planes(l2s_model* m, hipStream_t s) {
     return 0;
 }
 
-// bf16 planes of the post-net's Conv1d weights (layers 0-3: N = 512, K = 5 x Cin) for the split-bf16 GEMM's LDS-DMA weight operand: derived on the device
+// bf16 planes of the constant weights that meet the split-bf16 GEMM's wide tile (post-net layers 0-3, the BiLSTM input matrix, conv_last) for its LDS-DMA
+// weight operand: derived on the device
 // from the packed fp32 [N][K] matrices, after every pack and every device-side refresh
 static int derive_gemm_planes(l2s_model* m, hipStream_t s) {
     Weights& w = m->w;
     for (int i = 0; i < 5; ++i) w.post[i].W3 = nullptr;
-    if (!m->has_dec) return 0;
-    const int Ks[4] = {5 * NM, 5 * 512, 5 * 512, 5 * 512};
+    w.wih_cat3 = nullptr; w.conv_last.W3 = nullptr;
+    struct Item { const float* W; int N, K; const void** slot; };
+    std::vector<Item> items;
+    if (m->has_dec) {
+        const int Ks[4] = {5 * NM, 5 * 512, 5 * 512, 5 * 512};
+        for (int i = 0; i < 4; ++i) items.push_back({w.post[i].W, 512, Ks[i], &w.post[i].W3});
+        items.push_back({w.wih_cat, 4096, 1024, &w.wih_cat3});
+    }
+    if (m->has_enc) items.push_back({w.conv_last.W, LAST_CH, STAGE_CH[3], &w.conv_last.W3});
     int64_t total = 0;
-    for (int i = 0; i < 4; ++i) { if (!w.post[i].W) return 0; total += (int64_t)512 * Ks[i] * 6; }
+    for (const Item& it : items) { if (!it.W) return 0; total += (int64_t)it.N * it.K * 6; }
+    if (!total) return 0;
     if (!m->gemm_planes) L2S_CHECK_HIP(hipMalloc(&m->gemm_planes, total));
     char* base = reinterpret_cast<char*>(m->gemm_planes);
-    for (int i = 0; i < 4; ++i) {
-        if (launch_gemm_planes(w.post[i].W, 512, Ks[i], base, s)) return 1;
-        w.post[i].W3 = base;
-        base += (int64_t)512 * Ks[i] * 6;
+    for (const Item& it : items) {
+        if (launch_gemm_planes(it.W, it.N, it.K, base, s)) return 1;
+        *it.slot = base;
+        base += (int64_t)it.N * it.K * 6;
     }
     return 0;
 }
@@ -925,6 +934,7 @@ static GemmP pw_gemm(const float* A, int lda, int a_off, const ConvW& c, float* 
                      int64_t M, int N, int K, int act) {
     GemmP p = gemm_plain(A + a_off, lda, c.W, C + c_off, ldc, (int)M, N, K);
     p.scale = c.scale; p.shift = c.shift; p.actw = c.actw; p.act = act; p.c_cstride = cstride;
+    p.W3 = c.W3;
     return p;
 }
 
@@ -992,7 +1002,11 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
         std::swap(x, y);
     }
     const int64_t px = (int64_t)NF * h * h;
-    if (launch_gemm1(pw_gemm(x, STAGE_CH[3], 0, w.conv_last, last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3], ACT_RELU), s, "conv_last_gemm")) return 1;
+    {
+        GemmP pc = pw_gemm(x, STAGE_CH[3], 0, w.conv_last, last, LAST_CH, 0, 1, px, LAST_CH, STAGE_CH[3], ACT_RELU);
+        if (!m->opt.gemm_x3_dma) pc.W3 = nullptr;
+        if (launch_gemm1(pc, s, "conv_last_gemm")) return 1;
+    }
     if (launch_pool_norm_cat(last, NF, h * h, LAST_CH, emb, L2S_D_EMB, T, vis, L2S_D_VIS, feat, s)) return 1;
     return 0;
 }
@@ -1069,6 +1083,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     {
         GemmP p = gemm_plain(vis, 1024, w.wih_cat, gin, 4096, BT, 4096, 1024);
         p.shift = w.bih_cat;
+        if (m->opt.gemm_x3_dma) p.W3 = w.wih_cat3;
         if (launch_gemm1(p, s, "bilstm_input_gemm")) return 1;
     }
     // recurrence: h0 = c0 = s_e for both directions (decoder.py:386-389)

@@ -49,6 +49,7 @@ struct Weights {
     // decoder prologue
     ConvW resid, enc_site, attn_site, e_c, enc_proj;
     const float* wih_cat = nullptr; const float* bih_cat = nullptr;     // [4096][1024], [4096]
+    const void* wih_cat3 = nullptr;                                      // wih_cat as pre-split bf16 planes (GemmP::W3)
     SkW whh[2];                                                         // BiLSTM recurrent weights, permuted rows
     ConvW mh_branch[2][4], mh_bott[2];                                  // K, V
     const float* pos = nullptr;                                         // [300][512]
@@ -103,7 +104,7 @@ struct l2s_model {
     bool folded_valid = true;                                 // the phase-merged step weights match the current parameters
     bool planes_valid = true;                                 // the front-end's bf16 operand planes (w3 / w1) match the current parameters
     float* merge_scratch = nullptr;                           // device: the two products of the device-side re-merge (l2s_train_refresh_weights)
-    void* gemm_planes = nullptr;                              // device: bf16 planes of the post-net's Conv1d weights (option "gemm_x3_dma"); rebuilt like lstm_planes
+    void* gemm_planes = nullptr;                              // device: bf16 planes of the post-net's Conv1d weights, the BiLSTM input matrix and conv_last (option "gemm_x3_dma"); rebuilt like lstm_planes
     void* lstm_planes = nullptr;                              // device: bf16 planes of the decoder LSTM weights (split-bf16 LSTM blocks, option "lstm_x3"); rebuilt
                                                               //   from the packed fp32 fragments after every pack / device-side refresh
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics
