@@ -838,3 +838,41 @@ def test_forward_many_matches_forward_per_batch(synth_sd):
     igot = list(net.inference_many(icalls, group=4, n_inflight=2))
     for g, w in zip(igot, iwant):
         assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+
+
+@pytest.mark.gpu
+def test_stop_bookkeeping_matches_reference_golden(synth_sd):
+    """decoder.py:429-435 pinned against the reference where it is not trivial (tests/golden/make_stop_goldens.py: the checkpoint differs only
+    in the stop layer; the reference's first crossings spread over 13..286 and three clips of the B=32 batch never stop -> 300; at B=2 one clip
+    stops at 183, the other never): int64 equality of `output_lengths` through `l2s_inference` AND `l2s_inference_multi`, the stop logits
+    of the staged calls, and - B=2 - the FULL (2,300,29) post-softmax attention tensor."""
+    import parity_common as pc
+    cases = {}
+    for name, B, vtag, etag in (("stop_lrw_b2.npz", 2, "video-lrw2", "spk-lrw2"), ("stop_lrw_b32.npz", 32, "bench", "bench")):
+        g = pc.golden(name)
+        sd = dict(synth_sd)
+        sd["decoder.stop_token_layer.linear_layer.weight"] = g["stop_weight"]
+        sd["decoder.stop_token_layer.linear_layer.bias"] = g["stop_bias"]
+        own = pc.fresh_native_model(sd)
+        args = (synth.synth_video(B, 29, tag=vtag).cuda(), synth.synth_speaker_embedding(B, tag=etag).cuda(), g["gumbel"].cuda())
+        mel_post, lengths, attn = own.inference(*args, S=300, want_attn=True)
+        assert lengths.dtype == torch.int64 and torch.equal(lengths.cpu(), g["output_lengths"]), (name, lengths.cpu(), g["output_lengths"])
+        cases[name] = (own, args, g, mel_post.clone(), attn.clone())
+    # B=2: every element of the attention tensor and the mel against the reference
+    own, args, g, mel_post, attn = cases["stop_lrw_b2.npz"]
+    assert tuple(attn.shape) == (2, 300, 29) and pc.maxdiff(attn, g["attn"]) < MEL_TOL
+    assert pc.maxdiff(mel_post, pc.golden("inference_lrw_b2.npz")["mel_post"]) < MEL_TOL
+    lens2 = {int(x) for x in g["output_lengths"]}
+    assert 300 in lens2 and any(10 < x < 300 for x in lens2)
+    # B=32 through the grouped entry: the golden batch as group member 0 and 2 (other clips in between), lengths per batch
+    own, args, g, mel_post, attn = cases["stop_lrw_b32.npz"]
+    lens = g["output_lengths"]
+    assert len({int(x) for x in lens if int(x) > 10}) >= 5 and int((lens == 300).sum()) >= 2
+    other = (synth.synth_video(32, 29, tag="grp1").cuda(), synth.synth_speaker_embedding(32, tag="grp1").cuda(), synth.synth_gumbel(32 * 4, tag="grp1").cuda())
+    want_other = own.inference(*other, S=300)[1].clone()
+    got = own.inference_multi([args, other, args], S=300)
+    assert torch.equal(got[0][1].cpu(), lens) and torch.equal(got[2][1].cpu(), lens) and torch.equal(got[1][1], want_other)
+    assert got[0][1].dtype == torch.int64 and torch.equal(got[0][0], mel_post)
+    # the stop logits themselves (staged calls return them; forward_eval runs the same step with teacher = none for S = 300)
+    out = own.forward_eval(args[0], args[1], args[2], 300)
+    assert pc.maxdiff(out[2].reshape(32, 300), g["stop_logits"]) < 1e-3

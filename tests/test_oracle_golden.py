@@ -126,3 +126,23 @@ def test_oracle_matches_reference_on_variable_length_batches(golden_dir, synth_s
     amax, _ = _top2(attn)
     sure = g["attn_margin"][:, :S] > 1e-4
     assert torch.equal(amax[sure].to(torch.int64), g["attn_argmax"][:, :S][sure].to(torch.int64))
+
+
+@pytest.mark.parametrize("name,B,vtag,etag", [("stop_lrw_b2.npz", 2, "video-lrw2", "spk-lrw2"), ("stop_lrw_b32.npz", 32, "bench", "bench")])
+def test_oracle_stop_bookkeeping_matches_reference_golden(golden_dir, synth_sd, name, B, vtag, etag):
+    """decoder.py:429-435 with first crossings spread over the 300 steps and clips that never stop (tests/golden/make_stop_goldens.py:
+    a checkpoint that differs only in the stop layer): the oracle's int64 lengths equal the reference's, its stop logits follow."""
+    g = _load(golden_dir, name)
+    lens = g["output_lengths"]
+    assert lens.dtype == torch.int64 and int((lens == 300).sum()) >= (2 if B > 2 else 1)
+    assert B == 2 or len({int(x) for x in lens if 10 < int(x) < 300}) >= 5
+    sd = dict(synth_sd)
+    sd["decoder.stop_token_layer.linear_layer.weight"] = g["stop_weight"]
+    sd["decoder.stop_token_layer.linear_layer.bias"] = g["stop_bias"]
+    taps = {}
+    with torch.no_grad():
+        _, lengths, attn = orc.inference(sd, synth.synth_video(B, 29, tag=vtag), synth.synth_speaker_embedding(B, tag=etag), g["gumbel"], S=300, taps=taps)
+    assert lengths.dtype == torch.int64 and torch.equal(lengths, lens)
+    assert (taps["stop"].reshape(B, 300) - g["stop_logits"]).abs().max() < 1e-3
+    if "attn" in g:
+        assert (attn - g["attn"]).abs().max() < 1e-3           # the full (2,300,29) post-softmax attention of the reference
