@@ -73,6 +73,26 @@ def kernel_model(name, rows=B):
     return table.get(name)
 
 
+# which matrix pipe a kernel of the path runs on: "bf16x3" = the bf16 matrix cores through the exact three-way split (six
+# bf16 MFMAs per fp32 product: ceiling 2 500 / 6 = 416.7 TFLOP/s fp32-equivalent); "f32" = v_mfma_f32_*_f32 (157.3 TFLOP/s)
+KERNEL_PIPE = {"step_lstm_cell": "bf16x3", "postnet_conv_gemm": "bf16x3", "frontend3d_conv_bn_prelu_pool": "bf16x3",
+               "step_prenet1_q_cq_fc": "f32", "step_fc_out_stop": "f32", "step_attention_proj": "f32"}
+
+
+def mfma_roof(name, flops, avg_s):
+    """Pipe-aware MFMA roofline entry: `frac` is against the ceiling of the pipe the kernel RUNS on - for the split-bf16 kernels
+    executed bf16 FLOPs (6 x algorithmic) / duration / 2.5 PFLOP/s, i.e. algorithmic / 416.7 TFLOP/s - and can never exceed 1;
+    the ratio to the fp32 matrix peak (the data's dtype) is kept as `frac_fp32_equiv`."""
+    ach = flops / avg_s / 1e12
+    if KERNEL_PIPE.get(name) == "bf16x3":
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "frac_fp32_equiv": ach / FP32_MFMA_PEAK_TFLOPS,
+                "pipe": "bf16 matrix cores, exact three-way split: 6 bf16 MFMA products per fp32 product; peak = 2500 / 6 TFLOP/s fp32-equivalent",
+                "executed_bf16_tflops": 6 * ach}
+    return {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "pipe": "f32 matrix instructions (v_mfma_f32_*_f32)"}
+
+
 def executed_flops(name, rows=B):
     """FLOPs the launch really issues where they differ from the algorithmic count (phase-merged weights)."""
     return {"step_lstm_cell": 2 * rows * 2048 * (1024 + 1024) / 2}.get(name)      # both layers run K = 1024 (layer 0 on [content | prenet + a.V' | h0], option hoist_vproj = 2)
@@ -160,25 +180,13 @@ def train_kernel_model(name, Bt, St):
     return table.get(name)
 
 
-def train_main(args):
-    """Secondary bench line: training throughput.  One step = `Lip2Speech.forward` (encoder + decoder, S=77 targets) + 4-term loss +
-    backward through everything + bucketed gradient all-reduce (RCCL, N>1) + global-norm clip + fused AdamW(amsgrad) + device-side
-    re-pack of the weight blob, on B=8 clips per GPU, fp32, train() semantics: BatchNorm on batch statistics
-    with running-statistics updates, the five dropout sites live (masks drawn on the device every step), half the steps teacher-forced."""
+def train_setup(bf16, rank=0, world=1):
+    """Model, optimizer, reducer and inputs of the training bench; returns (step, ctx).  One step = `Lip2Speech.forward` (encoder + decoder,
+    S=77 targets) + 4-term loss + backward through everything + bucketed gradient all-reduce (RCCL, N>1) + global-norm clip + fused
+    AdamW(amsgrad) + device-side re-pack of the weight blob, on B=8 clips per GPU, train() semantics."""
     from model.model import get_network
     from lip2speech_amd.training import AdamWAmsgrad, GradAllReducer, draw_dropout, model_forward_backward
     Bt, St = 8, 77
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("L2S_BENCH_ONE_DEVICE"):      # test hook: several ranks on ONE GPU (with L2S_BENCH_BACKEND=gloo) to exercise the N>1 code path
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("L2S_BENCH_BACKEND", "nccl"))
     net = get_network("train").cuda()
     net.load_state_dict({k: v for k, v in synth.synth_state_dict().items() if k.startswith(("encoder.", "decoder."))}, strict=False)
     flat = net._train_state()
@@ -198,7 +206,7 @@ def train_main(args):
     mask[1::2] = True                                   # half of the steps teacher-forced (tf_ratio 0.5 regime)
 
     nm.train_set_bn(True, 0.1)
-    nm.set_option("train_bf16", 1 if args.bf16 else 0)
+    nm.set_option("train_bf16", 1 if bf16 else 0)
 
     def step():
         drop = draw_dropout(Bt, T, St, video.device)
@@ -210,6 +218,47 @@ def train_main(args):
         opt.step(max_norm=1.0, grad_mul=mul)
         nm.train_refresh_weights()
         return out
+
+    return step, {"Bt": Bt, "St": St, "net": net, "nm": nm, "opt": opt, "reducer": reducer}
+
+
+def train_leg(steps=5, warmup=3):
+    """`train_step_B8` of the default line (BASELINE.json configs[2] at its per-GPU shape, fp32): `warmup` untimed + `steps` timed training
+    steps between two device synchronisations, exactly the step `bench.py --mode train` times (train.py:150-193)."""
+    step, ctx = train_setup(False)
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = out["loss"].cpu()
+    assert torch.isfinite(loss).all(), "non-finite training loss"
+    return {"ms_per_step": dt / steps * 1e3, "value": ctx["Bt"] * steps / dt, "unit": "clips/s", "steps": steps, "warmup": warmup, "batch_per_gpu": ctx["Bt"],
+            "decode_steps": ctx["St"], "dtype": "f32", "final_loss": float(loss[4]),
+            "note": "one data-parallel training step per step at B=8 per GPU, T=29, S=77 (SURVEY.md section 8(d) config 3): forward with tapes + 4-term loss + "
+                    "backward + gradient bucketing (all-reduce is a no-op at one rank) + global-norm clip + fused AdamW-amsgrad + device re-pack of the "
+                    "weight blob; train() semantics (batch-statistics BatchNorm, five dropout sites, half the steps teacher-forced); the full line: "
+                    "`python bench.py --mode train`"}
+
+
+def train_main(args):
+    """Secondary bench line: training throughput (see train_setup), fp32 or --bf16 operands, N ranks."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("L2S_BENCH_ONE_DEVICE"):      # test hook: several ranks on ONE GPU (with L2S_BENCH_BACKEND=gloo) to exercise the N>1 code path
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("L2S_BENCH_BACKEND", "nccl"))
+    step, ctx = train_setup(args.bf16, rank, world)
+    Bt, St = ctx["Bt"], ctx["St"]
 
     for _ in range(args.warmup):
         out = step()
@@ -294,6 +343,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: 192 inference passes (0.9 s) / 20 training steps")
     ap.add_argument("--warmup", type=int, default=None, help="default: 16 / 3")
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    ap.add_argument("--skip-train-leg", action="store_true", help="inference mode: leave the train_step_B8 leg out of the line (profiler runs)")
     ap.add_argument("--group", type=int, default=8, help="independent B=32 batches advanced per launch chain (l2s_inference_multi, 1..8); 1 = one batch per chain")
     ap.add_argument("--inflight", type=int, default=2, help="launch chains in flight per GPU (HIP streams + host threads); 1 = strictly sequential chains "
                     "(measured at 8 batches per chain: 1 chain 4.78 ms per batch, 2 chains 4.30, 3 chains 4.22-4.33; their relative phase does not matter)")
@@ -431,6 +481,21 @@ def main():
     bf16_elapsed, outs16 = timed(lambda: pool16.map(work(args.steps), S=S))
     bf16_dev = max(float((a[0] - b[0]).abs().mean()) for a, b in zip(outs16[:n_distinct], outs[:n_distinct]))
 
+    # BASELINE.json configs[0] / demo.py:60-90: what ONE caller waits for a small batch on an otherwise idle GPU (B = 2 and B = 1, S = 300):
+    # median wall time of 7 calls after 3 warm-ups, each call bracketed by device synchronisations
+    def latency_ms(nb):
+        a = (video[:nb].contiguous(), emb[:nb].contiguous(), gum[:nb * native.min_T(T)].contiguous())
+        ts = []
+        for i in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nm.inference(*a, S=S)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts[3:])[3] * 1e3
+    lat = {nb: latency_ms(nb) for nb in (2, 1)} if world == 1 else None
+    train = train_leg() if (world == 1 and not args.skip_train_leg) else None
+
     if rank == 0:
         # per-kernel HIP-event timing in its own pass over ONE group (events around every launch perturb the pipeline)
         native.profile_enable(True)
@@ -459,28 +524,22 @@ def main():
                 ach = nbytes / avg_s / 1e9
                 roof.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
             else:
-                ach = flops / avg_s / 1e12
-                roof.update(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TFLOPS)
+                roof.update(mfma_roof(name, flops, avg_s))
             roof["algorithmic_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
             roof["arithmetic_intensity"] = ai
             ex = executed_flops(name, rows)
             if ex and roof["bound"] == "mfma":
                 roof["executed_flops"] = ex
-                roof["frac_executed"] = ex / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
-                roof["pipe"] = ("bf16 matrix cores through the exact three-way split (option lstm_x3, default): fp32 operands, six bf16 MFMAs per pair of "
-                                "fp32 K-chunks, fp32 accumulation; peak above is the FP32 matrix peak - the data's dtype")
-                roof["executed_bf16_flops"] = 6 * ex
-                roof["frac_bf16_pipe"] = 6 * ex / avg_s / 1e12 / BF16_MFMA_PEAK_TFLOPS
                 roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj, which the value "
-                                "projection hoisted into the prologue no longer executes per step) / measured duration / fp32 matrix peak; frac_executed "
-                                "counts the fp32-equivalent products the launch runs, frac_bf16_pipe the six bf16 products per fp32 product against the "
-                                "dense bf16 peak")
+                                "projection hoisted into the prologue no longer executes per step) / measured duration / the ceiling of the pipe the "
+                                "kernel runs on (bf16 matrix cores, six products per fp32 product: 416.7 TFLOP/s fp32-equivalent); frac_fp32_equiv is the "
+                                "same rate against the fp32 matrix peak of 157.3 TFLOP/s (the data's dtype; rounds 1-3 quoted that one)")
         # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
         # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None
         try:
-            pmc_file = next(f for f in ("r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k = pmc["kernels"].get(name)
             if k and pmc.get("rows_per_launch") == rows:
@@ -502,16 +561,16 @@ def main():
             oflops, obytes = om
             if oflops / obytes < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
                 o = {"bound": "hbm", "achieved": obytes / oavg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+                o["frac"] = o["achieved"] / o["peak"]
             else:
-                o = {"bound": "mfma", "achieved": oflops / oavg / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
-            o.update(kernel=oname, launches_per_group_pass=olaunches // 2, share_of_gpu_time=oms / gpu_ms, avg_us_event_per_launch=oavg * 1e6,
-                     frac=o["achieved"] / o["peak"])
+                o = mfma_roof(oname, oflops, oavg)
+            o.update(kernel=oname, launches_per_group_pass=olaunches // 2, share_of_gpu_time=oms / gpu_ms, avg_us_event_per_launch=oavg * 1e6)
             others.append(o)
         roof["other_kernels"] = others
         # whole-path figure against the fp32 matrix peak (36.18 MFLOP per mel frame)
         per_gpu = B * S * args.steps / elapsed
         roof["path_tflops"] = per_gpu * 36.18e6 / 1e12
-        roof["path_frac_fp32_peak"] = roof["path_tflops"] / FP32_MFMA_PEAK_TFLOPS
+        roof["path_frac_fp32_peak"] = roof["path_tflops"] / FP32_MFMA_PEAK_TFLOPS      # mixed pipes (f32 trunk / first phase, split-bf16 elsewhere): a ratio to the data's dtype peak, not a pipe roofline
 
         value = world * B * S * args.steps / elapsed
         line = {
@@ -547,6 +606,12 @@ def main():
                                                    "pinned host memory and normalised + padded by l2s_normalise_pad_frames one group ahead on the pool's copy stream; same grouping and chains as `value`"},
             "roofline": roof,
         }
+        if lat:
+            for nb, ms in lat.items():
+                line[f"latency_B{nb}_S300"] = {"ms": ms, "value": nb * S / ms * 1e3, "unit": "mel-frames/s",
+                                               "note": f"one l2s_inference call on B={nb} clips (T=29, S=300) alone on the GPU, call to results; median of 7"}
+        if train:
+            line["train_step_B8"] = train
         if world == 1 and not args.skip_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

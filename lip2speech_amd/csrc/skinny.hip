@@ -323,7 +323,10 @@ static unsigned long long* g_skinny_ts = nullptr;
 // "skinny_split" / "skinny_split8" = operand loads of the K <= 1536 / K <= 1024 instance in this many batches
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
 
-bool skinny_sum_supported(const Options& o) { return o.rc_jb == 0 && g_skinny_ts == nullptr; }
+static bool skinny_shape_known(int shape) { return shape == 0 || shape == 11 || shape == 21 || shape == 22 || shape == 42; }
+// a forced "skinny_rc" / "skinny_rc_multi" outside {11, 21, 22, 42} falls through to skinny_kernel<cls>, which knows nothing of SkinnyP::a_sum: the
+// caller then keeps LSTM layer 0 on [content | prenet | o | h0] (K = 1280, hoist_vproj = 1)
+bool skinny_sum_supported(const Options& o) { return o.rc_jb == 0 && g_skinny_ts == nullptr && skinny_shape_known(o.rc_shape) && skinny_shape_known(o.rc_shape_multi); }
 
 int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const Options& o) {
     L2S_REQUIRE(b.count >= 1 && b.count <= SKINNY_MAX_GROUP, "skinny group size");
@@ -393,7 +396,10 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
         }
     }
     for (int i = 0; i < bl.count; ++i)
-        L2S_REQUIRE(!bl.p[i].a_sum || (rc_lay == 6 && rc_kind == 2 && skinny_sum_supported(o)), "skinny: a summed segment needs the straight-line four-wave LSTM blocks");
+        L2S_REQUIRE(!bl.p[i].a_sum || (rc_lay == 6 && rc_kind == 2 && skinny_sum_supported(o) && skinny_shape_known(shape) && shape != 0),
+                    "skinny: a summed segment needs the straight-line LSTM blocks (shape 11 / 21 / 22 / 42, default operand batching)");
+    bool any_sum = false;
+    for (int i = 0; i < bl.count; ++i) any_sum = any_sum || bl.p[i].a_sum;
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
@@ -406,6 +412,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
     else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
     else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
+    else if (any_sum) L2S_REQUIRE(false, "skinny: no block form of this launch sums u = prenet + o in its loader (SkinnyP::a_sum would be ignored)");
     else if (cls == 4) hipLaunchKernelGGL(skinny_kernel<4>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8 && o.skinny_split8 == 2) hipLaunchKernelGGL((skinny_kernel_split<8, 2, 8>), dim3(maxt, mts, b.count), dim3(512), 0, s, bl);
     else if (cls == 8) hipLaunchKernelGGL(skinny_kernel<8>, dim3(maxt, mts, b.count), dim3(512), 0, s, bl);

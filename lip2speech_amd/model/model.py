@@ -58,8 +58,10 @@ class _HipTrainStep(torch.autograd.Function):
         video, emb, vis, etape, state, ptape, sctx, mel, post_tape, pdrop, fdrop = ctx.tapes
         B, S = mel.shape[0], mel.shape[1]
         flat = model._flat
-        live = model._grads_live() and not getattr(flat, "cleared", False)      # a fused zero_grad() just zeroed the buffer: nothing to accumulate
-        flat.cleared = False
+        # a fused zero_grad() just zeroed the buffer and nothing has written it through torch since (FlatBuffer.cleared_version): nothing to
+        # accumulate.  A manual p.grad.add_(), an all-reduce or another graph's backward in between bumps the version -> the accumulate path
+        live = model._grads_live() and not flat.is_cleared()
+        flat.mark_written()
         prev = flat.grad.clone() if live else None                    # gradient accumulation across backward() calls
         n_dec = model._n_decoder_elems()
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g  # noqa: E731
@@ -215,9 +217,11 @@ class Lip2Speech(NativeBacked):
         from ..parallel import InflightPool
         nm = self.native_model()
         pools = self.__dict__.setdefault("_pools", {})
-        key = (id(nm), group, n_inflight)
-        if key not in pools:
-            pools[key] = InflightPool(model=nm, n_inflight=n_inflight, group=group)
+        key = (group, n_inflight)
+        if key not in pools or pools[key].model is not nm:      # a re-packed / replaced NativeModel: the old pool (and its blob) is dropped
+            pools[key] = InflightPool(model=nm, n_inflight=n_inflight, group=group, device=self.decoder.BOS.device)
+        for k in [k for k, v in pools.items() if v.model is not nm]:
+            del pools[k]
         return pools[key]
 
     @staticmethod

@@ -94,6 +94,7 @@ class InflightPool:
         self.model = model
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_inflight))]
         self.copy_stream = None                       # created on first use of map(prepare=...): ONE stream for every chain's input staging
+        self._stats_lock = threading.Lock()
         self.stats = collections.Counter()            # imap(): groups / batches issued, by entry point ("inference_groups", "forward_batches", ...)
 
     @staticmethod
@@ -230,9 +231,10 @@ class InflightPool:
 
     def _run_group(self, jobs: List[dict]) -> List[tuple]:
         j0 = jobs[0]
-        self.stats[j0["entry"] + "_groups"] += 1
-        self.stats[j0["entry"] + "_batches"] += len(jobs)
-        self.stats["max_group"] = max(self.stats["max_group"], len(jobs))
+        with self._stats_lock:                                   # several worker threads run groups at once
+            self.stats[j0["entry"] + "_groups"] += 1
+            self.stats[j0["entry"] + "_batches"] += len(jobs)
+            self.stats["max_group"] = max(self.stats["max_group"], len(jobs))
         if j0["entry"] == "inference":
             if len(jobs) == 1:
                 return [self.model.inference(j0["video"], j0["emb"], j0["gumbel"], S=j0["S"], want_attn=j0.get("want_attn", False))]
@@ -348,7 +350,10 @@ class InflightPool:
                         break                                    # every worker has finished: the iterable is exhausted
                     job, r, done = results.pop(i)
                 caller_stream.wait_event(done)
-                for t in r:
+                # results come from a worker stream, the job's own tensors (what `prepare` staged: a `finish` closure may hand them on, e.g. the
+                # speaker embedding in forward_many's list of 7) from the copy stream: both are the caller's to read from here on, so their
+                # blocks must not be recycled under a kernel the caller still has queued
+                for t in list(r) + list(job.values()):
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(caller_stream)
                 finish = job.get("finish")

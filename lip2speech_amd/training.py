@@ -26,6 +26,10 @@ class FlatBuffer:
         self.numel = sum(p.numel() for p in self.params)
         self.data = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # `grad._version` at the moment a fused zero_grad() zeroed the buffer, else -1.  While it still equals `grad._version` nothing has written
+        # the gradient buffer through torch since (every in-place op on the buffer or on any p.grad view bumps the shared version counter), so
+        # the next backward() may overwrite instead of clone + add; the backward itself (native writes, invisible to the counter) resets it.
+        self.cleared_version = -1
         off = 0
         self.offsets: Dict[int, int] = {}
         for p in self.params:
@@ -35,6 +39,17 @@ class FlatBuffer:
             p.grad = self.grad[off:off + n].view_as(p)
             self.offsets[id(p)] = off
             off += n
+
+
+    def mark_cleared(self) -> None:
+        self.cleared_version = self.grad._version
+
+    def is_cleared(self) -> bool:
+        """True iff the gradient buffer is still the zeros a fused zero_grad() left (see `cleared_version`)."""
+        return self.cleared_version == self.grad._version
+
+    def mark_written(self) -> None:
+        self.cleared_version = -1
 
 
 class AdamWAmsgrad:
@@ -51,7 +66,7 @@ class AdamWAmsgrad:
 
     def zero_grad(self):
         self.flat.grad.zero_()
-        self.flat.cleared = True          # the next backward() overwrites: no clone + add of a zero buffer (154 MB each) for "accumulation"
+        self.flat.mark_cleared()          # the next backward() overwrites: no clone + add of a zero buffer (154 MB each) for "accumulation"
 
     def step(self, max_norm: Optional[float] = 1.0, grad_mul: float = 1.0) -> torch.Tensor:
         """Returns the (unclipped, averaged) total gradient norm as a device scalar - no host synchronisation."""
