@@ -133,6 +133,35 @@ int64_t l2s_speaker_workspace_bytes(int B, int n_samples);
 int l2s_speaker_encoder_fwd(l2s_model* m, const float* audio, int B, int n_samples, float* emb,
                             void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- vocoder + metric of evaluate.py -------------------------------------------------------------
+ * The reference vocodes the predicted mels with torchaudio 0.9.0 (datasets/spectograms.py:76-95: exp -> InverseMelScale ->
+ * GriffinLim, 256 iterations each) and scores them with pystoi 0.3.3 (evaluate.py:41-45: stoi(gt, pred, fs, extended=True)).
+ * Both packages are absent from the build image: these entry points run the published algorithms as restated in
+ * lip2speech_amd/datasets/spectrograms.py and lip2speech_amd/metrics.py - PARITY UNPINNED against the packages themselves.
+ * The random start iterates of both vocoder stages are INPUTS (the reference draws them with torch.rand).
+ *
+ * l2s_inverse_mel: torchaudio.transforms.InverseMelScale.forward.  mel dev (N, n_mels, L): power mel, or log-mel when log_input
+ *   (spectral_de_normalize = exp is then applied on the fly); fb dev (n_freqs, n_mels) with fb_nnz non-zero entries (exact count,
+ *   the caller knows its filterbank; at most 2048); init dev (N*L, n_freqs), row n*L + l = the start spectrum of frame l of clip n.
+ *   The N clips are N / rows_per_call independent calls (the SGD's 1/(rows*L) gradient scale, the loss mean and the two stopping
+ *   rules - loss < 1e-5, |loss - previous loss| < 1e-8, the update of the stopping iteration still applied - are per call).
+ *   spec dev (N, n_freqs, L) >= 0.  loss_per_iter dev (calls, iters) or NULL; iters_run dev int (calls) or NULL.
+ * l2s_griffin_lim: torchaudio.functional.griffinlim (power 2, rand_init replaced by init_angles dev (N, n_freqs, L, 2) used as
+ *   given, momentum 0.99): power_spec dev (N, 513, L) -> wave dev (N, hop*(L-1)).  n_fft = win_length = 1024, hop = 256, L <= 121.
+ * l2s_estoi: pystoi.stoi(clean, pred, fs, extended=True) per clip: clean / pred dev (N, n_samples); fir dev = the polyphase
+ *   resampling filter of scipy.signal.resample_poly(x, up, down) INCLUDING its leading zero pad (n_fir taps, already scaled by up),
+ *   n_pre_remove / n_resampled as resample_poly computes them, or fir = NULL when fs is already 10 kHz; band_lo_hi_host = HOST
+ *   array of 2 x 15 ints, first / last+1 bin of each one-third octave band; score dev (N). */
+int64_t l2s_inverse_mel_workspace_bytes(int N, int L, int n_mels, int n_freqs, int rows_per_call, int iters);
+int l2s_inverse_mel(const float* mel, int log_input, const float* fb, int fb_nnz, const float* init, int N, int L, int n_mels, int n_freqs,
+                    int rows_per_call, int iters, float* spec, float* loss_per_iter, int* iters_run, void* ws, int64_t ws_bytes, void* stream);
+int64_t l2s_griffin_lim_workspace_bytes(int N, int L);
+int l2s_griffin_lim(const float* power_spec, const float* init_angles, int N, int L, int n_fft, int hop, int iters, float momentum,
+                    float* wave, void* ws, int64_t ws_bytes, void* stream);
+int64_t l2s_estoi_workspace_bytes(int N);
+int l2s_estoi(const float* clean, const float* pred, int N, int n_samples, const float* fir, int n_fir, int up, int down, int n_pre_remove,
+              int n_resampled, const int* band_lo_hi_host, float* score, void* ws, int64_t ws_bytes, void* stream);
+
 /* decoder.py:429-435: lengths[b] = first i+1 with stop logit > 0, else S.  lengths dev (B) int64. */
 int l2s_output_lengths(const float* stop, int B, int S, int64_t* lengths, void* stream);
 

@@ -72,7 +72,7 @@ def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda", g
 
 
 def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", max_iters: int = 256, sampling_rate: int = None,
-                 group: int = 8, n_inflight: int = 2, timings: Optional[dict] = None) -> float:
+                 group: int = 8, n_inflight: int = 2, timings: Optional[dict] = None, vocoder_backend: str = "auto", metric: str = "auto") -> float:
     """Mean ESTOI of the vocoded predictions against the ground-truth audio (reference: evaluate.py:22-51): `net(..., tf_ratio=1)[1]`
     -> `MelSpec2Audio` (InverseMelScale + Griffin-Lim, `max_iters` each) -> `stoi(gt, pred, fs, extended=True)` per clip.  Vocoder and
     metric are restatements of third-party algorithms (parity unpinned); the mels come from the HIP path, `group` loader batches per launch
@@ -81,31 +81,44 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
     import time
     from .datasets.spectrograms import MelSpec2Audio
     from .hparams import create_hparams
-    from .metrics import stoi
+    from .metrics import estoi_device, stoi
     hp = create_hparams()
     fs = sampling_rate or hp.sampling_rate
-    vocoder = MelSpec2Audio(hp, max_iters=max_iters).to(device)
+    vocoder = MelSpec2Audio(hp, max_iters=max_iters, backend=vocoder_backend).to(device)
     scores = []
     was_training = net.training
     net.eval()
     t = {"model_wait_s": 0.0, "vocoder_s": 0.0, "estoi_s": 0.0, "clips": 0}
     def vocode_and_score(pending):
-        """One vocoder pass over the mels of up to `group` loader batches (the 256 + 256 iterations are ~5 000 small launches whatever the
-        batch size: vocoding a group at once amortises them), then ESTOI per clip on the host."""
+        """One vocoder pass over the mels of up to `group` loader batches, then ESTOI per clip.  On the device path (`metric="hip"`, default
+        where the shapes allow: vocoder.hip) the vocoder is three launches per pass and the metric one block per clip - the predictions never
+        leave the GPU, one (N,) score vector comes back per group; `metric="host"` scores with the numpy restatement like the reference."""
         t1 = time.perf_counter()
         same = all(m.shape[0] == pending[0][1].shape[0] for _, m in pending)
         if same:        # InverseMelScale's SGD normalises by the call's own B*L: the loader batches stay separate calls inside the one pass
-            pred = vocoder(torch.cat([m for _, m in pending], dim=0), rows_per_call=pending[0][1].shape[0]).cpu().numpy()
+            pred_dev = vocoder(torch.cat([m for _, m in pending], dim=0), rows_per_call=pending[0][1].shape[0])
         else:
-            pred = torch.cat([vocoder(m) for _, m in pending], dim=0).cpu().numpy()
-        t2 = time.perf_counter()
-        row = 0
-        for audios, m in pending:
-            gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
-            for i in range(gt.shape[0]):
-                n = min(gt.shape[1], pred.shape[1])
-                scores.append(stoi(gt[i, :n], pred[row + i, :n], fs, extended=True))
-            row += gt.shape[0]
+            pred_dev = torch.cat([vocoder(m) for _, m in pending], dim=0)
+        n = min(min(a.shape[1] for a, _ in pending), pred_dev.shape[1])
+        on_device = metric != "host" and pred_dev.is_cuda and all(a.shape[1] == pending[0][0].shape[1] for a, _ in pending) and \
+            -(-n * 10000 // fs) <= 16512
+        if metric == "hip" and not on_device:
+            raise RuntimeError("evaluate_net(metric='hip'): needs device predictions and clips of at most 1.65 s")
+        if on_device:
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            gt_dev = torch.cat([a[:, :n] for a, _ in pending], dim=0).to(pred_dev.device, non_blocking=True).float().contiguous()
+            scores.extend(float(v) for v in estoi_device(gt_dev, pred_dev[:, :n].contiguous(), fs).cpu())
+            row = gt_dev.shape[0]
+        else:
+            pred = pred_dev.cpu().numpy()
+            t2 = time.perf_counter()
+            row = 0
+            for audios, m in pending:
+                gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
+                for i in range(gt.shape[0]):
+                    scores.append(stoi(gt[i, :n], pred[row + i, :n], fs, extended=True))
+                row += gt.shape[0]
         t3 = time.perf_counter()
         t["vocoder_s"] += t2 - t1
         t["estoi_s"] += t3 - t2

@@ -69,13 +69,25 @@ class MelSpec2Audio(torch.nn.Module):
     random start, power 2).  torchaudio is absent here: both published algorithms are restated on torch ops (torch.stft/istft on the
     device) - PARITY UNPINNED, and stochastic in the reference as well.  Not part of the mel-frames/s path."""
 
-    def __init__(self, hparams=None, max_iters: int = 256):
+    def __init__(self, hparams=None, max_iters: int = 256, backend: str = "auto"):
+        """`backend`: "hip" = the fused device kernels behind `l2s_inverse_mel` / `l2s_griffin_lim` (vocoder.hip: one wave per mel frame for
+        the SGD, one block per clip with the waveform in LDS and wave-level FFTs for Griffin-Lim); "torch" = the same algorithms as ~5 000
+        torch launches per call (the restatement the kernels are tested against); "auto" = "hip" for device tensors of a supported shape
+        (n_fft = win = 1024, hop 256, at most 121 frames per clip), else "torch".  Both draw the same random start iterates in the same order."""
         super().__init__()
         hp = hparams or create_hparams()
         self.n_fft, self.hop, self.win, self.sr = hp.filter_length, hp.hop_length, hp.win_length, hp.sampling_rate
         self.max_iters = max_iters
+        self.backend = backend
         self.register_buffer("window", torch.hann_window(self.win, periodic=True))
         self.register_buffer("fb", mel_filterbank(self.n_fft // 2 + 1, hp.mel_fmin, hp.mel_fmax, hp.n_mel_channels, self.sr))
+        self.fb_nnz = int((self.fb != 0).sum())
+
+    def _use_hip(self, t: torch.Tensor, L: int) -> bool:
+        ok = t.is_cuda and self.n_fft == 1024 and self.win == 1024 and self.hop == 256 and 5 <= L <= 121 and self.fb_nnz <= 2048
+        if self.backend == "hip" and not ok:
+            raise RuntimeError("MelSpec2Audio(backend='hip'): needs device tensors, n_fft = win = 1024, hop 256 and 5..121 frames per clip")
+        return ok and self.backend in ("auto", "hip")
 
     # -- torchaudio.transforms.InverseMelScale.forward (0.9.0)
     def inverse_mel(self, mel: torch.Tensor, generator=None, rows_per_call: int = None) -> torch.Tensor:
@@ -90,6 +102,9 @@ class MelSpec2Audio(torch.nn.Module):
         G = N // R
         target = mel.transpose(1, 2).reshape(G, R * L, -1)                        # (G, R*L, n_mels)
         spec = torch.rand(G, R * L, self.fb.shape[0], device=mel.device, dtype=mel.dtype, generator=generator)
+        if self._use_hip(mel, L):
+            from .. import native
+            return native.inverse_mel(mel, self.fb, self.fb_nnz, spec.reshape(N * L, -1), self.max_iters, rows_per_call=R)
         vel = torch.zeros_like(spec)
         loss = torch.full((G, 1, 1), float("inf"), device=mel.device, dtype=mel.dtype)
         active = torch.ones((G, 1, 1), device=mel.device, dtype=torch.bool)
@@ -112,6 +127,9 @@ class MelSpec2Audio(torch.nn.Module):
         B, _, L = mag.shape
         length = self.hop * (L - 1)
         ang = torch.view_as_complex(torch.rand(*mag.shape, 2, device=mag.device, dtype=mag.dtype, generator=generator))
+        if self._use_hip(power_spec, L):
+            from .. import native
+            return native.griffin_lim(power_spec, ang, self.max_iters, self.n_fft, self.hop, 0.99)
         momentum = 0.99 / (1 + 0.99)
         prev = torch.zeros_like(ang)
         stft = lambda x: torch.stft(x, self.n_fft, self.hop, self.win, self.window, center=True, pad_mode="reflect",      # noqa: E731

@@ -102,3 +102,58 @@ def stoi(x, y, fs_sig: int, extended: bool = False) -> float:
     xc = xc / (np.linalg.norm(xc, axis=2, keepdims=True) + EPS)
     yc = yc / (np.linalg.norm(yc, axis=2, keepdims=True) + EPS)
     return float(np.sum(xc * yc) / (xc.shape[0] * xc.shape[1]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- on the device (l2s_estoi)
+def resample_poly_plan(n_in: int, up: int, down: int):
+    """What scipy.signal.resample_poly(x, up, down) (default Kaiser-5 window, zero-padded ends) computes before it filters: the FIR it
+    designs - scaled by `up`, with its leading / trailing zero pads - the number of leading outputs it drops and its output length.
+    Returns (h float64, up, down, n_pre_remove, n_out) with up / down reduced, or (None, 1, 1, 0, n_in) when there is nothing to do."""
+    from scipy.signal import firwin
+    g = int(np.gcd(int(up), int(down)))
+    up, down = int(up) // g, int(down) // g
+    if up == down == 1:
+        return None, 1, 1, 0, n_in
+    n_out = n_in * up
+    n_out = n_out // down + bool(n_out % down)
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = down - half_len % down
+    n_post_pad = 0
+    n_pre_remove = (half_len + n_pre_pad) // down
+    out_len = lambda len_h: (((n_in - 1) * up + len_h) - 1) // down + 1      # noqa: E731  (scipy.signal._upfirdn._output_len)
+    while out_len(len(h) + n_pre_pad + n_post_pad) < n_out + n_pre_remove:
+        n_post_pad += 1
+    h = np.concatenate((np.zeros(n_pre_pad), h, np.zeros(n_post_pad)))
+    return h, up, down, n_pre_remove, n_out
+
+
+def band_edges():
+    """First / last+1 bin of the 15 one-third octave bands (rows of `thirdoct`'s matrix), as l2s_estoi takes them: lo[0..14] + hi[0..14]."""
+    obm, _ = thirdoct(FS, NFFT, NUMBAND, MINFREQ)
+    lo, hi = [], []
+    for row in obm:
+        nz = np.flatnonzero(row)
+        lo.append(int(nz[0]) if len(nz) else 0)
+        hi.append(int(nz[-1]) + 1 if len(nz) else 0)
+        assert len(nz) == 0 or np.all(row[lo[-1]:hi[-1]] == 1), "bands are contiguous runs of ones"
+    return lo + hi
+
+
+_plans = {}
+
+
+def estoi_device(clean, pred, fs_sig: int):
+    """ESTOI of every row of `pred` against the same row of `clean` (device tensors (N, n_samples)) by the HIP kernel behind `l2s_estoi`:
+    the algorithm of `stoi(x, y, fs_sig, extended=True)` above, one block per clip.  Returns a device tensor (N,)."""
+    import torch
+    from . import native
+    n = int(clean.shape[1])
+    key = (n, int(fs_sig), str(clean.device))
+    if key not in _plans:
+        h, up, down, n_pre, n_out = resample_poly_plan(n, FS, fs_sig)
+        fir = None if h is None else torch.from_numpy(h.astype(np.float32)).to(clean.device)
+        _plans[key] = (fir, up, down, n_pre, n_out, band_edges())
+    fir, up, down, n_pre, n_out, bands = _plans[key]
+    return native.estoi(clean, pred, fir, up, down, n_pre, n_out, bands)

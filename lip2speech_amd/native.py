@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
+    "l2s_inverse_mel_workspace_bytes", "l2s_inverse_mel", "l2s_griffin_lim_workspace_bytes", "l2s_griffin_lim", "l2s_estoi_workspace_bytes", "l2s_estoi",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
@@ -135,6 +136,15 @@ def lib() -> ctypes.CDLL:
     L.l2s_grad_norm.argtypes = [_fp, _i64, _vp, _fp, _vp]
     _f = ctypes.c_float
     L.l2s_adamw_amsgrad_step.argtypes = [_fp] * 5 + [_i64, _f, _f, _f, _f, _f, _i, _fp, _f, _f, _vp]
+    L.l2s_inverse_mel_workspace_bytes.argtypes = [_i] * 6
+    L.l2s_inverse_mel_workspace_bytes.restype = _i64
+    L.l2s_inverse_mel.argtypes = [_fp, _i, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp, _i64, _vp]
+    L.l2s_griffin_lim_workspace_bytes.argtypes = [_i, _i]
+    L.l2s_griffin_lim_workspace_bytes.restype = _i64
+    L.l2s_griffin_lim.argtypes = [_fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp, _vp, _i64, _vp]
+    L.l2s_estoi_workspace_bytes.argtypes = [_i]
+    L.l2s_estoi_workspace_bytes.restype = _i64
+    L.l2s_estoi.argtypes = [_fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _fp, _vp, _i64, _vp]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -623,3 +633,52 @@ def profile_read():
         check(L.l2s_profile_get(i, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms)))
         out.append((name.value.decode(), int(n.value), float(ms.value)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- vocoder + metric (evaluate.py)
+def inverse_mel(mel: torch.Tensor, fb: torch.Tensor, fb_nnz: int, init: torch.Tensor, iters: int, rows_per_call: Optional[int] = None,
+                log_input: bool = False, want_loss: bool = False):
+    """`l2s_inverse_mel`: mel (N, n_mels, L), fb (n_freqs, n_mels), init (N*L, n_freqs) -> spec (N, n_freqs, L)
+    [, loss (calls, iters), iterations run per call (calls,) int32]."""
+    mel, fb, init = _f32(mel), _f32(fb), _f32(init)
+    N, M, Lf = mel.shape
+    F = fb.shape[0]
+    assert fb.shape[1] == M and tuple(init.shape) == (N * Lf, F), (fb.shape, init.shape)
+    R = rows_per_call or N
+    L = lib()
+    ws = torch.empty(int(L.l2s_inverse_mel_workspace_bytes(N, Lf, M, F, R, iters)), dtype=torch.uint8, device=mel.device)
+    spec = torch.empty(N, F, Lf, dtype=torch.float32, device=mel.device)
+    loss = torch.empty(N // R, max(iters, 1), dtype=torch.float32, device=mel.device) if want_loss else None
+    ran = torch.empty(N // R, dtype=torch.int32, device=mel.device) if want_loss else None
+    check(L.l2s_inverse_mel(mel.data_ptr(), int(log_input), fb.data_ptr(), int(fb_nnz), init.data_ptr(), N, Lf, M, F, R, iters, spec.data_ptr(),
+                            _ptr(loss), _ptr(ran), ws.data_ptr(), ws.numel(), _stream()))
+    return (spec, loss, ran) if want_loss else spec
+
+
+def griffin_lim(power_spec: torch.Tensor, init_angles: torch.Tensor, iters: int, n_fft: int = 1024, hop: int = 256, momentum: float = 0.99) -> torch.Tensor:
+    """`l2s_griffin_lim`: power_spec (N, n_fft/2+1, L), init_angles complex (N, n_fft/2+1, L) or float (..., 2) -> wave (N, hop*(L-1))."""
+    power_spec = _f32(power_spec)
+    ang = torch.view_as_real(init_angles) if init_angles.is_complex() else init_angles
+    ang = _f32(ang)
+    N, F, Lf = power_spec.shape
+    assert tuple(ang.shape) == (N, F, Lf, 2), ang.shape
+    L = lib()
+    ws = torch.empty(int(L.l2s_griffin_lim_workspace_bytes(N, Lf)), dtype=torch.uint8, device=power_spec.device)
+    wave = torch.empty(N, hop * (Lf - 1), dtype=torch.float32, device=power_spec.device)
+    check(L.l2s_griffin_lim(power_spec.data_ptr(), ang.data_ptr(), N, Lf, n_fft, hop, iters, momentum, wave.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return wave
+
+
+def estoi(clean: torch.Tensor, pred: torch.Tensor, fir: Optional[torch.Tensor], up: int, down: int, n_pre_remove: int, n_resampled: int,
+          band_lo_hi) -> torch.Tensor:
+    """`l2s_estoi`: clean / pred (N, n_samples) on the device -> ESTOI per clip (N,).  `fir`: the padded polyphase filter (device) or None."""
+    clean, pred = _f32(clean), _f32(pred)
+    N, n = clean.shape
+    assert pred.shape == clean.shape
+    L = lib()
+    bands = (ctypes.c_int * 30)(*[int(v) for v in band_lo_hi])
+    ws = torch.empty(int(L.l2s_estoi_workspace_bytes(N)), dtype=torch.uint8, device=clean.device)
+    score = torch.empty(N, dtype=torch.float32, device=clean.device)
+    check(L.l2s_estoi(clean.data_ptr(), pred.data_ptr(), N, n, _ptr(fir), 0 if fir is None else fir.numel(), up, down, n_pre_remove, n_resampled,
+                      bands, score.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return score

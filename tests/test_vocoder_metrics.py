@@ -121,3 +121,164 @@ def test_inverse_mel_device_stopping_rule_and_grouped_calls():
     sep = torch.cat([voc.inverse_mel(mel[:2], generator=gen), voc.inverse_mel(mel[2:], generator=gen)], dim=0)
     assert torch.allclose(one_pass, sep, rtol=1e-5, atol=1e-6)
     assert 1 <= iters <= voc.max_iters
+
+
+def test_resample_plan_and_band_edges_reproduce_scipy_and_thirdoct():
+    """The host-side constants handed to `l2s_estoi`: the polyphase FIR / offsets of scipy.signal.resample_poly (the kernel computes
+    out[n] = sum_i x[i] h[(n + n_pre_remove) down - i up]) and the one-third octave band edges."""
+    from scipy.signal import resample_poly
+    rng = np.random.default_rng(5)
+    for n_in, fs in ((19456, 16000), (4001, 16000), (3000, 22050), (5000, 8000)):
+        x = rng.standard_normal(n_in)
+        h, up, down, n_pre, n_out = metrics.resample_poly_plan(n_in, metrics.FS, fs)
+        want = resample_poly(x, up, down)
+        assert len(want) == n_out
+        got = np.zeros(n_out)
+        for n in range(0, n_out, 7):                     # every 7th output, by the kernel's formula
+            c = (n + n_pre) * down
+            i = np.arange(max(0, -(-(c - (len(h) - 1)) // up)), min(n_in - 1, c // up) + 1)
+            got[n] = np.dot(x[i], h[c - i * up])
+        assert np.abs(got[::7] - want[::7]).max() < 1e-12
+    assert metrics.resample_poly_plan(1000, 10000, 10000)[0] is None
+    be = metrics.band_edges()
+    obm, _ = metrics.thirdoct(metrics.FS, metrics.NFFT, metrics.NUMBAND, metrics.MINFREQ)
+    for b in range(15):
+        row = np.zeros(257)
+        row[be[b]:be[15 + b]] = 1
+        assert np.array_equal(row, obm[b])
+    assert all(be[b] <= be[b + 1] for b in range(14))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,R,iters", [(4, 77, 2, 256), (3, 20, 3, 40), (2, 77, 1, 0)])
+def test_inverse_mel_kernel_matches_the_torch_restatement(N, L, R, iters):
+    """`l2s_inverse_mel` (one wave per mel frame, banded filterbank, stopping rules on the device) against `MelSpec2Audio.inverse_mel` on
+    torch ops, same start iterate: every spectrum value, the per-iteration losses, and the iteration count the stopping rules leave."""
+    from lip2speech_amd import native
+    voc_t = MelSpec2Audio(max_iters=iters, backend="torch").cuda()
+    voc_h = MelSpec2Audio(max_iters=iters, backend="hip").cuda()
+    g = torch.Generator(device="cuda")
+    mel = torch.exp(torch.randn(N, 80, L, device="cuda", generator=g.manual_seed(1)) * 2.0 - 5.0)
+    want = voc_t.inverse_mel(mel, g.manual_seed(7), rows_per_call=R)
+    got = voc_h.inverse_mel(mel, g.manual_seed(7), rows_per_call=R)
+    assert got.shape == want.shape == (N, 513, L)
+    assert float((got - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    if iters:
+        init = torch.rand(N // R, R * L, 513, device="cuda", generator=g.manual_seed(7)).reshape(N * L, 513)
+        spec, loss, ran = native.inverse_mel(mel, voc_h.fb, voc_h.fb_nnz, init, iters, rows_per_call=R, want_loss=True)
+        assert torch.equal(spec, got)
+        assert ran.dtype == torch.int32 and int(ran.min()) >= 1 and int(ran.max()) <= iters
+        # the loss of iteration 0 is the start iterate's: mean over the call's rows of |mel - init @ fb|^2
+        l0 = (mel.transpose(1, 2).reshape(N // R, R * L, 80) - init.reshape(N // R, R * L, 513) @ voc_h.fb).pow(2).sum(-1).mean(-1)
+        assert torch.allclose(loss[:, 0], l0, rtol=1e-4)
+    # log-mel input: exp applied on the fly
+    got_log = native.inverse_mel(torch.log(mel), voc_h.fb, voc_h.fb_nnz,
+                                 torch.rand(N // R, R * L, 513, device="cuda", generator=g.manual_seed(7)).reshape(N * L, 513), iters, rows_per_call=R, log_input=True)
+    assert float((got_log - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,iters,tol", [(3, 77, 0, 2e-5), (3, 77, 1, 5e-5), (2, 77, 4, 1e-4), (2, 40, 8, 2e-4), (1, 100, 2, 1e-4)])
+def test_griffin_lim_kernel_matches_the_torch_restatement(N, L, iters, tol):
+    """`l2s_griffin_lim` (one block per clip, waveform in LDS, radix-8 wave FFTs, deterministic four-phase overlap-add) against
+    `MelSpec2Audio.griffin_lim` on torch.stft / istft, same start angles (a C2R transform ignores the imaginary parts of the DC and
+    Nyquist bins; the start angles get real ones so that the comparison does not hinge on that convention)."""
+    from lip2speech_amd import native
+    g = torch.Generator(device="cuda")
+    power = torch.rand(N, 513, L, device="cuda", generator=g.manual_seed(2)) ** 4 * 3.0
+    ang = torch.rand(N, 513, L, 2, device="cuda", generator=g.manual_seed(3))
+    ang[:, 0, :, 1] = 0
+    ang[:, 512, :, 1] = 0
+    voc = MelSpec2Audio(max_iters=iters, backend="torch").cuda()
+    # the restatement with explicit angles
+    mag = power.sqrt()
+    a = torch.view_as_complex(ang.clone())
+    prev = torch.zeros_like(a)
+    length = 256 * (L - 1)
+    stft = lambda x: torch.stft(x, 1024, 256, 1024, voc.window, center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)   # noqa: E731
+    istft = lambda z: torch.istft(z, 1024, 256, 1024, voc.window, length=length)          # noqa: E731
+    for _ in range(iters):
+        rebuilt = stft(istft(mag * a))
+        a = rebuilt - prev * (0.99 / 1.99)
+        a = a / (a.abs() + 1e-16)
+        prev = rebuilt
+    want = istft(mag * a)
+    got = native.griffin_lim(power, ang, iters)
+    assert got.shape == want.shape == (N, length)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < tol * max(1.0, scale), (float((got - want).abs().max()), scale)
+
+
+@pytest.mark.gpu
+def test_griffin_lim_kernel_full_length_run_converges_like_the_restatement():
+    """256 iterations (evaluate.py's setting): phase retrieval amplifies rounding differences between two FFT implementations, so the
+    two waveforms are compared through what Griffin-Lim optimises - the spectral inconsistency |  |stft(y)| - mag | / |mag| - and through
+    their magnitude spectrograms."""
+    from lip2speech_amd import native
+    g = torch.Generator(device="cuda")
+    x = torch.from_numpy(np.stack([speechlike(256 * 76, seed=s) for s in range(2)])).float().cuda()
+    win = torch.hann_window(1024, periodic=True, device="cuda")
+    stft = lambda v: torch.stft(v, 1024, 256, 1024, win, center=True, pad_mode="reflect", return_complex=True)       # noqa: E731
+    power = stft(x).abs() ** 2
+    ang = torch.rand(2, 513, 77, 2, device="cuda", generator=g.manual_seed(3))
+    voc = MelSpec2Audio(max_iters=256, backend="torch").cuda()
+    got = native.griffin_lim(power, ang, 256)
+    torch.manual_seed(0)
+    want = voc.griffin_lim(power, g.manual_seed(3))
+    mag = power.sqrt()
+    inc = lambda y: float(((stft(y).abs() - mag).norm() / mag.norm()))      # noqa: E731
+    assert torch.isfinite(got).all()
+    assert inc(got) < 1.15 * inc(want) + 1e-3, (inc(got), inc(want))
+    assert inc(got) < 0.35
+
+
+@pytest.mark.gpu
+def test_estoi_kernel_matches_the_numpy_restatement_on_sample_lrw():
+    """`l2s_estoi` per clip against `metrics.stoi(., ., 16000, extended=True)` (fp64 numpy) on the ten SAMPLE_LRW clips' audio: degraded
+    copies at four noise levels, a vocoded copy, and the clean signal itself (-> 1)."""
+    import os
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_lrw")
+    clean = np.stack([np.load(os.path.join(sample, f"ABOUT_{i:05d}.npz"))["data"] for i in range(1, 11)]).astype(np.float32)
+    assert clean.shape == (10, 19456)
+    rng = np.random.default_rng(0)
+    for level in (0.0, 0.1, 0.5, 2.0, 8.0):
+        pred = (clean + level * clean.std(axis=1, keepdims=True) * rng.standard_normal(clean.shape)).astype(np.float32)
+        want = np.array([metrics.stoi(clean[i], pred[i], 16000, extended=True) for i in range(10)])
+        got = metrics.estoi_device(torch.from_numpy(clean).cuda(), torch.from_numpy(pred).cuda(), 16000).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-4, (level, got, want)
+    # a clip too short for one segment: pystoi's 1e-5
+    short = torch.from_numpy(clean[:, :4000]).cuda()
+    assert np.allclose(metrics.estoi_device(short, short, 16000).cpu().numpy(), 1e-5)
+    assert metrics.stoi(clean[0, :4000], clean[0, :4000], 16000, extended=True) == 1e-5
+    # already at 10 kHz: no resampler
+    x10 = torch.from_numpy(clean[:, :12160]).cuda()
+    y10 = x10 + 0.3 * x10.std() * torch.randn(x10.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    want = np.array([metrics.stoi(x10[i].cpu().numpy(), y10[i].cpu().numpy(), 10000, extended=True) for i in range(10)])
+    assert np.abs(metrics.estoi_device(x10, y10, 10000).cpu().numpy() - want).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_evaluate_net_device_tail_matches_host_tail():
+    """evaluate.py:22-51 with the vocoder and the metric on the device against the same run scored on the host (numpy ESTOI of the same
+    device-vocoded waveforms), and the hip vocoder against the torch one through ESTOI (both start from the same random iterates)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from model.model import get_network
+    from lip2speech_amd import callers, synth
+    B, T, S = 4, 29, 77
+    net = get_network("test").cuda()
+    audio = torch.from_numpy(np.stack([speechlike(256 * (S - 1), seed=s) for s in range(B)])).float()
+    mel_t = MelSpectrogram()
+    batches = [((synth.synth_video(B, T, tag=f"ev{i}"), torch.full((B,), T)), (audio, torch.full((B,), audio.shape[1])),
+                (mel_t(audio)[:, :, :S], torch.full((B,), S), torch.zeros(B, S)), None) for i in range(3)]
+
+    class Spk:
+        def inference(self, a):
+            return synth.synth_speaker_embedding(a.shape[0], tag="ev").to(a.device)
+    scores = {}
+    for vb, me in (("hip", "hip"), ("hip", "host"), ("torch", "host")):
+        torch.manual_seed(0)
+        scores[vb, me] = callers.evaluate_net(net, batches, speaker_encoder=Spk(), max_iters=32, vocoder_backend=vb, metric=me)
+    assert abs(scores["hip", "hip"] - scores["hip", "host"]) < 1e-4, scores
+    assert abs(scores["hip", "host"] - scores["torch", "host"]) < 5e-3, scores
