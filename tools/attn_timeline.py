@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Timeline of the attention blocks of the step's second launch (step_attn_kernel) from the stamped build (`l2s_op_attn_timeline`): thread 0 of every
 attention block stamps the 100 MHz wall clock at entry / requests issued / q visible / logits computed / after the barrier / weights visible / stored.
-ROWS env (default 256): clips per launch; the launch runs alone, 40 times back to back, the last one's stamps are read."""
+ROWS env (default 256): clips per launch; the launch runs alone, 40 times back to back, the last one's stamps are read.
+-> profiles/rNN_attn_timeline.txt"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lip2speech_amd import native, synth

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Phase timeline of the decode step's FIRST launch at 256 rows (skinny_flat_kernel: prenet1 o fc_out, Q, content Q, fc_out + stop as one flat grid of
 per-group block shapes) from its stamped build (`l2s_op_flat_timeline`): thread 0 of every block stamps the 100 MHz wall clock.  A grouped pass of
-a few steps runs; the last first-phase launch leaves its stamps."""
+a few steps runs; the last first-phase launch leaves its stamps.
+-> profiles/rNN_flat_timeline.txt"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Phase timeline of the fused stride-1 ShuffleNet units (B env, default 32, T=29): the stamped build of one stage at a time; the last launch of
-that stage leaves its stamps."""
+that stage leaves its stamps.
+-> profiles/rNN_fused_unit_timeline_256clips.txt (B=256)"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

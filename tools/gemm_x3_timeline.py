@@ -1,6 +1,7 @@
 """K-tile timeline of the split-bf16 GEMM from the stamped measurement build (`l2s_op_gemm_x3_timeline`): lane 0 of each of the eight waves of ONE block
 stamps the shader clock per K tile - consumers (waves 0-3): tile start / first 24 MFMAs issued / past the barrier / second 24 issued; producers (waves 4-7):
-tile start / older register set landed / split + LDS writes done / past the barrier.  Usage: python tools/gemm_x3_timeline.py [M N K] [block]"""
+tile start / older register set landed / split + LDS writes done / past the barrier.  Usage: python tools/gemm_x3_timeline.py [M N K] [block]
+-> profiles/rNN_gemm_x3_timeline.txt (`dma`: rNN_gemm_x3_timeline_dma.txt)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """SHA-256 of the visual encoder's features at B = 32 (88x88 and 96x96 crops) and B = 256 (the grouped shapes: five frames per 3x3 block) plus the
 per-kernel-name times of the B = 256 pass: a pure data-movement change of the fused ShuffleNet units must not change the hashes.
-L2S_LIB=<other build> python tools/hash_encoder.py for the A/B."""
+L2S_LIB=<other build> python tools/hash_encoder.py for the A/B.
+-> profiles/rNN_encoder_hash.txt"""
 import os, sys, hashlib, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

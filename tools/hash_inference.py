@@ -1,5 +1,6 @@
 """SHA-256 of Lip2Speech.inference outputs (mel_post, lengths, attention) at B = 32 and as a group of 8 batches: a change that claims the same bits
-(data movement, instruction scheduling) must not change the hashes.  L2S_LIB=<other build> python tools/hash_inference.py for the A/B."""
+(data movement, instruction scheduling) must not change the hashes.  L2S_LIB=<other build> python tools/hash_inference.py for the A/B.
+-> profiles/rNN_inference_hash.txt"""
 import os, sys, hashlib, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

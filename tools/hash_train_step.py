@@ -1,5 +1,6 @@
 """SHA-256 over the outputs, all parameter gradients and the updated running statistics of ONE train()-mode forward + backward (B=8, T=29, S=77,
-fixed masks): a change that is meant to be arithmetic-neutral (launch restructuring) must leave this hash unchanged.  L2S_LIB selects the build."""
+fixed masks): a change that is meant to be arithmetic-neutral (launch restructuring) must leave this hash unchanged.  L2S_LIB selects the build.
+-> profiles/rNN_train_hash.txt"""
 import os, sys, hashlib, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth, training

@@ -1,4 +1,5 @@
-"""VGPR / LDS / occupancy of every kernel of a .hip unit (hipcc -Rpass-analysis=kernel-resource-usage), one line per kernel."""
+"""VGPR / LDS / occupancy of every kernel of a .hip unit (hipcc -Rpass-analysis=kernel-resource-usage), one line per kernel.
+-> profiles/rNN_kernel_resources.txt"""
 import re, subprocess, sys, os
 src = sys.argv[1]
 r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", "/dev/null",

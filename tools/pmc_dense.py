@@ -1,5 +1,6 @@
 """The encoder of one grouped pass at 256 clips (front-end conv, ShuffleNet trunk units, conv_last), for
-rocprofv3 --pmc / --kernel-trace passes (tools/pmc_dense_kernels.sh)."""
+rocprofv3 --pmc / --kernel-trace passes (tools/pmc_dense_kernels.sh).
+-> profiles/rNN_pmc_dense_kernels.txt (through tools/pmc_dense_kernels.sh)"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

@@ -1,4 +1,5 @@
-"""Print per-kernel averages of the counters in a rocprofv3 rocpd database."""
+"""Print per-kernel averages of the counters in a rocprofv3 rocpd database.
+-> the counter rows of profiles/rNN_pmc_dense_kernels.txt / rNN_pmc_step_kernels.txt"""
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]

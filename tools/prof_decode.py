@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Run only the decode loop (prologue once, then REPS x 300 steps over ROWS clips; ROWS = 32 x batches per launch chain, default 256) - for
-rocprofv3 counter passes."""
+rocprofv3 counter passes.
+-> profiles/rNN_kernel_stats_decode256.md, rNN_pmc_decode.json (through tools/profile_r4.sh)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

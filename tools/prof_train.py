@@ -1,4 +1,5 @@
-"""Per-kernel-name GPU time of one train()-mode training step (B=8, T=29, S=77)."""
+"""Per-kernel-name GPU time of one train()-mode training step (B=8, T=29, S=77).
+-> profiles/rNN_train_kernels.txt"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 rocpd database: per kernel and per launch shape (name, grid) statistics -> markdown."""
+"""Summarise a rocprofv3 rocpd database: per kernel and per launch shape (name, grid) statistics -> markdown.
+-> profiles/rNN_kernel_stats*.md"""
 import sqlite3, sys
 db, title = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 c = sqlite3.connect(db)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Phase timeline of the fused stride-2 ShuffleNet units (B env, default 256, T=29) from the stamped build (`l2s_op_fused_unit_timeline(ts, -H)`,
-H = the unit's input size): thread 0 of every block stamps the 100 MHz wall clock after each phase."""
+H = the unit's input size): thread 0 of every block stamps the 100 MHz wall clock after each phase.
+-> profiles/rNN_s2_unit_timeline_256clips.txt"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Phase timeline of the decoder LSTM-cell kernel: the stamped build of skinny_kernel inside a chain of dependent launches."""
+"""Phase timeline of the decoder LSTM-cell kernel: the stamped build of skinny_kernel inside a chain of dependent launches.
+-> profiles/rNN_lstm_timeline_x3.txt (X3=2), rNN_lstm_timeline_4wave.txt (X3=1)"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

@@ -1,5 +1,6 @@
 """Front-end conv kernel: the split-bf16 path in both forms (two output frames per block = option frontend_x3 2, default; one frame per block = 1) vs the
-f32 MFMA path (0), time per batch and difference."""
+f32 MFMA path (0), time per batch and difference.
+-> profiles/rNN_frontend_forms.txt"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth

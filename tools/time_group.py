@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """What does advancing G independent B=32 batches per launch chain buy?  `l2s_inference` over B = 32*G rows, one chain at a time and
-NT chains in flight, with the HIP-event per-kernel breakdown of one pass (tools: G env = comma list, NT env = chains in flight)."""
+NT chains in flight, with the HIP-event per-kernel breakdown of one pass (tools: G env = comma list, NT env = chains in flight).
+-> profiles/rNN_group8_breakdown.txt (G=8 NT=2)"""
 import os, sys, time, threading
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch

@@ -1,5 +1,6 @@
 """Decode-step phase times at G batches per chain (rows = 32 G): HIP-event brackets per kernel name over one grouped pass (l2s_profile_*),
-A/B over a run-time option.  Usage: python tools/time_step_phases.py [G] [option=value ...]   (each option is toggled against the default)"""
+A/B over a run-time option.  Usage: python tools/time_step_phases.py [G] [option=value ...]   (each option is toggled against the default)
+-> profiles/rNN_step_phases.txt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

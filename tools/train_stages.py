@@ -1,5 +1,6 @@
 """GPU time of every stage of one training step (forward + backward, B=8, T=29, S=77, train() semantics): CUDA events around each
-native entry point of lip2speech_amd.training.model_forward_backward, averaged over N steps."""
+native entry point of lip2speech_amd.training.model_forward_backward, averaged over N steps.
+-> profiles/rNN_train_stages.txt"""
 import os, sys, collections, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth, training
