@@ -13,7 +13,7 @@ TOOLS = os.path.join(ROOT, "tools")
 RUNS = {
     "attn_timeline.py": ([], {"ROWS": "32"}),
     "flat_timeline.py": ([], {}),
-    "fused_unit_timeline.py": ([], {"B": "8"}),
+    "fused_unit_timeline.py": ([], {"B": "32"}),
     "gemm_x3_timeline.py": (["1024", "512", "512"], {}),
     "hash_encoder.py": ([], {}),
     "hash_inference.py": ([], {}),
