@@ -337,6 +337,8 @@ int l2s_op_attn_timeline(void* ts_dev);
 /* and for the step's first launch (the flat grid of per-group block shapes, at >= 128 rows): 8 stamps per block as for l2s_op_skinny_timeline; the last
    such launch leaves its stamps.  tools/flat_timeline.py */
 int l2s_op_flat_timeline(void* ts_dev);
+/* persistent decode loop (option "persist_decode"): ts_dev = [256 workgroups][16] uint64 stamps of step `step` (100 MHz clock), or NULL to stop */
+int l2s_op_pdecode_timeline(void* ts_dev, int step);
 /* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
    ([12 waves][96 K tiles][8 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block);

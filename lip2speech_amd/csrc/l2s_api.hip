@@ -4,6 +4,7 @@
 #include "../../include/l2s.h"
 #include "l2s_common.h"
 #include "l2s_model.h"
+#include "pdecode.h"
 
 #include <cmath>
 #include <functional>
@@ -30,7 +31,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3}, {"gemm_x3_dma", &Options::gemm_x3_dma},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
-        {"infer_bf16", &Options::infer_bf16}};
+        {"infer_bf16", &Options::infer_bf16}, {"persist_decode", &Options::persist}};
     for (auto& t : table)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
     return 1;
@@ -924,7 +925,7 @@ static int64_t prologue_ws_floats(int B, int T) {
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
-    return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24;
+    return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24 + (B <= 8 ? pdecode_ws_bytes(B) / 4 + 64 : 0);
 }
 static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
 
@@ -1322,6 +1323,26 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
                       float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
     const bool fold = m->opt.fold != 0 && m->folded_valid;
+    if (!teacher && fold && m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1) {      // the latency form: one launch for the whole loop
+        const Weights& w = m->w;
+        StateLayout sl = state_layout(B, T);
+        if (pdecode_supported(B, T, sl.m) && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) {
+            PDecP p{};
+            p.Wq = w.q.W; p.bq = w.q.bias; p.aq = w.q.actw;
+            p.Wcq = w.cq.W; p.bcq = w.cq.bias;
+            p.Wp1f = w.pre1f.W; p.bp1f = w.pre1f.bias; p.ap1 = w.pre1f.actw;
+            p.Wp1 = w.pre1.W; p.bp1 = w.pre1.bias;
+            p.Wp2 = w.pre2.W; p.bp2 = w.pre2.bias; p.ap2 = w.pre2.actw;
+            p.Wl0 = w.lstm0.W; p.bl0 = w.lstm0.bias; p.Wl1 = w.lstm1.W; p.bl1 = w.lstm1.bias;
+            p.Wfc = w.fc.W; p.bfc = w.fc.bias;
+            p.pos = w.pos; p.tau = w.tau; p.tau_c = w.tau_c; p.bos = w.bos;
+            p.k = state + sl.k; p.vp = state + sl.vp; p.ckey = state + sl.ckey; p.cval = state + sl.cval;
+            p.h_init = state + sl.h; p.stop_const = state + sl.stopc;
+            p.mel = mel; p.stop = stop; p.attn = attn; p.attn_logits = attn_logits;
+            p.B = B; p.T = T; p.m = sl.m; p.S = S;
+            return launch_pdecode(p, ws, ws_bytes, s);
+        }
+    }
     const bool use_graph = m->opt.graph && !teacher && !g_prof_on;
     if (!use_graph) return decode_launches(m, state, B, T, S, teacher, teacher_mask, mel, stop, attn, attn_logits, ws, ws_bytes, s, fold);
 
@@ -1917,6 +1938,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_flat_timeline(void* ts_dev) { skinny_set_flat_timeline((unsigned long long*)ts_dev); return 0; }
+int l2s_op_pdecode_timeline(void* ts_dev, int step) { if (step <= -100) pdecode_set_replicas(-step - 100); else pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block) { gemm_x3_set_timeline((unsigned long long*)ts_dev, block); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
 

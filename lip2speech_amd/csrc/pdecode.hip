@@ -1,0 +1,581 @@
+// The latency form of the autoregressive decode loop (reference/model/modules/decoder.py:412-435) for one or two clips (demo.py:60-90 runs batch_size = 1,
+// BASELINE config 1 runs 2): ONE launch for all S steps, weight-stationary.
+//
+// At <= 32 rows the launch-per-phase loop (l2s_api.hip decode_launches) is bound by four dependent launches per step (~20-23 us: boundary, first-operand
+// latency and 21 MB of step weights streamed from the Infinity Cache 300 times).  Here the 5.25 M step weights live in the REGISTERS of 256 resident
+// workgroups (one per CU, 81 VGPRs per thread): workgroup j owns hidden units 2j, 2j+1 of both LSTM layers (8 gate columns each), columns 2j, 2j+1 of Q,
+// column j of content-Q, of prenet1 o fc_out, of prenet2 and (j < 81) of fc_out+stop; thread t owns k = 2t, 2t+1 of every 512-long half of a column.
+// The per-step activations (h, c, q, qc, prenet: 3 072 floats per clip) cross the chip between the phases of a step as 8-byte {value, tag} granules,
+// written with one write-through store each and polled by the threads that consume them - the data is the flag (cdna_hip_programming.md section 6
+// Guideline 16 R2); a thread reads exactly the granules of its own K slice, straight into registers.  Every phase consumes a full vector from all 256
+// producers, so a phase is also a chip-wide barrier and single-buffered granules are safe.  Keys, projected values, content keys / values of the clips
+// sit in every workgroup's registers (keys of two clips: LDS), so attention is computed whole and locally (T <= 32 frames).
+//
+// Measured on MI355X (profiles/r04_persist_edge_probe.txt, r04_pdecode_timeline.txt, r04_latency_path.txt): one all-to-all edge costs 1.4-1.7 us with
+// the exchange buffer replicated per XCD (2.1-2.6 with all 256 workgroups polling one copy), growing linearly beyond 2 048 floats (9.5 us at 16 384): the
+// form pays for one or two clips and is not used above.  Arithmetic: fp32 FMAs over the K slices, DPP / row-swap trees across the 256 threads - another
+// order of the same sums as the launch path (both within 1e-3 of the reference; tests/test_gpu_parity.py::test_persistent_decode_*).
+#include "l2s_common.h"
+#include "l2s_model.h"
+#include "pdecode.h"
+
+#include <mutex>
+
+namespace l2s {
+
+constexpr int PD_WG = 256;                // workgroups = CUs
+constexpr int PD_NT = 256;                // threads per workgroup
+constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 2;
+constexpr int PD_LDS_FLOATS = 21 * 1024;  // 84 KB: more than half of a CU's LDS, so the 256 workgroups sit one per CU (two clips: + their keys, 148 KB)
+// granule arrays, in u64 units per row count NB: [h0 | h1 | c0 | c1 | q: NB x 512 each][qc, p1, o, cc, p2: NB x 256 each]
+__host__ __device__ constexpr int pd_off_h0(int NB) { return 0; }
+__host__ __device__ constexpr int pd_off_h1(int NB) { return NB * 512; }
+__host__ __device__ constexpr int pd_off_c0(int NB) { return 2 * NB * 512; }
+__host__ __device__ constexpr int pd_off_c1(int NB) { return 3 * NB * 512; }
+__host__ __device__ constexpr int pd_off_q(int NB) { return 4 * NB * 512; }
+__host__ __device__ constexpr int pd_off_qc(int NB) { return 5 * NB * 512; }
+__host__ __device__ constexpr int pd_off_p1(int NB) { return pd_off_qc(NB) + NB * 256; }
+__host__ __device__ constexpr int pd_off_o(int NB) { return pd_off_p1(NB) + NB * 256; }
+__host__ __device__ constexpr int pd_off_cc(int NB) { return pd_off_o(NB) + NB * 256; }
+__host__ __device__ constexpr int pd_off_p2(int NB) { return pd_off_cc(NB) + NB * 256; }
+__host__ __device__ constexpr int pd_granules(int NB) { return pd_off_p2(NB) + NB * 256; }
+constexpr int PD_MAXREP = 8;
+__host__ __device__ constexpr int pd_rstride(int NB) { return pd_granules(NB) + 520; }      // replicas 4 KB + 64 B off a power-of-two pitch
+
+#define PD_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+template <int CTRL>
+__device__ __forceinline__ float pd_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// add the other three rows of the wave: v_permlane16_swap / v_permlane32_swap exchange whole rows of 16 lanes (gfx950)
+__device__ __forceinline__ float pd_rows_sum(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const float s1 = __builtin_bit_cast(float, (int)a[0]) + __builtin_bit_cast(float, (int)a[1]);
+    const int y = __builtin_bit_cast(int, s1);
+    auto b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return __builtin_bit_cast(float, (int)b[0]) + __builtin_bit_cast(float, (int)b[1]);
+}
+__device__ __forceinline__ float pd_rows_max(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const float s1 = fmaxf(__builtin_bit_cast(float, (int)a[0]), __builtin_bit_cast(float, (int)a[1]));
+    const int y = __builtin_bit_cast(int, s1);
+    auto b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return fmaxf(__builtin_bit_cast(float, (int)b[0]), __builtin_bit_cast(float, (int)b[1]));
+}
+// sum / max over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ float pd_wave_sum(float v) {
+    v += pd_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += pd_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += pd_dpp<0x124>(v);      // row_ror:4
+    v += pd_dpp<0x128>(v);      // row_ror:8
+    return pd_rows_sum(v);
+}
+__device__ __forceinline__ float pd_wave_max(float v) {
+    v = fmaxf(v, pd_dpp<0xB1>(v)); v = fmaxf(v, pd_dpp<0x4E>(v)); v = fmaxf(v, pd_dpp<0x124>(v)); v = fmaxf(v, pd_dpp<0x128>(v));
+    return pd_rows_max(v);
+}
+// V per-thread values summed over the wave at once (V a multiple of 4): two transposing quad steps (a lane keeps half of its values and hands the other
+// half to its partner), two row rotations, the row exchange - 1.9 V + 6 V / 4 instructions instead of 11 V.  Afterwards lane l holds the wave total of
+// value 4 j + (l & 3) in v[j], j < V / 4.
+template <int V>
+__device__ __forceinline__ void pd_wave_sum_multi(float (&v)[V], int lane) {
+    static_assert(V % 4 == 0, "values in fours");
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+        const float keep = b0 ? v[2 * j + 1] : v[2 * j], send = b0 ? v[2 * j] : v[2 * j + 1];
+        v[j] = keep + pd_dpp<0xB1>(send);
+    }
+#pragma unroll
+    for (int j = 0; j < V / 4; ++j) {
+        const float keep = b1 ? v[2 * j + 1] : v[2 * j], send = b1 ? v[2 * j] : v[2 * j + 1];
+        float x = keep + pd_dpp<0x4E>(send);
+        x += pd_dpp<0x124>(x);
+        x += pd_dpp<0x128>(x);
+        v[j] = pd_rows_sum(x);
+    }
+}
+// the cells' gate non-linearities on the hardware exp2 / rcp (1 ulp each): absolute error < 3e-7 on values in [0, 1] / [-1, 1], a fifth of the
+// instructions of expf / tanhf / an IEEE division (12.2 against 13.0 us per step at one clip; same deviation from the launch path)
+__device__ __forceinline__ float pd_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float pd_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+// one 8-byte write-through store per replica: value and tag land together.  The exchange buffer exists `nrep` times, `rstride` granules apart: every
+// producer writes all replicas, a consumer polls replica (workgroup % nrep) - the 256 pollers of a granule line become 256 / nrep per copy
+__device__ __forceinline__ void pd_publish(u64* g, unsigned tag, float v, int nrep, int rstride) {
+    const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+    for (int r = 0; r < nrep; ++r) __hip_atomic_store(g + (int64_t)r * rstride, x, PD_RLX);
+}
+
+// One poll pass = every load of the phase issued, then every tag compared; repeated (with a short sleep) until the whole WAVE has fresh granules, so the
+// wave stays converged for the DPP reductions that follow.  A pass that keeps failing for ~2 s of wall clock raises status[0] and every workgroup leaves.
+struct PdPoll {
+    unsigned* status; unsigned long long t0; unsigned spins; bool dead;
+    __device__ __forceinline__ PdPoll(unsigned* st) : status(st), t0(0), spins(0), dead(false) {}
+    __device__ __forceinline__ bool retry(bool ok) {      // true: go around again
+        if (__all(ok)) { spins = 0; return false; }
+        if (spins == 0) t0 = wall_clock64();
+        if ((++spins & 255u) == 0) {
+            if (__hip_atomic_load(status, PD_RLX) != 0u) { dead = true; return false; }
+            if (wall_clock64() - t0 > 200000000ull) { __hip_atomic_store(status, 1u, PD_RLX); dead = true; return false; }      // 100 MHz clock: 2 s
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        return true;
+    }
+};
+// two adjacent granules {value, tag} x 2 as ONE 16-byte L1-bypassing load (buffer_load_dwordx4 ... sc1) through the exchange buffer's descriptor
+__device__ __forceinline__ uint4 pd_load16(__amdgpu_buffer_rsrc_t rs, int granule) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, granule * 8, 0, 16));
+}
+__device__ __forceinline__ u64 pd_load8(__amdgpu_buffer_rsrc_t rs, int granule) {
+    return __builtin_bit_cast(u64, __builtin_amdgcn_raw_buffer_load_b64(rs, granule * 8, 0, 16));
+}
+// frag16 address of W[n][k .. k+1] (k even) in a packed [N][K] matrix with NC = K / 16 chunks per 16-row tile
+__device__ __forceinline__ float2 pd_w2(const float* W, int NC, int n, int k) {
+    return *reinterpret_cast<const float2*>(W + ((int64_t)((n >> 4) * NC + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3));
+}
+
+// NB = clips of the launch (1 or 2).
+// A step is four phases, and every phase polls ONLY what the phase before it produced (each vector crosses the chip once per step):
+//   1: h1', c1' (of the previous step) -> the h1 / c1 halves of Q, content-Q; prenet1 o fc_out; W_hh1 h1'; mel frame + stop logit of the previous step
+//   2: wave 3 alone turns prenet1 into prenet2 column j and publishes it at once; q, qc -> while prenet2 crosses the chip - attention and content
+//      attention of EVERY clip, whole, in every workgroup (keys, values, content keys / values of all clips sit in its registers / LDS): o and cc never leave the CU
+//   3: prenet2 (+ the local o = u, local cc) -> W_ih0 [cc | u]; with W_hh0 h0 kept from phase 4 of the previous step: the layer-0 cells of units 2j, 2j+1
+//   4: h0', c0' -> W_ih1 h0'; with W_hh1 h1 kept from phase 1: the layer-1 cells; and for the next step the h0 / c0 halves of Q, content-Q and W_hh0 h0'
+// Only what the NEXT phase waits for is summed across the threads before a phase publishes (4 values per clip in phase 1, the 8 gates in phases 3 / 4); the
+// sums a later phase needs (W_hh products, the mel frame) are reduced after the publish, while the vector is on its way.
+template <int NB>
+__global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
+    constexpr bool KREG = NB == 1;                          // one clip: its keys live in registers; two clips: in LDS (2 x 64 registers more would spill)
+    __shared__ __attribute__((aligned(16))) float sm[KREG ? PD_LDS_FLOATS : PD_LDS_FLOATS + (NB * PD_MAXT - 32) * 512];
+    float* const qs = sm;                                   // [NB][512]          q * tau
+    float* const qcs = qs + NB * 512;                       // [NB][256]          qc * tau_c
+    float* const sc = qcs + NB * 256;                       // [NB][48]           attention logits [0, 32), content logits [32, 48)
+    constexpr int RS = 8 * NB, RD = 12 * NB;                // floats per wave: a phase's critical sums, its deferred sums
+    float* const red = sc + NB * 48;                        // [2][4 waves][RS]   critical sums, ping-pong by phase
+    float* const redB = red + 2 * 4 * RS;                   // [4 waves][RD]      phase 1's deferred sums: fc, W_hh1 h1'
+    float* const redC = redB + 4 * RD;                      // [4 waves][RD]      phase 4's deferred sums: W_hh0 h0', the h0 / c0 parts of q0, q1, qc
+    float* const Ks = redC + 4 * RD;                        // [NB][T][512]       (two clips) the clips' keys
+
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, M = p.m, S = p.S;
+    u64* const X = p.xch;
+    const int NR = p.nrep, RSTR = pd_rstride(NB);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % NR) * RSTR, 0, pd_granules(NB) * 8, 0x00020000);      // this workgroup's replica
+    PdPoll poll(p.status);
+    unsigned long long* const ts = p.ts ? p.ts + (int64_t)j * 16 : nullptr;      // measurement: thread 0 of every workgroup stamps the phases of step p.ts_step
+#define PD_STAMP(i) do { if (ts && s == p.ts_step && tid == 0) ts[i] = wall_clock64(); } while (0)
+
+    // ---------------------------------------------------------------- weights into registers: thread t owns k = 2t, 2t + 1 of every 512-long half
+    float2 wl0i[8], wl0h[8], wl1i[8], wl1h[8], wq0[2], wq1[2], wcq0, wcq1, wp1, wfc;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        wl0i[c] = pd_w2(p.Wl0, 64, 8 * j + c, 2 * tid); wl0h[c] = pd_w2(p.Wl0, 64, 8 * j + c, 512 + 2 * tid);
+        wl1i[c] = pd_w2(p.Wl1, 64, 8 * j + c, 2 * tid); wl1h[c] = pd_w2(p.Wl1, 64, 8 * j + c, 512 + 2 * tid);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { wq0[c] = pd_w2(p.Wq, 64, 2 * j + c, 2 * tid); wq1[c] = pd_w2(p.Wq, 64, 2 * j + c, 512 + 2 * tid); }
+    wcq0 = pd_w2(p.Wcq, 64, j, 2 * tid); wcq1 = pd_w2(p.Wcq, 64, j, 512 + 2 * tid);
+    wp1 = pd_w2(p.Wp1f, 32, j, 2 * tid);
+    wfc = j < 96 ? pd_w2(p.Wfc, 32, j, 2 * tid) : make_float2(0.f, 0.f);
+    // prenet2 column j over k = 4 lane .. 4 lane + 3 (K = 256: one wave covers it; wave 3 does)
+    const float4 wp2 = *reinterpret_cast<const float4*>(p.Wp2 + ((int64_t)((j >> 4) * 16 + (lane >> 2)) * 64 + (lane & 3) * 16 + (j & 15)) * 4);
+    const float tau = p.tau[0], tau_c = p.tau_c[0];
+    // epilogue constants of the threads that finish a phase (tid < 4 NB in phase 1, lanes < NB of wave 3 in phase 2, tid < 2 NB in the cells)
+    const int fb = tid >> 2, fk = tid & 3;                  // phase-1 finisher: row fb, value fk (q0, q1, qc, p1)
+    const float e_b1 = fk < 2 ? p.bq[2 * j + fk] : fk == 2 ? p.bcq[j] : p.bp1f[j];
+    const float e_a1 = fk < 2 ? p.aq[2 * j + fk] : p.ap1[j];
+    const float e_bfc = j < 96 ? p.bfc[j] : 0.f;
+    const float e_b2 = p.bp2[j], e_a2 = p.ap2[j];
+    const int cb = tid >> 1, cu = tid & 1;                  // cell thread: row cb, unit 2j + cu
+    float e_bl0[4], e_bl1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { e_bl0[g] = p.bl0[8 * j + 4 * cu + g]; e_bl1[g] = p.bl1[8 * j + 4 * cu + g]; }
+    float c0 = 0.f, c1 = 0.f;                               // cell states of the cell threads (decoder.py:406: zeros)
+    const float stopc = p.stop_const[tid < NB ? tid : NB - 1];
+
+    // ---------------------------------------------------------------- every clip's keys / values / content keys / content values into registers
+    const int kf = tid >> 3, kp = tid & 7;                  // attention logits: 8 threads per frame, 64 k each (k = 4 kp + 32 i + e)
+    const int cf = tid >> 4, cp = tid & 15;                 // content logits: 16 threads per content frame, 16 k each
+    const bool o_role = tid >= 128;                         // waves 2, 3 form u[2 (tid - 128) ..] = prenet2 + o; waves 0, 1 form cc[2 tid ..]
+    const int xc = o_role ? 2 * (tid - 128) : 2 * tid;      // this thread's pair of columns of o / cc
+    float4 kreg[KREG ? NB : 1][16], ckreg[NB][4];
+    float2 vreg[NB][PD_MAXT];                               // o role: V'[b][f][xc ..]; cc role: cval[b][i][xc ..] (i < PD_MAXM)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if constexpr (KREG) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                kreg[b][i] = kf < T ? *reinterpret_cast<const float4*>(p.k + ((int64_t)b * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int i = tid; i < T * 128; i += PD_NT) *reinterpret_cast<float4*>(Ks + (int64_t)b * T * 512 + 4 * i) = *reinterpret_cast<const float4*>(p.k + (int64_t)b * T * 512 + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ckreg[b][i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)b * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int f = 0; f < PD_MAXT; ++f) {
+            if (o_role) vreg[b][f] = f < T ? *reinterpret_cast<const float2*>(p.vp + ((int64_t)b * T + f) * 256 + xc) : make_float2(0.f, 0.f);
+            else vreg[b][f] = f < M ? *reinterpret_cast<const float2*>(p.cval + ((int64_t)b * M + f) * 256 + xc) : make_float2(0.f, 0.f);
+        }
+    }
+    // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): column j, the same for every row
+    float p1_bos;
+    {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = lane + 64 * r;
+            if (k < 80) a = fmaf(p.Wp1[(((int64_t)((j >> 4) * 5 + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (j & 15)) * 4) + (k & 3)], p.bos[k], a);
+        }
+        p1_bos = sinf(pd_wave_sum(a) + p.bp1[j]) * p.ap1[j];
+    }
+
+    // cross-thread sums: V values per thread -> wave totals (pd_wave_sum_multi: lane l < 4 ends with value 4 i + l in vals[i]) -> dst[wave][..]; after the
+    // block's next barrier PD_SUM4(dst, stride, i) adds the four waves' totals of value i
+    int rpar = 0;
+#define PD_WSUM(vals, V, dst, stride)                                                                             \
+    do {                                                                                                          \
+        pd_wave_sum_multi<(V)>(vals, lane);                                                                       \
+        if (lane < 4) { _Pragma("unroll") for (int _i = 0; _i < (V) / 4; ++_i) (dst)[wave * (stride) + 4 * _i + lane] = (vals)[_i]; } \
+    } while (0)
+#define PD_SUM4(src, stride, i) (((src)[(i)] + (src)[(stride) + (i)]) + ((src)[2 * (stride) + (i)] + (src)[3 * (stride) + (i)]))
+
+    // what phase 4 of "step -1" would have left in redC: W_hh0 h0 and the h0 halves of Q from the prologue's h0 (c0 = 0: nothing for content-Q); h1 / c1 as granules
+    float l0hh[4] = {0.f, 0.f, 0.f, 0.f}, l1hh[4] = {0.f, 0.f, 0.f, 0.f};      // cell threads: W_hh0 h0 / W_hh1 h1 of their four gates
+    {
+        const int64_t hb = (int64_t)((NB + 15) & ~15) * 512;
+        float v[12 * NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float2 h = *reinterpret_cast<const float2*>(p.h_init + frag16_index(b, 2 * tid, 512));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl0h[c].y, h.y, wl0h[c].x * h.x);
+            v[12 * b + 8] = fmaf(wq0[0].y, h.y, wq0[0].x * h.x);
+            v[12 * b + 9] = fmaf(wq0[1].y, h.y, wq0[1].x * h.x);
+            v[12 * b + 10] = 0.f; v[12 * b + 11] = 0.f;
+        }
+        PD_WSUM(v, 12 * NB, redC, RD);
+        if (tid < 2 * NB) {
+            const int unit = 2 * j + cu;
+            pd_publish(X + pd_off_h1(NB) + cb * 512 + unit, 1u, p.h_init[hb + frag16_index(cb, unit, 512)], NR, RSTR);
+            pd_publish(X + pd_off_c1(NB) + cb * 512 + unit, 1u, 0.f, NR, RSTR);
+        }
+        __syncthreads();
+    }
+
+    for (int s = 0; s <= S; ++s) {
+        const unsigned tag_prev = (unsigned)s + 1u, tag_now = (unsigned)s + 2u;
+        PD_STAMP(0);
+        // ------------------------------------------------------------ phase 1
+        {
+            const float posv = (s < S && tid < 4 * NB && fk < 2) ? p.pos[(int64_t)s * 512 + 2 * j + fk] : 0.f;      // requested before the poll, used after it
+            float2 hy[NB], cy[NB];
+            do {
+                bool ok = true;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const uint4 a = pd_load16(rs, pd_off_h1(NB) + b * 512 + 2 * tid), c = pd_load16(rs, pd_off_c1(NB) + b * 512 + 2 * tid);
+                    ok &= a.y == tag_prev && a.w == tag_prev && c.y == tag_prev && c.w == tag_prev;
+                    hy[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                    cy[b] = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
+                }
+                if (!poll.retry(ok)) break;
+            } while (true);
+            if (poll.dead) return;
+            PD_STAMP(1);
+            if (s < S) {
+                float v[4 * NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    v[4 * b + 0] = fmaf(wq1[0].y, hy[b].y, wq1[0].x * hy[b].x);
+                    v[4 * b + 1] = fmaf(wq1[1].y, hy[b].y, wq1[1].x * hy[b].x);
+                    v[4 * b + 2] = fmaf(wcq1.y, cy[b].y, wcq1.x * cy[b].x);
+                    v[4 * b + 3] = fmaf(wp1.y, hy[b].y, wp1.x * hy[b].x);
+                }
+                PD_WSUM(v, 4 * NB, red + rpar * 4 * RS, RS);
+                __syncthreads();
+                PD_STAMP(2);
+                if (tid < 4 * NB) {                          // q0, q1, qc, p1 of row fb: one sinf and one expf for the four lanes, then a select
+                    const float qh = fk < 3 ? PD_SUM4(redC, RD, 12 * fb + 8 + fk) : 0.f;      // the h0 / c0 part, from phase 4 of the previous step
+                    const float x = PD_SUM4(red + rpar * 4 * RS, RS, 4 * fb + fk) + qh + e_b1;
+                    const float sx = sinf(x) * e_a1, ex = x / (1.0f + expf(-x));
+                    const float val = fk < 2 ? sx + posv : fk == 2 ? ex : (s == 0 ? p1_bos : sx);
+                    const int g = fk < 2 ? pd_off_q(NB) + fb * 512 + 2 * j + fk : fk == 2 ? pd_off_qc(NB) + fb * 256 + j : pd_off_p1(NB) + fb * 256 + j;
+                    pd_publish(X + g, tag_now, val, NR, RSTR);
+                }
+                rpar ^= 1;
+            }
+            PD_STAMP(3);
+            {   // deferred: the mel frame / stop logit of step s - 1, W_hh1 h1' for phase 4
+                float v[12 * NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl1h[c].y, hy[b].y, wl1h[c].x * hy[b].x);
+                    v[12 * b + 8] = fmaf(wfc.y, hy[b].y, wfc.x * hy[b].x);
+                    v[12 * b + 9] = 0.f; v[12 * b + 10] = 0.f; v[12 * b + 11] = 0.f;
+                }
+                PD_WSUM(v, 12 * NB, redB, RD);
+            }
+        }
+        if (s == S) {                                        // the last mel frame
+            __syncthreads();
+            if (tid < NB && j <= 80) {
+                const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
+                if (j < 80) p.mel[((int64_t)tid * S + (S - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (S - 1)] = x + stopc;
+            }
+            break;
+        }
+        // ------------------------------------------------------------ phase 2
+        float2 xin[NB];                                      // this thread's pair of layer-0 inputs: cc (waves 0, 1) or o (waves 2, 3; prenet2 is added in phase 3)
+        {
+            float2 qv[NB]; float qcv[NB];
+            float4 pv[NB];
+            do {
+                bool ok = true;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const uint4 a = pd_load16(rs, pd_off_q(NB) + b * 512 + 2 * tid);
+                    const u64 c = pd_load8(rs, pd_off_qc(NB) + b * 256 + tid);
+                    ok &= a.y == tag_now && a.w == tag_now && (unsigned)(c >> 32) == tag_now;
+                    qv[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                    qcv[b] = __uint_as_float((unsigned)c);
+                    if (wave == 3) {                         // prenet1 of row b, k = 4 lane .. 4 lane + 3
+                        const uint4 x0 = pd_load16(rs, pd_off_p1(NB) + b * 256 + 4 * lane), x1 = pd_load16(rs, pd_off_p1(NB) + b * 256 + 4 * lane + 2);
+                        ok &= x0.y == tag_now && x0.w == tag_now && x1.y == tag_now && x1.w == tag_now;
+                        pv[b] = make_float4(__uint_as_float(x0.x), __uint_as_float(x0.z), __uint_as_float(x1.x), __uint_as_float(x1.z));
+                    }
+                }
+                if (!poll.retry(ok)) break;
+            } while (true);
+            if (poll.dead) return;
+            PD_STAMP(4);
+            if (wave == 3) {                                 // prenet2 column j: this wave's own sum, out at once
+                float mine = 0.f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float t2 = pd_wave_sum(fmaf(wp2.w, pv[b].w, fmaf(wp2.z, pv[b].z, fmaf(wp2.y, pv[b].y, wp2.x * pv[b].x))));
+                    if (lane == b) mine = t2;
+                }
+                if (lane < NB) pd_publish(X + pd_off_p2(NB) + lane * 256 + j, tag_now, sinf(mine + e_b2) * e_a2, NR, RSTR);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                *reinterpret_cast<float2*>(qs + b * 512 + 2 * tid) = make_float2(qv[b].x * tau, qv[b].y * tau);
+                qcs[b * 256 + tid] = qcv[b] * tau_c;
+            }
+            __syncthreads();                                 // qs / qcs visible to the block (and phase 1's deferred sums in redB)
+            if (s > 0 && tid < NB && j <= 80) {              // mel frame / stop logit of step s - 1 (decoder.py:423-428)
+                const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
+                if (j < 80) p.mel[((int64_t)tid * S + (s - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (s - 1)] = x + stopc;
+            }
+            if (tid < 2 * NB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l1hh[g] = PD_SUM4(redB, RD, 12 * cb + 4 * cu + g);
+            }
+            PD_STAMP(5);
+            // logits: 8 threads per frame (keys in registers, q from LDS: the 8 frames of a wave read the same addresses), 16 threads per content frame
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const float* qr = qs + b * 512 + 4 * kp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qr + 32 * i);
+                    float4 kk;
+                    if constexpr (KREG) kk = kreg[b][i];
+                    else kk = kf < T ? *reinterpret_cast<const float4*>(Ks + ((int64_t)b * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    a0 = fmaf(qq.x, kk.x, a0); a1 = fmaf(qq.y, kk.y, a1); a2 = fmaf(qq.z, kk.z, a2); a3 = fmaf(qq.w, kk.w, a3);
+                }
+                float a = (a0 + a1) + (a2 + a3);
+                a += pd_dpp<0xB1>(a); a += pd_dpp<0x4E>(a); a += pd_dpp<0x141>(a);      // the 8 lanes of a frame (row_half_mirror)
+                if (kp == 0 && kf < T) sc[b * 48 + kf] = a;
+                float c0a = 0.f, c1a = 0.f, c2a = 0.f, c3a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qcs + b * 256 + 4 * (cp + 16 * i));
+                    c0a = fmaf(qq.x, ckreg[b][i].x, c0a); c1a = fmaf(qq.y, ckreg[b][i].y, c1a); c2a = fmaf(qq.z, ckreg[b][i].z, c2a); c3a = fmaf(qq.w, ckreg[b][i].w, c3a);
+                }
+                float ca = (c0a + c1a) + (c2a + c3a);
+                ca += pd_dpp<0xB1>(ca); ca += pd_dpp<0x4E>(ca); ca += pd_dpp<0x124>(ca); ca += pd_dpp<0x128>(ca);      // the 16 lanes of a content frame
+                if (cp == 0 && cf < M) sc[b * 48 + 32 + cf] = ca;
+            }
+            __syncthreads();
+            PD_STAMP(6);
+            // every wave: softmax of its role's logits (lane = frame), then its threads' two columns of a @ V' / alpha @ value (decoder.py:414-419, 262-271)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int n = o_role ? T : M;
+                const bool on = lane < n;
+                const float x = on ? sc[b * 48 + (o_role ? 0 : 32) + lane] : -INFINITY;
+                const float mx = pd_wave_max(x);
+                const float ex = on ? expf(x - mx) : 0.f;
+                const float aw = ex * __frcp_rn(pd_wave_sum(ex));
+                if (wave == 2 && j == b && on && p.attn) p.attn[((int64_t)b * S + s) * T + lane] = p.attn_logits ? x : aw;
+                float ox = 0.f, oy = 0.f, ox2 = 0.f, oy2 = 0.f;
+                const int awi = __builtin_bit_cast(int, aw);
+#pragma unroll
+                for (int f = 0; f < PD_MAXT; f += 2) {
+                    if (f < n) {
+                        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f));
+                        ox = fmaf(w, vreg[b][f].x, ox); oy = fmaf(w, vreg[b][f].y, oy);
+                    }
+                    if (f + 1 < n) {
+                        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f + 1));
+                        ox2 = fmaf(w, vreg[b][f + 1].x, ox2); oy2 = fmaf(w, vreg[b][f + 1].y, oy2);
+                    }
+                }
+                xin[b] = make_float2(ox + ox2, oy + oy2);
+            }
+            PD_STAMP(7);
+        }
+        // ------------------------------------------------------------ phase 3: layer-0 cells
+        {
+            if (o_role) {                                    // u = prenet + o (decoder.py:421): waves 2, 3 wait for prenet2
+                do {
+                    bool ok = true;
+                    float2 pp[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const uint4 a = pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
+                        ok &= a.y == tag_now && a.w == tag_now;
+                        pp[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                    }
+                    if (poll.retry(ok)) continue;            // stale: go around again
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { xin[b].x += pp[b].x; xin[b].y += pp[b].y; }
+                    break;
+                } while (true);
+            }
+            if (poll.dead) return;
+            PD_STAMP(8);
+            float v[8 * NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl0i[c].y, xin[b].y, wl0i[c].x * xin[b].x);
+            PD_WSUM(v, 8 * NB, red + rpar * 4 * RS, RS);
+            __syncthreads();
+            PD_STAMP(9);
+            if (tid < 2 * NB) {
+                const float* r = red + rpar * 4 * RS;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l0hh[g] = PD_SUM4(redC, RD, 12 * cb + 4 * cu + g);      // W_hh0 h0 from phase 4 of the previous step
+                const float gi = PD_SUM4(r, RS, 8 * cb + 4 * cu + 0) + l0hh[0] + e_bl0[0], gf = PD_SUM4(r, RS, 8 * cb + 4 * cu + 1) + l0hh[1] + e_bl0[1];
+                const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l0hh[2] + e_bl0[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l0hh[3] + e_bl0[3];
+                c0 = pd_sigmoid(gf) * c0 + pd_sigmoid(gi) * pd_tanh(gg);
+                const float hn = pd_sigmoid(go) * pd_tanh(c0);
+                pd_publish(X + pd_off_h0(NB) + cb * 512 + 2 * j + cu, tag_now, hn, NR, RSTR);
+                pd_publish(X + pd_off_c0(NB) + cb * 512 + 2 * j + cu, tag_now, c0, NR, RSTR);
+            }
+            rpar ^= 1;
+            PD_STAMP(10);
+        }
+        // ------------------------------------------------------------ phase 4: layer-1 cells; the h0 / c0 parts of the next step
+        {
+            float2 hx[NB], cx[NB];
+            do {
+                bool ok = true;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const uint4 a = pd_load16(rs, pd_off_h0(NB) + b * 512 + 2 * tid), c = pd_load16(rs, pd_off_c0(NB) + b * 512 + 2 * tid);
+                    ok &= a.y == tag_now && a.w == tag_now && c.y == tag_now && c.w == tag_now;
+                    hx[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                    cx[b] = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
+                }
+                if (!poll.retry(ok)) break;
+            } while (true);
+            if (poll.dead) return;
+            PD_STAMP(11);
+            float v[8 * NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl1i[c].y, hx[b].y, wl1i[c].x * hx[b].x);
+            PD_WSUM(v, 8 * NB, red + rpar * 4 * RS, RS);
+            __syncthreads();
+            PD_STAMP(12);
+            if (tid < 2 * NB) {
+                const float* r = red + rpar * 4 * RS;
+                const float gi = PD_SUM4(r, RS, 8 * cb + 4 * cu + 0) + l1hh[0] + e_bl1[0], gf = PD_SUM4(r, RS, 8 * cb + 4 * cu + 1) + l1hh[1] + e_bl1[1];
+                const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l1hh[2] + e_bl1[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l1hh[3] + e_bl1[3];
+                c1 = pd_sigmoid(gf) * c1 + pd_sigmoid(gi) * pd_tanh(gg);
+                const float hn = pd_sigmoid(go) * pd_tanh(c1);
+                pd_publish(X + pd_off_h1(NB) + cb * 512 + 2 * j + cu, tag_now, hn, NR, RSTR);
+                pd_publish(X + pd_off_c1(NB) + cb * 512 + 2 * j + cu, tag_now, c1, NR, RSTR);
+            }
+            rpar ^= 1;
+            PD_STAMP(13);
+            {   // deferred, for the next step: W_hh0 h0' (phase 3) and the h0 / c0 parts of q0, q1, qc (phase 1)
+                float w[12 * NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[12 * b + c] = fmaf(wl0h[c].y, hx[b].y, wl0h[c].x * hx[b].x);
+                    w[12 * b + 8] = fmaf(wq0[0].y, hx[b].y, wq0[0].x * hx[b].x);
+                    w[12 * b + 9] = fmaf(wq0[1].y, hx[b].y, wq0[1].x * hx[b].x);
+                    w[12 * b + 10] = fmaf(wcq0.y, cx[b].y, wcq0.x * cx[b].x);
+                    w[12 * b + 11] = 0.f;
+                }
+                PD_WSUM(w, 12 * NB, redC, RD);
+            }
+        }
+    }
+#undef PD_WSUM
+#undef PD_SUM4
+#undef PD_STAMP
+}
+
+int64_t pdecode_ws_bytes(int B) {
+    int nb = 1; while (nb < B) nb *= 2;
+    return (int64_t)pd_rstride(nb) * 8 * PD_MAXREP + 256;
+}
+bool pdecode_supported(int B, int T, int m) { return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM; }
+
+// every persistent launch needs all 256 workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
+// wait for the other half for ever, so they are chained through one event (a launch waits for the previous persistent launch of the process)
+static std::mutex g_pd_mu;
+static hipEvent_t g_pd_ev = nullptr;
+static int g_pd_cus = -1;
+static unsigned long long* g_pd_ts = nullptr;
+static int g_pd_ts_step = 0;
+static int g_pd_nrep = 8;
+void pdecode_set_replicas(int n) { g_pd_nrep = n < 1 ? 1 : n > PD_MAXREP ? PD_MAXREP : n; }
+void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
+
+int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
+    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames");
+    L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(p.B), "persistent decode: exchange buffer too small");
+    int nb = 1; while (nb < p.B) nb *= 2;
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    if (g_pd_cus < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        L2S_CHECK_HIP(hipGetDevice(&dev));
+        L2S_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_pd_cus = prop.multiProcessorCount;
+        L2S_CHECK_HIP(hipEventCreateWithFlags(&g_pd_ev, hipEventDisableTiming));
+        L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    }
+    L2S_REQUIRE(g_pd_cus >= PD_WG, "persistent decode needs 256 compute units (one resident workgroup each)");
+    PDecP q = p;
+    q.xch = reinterpret_cast<u64*>(ws);
+    q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pd_rstride(nb) * 8 * PD_MAXREP);
+    q.nrep = g_pd_nrep;
+    q.ts = g_pd_ts; q.ts_step = g_pd_ts_step;
+    L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(p.B), s));      // tags and the status word start at zero EVERY call
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
+    ProfScope ps("decode_persistent", s);
+    if (nb == 1) hipLaunchKernelGGL(pdecode_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    else hipLaunchKernelGGL(pdecode_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    L2S_CHECK_HIP(hipGetLastError());
+    L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    return 0;
+}
+
+}  // namespace l2s

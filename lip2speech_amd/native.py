@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_inverse_mel_workspace_bytes", "l2s_inverse_mel", "l2s_griffin_lim_workspace_bytes", "l2s_griffin_lim", "l2s_estoi_workspace_bytes", "l2s_estoi",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain",
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_pdecode_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
@@ -97,6 +97,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_op_skinny_timeline.argtypes = [_vp]
     L.l2s_op_attn_timeline.argtypes = [_vp]
     L.l2s_op_flat_timeline.argtypes = [_vp]
+    L.l2s_op_pdecode_timeline.argtypes = [_vp, ctypes.c_int]
     L.l2s_op_gemm_x3_timeline.argtypes = [_vp, ctypes.c_int]
     L.l2s_op_fused_unit_timeline.argtypes = [_vp, _i]
     L.l2s_op_launch_chain2.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp, _vp]

@@ -876,3 +876,55 @@ def test_stop_bookkeeping_matches_reference_golden(synth_sd):
     # the stop logits themselves (staged calls return them; forward_eval runs the same step with teacher = none for S = 300)
     out = own.forward_eval(args[0], args[1], args[2], 300)
     assert pc.maxdiff(out[2].reshape(32, 300), g["stop_logits"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_persistent_decode_matches_reference_golden(synth_sd, nm):
+    """Option "persist_decode" (pdecode.hip: the whole free-running loop as ONE weight-stationary launch for one or two clips; demo.py:60-90 runs one clip,
+    BASELINE config 1 two) against the REFERENCE's B=2 golden - mel, lengths, attention argmax, and the full (2,300,29) attention tensor of the
+    stop-layer golden with its non-trivial output lengths - and against the launch path (another order of the same fp32 sums)."""
+    import parity_common as pc
+    g, video, emb = pc.lrw2_inputs()
+    own = pc.fresh_native_model(synth_sd, persist_decode=8)
+    args = (video.cuda(), emb.cuda(), g["gumbel"].cuda())
+    for _ in range(2):                                     # twice: the exchange buffer is re-zeroed per call
+        mel_post, lengths, attn = own.inference(*args, S=300, want_attn=True)
+    assert torch.isfinite(mel_post).all()
+    assert pc.maxdiff(mel_post, g["mel_post"]) < MEL_TOL
+    assert torch.equal(lengths.cpu(), g["output_lengths"])
+    amax, _ = pc.top2(attn.cpu())
+    sure = g["attn_margin"] > 1e-4
+    assert torch.equal(amax[sure], g["attn_argmax"][sure])
+    ref = nm.inference(*args, S=300, want_attn=True)
+    assert pc.maxdiff(mel_post, ref[0]) < 5e-4 and pc.maxdiff(attn, ref[2]) < 5e-4
+    # the staged entry point takes the same route (l2s_decode_steps): stop logits and the pre-post-net mel
+    gs = pc.golden("stop_lrw_b2.npz")
+    sd = dict(synth_sd)
+    sd["decoder.stop_token_layer.linear_layer.weight"] = gs["stop_weight"]
+    sd["decoder.stop_token_layer.linear_layer.bias"] = gs["stop_bias"]
+    own2 = pc.fresh_native_model(sd, persist_decode=8)
+    sargs = (synth.synth_video(2, 29, tag="video-lrw2").cuda(), synth.synth_speaker_embedding(2, tag="spk-lrw2").cuda(), gs["gumbel"].cuda())
+    mel_post, lengths, attn = own2.inference(*sargs, S=300, want_attn=True)
+    assert torch.equal(lengths.cpu(), gs["output_lengths"]) and pc.maxdiff(attn, gs["attn"]) < MEL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,HW,S", [(1, 29, 96, 300), (2, 13, 88, 25), (2, 32, 88, 12), (1, 7, 96, 1), (2, 8, 96, 9), (1, 32, 96, 5)])
+def test_persistent_decode_shapes_against_launch_path(synth_sd, nm, B, T, HW, S):
+    """One and two clips, T up to the 32 frames whose keys / values a workgroup holds, S = 1: the persistent loop against the launch-per-phase loop on
+    the same inputs (another order of the same fp32 sums); calls outside its limits (3 clips, 33 frames) take the launch path: same bits."""
+    import parity_common as pc
+    own = pc.fresh_native_model(synth_sd, persist_decode=8)
+    video = synth.synth_video(B, T, H=HW, W=HW, tag=f"pd{B}").cuda()
+    emb = synth.synth_speaker_embedding(B, tag=f"pd{B}").cuda()
+    gum = synth.synth_gumbel(B * native.min_T(T), tag=f"pd{B}").cuda()
+    a = own.inference(video, emb, gum, S=S, want_attn=True)
+    b = nm.inference(video, emb, gum, S=S, want_attn=True)
+    assert torch.isfinite(a[0]).all()
+    assert not torch.equal(a[0], b[0])                     # (it did take the other route)
+    assert pc.maxdiff(a[0], b[0]) < 5e-4 and torch.equal(a[1], b[1]) and pc.maxdiff(a[2], b[2]) < 5e-4
+    if B == 1 and S == 300:
+        v3 = synth.synth_video(3, 8, tag="pd3").cuda(); e3 = synth.synth_speaker_embedding(3, tag="pd3").cuda(); g3 = synth.synth_gumbel(3 * native.min_T(8), tag="pd3").cuda()
+        assert torch.equal(own.inference(v3, e3, g3, S=5)[0], nm.inference(v3, e3, g3, S=5)[0])          # > 2 clips: the launch path, same bits
+        v33 = synth.synth_video(2, 33, tag="pd33").cuda(); e33 = synth.synth_speaker_embedding(2, tag="pd33").cuda(); g33 = synth.synth_gumbel(2 * native.min_T(33), tag="pd33").cuda()
+        assert torch.equal(own.inference(v33, e33, g33, S=5)[0], nm.inference(v33, e33, g33, S=5)[0])    # > 32 frames: the launch path

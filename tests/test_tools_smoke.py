@@ -19,6 +19,7 @@ RUNS = {
     "hash_inference.py": ([], {}),
     "hash_train_step.py": ([], {}),
     "kernel_resources.py": ([os.path.join(ROOT, "lip2speech_amd", "csrc", "decoder_kernels.hip")], {}),
+    "pdecode_timeline.py": ([], {"B": "2", "S": "20"}),
     "pmc_dense.py": ([], {"ROWS": "32"}),
     "prof_decode.py": ([], {"ROWS": "32", "REPS": "1"}),
     "prof_train.py": ([], {}),
@@ -27,6 +28,7 @@ RUNS = {
     "time_evaluate_net.py": ([], {"N": "2", "ITERS": "4"}),
     "time_frontend.py": ([], {}),
     "time_group.py": ([], {"G": "1", "NT": "1"}),
+    "time_latency.py": ([], {"ROWS": "2", "REPS": "1", "S": "20"}),
     "time_step_phases.py": (["1"], {}),
     "time_vocoder.py": ([], {"N": "8", "ITERS": "4"}),
     "train_stages.py": ([], {}),
