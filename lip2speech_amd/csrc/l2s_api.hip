@@ -1938,7 +1938,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_flat_timeline(void* ts_dev) { skinny_set_flat_timeline((unsigned long long*)ts_dev); return 0; }
-int l2s_op_pdecode_timeline(void* ts_dev, int step) { if (step <= -100) pdecode_set_replicas(-step - 100); else pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }
+int l2s_op_pdecode_timeline(void* ts_dev, int step) { pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block) { gemm_x3_set_timeline((unsigned long long*)ts_dev, block); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
 

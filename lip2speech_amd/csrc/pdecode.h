@@ -23,14 +23,13 @@ struct PDecP {
     float *mel, *stop, *attn;             // [B][S][80], [B][S], [B][S][T] or null
     u64* xch;                             // exchange granules (zeroed before the launch)
     unsigned* status;                     // [0]: set to 1 by a workgroup whose poll timed out (every workgroup then leaves)
-    int attn_logits, B, T, m, S, nrep;
+    int attn_logits, B, T, m, S;
     unsigned long long* ts; int ts_step;  // measurement (tools/pdecode_timeline.py): [256 workgroups][16] stamps of step ts_step, or null
 };
 
 int64_t pdecode_ws_bytes(int B);                       // exchange granules + status word
 bool pdecode_supported(int B, int T, int m);            // <= 8 clips of <= 32 frames
 void pdecode_set_timeline(unsigned long long* ts, int step);      // non-null: thread 0 of every workgroup stamps the phases of that step
-void pdecode_set_replicas(int n);                       // 1..8 copies of the exchange buffer (experiments; default 8)
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s);      // xch / status are carved from ws
 
 }  // namespace l2s

@@ -103,11 +103,15 @@ __device__ __forceinline__ void pd_wave_sum_multi(float (&v)[V], int lane) {
 __device__ __forceinline__ float pd_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float pd_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
-// one 8-byte write-through store per replica: value and tag land together.  The exchange buffer exists `nrep` times, `rstride` granules apart: every
-// producer writes all replicas, a consumer polls replica (workgroup % nrep) - the 256 pollers of a granule line become 256 / nrep per copy
-__device__ __forceinline__ void pd_publish(u64* g, unsigned tag, float v, int nrep, int rstride) {
-    const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
-    for (int r = 0; r < nrep; ++r) __hip_atomic_store(g + (int64_t)r * rstride, x, PD_RLX);
+// one 8-byte write-through store per replica: value and tag land together.  The exchange buffer exists PD_MAXREP times, pd_rstride granules apart:
+// every producer writes all replicas (the replica as the buffer instruction's scalar offset), a consumer polls replica (workgroup % 8) - its XCD's own
+// copy, so the 256 pollers of a granule line become 32 per copy (one copy: 16.7 us per step at one clip, two: 14.4, four: 13.2, eight: 13.1)
+typedef unsigned pd_u2 __attribute__((ext_vector_type(2)));
+template <int NB>
+__device__ __forceinline__ void pd_publish(__amdgpu_buffer_rsrc_t rsall, int granule, unsigned tag, float v) {
+    pd_u2 x; x.x = __float_as_uint(v); x.y = tag;
+#pragma unroll
+    for (int r = 0; r < PD_MAXREP; ++r) __builtin_amdgcn_raw_buffer_store_b64(x, rsall, granule * 8, r * pd_rstride(NB) * 8, 16);
 }
 
 // One poll pass = every load of the phase issued, then every tag compared; repeated (with a short sleep) until the whole WAVE has fresh granules, so the
@@ -160,13 +164,15 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     float* const redB = red + 2 * 4 * RS;                   // [4 waves][RD]      phase 1's deferred sums: fc, W_hh1 h1'
     float* const redC = redB + 4 * RD;                      // [4 waves][RD]      phase 4's deferred sums: W_hh0 h0', the h0 / c0 parts of q0, q1, qc
     float* const Ks = redC + 4 * RD;                        // [NB][T][512]       (two clips) the clips' keys
+    float* const vs = redC + 4 * RD;                        // [32][256] + [16][256]  (one clip) its projected values V' and content values, rows past T / m zero
+    float* const aws = vs + (PD_MAXT + PD_MAXM) * 256;      // [4 waves][32]      (one clip) each wave's softmax weights, for broadcast reads
 
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, M = p.m, S = p.S;
     u64* const X = p.xch;
-    const int NR = p.nrep, RSTR = pd_rstride(NB);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % NR) * RSTR, 0, pd_granules(NB) * 8, 0x00020000);      // this workgroup's replica
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % PD_MAXREP) * pd_rstride(NB), 0, pd_granules(NB) * 8, 0x00020000);      // this workgroup's replica
+    const __amdgpu_buffer_rsrc_t rsall = __builtin_amdgcn_make_buffer_rsrc(X, 0, PD_MAXREP * pd_rstride(NB) * 8, 0x00020000);
     PdPoll poll(p.status);
     unsigned long long* const ts = p.ts ? p.ts + (int64_t)j * 16 : nullptr;      // measurement: thread 0 of every workgroup stamps the phases of step p.ts_step
 #define PD_STAMP(i) do { if (ts && s == p.ts_step && tid == 0) ts[i] = wall_clock64(); } while (0)
@@ -202,10 +208,11 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     // ---------------------------------------------------------------- every clip's keys / values / content keys / content values into registers
     const int kf = tid >> 3, kp = tid & 7;                  // attention logits: 8 threads per frame, 64 k each (k = 4 kp + 32 i + e)
     const int cf = tid >> 4, cp = tid & 15;                 // content logits: 16 threads per content frame, 16 k each
-    const bool o_role = tid >= 128;                         // waves 2, 3 form u[2 (tid - 128) ..] = prenet2 + o; waves 0, 1 form cc[2 tid ..]
+    const bool o_role = wave >= 2;                          // waves 2, 3 form u[2 (tid - 128) ..] = prenet2 + o; waves 0, 1 form cc[2 tid ..] (wave-uniform: a scalar)
     const int xc = o_role ? 2 * (tid - 128) : 2 * tid;      // this thread's pair of columns of o / cc
     float4 kreg[KREG ? NB : 1][16], ckreg[NB][4];
-    float2 vreg[NB][PD_MAXT];                               // o role: V'[b][f][xc ..]; cc role: cval[b][i][xc ..] (i < PD_MAXM)
+    float2 vreg[KREG ? 1 : NB][KREG ? 1 : PD_MAXT];         // (two clips) o role: V'[b][f][xc ..]; cc role: cval[b][i][xc ..] (i < PD_MAXM)
+    const float* const vrow = vs + (o_role ? 0 : PD_MAXT * 256) + xc;      // (one clip) this thread's pair of columns in LDS, row pitch 256
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if constexpr (KREG) {
@@ -218,10 +225,15 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             ckreg[b][i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)b * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (KREG) {
+            for (int i = tid; i < PD_MAXT * 64; i += PD_NT) *reinterpret_cast<float4*>(vs + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = tid; i < PD_MAXM * 64; i += PD_NT) *reinterpret_cast<float4*>(vs + PD_MAXT * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
 #pragma unroll
-        for (int f = 0; f < PD_MAXT; ++f) {
-            if (o_role) vreg[b][f] = f < T ? *reinterpret_cast<const float2*>(p.vp + ((int64_t)b * T + f) * 256 + xc) : make_float2(0.f, 0.f);
-            else vreg[b][f] = f < M ? *reinterpret_cast<const float2*>(p.cval + ((int64_t)b * M + f) * 256 + xc) : make_float2(0.f, 0.f);
+            for (int f = 0; f < PD_MAXT; ++f) {
+                if (o_role) vreg[b][f] = f < T ? *reinterpret_cast<const float2*>(p.vp + ((int64_t)b * T + f) * 256 + xc) : make_float2(0.f, 0.f);
+                else vreg[b][f] = f < M ? *reinterpret_cast<const float2*>(p.cval + ((int64_t)b * M + f) * 256 + xc) : make_float2(0.f, 0.f);
+            }
         }
     }
     // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): column j, the same for every row
@@ -263,8 +275,8 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
         PD_WSUM(v, 12 * NB, redC, RD);
         if (tid < 2 * NB) {
             const int unit = 2 * j + cu;
-            pd_publish(X + pd_off_h1(NB) + cb * 512 + unit, 1u, p.h_init[hb + frag16_index(cb, unit, 512)], NR, RSTR);
-            pd_publish(X + pd_off_c1(NB) + cb * 512 + unit, 1u, 0.f, NR, RSTR);
+            pd_publish<NB>(rsall, pd_off_h1(NB) + cb * 512 + unit, 1u, p.h_init[hb + frag16_index(cb, unit, 512)]);
+            pd_publish<NB>(rsall, pd_off_c1(NB) + cb * 512 + unit, 1u, 0.f);
         }
         __syncthreads();
     }
@@ -307,11 +319,15 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                     const float sx = sinf(x) * e_a1, ex = x / (1.0f + expf(-x));
                     const float val = fk < 2 ? sx + posv : fk == 2 ? ex : (s == 0 ? p1_bos : sx);
                     const int g = fk < 2 ? pd_off_q(NB) + fb * 512 + 2 * j + fk : fk == 2 ? pd_off_qc(NB) + fb * 256 + j : pd_off_p1(NB) + fb * 256 + j;
-                    pd_publish(X + g, tag_now, val, NR, RSTR);
+                    pd_publish<NB>(rsall, g, tag_now, val);
                 }
                 rpar ^= 1;
             }
             PD_STAMP(3);
+            if (s < S && tid < 2 * NB) {                     // W_hh0 h0 from phase 4 of the previous step, for phase 3 (redC is valid since this phase's barrier)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l0hh[g] = PD_SUM4(redC, RD, 12 * cb + 4 * cu + g);
+            }
             {   // deferred: the mel frame / stop logit of step s - 1, W_hh1 h1' for phase 4
                 float v[12 * NB];
 #pragma unroll
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                     const float t2 = pd_wave_sum(fmaf(wp2.w, pv[b].w, fmaf(wp2.z, pv[b].z, fmaf(wp2.y, pv[b].y, wp2.x * pv[b].x))));
                     if (lane == b) mine = t2;
                 }
-                if (lane < NB) pd_publish(X + pd_off_p2(NB) + lane * 256 + j, tag_now, sinf(mine + e_b2) * e_a2, NR, RSTR);
+                if (lane < NB) pd_publish<NB>(rsall, pd_off_p2(NB) + lane * 256 + j, tag_now, __sinf(mine + e_b2) * e_a2);
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -371,14 +387,6 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 qcs[b * 256 + tid] = qcv[b] * tau_c;
             }
             __syncthreads();                                 // qs / qcs visible to the block (and phase 1's deferred sums in redB)
-            if (s > 0 && tid < NB && j <= 80) {              // mel frame / stop logit of step s - 1 (decoder.py:423-428)
-                const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
-                if (j < 80) p.mel[((int64_t)tid * S + (s - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (s - 1)] = x + stopc;
-            }
-            if (tid < 2 * NB) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) l1hh[g] = PD_SUM4(redB, RD, 12 * cb + 4 * cu + g);
-            }
             PD_STAMP(5);
             // logits: 8 threads per frame (keys in registers, q from LDS: the 8 frames of a wave read the same addresses), 16 threads per content frame
 #pragma unroll
@@ -419,16 +427,31 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 const float aw = ex * __frcp_rn(pd_wave_sum(ex));
                 if (wave == 2 && j == b && on && p.attn) p.attn[((int64_t)b * S + s) * T + lane] = p.attn_logits ? x : aw;
                 float ox = 0.f, oy = 0.f, ox2 = 0.f, oy2 = 0.f;
-                const int awi = __builtin_bit_cast(int, aw);
-#pragma unroll
-                for (int f = 0; f < PD_MAXT; f += 2) {
-                    if (f < n) {
-                        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f));
-                        ox = fmaf(w, vreg[b][f].x, ox); oy = fmaf(w, vreg[b][f].y, oy);
+                if constexpr (KREG) {
+                    // the wave's weights through LDS (lanes past n hold 0, value rows past T / m are 0): four frames per trip, no per-frame predicate
+                    if (lane < 32) aws[wave * 32 + lane] = aw;
+                    __builtin_amdgcn_wave_barrier();
+                    const int n4 = (n + 3) & ~3;
+#pragma unroll 2
+                    for (int f = 0; f < n4; f += 4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(aws + wave * 32 + f);
+                        const float2 v0 = *reinterpret_cast<const float2*>(vrow + f * 256), v1 = *reinterpret_cast<const float2*>(vrow + (f + 1) * 256);
+                        const float2 v2 = *reinterpret_cast<const float2*>(vrow + (f + 2) * 256), v3 = *reinterpret_cast<const float2*>(vrow + (f + 3) * 256);
+                        ox = fmaf(w4.x, v0.x, ox); oy = fmaf(w4.x, v0.y, oy); ox2 = fmaf(w4.y, v1.x, ox2); oy2 = fmaf(w4.y, v1.y, oy2);
+                        ox = fmaf(w4.z, v2.x, ox); oy = fmaf(w4.z, v2.y, oy); ox2 = fmaf(w4.w, v3.x, ox2); oy2 = fmaf(w4.w, v3.y, oy2);
                     }
-                    if (f + 1 < n) {
-                        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f + 1));
-                        ox2 = fmaf(w, vreg[b][f + 1].x, ox2); oy2 = fmaf(w, vreg[b][f + 1].y, oy2);
+                } else {
+                    const int awi = __builtin_bit_cast(int, aw);
+#pragma unroll
+                    for (int f = 0; f < PD_MAXT; f += 2) {
+                        if (f < n) {
+                            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f));
+                            ox = fmaf(w, vreg[b][f].x, ox); oy = fmaf(w, vreg[b][f].y, oy);
+                        }
+                        if (f + 1 < n) {
+                            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f + 1));
+                            ox2 = fmaf(w, vreg[b][f + 1].x, ox2); oy2 = fmaf(w, vreg[b][f + 1].y, oy2);
+                        }
                     }
                 }
                 xin[b] = make_float2(ox + ox2, oy + oy2);
@@ -465,17 +488,25 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             PD_STAMP(9);
             if (tid < 2 * NB) {
                 const float* r = red + rpar * 4 * RS;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) l0hh[g] = PD_SUM4(redC, RD, 12 * cb + 4 * cu + g);      // W_hh0 h0 from phase 4 of the previous step
                 const float gi = PD_SUM4(r, RS, 8 * cb + 4 * cu + 0) + l0hh[0] + e_bl0[0], gf = PD_SUM4(r, RS, 8 * cb + 4 * cu + 1) + l0hh[1] + e_bl0[1];
                 const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l0hh[2] + e_bl0[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l0hh[3] + e_bl0[3];
                 c0 = pd_sigmoid(gf) * c0 + pd_sigmoid(gi) * pd_tanh(gg);
                 const float hn = pd_sigmoid(go) * pd_tanh(c0);
-                pd_publish(X + pd_off_h0(NB) + cb * 512 + 2 * j + cu, tag_now, hn, NR, RSTR);
-                pd_publish(X + pd_off_c0(NB) + cb * 512 + 2 * j + cu, tag_now, c0, NR, RSTR);
+                pd_publish<NB>(rsall, pd_off_h0(NB) + cb * 512 + 2 * j + cu, tag_now, hn);
+                pd_publish<NB>(rsall, pd_off_c0(NB) + cb * 512 + 2 * j + cu, tag_now, c0);
             }
             rpar ^= 1;
             PD_STAMP(10);
+            // while h0' / c0' cross the chip: phase 1's deferred sums (valid since phase 2's first barrier) - the mel frame / stop logit of step s - 1
+            // (decoder.py:423-428) and W_hh1 h1 for phase 4
+            if (s > 0 && tid < NB && j <= 80) {
+                const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
+                if (j < 80) p.mel[((int64_t)tid * S + (s - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (s - 1)] = x + stopc;
+            }
+            if (tid < 2 * NB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l1hh[g] = PD_SUM4(redB, RD, 12 * cb + 4 * cu + g);
+            }
         }
         // ------------------------------------------------------------ phase 4: layer-1 cells; the h0 / c0 parts of the next step
         {
@@ -507,8 +538,8 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l1hh[2] + e_bl1[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l1hh[3] + e_bl1[3];
                 c1 = pd_sigmoid(gf) * c1 + pd_sigmoid(gi) * pd_tanh(gg);
                 const float hn = pd_sigmoid(go) * pd_tanh(c1);
-                pd_publish(X + pd_off_h1(NB) + cb * 512 + 2 * j + cu, tag_now, hn, NR, RSTR);
-                pd_publish(X + pd_off_c1(NB) + cb * 512 + 2 * j + cu, tag_now, c1, NR, RSTR);
+                pd_publish<NB>(rsall, pd_off_h1(NB) + cb * 512 + 2 * j + cu, tag_now, hn);
+                pd_publish<NB>(rsall, pd_off_c1(NB) + cb * 512 + 2 * j + cu, tag_now, c1);
             }
             rpar ^= 1;
             PD_STAMP(13);
@@ -532,6 +563,14 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
 #undef PD_STAMP
 }
 
+// a launch whose workgroups gave up (a poll without progress for 2 s: the chip was not theirs) must not hand back plausible numbers
+__global__ void pdecode_guard_kernel(const unsigned* status, float* mel, float* stop, int n_mel, int n_stop) {
+    if (__hip_atomic_load(status, PD_RLX) == 0u) return;
+    const float nan = __uint_as_float(0x7fc00000u);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mel; i += gridDim.x * blockDim.x) mel[i] = nan;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_stop; i += gridDim.x * blockDim.x) stop[i] = nan;
+}
+
 int64_t pdecode_ws_bytes(int B) {
     int nb = 1; while (nb < B) nb *= 2;
     return (int64_t)pd_rstride(nb) * 8 * PD_MAXREP + 256;
@@ -545,8 +584,7 @@ static hipEvent_t g_pd_ev = nullptr;
 static int g_pd_cus = -1;
 static unsigned long long* g_pd_ts = nullptr;
 static int g_pd_ts_step = 0;
-static int g_pd_nrep = 8;
-void pdecode_set_replicas(int n) { g_pd_nrep = n < 1 ? 1 : n > PD_MAXREP ? PD_MAXREP : n; }
+
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -566,13 +604,14 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     PDecP q = p;
     q.xch = reinterpret_cast<u64*>(ws);
     q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pd_rstride(nb) * 8 * PD_MAXREP);
-    q.nrep = g_pd_nrep;
+
     q.ts = g_pd_ts; q.ts_step = g_pd_ts_step;
     L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(p.B), s));      // tags and the status word start at zero EVERY call
     L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
     ProfScope ps("decode_persistent", s);
     if (nb == 1) hipLaunchKernelGGL(pdecode_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
     else hipLaunchKernelGGL(pdecode_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
     L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
     return 0;

@@ -30,7 +30,7 @@ RUNS = {
     "time_group.py": ([], {"G": "1", "NT": "1"}),
     "time_latency.py": ([], {"ROWS": "2", "REPS": "1", "S": "20"}),
     "time_step_phases.py": (["1"], {}),
-    "time_vocoder.py": ([], {"N": "8", "ITERS": "4"}),
+    "time_vocoder.py": ([], {"N": "32", "ITERS": "4"}),
     "train_stages.py": ([], {}),
 }
 SYNTAX_ONLY = ["pmc_decode_json.py", "pmc_read.py", "rocprof_summary.py"]

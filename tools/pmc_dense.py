@@ -10,3 +10,4 @@ nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd
 video = torch.cat([synth.synth_video(32, 29, tag=f"b{i}") for i in range(ROWS // 32)]).cuda()
 nm.encoder_fwd(video)
 torch.cuda.synchronize()
+print(f"encoder forward of {ROWS} clips done (run under rocprofv3: tools/pmc_dense_kernels.sh)")

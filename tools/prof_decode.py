@@ -22,3 +22,4 @@ state, _ = nm.decoder_prologue(native.build_visual(feat, emb), emb, gum)
 for _ in range(int(os.environ.get("REPS", "3"))):
     nm.decode_steps(state, B, T, S, want_attn=False)
 torch.cuda.synchronize()
+print(f"decode loop: {B} rows, S={S}, done (run under rocprofv3: tools/profile_r4.sh)")
