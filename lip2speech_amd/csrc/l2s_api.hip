@@ -927,7 +927,8 @@ static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
     return Bp * (512 * 4 + 512 * 2 + 512 + 256 * 4 + 96) + (int64_t)B * (512 + 256 + 256) + 64 * 24 + (B <= 8 ? pdecode_ws_bytes(B) / 4 + 64 : 0);
 }
-static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * 4 + 64 * 6; }
+constexpr int POST_TAPSPLIT_ROWS = 640;      // a batch with at most this many post-net rows (one or two clips of 300 frames) runs its Conv1d layers one K slice per tap
+static int64_t postnet_ws_floats(int B, int S) { return (int64_t)B * S * 512 * ((int64_t)B * S <= POST_TAPSPLIT_ROWS * MAX_GROUP ? 9 : 4) + 64 * 7; }
 
 // ------------------------------------------------------------------------------------------------ encoder
 
@@ -1382,10 +1383,14 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ postnet
-struct PostBufs { float* x[4]; };
+struct PostBufs { float* x[4]; float* part = nullptr; };
 
 static int postnet_alloc(Bump& bp, int B, int S, PostBufs& pb) {
     for (int i = 0; i < 4; ++i) pb.x[i] = bp.f((int64_t)B * S * 512);
+    // few rows (one or two clips alone: 5-10 row tiles x 8 column tiles on 256 CUs, K = 2560 deep: 67 us per layer): one K slice per tap in one grouped
+    // launch + a finish kernel that adds the taps in order (launch_gemm_tapsplit; 40 -> 200 tiles).  Decided on the rows of ONE batch, so that a batch
+    // meets the same arithmetic alone and in a group.
+    pb.part = ((int64_t)B * S / gemm_x3_group() <= POST_TAPSPLIT_ROWS) ? bp.f((int64_t)B * S * 512 * 5) : nullptr;
     return bp.overflow ? 1 : 0;
 }
 
@@ -1402,6 +1407,12 @@ static int postnet_layer(const Weights& w, int layer, const float* mel, const Po
     if (layer >= 1 && layer <= 3) { p.R1 = in; p.ldr1 = 512; p.r1_mod = 0; }
     if (layer == 4) { p.R1 = mel; p.ldr1 = NM; p.r1_mod = 0; p.c_tr_T = S; }
     if (!dma_weights) p.W3 = nullptr;
+    if (pb.part && t0 == 0 && t1 == S) {
+        p.win_T = 0; p.win_off = 0; p.W3 = nullptr;
+        GemmBatch gb{};
+        gb.p[0] = p; gb.count = 1;
+        return launch_gemm_tapsplit(gb, pb.part, s, "postnet_conv_gemm");
+    }
     return launch_gemm1(p, s, "postnet_conv_gemm");
 }
 

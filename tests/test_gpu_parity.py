@@ -322,7 +322,8 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
 
 @pytest.mark.parametrize("opts,exact", [
     ({"use_graph": 1}, True),              # BASELINE.json configs[3]: the decode loop replayed from a captured hipGraph - same kernels, same order
-    ({"overlap_postnet": 1}, True),        # windowed post-net on a second stream: every output frame sees the same taps
+    ({"overlap_postnet": 1}, False),       # windowed post-net on a second stream: every output frame sees the same taps (at <= 640 rows per batch the default
+                                           # post-net adds its five taps as separate K slices, the windows do not: another order of the same sums)
     ({"skinny_static": 1}, True),          # compile-time K-segment layouts: same chunk -> wave assignment and summation order
     ({"skinny_sized": 0}, True), ({"skinny_split": 1}, True), ({"skinny_split": 3}, True), ({"skinny_split8": 2}, True),
     ({"fold_step_weights": 0}, False),     # literal 6-phase step: different (unmerged) weights, same mathematics
