@@ -114,21 +114,24 @@ __device__ __forceinline__ void pd_publish(__amdgpu_buffer_rsrc_t rsall, int gra
     for (int r = 0; r < PD_MAXREP; ++r) __builtin_amdgcn_raw_buffer_store_b64(x, rsall, granule * 8, r * pd_rstride(NB) * 8, 16);
 }
 
-// One poll pass = every load of the phase issued, then every tag compared; repeated (with a short sleep) until the whole WAVE has fresh granules, so the
-// wave stays converged for the DPP reductions that follow.  A pass that keeps failing for ~2 s of wall clock raises status[0] and every workgroup leaves.
+// One poll pass = every load of the phase issued, then every tag compared; repeated until the whole WAVE has fresh granules, so the wave stays
+// converged for the DPP reductions that follow.  A wave that has gone around PD_SPIN_LIMIT times (seconds) raises status[0] and leaves, and so, each on its
+// own count, does every other wave that waits for it.  (Two passes in flight half a round trip apart - register sets taking turns, one exit branch so that
+// the compiler waits for the older pass alone - were measured: 9.6-10.0 against 9.7 us per step; more polling is more contention, not a shorter edge.)
+constexpr unsigned PD_SPIN_LIMIT = 3000000u;
 struct PdPoll {
-    unsigned* status; unsigned long long t0; unsigned spins; bool dead;
-    __device__ __forceinline__ PdPoll(unsigned* st) : status(st), t0(0), spins(0), dead(false) {}
-    __device__ __forceinline__ bool retry(bool ok) {      // true: go around again
+    unsigned* status; unsigned spins; bool dead;
+    __device__ __forceinline__ PdPoll(unsigned* st) : status(st), spins(0), dead(false) {}
+    __device__ __forceinline__ bool retry(bool ok) {         // true: go around again
         if (__all(ok)) { spins = 0; return false; }
-        if (spins == 0) t0 = wall_clock64();
-        if ((++spins & 255u) == 0) {
-            if (__hip_atomic_load(status, PD_RLX) != 0u) { dead = true; return false; }
-            if (wall_clock64() - t0 > 200000000ull) { __hip_atomic_store(status, 1u, PD_RLX); dead = true; return false; }      // 100 MHz clock: 2 s
-        }
+        if (++spins > PD_SPIN_LIMIT) { dead = true; return false; }
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         return true;
+    }
+    __device__ __forceinline__ bool gave_up() {              // after a poll loop
+        if (dead) __hip_atomic_store(status, 1u, PD_RLX);
+        return dead;
     }
 };
 // two adjacent granules {value, tag} x 2 as ONE 16-byte L1-bypassing load (buffer_load_dwordx4 ... sc1) through the exchange buffer's descriptor
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 }
                 if (!poll.retry(ok)) break;
             } while (true);
-            if (poll.dead) return;
+            if (poll.gave_up()) return;
             PD_STAMP(1);
             if (s < S) {
                 float v[4 * NB];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 }
                 if (!poll.retry(ok)) break;
             } while (true);
-            if (poll.dead) return;
+            if (poll.gave_up()) return;
             PD_STAMP(4);
             if (wave == 3) {                                 // prenet2 column j: this wave's own sum, out at once
                 float mine = 0.f;
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                     break;
                 } while (true);
             }
-            if (poll.dead) return;
+            if (poll.gave_up()) return;
             PD_STAMP(8);
             float v[8 * NB];
 #pragma unroll
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 }
                 if (!poll.retry(ok)) break;
             } while (true);
-            if (poll.dead) return;
+            if (poll.gave_up()) return;
             PD_STAMP(11);
             float v[8 * NB];
 #pragma unroll
