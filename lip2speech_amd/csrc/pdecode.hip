@@ -155,6 +155,9 @@ __device__ __forceinline__ float2 pd_w2(const float* W, int NC, int n, int k) {
 //   4: h0', c0' -> W_ih1 h0'; with W_hh1 h1 kept from phase 1: the layer-1 cells; and for the next step the h0 / c0 halves of Q, content-Q and W_hh0 h0'
 // Only what the NEXT phase waits for is summed across the threads before a phase publishes (4 values per clip in phase 1, the 8 gates in phases 3 / 4); the
 // sums a later phase needs (W_hh products, the mel frame) are reduced after the publish, while the vector is on its way.
+// (The same loop on EIGHT waves - 512 threads, k = t, two waves per SIMD to issue from, values in LDS, keys in 32 registers per clip - was built and is the
+// same bits of work per thread halved: 9.41 against 9.48 us per step at one clip, 14.3 against 12.7 at two (31 spilled registers): its logits are faster
+// (0.56 against 0.84 us) and phase 3 then simply waits longer for prenet2 - a step is its four edges, 4 x ~1.75 us, plus ~2.4 us; not kept.)
 template <int NB>
 __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     constexpr bool KREG = NB == 1;                          // one clip: its keys live in registers; two clips: in LDS (2 x 64 registers more would spill)

@@ -12,7 +12,6 @@ v = synth.synth_video(B, T, tag=f"lat{B}").cuda(); e = synth.synth_speaker_embed
 feat = nm.encoder_fwd(v); vis = native.build_visual(feat, e); state, _ = nm.decoder_prologue(vis, e, g)
 for _ in range(2): nm.decode_steps(state, B, T, S)
 L = native.lib()
-if "NREP" in os.environ: native.check(L.l2s_op_pdecode_timeline(None, -100 - int(os.environ["NREP"])))
 names = ["step start", "P1 granules in", "P1 reduced", "P1 published", "P2 granules in", "P2 prenet2 reduced", "P2 logits", "P2 published",
          "P3 granules in", "P3 reduced", "P3 published", "P4 granules in", "P4 reduced", "P4 published"]
 rows = []

@@ -13,7 +13,6 @@ def model(persist):
     nm = native.NativeModel(); nm.set_option("persist_decode", persist)
     nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys())); return nm
 base, pers = model(0), model(8)
-if "NREP" in os.environ: native.check(native.lib().l2s_op_pdecode_timeline(None, -100 - int(os.environ["NREP"])))      # experiment: copies of the exchange buffer
 def med(f):
     ts = []
     for _ in range(reps):
