@@ -155,6 +155,9 @@ __device__ __forceinline__ float2 pd_w2(const float* W, int NC, int n, int k) {
 //   4: h0', c0' -> W_ih1 h0'; with W_hh1 h1 kept from phase 1: the layer-1 cells; and for the next step the h0 / c0 halves of Q, content-Q and W_hh0 h0'
 // Only what the NEXT phase waits for is summed across the threads before a phase publishes (4 values per clip in phase 1, the 8 gates in phases 3 / 4); the
 // sums a later phase needs (W_hh products, the mel frame) are reduced after the publish, while the vector is on its way.
+// (prenet2 computed once PER XCD - eight columns per workgroup, a plain store that stays in the XCD's L2, its 32 workgroups polling it there; each
+// workgroup reads HW_REG_XCC_ID, takes a ticket at its XCC's counter and all fall back unless the eight counters read 32; block b did sit on XCC b % 8, 32
+// per XCC - was built and is no faster, 9.28 against 9.18 us: by the time the attention is done the chip-wide vector has arrived as well.)
 // (The same loop on EIGHT waves - 512 threads, k = t, two waves per SIMD to issue from, values in LDS, keys in 32 registers per clip - was built and is the
 // same bits of work per thread halved: 9.41 against 9.48 us per step at one clip, 14.3 against 12.7 at two (31 spilled registers): its logits are faster
 // (0.56 against 0.84 us) and phase 3 then simply waits longer for prenet2 - a step is its four edges, 4 x ~1.75 us, plus ~2.4 us; not kept.)
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
         }
         // ------------------------------------------------------------ phase 2
         float2 xin[NB];                                      // this thread's pair of layer-0 inputs: cc (waves 0, 1) or o (waves 2, 3; prenet2 is added in phase 3)
+        uint4 ppre[NB];                                      // waves 2, 3: prenet2 requested ahead of the soft-max (published ~1.5 us earlier: it is usually there)
         {
             float2 qv[NB]; float qcv[NB];
             float4 pv[NB];
@@ -422,6 +426,10 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             }
             __syncthreads();
             PD_STAMP(6);
+            if (o_role) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) ppre[b] = pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
+            }
             // every wave: softmax of its role's logits (lane = frame), then its threads' two columns of a @ V' / alpha @ value (decoder.py:414-419, 262-271)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -466,16 +474,18 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
         }
         // ------------------------------------------------------------ phase 3: layer-0 cells
         {
-            if (o_role) {                                    // u = prenet + o (decoder.py:421): waves 2, 3 wait for prenet2
+            if (o_role) {                                    // u = prenet + o (decoder.py:421): waves 2, 3 need prenet2 - first what was requested ahead
+                bool first = true;
                 do {
                     bool ok = true;
                     float2 pp[NB];
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        const uint4 a = pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
+                        const uint4 a = first ? ppre[b] : pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
                         ok &= a.y == tag_now && a.w == tag_now;
                         pp[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
                     }
+                    first = false;
                     if (poll.retry(ok)) continue;            // stale: go around again
 #pragma unroll
                     for (int b = 0; b < NB; ++b) { xin[b].x += pp[b].x; xin[b].y += pp[b].y; }
