@@ -19,6 +19,7 @@
 #include "l2s_model.h"
 #include "pdecode.h"
 
+#include <algorithm>
 #include <mutex>
 
 namespace l2s {
@@ -26,7 +27,12 @@ namespace l2s {
 constexpr int PD_WG = 256;                // workgroups = CUs
 constexpr int PD_NT = 256;                // threads per workgroup
 constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 2;
-constexpr int PD_LDS_FLOATS = 21 * 1024;  // 84 KB: more than half of a CU's LDS, so the 256 workgroups sit one per CU (two clips: + their keys, 148 KB)
+constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the 256 workgroups sit one per CU
+constexpr int PD_LDS_MAX = 160 * 1024;
+// LDS of a workgroup, in floats: the fixed part, then per clip its projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
+// the rows past T / m are zero), then - two clips - the second clip's keys [T][512] (the first clip's sit in registers)
+__host__ __device__ constexpr int pd_lds_fixed(int NB) { return NB * 512 + NB * 256 + NB * 48 + 2 * 4 * 8 * NB + 2 * 4 * 12 * NB + 4 * 32; }
+__host__ __device__ inline int pd_lds_floats(int NB, int T, int m) { return pd_lds_fixed(NB) + NB * (((T + 3) & ~3) + ((m + 3) & ~3)) * 256 + (NB - 1) * T * 512; }
 // granule arrays, in u64 units per row count NB: [h0 | h1 | c0 | c1 | q: NB x 512 each][qc, p1, o, cc, p2: NB x 256 each]
 __host__ __device__ constexpr int pd_off_h0(int NB) { return 0; }
 __host__ __device__ constexpr int pd_off_h1(int NB) { return NB * 512; }
@@ -107,6 +113,7 @@ __device__ __forceinline__ float pd_tanh(float x) { return 1.0f - 2.0f * __frcp_
 // every producer writes all replicas (the replica as the buffer instruction's scalar offset), a consumer polls replica (workgroup % 8) - its XCD's own
 // copy, so the 256 pollers of a granule line become 32 per copy (one copy: 16.7 us per step at one clip, two: 14.4, four: 13.2, eight: 13.1)
 typedef unsigned pd_u2 __attribute__((ext_vector_type(2)));
+typedef float pd_f2 __attribute__((ext_vector_type(2)));
 template <int NB>
 __device__ __forceinline__ void pd_publish(__amdgpu_buffer_rsrc_t rsall, int granule, unsigned tag, float v) {
     pd_u2 x; x.x = __float_as_uint(v); x.y = tag;
@@ -163,8 +170,7 @@ __device__ __forceinline__ float2 pd_w2(const float* W, int NC, int n, int k) {
 // (0.56 against 0.84 us) and phase 3 then simply waits longer for prenet2 - a step is its four edges, 4 x ~1.75 us, plus ~2.4 us; not kept.)
 template <int NB>
 __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
-    constexpr bool KREG = NB == 1;                          // one clip: its keys live in registers; two clips: in LDS (2 x 64 registers more would spill)
-    __shared__ __attribute__((aligned(16))) float sm[KREG ? PD_LDS_FLOATS : PD_LDS_FLOATS + (NB * PD_MAXT - 32) * 512];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* const qs = sm;                                   // [NB][512]          q * tau
     float* const qcs = qs + NB * 512;                       // [NB][256]          qc * tau_c
     float* const sc = qcs + NB * 256;                       // [NB][48]           attention logits [0, 32), content logits [32, 48)
@@ -172,9 +178,10 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     float* const red = sc + NB * 48;                        // [2][4 waves][RS]   critical sums, ping-pong by phase
     float* const redB = red + 2 * 4 * RS;                   // [4 waves][RD]      phase 1's deferred sums: fc, W_hh1 h1'
     float* const redC = redB + 4 * RD;                      // [4 waves][RD]      phase 4's deferred sums: W_hh0 h0', the h0 / c0 parts of q0, q1, qc
-    float* const Ks = redC + 4 * RD;                        // [NB][T][512]       (two clips) the clips' keys
-    float* const vs = redC + 4 * RD;                        // [32][256] + [16][256]  (one clip) its projected values V' and content values, rows past T / m zero
-    float* const aws = vs + (PD_MAXT + PD_MAXM) * 256;      // [4 waves][32]      (one clip) each wave's softmax weights, for broadcast reads
+    float* const aws = redC + 4 * RD;                       // [4 waves][32]      each wave's softmax weights, for broadcast reads
+    float* const vs = aws + 4 * 32;                         // [NB][T4 + m4][256] projected values V' and content values of every clip, rows past T / m zero
+    const int T4 = (p.T + 3) & ~3, M4 = (p.m + 3) & ~3, VR = T4 + M4;
+    float* const Ks = vs + NB * VR * 256;                   // [T][512]           (two clips) the second clip's keys
 
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,31 +226,24 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     const int cf = tid >> 4, cp = tid & 15;                 // content logits: 16 threads per content frame, 16 k each
     const bool o_role = wave >= 2;                          // waves 2, 3 form u[2 (tid - 128) ..] = prenet2 + o; waves 0, 1 form cc[2 tid ..] (wave-uniform: a scalar)
     const int xc = o_role ? 2 * (tid - 128) : 2 * tid;      // this thread's pair of columns of o / cc
-    float4 kreg[KREG ? NB : 1][16], ckreg[NB][4];
-    float2 vreg[KREG ? 1 : NB][KREG ? 1 : PD_MAXT];         // (two clips) o role: V'[b][f][xc ..]; cc role: cval[b][i][xc ..] (i < PD_MAXM)
-    const float* const vrow = vs + (o_role ? 0 : PD_MAXT * 256) + xc;      // (one clip) this thread's pair of columns in LDS, row pitch 256
+    float4 kreg[16], ckreg[NB][4];                          // the first clip's keys (8 threads per frame, 64 k each) in registers
+    const float* const vrow = vs + (o_role ? 0 : T4 * 256) + xc;      // this thread's pair of columns in LDS: row pitch 256, clip pitch VR * 256
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        if constexpr (KREG) {
+        if (b == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                kreg[b][i] = kf < T ? *reinterpret_cast<const float4*>(p.k + ((int64_t)b * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                kreg[i] = kf < T ? *reinterpret_cast<const float4*>(p.k + (int64_t)kf * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            for (int i = tid; i < T * 128; i += PD_NT) *reinterpret_cast<float4*>(Ks + (int64_t)b * T * 512 + 4 * i) = *reinterpret_cast<const float4*>(p.k + (int64_t)b * T * 512 + 4 * i);
+            for (int i = tid; i < T * 128; i += PD_NT) *reinterpret_cast<float4*>(Ks + 4 * i) = *reinterpret_cast<const float4*>(p.k + (int64_t)b * T * 512 + 4 * i);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             ckreg[b][i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)b * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (KREG) {
-            for (int i = tid; i < PD_MAXT * 64; i += PD_NT) *reinterpret_cast<float4*>(vs + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = tid; i < PD_MAXM * 64; i += PD_NT) *reinterpret_cast<float4*>(vs + PD_MAXT * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-#pragma unroll
-            for (int f = 0; f < PD_MAXT; ++f) {
-                if (o_role) vreg[b][f] = f < T ? *reinterpret_cast<const float2*>(p.vp + ((int64_t)b * T + f) * 256 + xc) : make_float2(0.f, 0.f);
-                else vreg[b][f] = f < M ? *reinterpret_cast<const float2*>(p.cval + ((int64_t)b * M + f) * 256 + xc) : make_float2(0.f, 0.f);
-            }
-        }
+        for (int i = tid; i < T4 * 64; i += PD_NT)
+            *reinterpret_cast<float4*>(vs + (int64_t)b * VR * 256 + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + (int64_t)b * T * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < M4 * 64; i += PD_NT)
+            *reinterpret_cast<float4*>(vs + ((int64_t)b * VR + T4) * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + (int64_t)b * M * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): column j, the same for every row
     float p1_bos;
@@ -401,17 +401,18 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             // logits: 8 threads per frame (keys in registers, q from LDS: the 8 frames of a wave read the same addresses), 16 threads per content frame
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                pd_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};     // two packed accumulators: v_pk_fma_f32, two products per instruction
                 const float* qr = qs + b * 512 + 4 * kp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float4 qq = *reinterpret_cast<const float4*>(qr + 32 * i);
                     float4 kk;
-                    if constexpr (KREG) kk = kreg[b][i];
-                    else kk = kf < T ? *reinterpret_cast<const float4*>(Ks + ((int64_t)b * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    a0 = fmaf(qq.x, kk.x, a0); a1 = fmaf(qq.y, kk.y, a1); a2 = fmaf(qq.z, kk.z, a2); a3 = fmaf(qq.w, kk.w, a3);
+                    if (b == 0) kk = kreg[i];
+                    else kk = kf < T ? *reinterpret_cast<const float4*>(Ks + (int64_t)kf * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    a01 = __builtin_elementwise_fma(pd_f2{qq.x, qq.y}, pd_f2{kk.x, kk.y}, a01);
+                    a23 = __builtin_elementwise_fma(pd_f2{qq.z, qq.w}, pd_f2{kk.z, kk.w}, a23);
                 }
-                float a = (a0 + a1) + (a2 + a3);
+                float a = (a01.x + a01.y) + (a23.x + a23.y);
                 a += pd_dpp<0xB1>(a); a += pd_dpp<0x4E>(a); a += pd_dpp<0x141>(a);      // the 8 lanes of a frame (row_half_mirror)
                 if (kp == 0 && kf < T) sc[b * 48 + kf] = a;
                 float c0a = 0.f, c1a = 0.f, c2a = 0.f, c3a = 0.f;
@@ -441,32 +442,21 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 const float aw = ex * __frcp_rn(pd_wave_sum(ex));
                 if (wave == 2 && j == b && on && p.attn) p.attn[((int64_t)b * S + s) * T + lane] = p.attn_logits ? x : aw;
                 float ox = 0.f, oy = 0.f, ox2 = 0.f, oy2 = 0.f;
-                if constexpr (KREG) {
+                {
                     // the wave's weights through LDS (lanes past n hold 0, value rows past T / m are 0): four frames per trip, no per-frame predicate
                     if (lane < 32) aws[wave * 32 + lane] = aw;
                     __builtin_amdgcn_wave_barrier();
+                    const float* vr = vrow + (int64_t)b * VR * 256;
                     const int n4 = (n + 3) & ~3;
 #pragma unroll 2
                     for (int f = 0; f < n4; f += 4) {
                         const float4 w4 = *reinterpret_cast<const float4*>(aws + wave * 32 + f);
-                        const float2 v0 = *reinterpret_cast<const float2*>(vrow + f * 256), v1 = *reinterpret_cast<const float2*>(vrow + (f + 1) * 256);
-                        const float2 v2 = *reinterpret_cast<const float2*>(vrow + (f + 2) * 256), v3 = *reinterpret_cast<const float2*>(vrow + (f + 3) * 256);
+                        const float2 v0 = *reinterpret_cast<const float2*>(vr + f * 256), v1 = *reinterpret_cast<const float2*>(vr + (f + 1) * 256);
+                        const float2 v2 = *reinterpret_cast<const float2*>(vr + (f + 2) * 256), v3 = *reinterpret_cast<const float2*>(vr + (f + 3) * 256);
                         ox = fmaf(w4.x, v0.x, ox); oy = fmaf(w4.x, v0.y, oy); ox2 = fmaf(w4.y, v1.x, ox2); oy2 = fmaf(w4.y, v1.y, oy2);
                         ox = fmaf(w4.z, v2.x, ox); oy = fmaf(w4.z, v2.y, oy); ox2 = fmaf(w4.w, v3.x, ox2); oy2 = fmaf(w4.w, v3.y, oy2);
                     }
-                } else {
-                    const int awi = __builtin_bit_cast(int, aw);
-#pragma unroll
-                    for (int f = 0; f < PD_MAXT; f += 2) {
-                        if (f < n) {
-                            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f));
-                            ox = fmaf(w, vreg[b][f].x, ox); oy = fmaf(w, vreg[b][f].y, oy);
-                        }
-                        if (f + 1 < n) {
-                            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(awi, f + 1));
-                            ox2 = fmaf(w, vreg[b][f + 1].x, ox2); oy2 = fmaf(w, vreg[b][f + 1].y, oy2);
-                        }
-                    }
+                    __builtin_amdgcn_wave_barrier();         // (the next clip's weights overwrite aws)
                 }
                 xin[b] = make_float2(ox + ox2, oy + oy2);
             }
@@ -591,7 +581,9 @@ int64_t pdecode_ws_bytes(int B) {
     int nb = 1; while (nb < B) nb *= 2;
     return (int64_t)pd_rstride(nb) * 8 * PD_MAXREP + 256;
 }
-bool pdecode_supported(int B, int T, int m) { return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM; }
+bool pdecode_supported(int B, int T, int m) {
+    return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM && pd_lds_floats(B, T, m) * 4 <= PD_LDS_MAX;
+}
 
 // every persistent launch needs all 256 workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
 // wait for the other half for ever, so they are chained through one event (a launch waits for the previous persistent launch of the process)
@@ -604,7 +596,7 @@ static int g_pd_ts_step = 0;
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
-    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames");
+    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames whose values (and second clip's keys) fit the LDS");
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(p.B), "persistent decode: exchange buffer too small");
     int nb = 1; while (nb < p.B) nb *= 2;
     std::lock_guard<std::mutex> lock(g_pd_mu);
@@ -625,8 +617,15 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(p.B), s));      // tags and the status word start at zero EVERY call
     L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
     ProfScope ps("decode_persistent", s);
-    if (nb == 1) hipLaunchKernelGGL(pdecode_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
-    else hipLaunchKernelGGL(pdecode_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    const int lds = std::max(pd_lds_floats(nb, p.T, p.m) * 4, PD_LDS_MIN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
+        attr_set = true;
+    }
+    if (nb == 1) hipLaunchKernelGGL(pdecode_kernel<1>, dim3(PD_WG), dim3(PD_NT), lds, s, q);
+    else hipLaunchKernelGGL(pdecode_kernel<2>, dim3(PD_WG), dim3(PD_NT), lds, s, q);
     hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
     L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
