@@ -28,7 +28,7 @@ constexpr int PD_WG = 256;                // workgroups = CUs
 constexpr int PD_NT = 256;                // threads per workgroup
 constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 2;
 constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the 256 workgroups sit one per CU
-constexpr int PD_LDS_MAX = 160 * 1024;
+constexpr int PD_LDS_MAX = 159 * 1024;      // dynamic part
 // LDS of a workgroup, in floats: the fixed part, then per clip its projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
 // the rows past T / m are zero), then - two clips - the second clip's keys [T][512] (the first clip's sit in registers)
 __host__ __device__ constexpr int pd_lds_fixed(int NB) { return NB * 512 + NB * 256 + NB * 48 + 2 * 4 * 8 * NB + 2 * 4 * 12 * NB + 4 * 32; }
