@@ -898,7 +898,13 @@ def test_persistent_decode_matches_reference_golden(synth_sd, nm):
     assert torch.equal(amax[sure], g["attn_argmax"][sure])
     ref = nm.inference(*args, S=300, want_attn=True)
     assert pc.maxdiff(mel_post, ref[0]) < 5e-4 and pc.maxdiff(attn, ref[2]) < 5e-4
-    # the staged entry point takes the same route (l2s_decode_steps): stop logits and the pre-post-net mel
+    # the staged entry point takes the same route (l2s_decode_steps); pre-softmax attention LOGITS (what forward() returns; |values| in the thousands,
+    # fp64-accumulated on the launch path, fp32 here), the pre-post-net mel and the stop logits against the launch path
+    feat = nm.encoder_fwd(args[0]); vis = native.build_visual(feat, args[1]); state, _ = nm.decoder_prologue(vis, args[1], args[2])
+    pa = own.decode_steps(state, 2, 29, 60, attn_logits=True)
+    pb = nm.decode_steps(state, 2, 29, 60, attn_logits=True)
+    assert not torch.equal(pa[0], pb[0]) and pc.maxdiff(pa[0], pb[0]) < 2e-4 and pc.maxdiff(pa[1], pb[1]) < 2e-4
+    assert pc.maxdiff(pa[2], pb[2]) / pb[2].abs().max().item() < 1e-5
     gs = pc.golden("stop_lrw_b2.npz")
     sd = dict(synth_sd)
     sd["decoder.stop_token_layer.linear_layer.weight"] = gs["stop_weight"]
