@@ -2,19 +2,19 @@
 // BASELINE config 1 runs 2): ONE launch for all S steps, weight-stationary.
 //
 // At <= 32 rows the launch-per-phase loop (l2s_api.hip decode_launches) is bound by four dependent launches per step (~20-23 us: boundary, first-operand
-// latency and 21 MB of step weights streamed from the Infinity Cache 300 times).  Here the 5.25 M step weights live in the REGISTERS of 256 resident
-// workgroups (one per CU, 81 VGPRs per thread): workgroup j owns hidden units 2j, 2j+1 of both LSTM layers (8 gate columns each), columns 2j, 2j+1 of Q,
-// column j of content-Q, of prenet1 o fc_out, of prenet2 and (j < 81) of fc_out+stop; thread t owns k = 2t, 2t+1 of every 512-long half of a column.
-// The per-step activations (h, c, q, qc, prenet: 3 072 floats per clip) cross the chip between the phases of a step as 8-byte {value, tag} granules,
-// written with one write-through store each and polled by the threads that consume them - the data is the flag (cdna_hip_programming.md section 6
-// Guideline 16 R2); a thread reads exactly the granules of its own K slice, straight into registers.  Every phase consumes a full vector from all 256
-// producers, so a phase is also a chip-wide barrier and single-buffered granules are safe.  Keys, projected values, content keys / values of the clips
-// sit in every workgroup's registers (keys of two clips: LDS), so attention is computed whole and locally (T <= 32 frames).
+// latency and 21 MB of step weights streamed from the Infinity Cache 300 times).  Here the 5.25 M step weights live in the REGISTERS of 128 resident
+// workgroups per clip (162 VGPRs per thread): a workgroup owns four hidden units of both LSTM layers (16 gate columns each), four columns of Q, two of
+// content-Q, of prenet1 o fc_out, of prenet2 and of fc_out+stop; thread t owns k = 2t, 2t+1 of every 512-long half of a column.  The per-step activations
+// (h, c, q, qc, prenet: 3 072 floats per clip) cross the chip between the phases of a step as 8-byte {value, tag} granules, written with one write-through
+// store each and polled by the threads that consume them - the data is the flag (cdna_hip_programming.md section 6 Guideline 16 R2); a thread reads
+// exactly the granules of its own K slice, straight into registers.  Every phase consumes a full vector from all of the clip's producers, so a phase is
+// also a barrier among them and single-buffered granules are safe.  Keys (registers), projected values and content values (LDS) of the clip sit in every
+// one of its workgroups, so attention is computed whole and locally (T <= 32 frames).  Two clips share nothing: each has its half of the chip.
 //
-// Measured on MI355X (profiles/r04_persist_edge_probe.txt, r04_pdecode_timeline.txt, r04_latency_path.txt): one all-to-all edge costs 1.4-1.7 us with
-// the exchange buffer replicated per XCD (2.1-2.6 with all 256 workgroups polling one copy), growing linearly beyond 2 048 floats (9.5 us at 16 384): the
-// form pays for one or two clips and is not used above.  Arithmetic: fp32 FMAs over the K slices, DPP / row-swap trees across the 256 threads - another
-// order of the same sums as the launch path (both within 1e-3 of the reference; tests/test_gpu_parity.py::test_persistent_decode_*).
+// Measured on MI355X (profiles/r04_persist_edge_probe.txt, r04_pdecode_timeline.txt, r04_latency_path.txt): one all-to-all edge costs ~1.2 us among 128
+// workgroups and ~1.8 among 256 with the exchange buffer replicated per XCD (2.1-2.6 with all 256 polling one copy), growing linearly beyond 2 048 floats
+// (9.5 us at 16 384): the form pays for one or two clips and is not used above.  Arithmetic: fp32 FMAs over the K slices, DPP / row-swap trees across the
+// 256 threads - another order of the same sums as the launch path (both within 1e-3 of the reference; tests/test_gpu_parity.py::test_persistent_decode_*).
 #include "l2s_common.h"
 #include "l2s_model.h"
 #include "pdecode.h"
@@ -29,10 +29,10 @@ constexpr int PD_NT = 256;                // threads per workgroup
 constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 2;
 constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the 256 workgroups sit one per CU
 constexpr int PD_LDS_MAX = 159 * 1024;      // dynamic part
-// LDS of a workgroup, in floats: the fixed part, then per clip its projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
-// the rows past T / m are zero), then - two clips - the second clip's keys [T][512] (the first clip's sit in registers)
-__host__ __device__ constexpr int pd_lds_fixed(int NB) { return NB * 512 + NB * 256 + NB * 48 + 2 * 4 * 8 * NB + 2 * 4 * 12 * NB + 4 * 32; }
-__host__ __device__ inline int pd_lds_floats(int NB, int T, int m) { return pd_lds_fixed(NB) + NB * (((T + 3) & ~3) + ((m + 3) & ~3)) * 256 + (NB - 1) * T * 512; }
+// LDS of a workgroup, in floats: the fixed part, then its clip's projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
+// the rows past T / m are zero)
+__host__ __device__ constexpr int pd_lds_fixed(int V) { return 512 + 256 + 48 + 2 * 4 * 8 * V + 2 * 4 * 12 * V + 4 * 32; }
+__host__ __device__ inline int pd_lds_floats(int V, int T, int m) { return pd_lds_fixed(V) + (((T + 3) & ~3) + ((m + 3) & ~3)) * 256; }
 // granule arrays, in u64 units per row count NB: [h0 | h1 | c0 | c1 | q: NB x 512 each][qc, p1, o, cc, p2: NB x 256 each]
 __host__ __device__ constexpr int pd_off_h0(int NB) { return 0; }
 __host__ __device__ constexpr int pd_off_h1(int NB) { return NB * 512; }
@@ -153,108 +153,123 @@ __device__ __forceinline__ float2 pd_w2(const float* W, int NC, int n, int k) {
     return *reinterpret_cast<const float2*>(W + ((int64_t)((n >> 4) * NC + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3));
 }
 
-// NB = clips of the launch (1 or 2).
+// NG = clips of the launch, V = "virtual" workgroups per workgroup.  Clip g is served by the 256 / V workgroups g * 256 / V ..., and such a workgroup
+// stands for V workgroups jv = V * (j mod 256 / V) + b of the one-per-CU layout (units 2 jv, 2 jv + 1 of both layers, columns 2 jv, 2 jv + 1 of Q,
+// column jv of content-Q / prenet1 o fc_out / prenet2 / fc_out+stop: 81 V weight registers per thread).  An all-to-all edge is cheaper the fewer
+// workgroups take part (128: ~1.3 us, 256: ~1.8), more than the doubled per-thread work costs: V = 2 for one clip (half the chip idle) and for two.  The clips never meet:
+// a workgroup polls and publishes its own clip's vectors only, holds its own clip's keys / values only - two clips run as two one-clip loops side by
+// side on half the chip each (11.6 -> ~9.8 us per step against the form in which every workgroup served both clips and did both clips' attention).
 // A step is four phases, and every phase polls ONLY what the phase before it produced (each vector crosses the chip once per step):
 //   1: h1', c1' (of the previous step) -> the h1 / c1 halves of Q, content-Q; prenet1 o fc_out; W_hh1 h1'; mel frame + stop logit of the previous step
-//   2: wave 3 alone turns prenet1 into prenet2 column j and publishes it at once; q, qc -> while prenet2 crosses the chip - attention and content
-//      attention of EVERY clip, whole, in every workgroup (keys, values, content keys / values of all clips sit in its registers / LDS): o and cc never leave the CU
-//   3: prenet2 (+ the local o = u, local cc) -> W_ih0 [cc | u]; with W_hh0 h0 kept from phase 4 of the previous step: the layer-0 cells of units 2j, 2j+1
+//   2: wave 3 alone turns prenet1 into this workgroup's prenet2 columns and publishes them at once; q, qc -> while prenet2 crosses the chip - attention and
+//      content attention of the clip, whole, in every one of its workgroups (keys in registers, values in LDS): o and cc never leave the CU
+//   3: prenet2 (+ the local o = u, local cc) -> W_ih0 [cc | u]; with W_hh0 h0 kept from phase 4 of the previous step: the layer-0 cells
 //   4: h0', c0' -> W_ih1 h0'; with W_hh1 h1 kept from phase 1: the layer-1 cells; and for the next step the h0 / c0 halves of Q, content-Q and W_hh0 h0'
-// Only what the NEXT phase waits for is summed across the threads before a phase publishes (4 values per clip in phase 1, the 8 gates in phases 3 / 4); the
+// Only what the NEXT phase waits for is summed across the threads before a phase publishes (4 NG values in phase 1, the 8 NG gates in phases 3 / 4); the
 // sums a later phase needs (W_hh products, the mel frame) are reduced after the publish, while the vector is on its way.
-// (prenet2 computed once PER XCD - eight columns per workgroup, a plain store that stays in the XCD's L2, its 32 workgroups polling it there; each
-// workgroup reads HW_REG_XCC_ID, takes a ticket at its XCC's counter and all fall back unless the eight counters read 32; block b did sit on XCC b % 8, 32
-// per XCC - was built and is no faster, 9.28 against 9.18 us: by the time the attention is done the chip-wide vector has arrived as well.)
-// (The same loop on EIGHT waves - 512 threads, k = t, two waves per SIMD to issue from, values in LDS, keys in 32 registers per clip - was built and is the
-// same bits of work per thread halved: 9.41 against 9.48 us per step at one clip, 14.3 against 12.7 at two (31 spilled registers): its logits are faster
-// (0.56 against 0.84 us) and phase 3 then simply waits longer for prenet2 - a step is its four edges, 4 x ~1.75 us, plus ~2.4 us; not kept.)
-template <int NB>
+// (Measured and not kept: prenet2 computed once PER XCD - eight columns per workgroup, a plain store that stays in the XCD's L2, its 32 workgroups polling
+// it there, XCC ids and ranks taken at start - 9.24 against 9.33 us; the same loop on EIGHT waves, 512 threads with k = t - 9.41 against 9.48 at one clip,
+// 14.3 against 12.7 at two: a step is its four edges, 4 x ~1.75 us, plus ~2.4 us.)
+template <int NG, int V>
 __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* const qs = sm;                                   // [NB][512]          q * tau
-    float* const qcs = qs + NB * 512;                       // [NB][256]          qc * tau_c
-    float* const sc = qcs + NB * 256;                       // [NB][48]           attention logits [0, 32), content logits [32, 48)
-    constexpr int RS = 8 * NB, RD = 12 * NB;                // floats per wave: a phase's critical sums, its deferred sums
-    float* const red = sc + NB * 48;                        // [2][4 waves][RS]   critical sums, ping-pong by phase
-    float* const redB = red + 2 * 4 * RS;                   // [4 waves][RD]      phase 1's deferred sums: fc, W_hh1 h1'
+    float* const qs = sm;                                   // [512]              q * tau
+    float* const qcs = qs + 512;                            // [256]              qc * tau_c
+    float* const sc = qcs + 256;                            // [48]               attention logits [0, 32), content logits [32, 48)
+    constexpr int RS = 8 * V, RD = 12 * V;                // floats per wave: a phase's critical sums, its deferred sums
+    float* const red = sc + 48;                             // [2][4 waves][RS]   critical sums, ping-pong by phase
+    float* const redB = red + 2 * 4 * RS;                   // [4 waves][RD]      phase 1's deferred sums: W_hh1 h1', fc
     float* const redC = redB + 4 * RD;                      // [4 waves][RD]      phase 4's deferred sums: W_hh0 h0', the h0 / c0 parts of q0, q1, qc
     float* const aws = redC + 4 * RD;                       // [4 waves][32]      each wave's softmax weights, for broadcast reads
-    float* const vs = aws + 4 * 32;                         // [NB][T4 + m4][256] projected values V' and content values of every clip, rows past T / m zero
-    const int T4 = (p.T + 3) & ~3, M4 = (p.m + 3) & ~3, VR = T4 + M4;
-    float* const Ks = vs + NB * VR * 256;                   // [T][512]           (two clips) the second clip's keys
+    float* const vs = aws + 4 * 32;                         // [T4 + m4][256]     projected values V' and content values of the clip, rows past T / m zero
+    const int T4 = (p.T + 3) & ~3, M4 = (p.m + 3) & ~3;
 
+    constexpr int WPG = PD_WG / V;                          // workgroups per clip (the launch has NG * WPG of them)
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int g = j / WPG, jl = j - g * WPG;                // this workgroup's clip, its index among the clip's workgroups
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, M = p.m, S = p.S;
     u64* const X = p.xch;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % PD_MAXREP) * pd_rstride(NB), 0, pd_granules(NB) * 8, 0x00020000);      // this workgroup's replica
-    const __amdgpu_buffer_rsrc_t rsall = __builtin_amdgcn_make_buffer_rsrc(X, 0, PD_MAXREP * pd_rstride(NB) * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % PD_MAXREP) * pd_rstride(NG), 0, pd_granules(NG) * 8, 0x00020000);      // this workgroup's replica
+    const __amdgpu_buffer_rsrc_t rsall = __builtin_amdgcn_make_buffer_rsrc(X, 0, PD_MAXREP * pd_rstride(NG) * 8, 0x00020000);
+    // this clip's vectors inside a replica
+    const int gH0 = pd_off_h0(NG) + g * 512, gH1 = pd_off_h1(NG) + g * 512, gC0 = pd_off_c0(NG) + g * 512, gC1 = pd_off_c1(NG) + g * 512;
+    const int gQ = pd_off_q(NG) + g * 512, gQC = pd_off_qc(NG) + g * 256, gP1 = pd_off_p1(NG) + g * 256, gP2 = pd_off_p2(NG) + g * 256;
     PdPoll poll(p.status);
     unsigned long long* const ts = p.ts ? p.ts + (int64_t)j * 16 : nullptr;      // measurement: thread 0 of every workgroup stamps the phases of step p.ts_step
 #define PD_STAMP(i) do { if (ts && s == p.ts_step && tid == 0) ts[i] = wall_clock64(); } while (0)
 
     // ---------------------------------------------------------------- weights into registers: thread t owns k = 2t, 2t + 1 of every 512-long half
-    float2 wl0i[8], wl0h[8], wl1i[8], wl1h[8], wq0[2], wq1[2], wcq0, wcq1, wp1, wfc;
+    float2 wl0i[V][8], wl0h[V][8], wl1i[V][8], wl1h[V][8], wq0[V][2], wq1[V][2], wcq0[V], wcq1[V], wp1[V], wfc[V];
+    float4 wp2[V];                                         // prenet2 column jv over k = 4 lane .. 4 lane + 3 (K = 256: one wave covers it; wave 3 does)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        wl0i[c] = pd_w2(p.Wl0, 64, 8 * j + c, 2 * tid); wl0h[c] = pd_w2(p.Wl0, 64, 8 * j + c, 512 + 2 * tid);
-        wl1i[c] = pd_w2(p.Wl1, 64, 8 * j + c, 2 * tid); wl1h[c] = pd_w2(p.Wl1, 64, 8 * j + c, 512 + 2 * tid);
+    for (int b = 0; b < V; ++b) {
+        const int jv = V * jl + b;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            wl0i[b][c] = pd_w2(p.Wl0, 64, 8 * jv + c, 2 * tid); wl0h[b][c] = pd_w2(p.Wl0, 64, 8 * jv + c, 512 + 2 * tid);
+            wl1i[b][c] = pd_w2(p.Wl1, 64, 8 * jv + c, 2 * tid); wl1h[b][c] = pd_w2(p.Wl1, 64, 8 * jv + c, 512 + 2 * tid);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { wq0[b][c] = pd_w2(p.Wq, 64, 2 * jv + c, 2 * tid); wq1[b][c] = pd_w2(p.Wq, 64, 2 * jv + c, 512 + 2 * tid); }
+        wcq0[b] = pd_w2(p.Wcq, 64, jv, 2 * tid); wcq1[b] = pd_w2(p.Wcq, 64, jv, 512 + 2 * tid);
+        wp1[b] = pd_w2(p.Wp1f, 32, jv, 2 * tid);
+        wfc[b] = jv < 96 ? pd_w2(p.Wfc, 32, jv, 2 * tid) : make_float2(0.f, 0.f);
+        wp2[b] = *reinterpret_cast<const float4*>(p.Wp2 + ((int64_t)((jv >> 4) * 16 + (lane >> 2)) * 64 + (lane & 3) * 16 + (jv & 15)) * 4);
     }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { wq0[c] = pd_w2(p.Wq, 64, 2 * j + c, 2 * tid); wq1[c] = pd_w2(p.Wq, 64, 2 * j + c, 512 + 2 * tid); }
-    wcq0 = pd_w2(p.Wcq, 64, j, 2 * tid); wcq1 = pd_w2(p.Wcq, 64, j, 512 + 2 * tid);
-    wp1 = pd_w2(p.Wp1f, 32, j, 2 * tid);
-    wfc = j < 96 ? pd_w2(p.Wfc, 32, j, 2 * tid) : make_float2(0.f, 0.f);
-    // prenet2 column j over k = 4 lane .. 4 lane + 3 (K = 256: one wave covers it; wave 3 does)
-    const float4 wp2 = *reinterpret_cast<const float4*>(p.Wp2 + ((int64_t)((j >> 4) * 16 + (lane >> 2)) * 64 + (lane & 3) * 16 + (j & 15)) * 4);
     const float tau = p.tau[0], tau_c = p.tau_c[0];
-    // epilogue constants of the threads that finish a phase (tid < 4 NB in phase 1, lanes < NB of wave 3 in phase 2, tid < 2 NB in the cells)
-    const int fb = tid >> 2, fk = tid & 3;                  // phase-1 finisher: row fb, value fk (q0, q1, qc, p1)
-    const float e_b1 = fk < 2 ? p.bq[2 * j + fk] : fk == 2 ? p.bcq[j] : p.bp1f[j];
-    const float e_a1 = fk < 2 ? p.aq[2 * j + fk] : p.ap1[j];
-    const float e_bfc = j < 96 ? p.bfc[j] : 0.f;
-    const float e_b2 = p.bp2[j], e_a2 = p.ap2[j];
-    const int cb = tid >> 1, cu = tid & 1;                  // cell thread: row cb, unit 2j + cu
+    // epilogue constants of the threads that finish a phase (tid < 4 V in phase 1, lanes < V of wave 3 in phase 2, tid < 2 V in the cells, tid < V for the mel)
+    const int fb = tid >> 2, fk = tid & 3;                  // phase-1 finisher: virtual workgroup fb, value fk (q0, q1, qc, p1)
+    const int fjv = V * jl + (fb < V ? fb : V - 1);
+    const float e_b1 = fk < 2 ? p.bq[2 * fjv + fk] : fk == 2 ? p.bcq[fjv] : p.bp1f[fjv];
+    const float e_a1 = fk < 2 ? p.aq[2 * fjv + fk] : p.ap1[fjv];
+    const int mjv = V * jl + (tid < V ? tid : V - 1);    // mel / stop: thread tid < V finishes column mjv (< 81)
+    const float e_bfc = mjv < 96 ? p.bfc[mjv] : 0.f;
+    const int pjv = V * jl + (lane < V ? lane : V - 1);  // prenet2: lane < V of wave 3 finishes column pjv
+    const float e_b2 = p.bp2[pjv], e_a2 = p.ap2[pjv];
+    const int cb = tid >> 1, cu = tid & 1;                  // cell thread: virtual workgroup cb, unit 2 jv + cu
+    const int cjv = V * jl + (cb < V ? cb : V - 1);
     float e_bl0[4], e_bl1[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { e_bl0[g] = p.bl0[8 * j + 4 * cu + g]; e_bl1[g] = p.bl1[8 * j + 4 * cu + g]; }
+    for (int q = 0; q < 4; ++q) { e_bl0[q] = p.bl0[8 * cjv + 4 * cu + q]; e_bl1[q] = p.bl1[8 * cjv + 4 * cu + q]; }
     float c0 = 0.f, c1 = 0.f;                               // cell states of the cell threads (decoder.py:406: zeros)
-    const float stopc = p.stop_const[tid < NB ? tid : NB - 1];
+    const float stopc = p.stop_const[g];
 
-    // ---------------------------------------------------------------- every clip's keys / values / content keys / content values into registers
+    // ---------------------------------------------------------------- the clip's keys / content keys into registers, its values into LDS
     const int kf = tid >> 3, kp = tid & 7;                  // attention logits: 8 threads per frame, 64 k each (k = 4 kp + 32 i + e)
     const int cf = tid >> 4, cp = tid & 15;                 // content logits: 16 threads per content frame, 16 k each
     const bool o_role = wave >= 2;                          // waves 2, 3 form u[2 (tid - 128) ..] = prenet2 + o; waves 0, 1 form cc[2 tid ..] (wave-uniform: a scalar)
     const int xc = o_role ? 2 * (tid - 128) : 2 * tid;      // this thread's pair of columns of o / cc
-    float4 kreg[16], ckreg[NB][4];                          // the first clip's keys (8 threads per frame, 64 k each) in registers
-    const float* const vrow = vs + (o_role ? 0 : T4 * 256) + xc;      // this thread's pair of columns in LDS: row pitch 256, clip pitch VR * 256
+    float4 kreg[16], ckreg[4];
+    const float* const vrow = vs + (o_role ? 0 : T4 * 256) + xc;      // this thread's pair of columns in LDS, row pitch 256
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        if (b == 0) {
+    for (int i = 0; i < 16; ++i)
+        kreg[i] = kf < T ? *reinterpret_cast<const float4*>(p.k + ((int64_t)g * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                kreg[i] = kf < T ? *reinterpret_cast<const float4*>(p.k + (int64_t)kf * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            for (int i = tid; i < T * 128; i += PD_NT) *reinterpret_cast<float4*>(Ks + 4 * i) = *reinterpret_cast<const float4*>(p.k + (int64_t)b * T * 512 + 4 * i);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ckreg[b][i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)b * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < T4 * 64; i += PD_NT)
-            *reinterpret_cast<float4*>(vs + (int64_t)b * VR * 256 + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + (int64_t)b * T * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < M4 * 64; i += PD_NT)
-            *reinterpret_cast<float4*>(vs + ((int64_t)b * VR + T4) * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + (int64_t)b * M * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): column j, the same for every row
+    for (int i = 0; i < 4; ++i)
+        ckreg[i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)g * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < T4 * 64; i += PD_NT)
+        *reinterpret_cast<float4*>(vs + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + (int64_t)g * T * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < M4 * 64; i += PD_NT)
+        *reinterpret_cast<float4*>(vs + T4 * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + (int64_t)g * M * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): the finisher's column (fk = 3 uses it)
     float p1_bos;
     {
-        float a = 0.f;
+        float bosv[V];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int k = lane + 64 * r;
-            if (k < 80) a = fmaf(p.Wp1[(((int64_t)((j >> 4) * 5 + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (j & 15)) * 4) + (k & 3)], p.bos[k], a);
+        for (int b = 0; b < V; ++b) {
+            const int jv = V * jl + b;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = lane + 64 * r;
+                if (k < 80) a = fmaf(p.Wp1[(((int64_t)((jv >> 4) * 5 + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (jv & 15)) * 4) + (k & 3)], p.bos[k], a);
+            }
+            bosv[b] = sinf(pd_wave_sum(a) + p.bp1[jv]) * p.ap1[jv];
         }
-        p1_bos = sinf(pd_wave_sum(a) + p.bp1[j]) * p.ap1[j];
+        p1_bos = bosv[0];
+#pragma unroll
+        for (int b = 1; b < V; ++b) if (fb == b) p1_bos = bosv[b];
     }
 
     // cross-thread sums: V values per thread -> wave totals (pd_wave_sum_multi: lane l < 4 ends with value 4 i + l in vals[i]) -> dst[wave][..]; after the
@@ -270,22 +285,22 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     // what phase 4 of "step -1" would have left in redC: W_hh0 h0 and the h0 halves of Q from the prologue's h0 (c0 = 0: nothing for content-Q); h1 / c1 as granules
     float l0hh[4] = {0.f, 0.f, 0.f, 0.f}, l1hh[4] = {0.f, 0.f, 0.f, 0.f};      // cell threads: W_hh0 h0 / W_hh1 h1 of their four gates
     {
-        const int64_t hb = (int64_t)((NB + 15) & ~15) * 512;
-        float v[12 * NB];
+        const int64_t hb = (int64_t)((p.B + 15) & ~15) * 512;
+        const float2 h = *reinterpret_cast<const float2*>(p.h_init + frag16_index(g, 2 * tid, 512));
+        float v[12 * V];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float2 h = *reinterpret_cast<const float2*>(p.h_init + frag16_index(b, 2 * tid, 512));
+        for (int b = 0; b < V; ++b) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl0h[c].y, h.y, wl0h[c].x * h.x);
-            v[12 * b + 8] = fmaf(wq0[0].y, h.y, wq0[0].x * h.x);
-            v[12 * b + 9] = fmaf(wq0[1].y, h.y, wq0[1].x * h.x);
+            for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl0h[b][c].y, h.y, wl0h[b][c].x * h.x);
+            v[12 * b + 8] = fmaf(wq0[b][0].y, h.y, wq0[b][0].x * h.x);
+            v[12 * b + 9] = fmaf(wq0[b][1].y, h.y, wq0[b][1].x * h.x);
             v[12 * b + 10] = 0.f; v[12 * b + 11] = 0.f;
         }
-        PD_WSUM(v, 12 * NB, redC, RD);
-        if (tid < 2 * NB) {
-            const int unit = 2 * j + cu;
-            pd_publish<NB>(rsall, pd_off_h1(NB) + cb * 512 + unit, 1u, p.h_init[hb + frag16_index(cb, unit, 512)]);
-            pd_publish<NB>(rsall, pd_off_c1(NB) + cb * 512 + unit, 1u, 0.f);
+        PD_WSUM(v, 12 * V, redC, RD);
+        if (tid < 2 * V) {
+            const int unit = 2 * cjv + cu;
+            pd_publish<NG>(rsall, gH1 + unit, 1u, p.h_init[hb + frag16_index(g, unit, 512)]);
+            pd_publish<NG>(rsall, gC1 + unit, 1u, 0.f);
         }
         __syncthreads();
     }
@@ -294,171 +309,146 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
         const unsigned tag_prev = (unsigned)s + 1u, tag_now = (unsigned)s + 2u;
         PD_STAMP(0);
         // ------------------------------------------------------------ phase 1
+        float2 hy, cy;
         {
-            const float posv = (s < S && tid < 4 * NB && fk < 2) ? p.pos[(int64_t)s * 512 + 2 * j + fk] : 0.f;      // requested before the poll, used after it
-            float2 hy[NB], cy[NB];
+            const float posv = (s < S && tid < 4 * V && fk < 2) ? p.pos[(int64_t)s * 512 + 2 * fjv + fk] : 0.f;      // requested before the poll, used after it
             do {
-                bool ok = true;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const uint4 a = pd_load16(rs, pd_off_h1(NB) + b * 512 + 2 * tid), c = pd_load16(rs, pd_off_c1(NB) + b * 512 + 2 * tid);
-                    ok &= a.y == tag_prev && a.w == tag_prev && c.y == tag_prev && c.w == tag_prev;
-                    hy[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
-                    cy[b] = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
-                }
+                const uint4 a = pd_load16(rs, gH1 + 2 * tid), c = pd_load16(rs, gC1 + 2 * tid);
+                const bool ok = a.y == tag_prev && a.w == tag_prev && c.y == tag_prev && c.w == tag_prev;
+                hy = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                cy = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
                 if (!poll.retry(ok)) break;
             } while (true);
             if (poll.gave_up()) return;
             PD_STAMP(1);
             if (s < S) {
-                float v[4 * NB];
+                float v[4 * V];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    v[4 * b + 0] = fmaf(wq1[0].y, hy[b].y, wq1[0].x * hy[b].x);
-                    v[4 * b + 1] = fmaf(wq1[1].y, hy[b].y, wq1[1].x * hy[b].x);
-                    v[4 * b + 2] = fmaf(wcq1.y, cy[b].y, wcq1.x * cy[b].x);
-                    v[4 * b + 3] = fmaf(wp1.y, hy[b].y, wp1.x * hy[b].x);
+                for (int b = 0; b < V; ++b) {
+                    v[4 * b + 0] = fmaf(wq1[b][0].y, hy.y, wq1[b][0].x * hy.x);
+                    v[4 * b + 1] = fmaf(wq1[b][1].y, hy.y, wq1[b][1].x * hy.x);
+                    v[4 * b + 2] = fmaf(wcq1[b].y, cy.y, wcq1[b].x * cy.x);
+                    v[4 * b + 3] = fmaf(wp1[b].y, hy.y, wp1[b].x * hy.x);
                 }
-                PD_WSUM(v, 4 * NB, red + rpar * 4 * RS, RS);
+                PD_WSUM(v, 4 * V, red + rpar * 4 * RS, RS);
                 __syncthreads();
                 PD_STAMP(2);
-                if (tid < 4 * NB) {                          // q0, q1, qc, p1 of row fb: one sinf and one expf for the four lanes, then a select
+                if (tid < 4 * V) {                          // q0, q1, qc, p1 of virtual workgroup fb: one sinf and one expf for the four lanes, then a select
                     const float qh = fk < 3 ? PD_SUM4(redC, RD, 12 * fb + 8 + fk) : 0.f;      // the h0 / c0 part, from phase 4 of the previous step
                     const float x = PD_SUM4(red + rpar * 4 * RS, RS, 4 * fb + fk) + qh + e_b1;
                     const float sx = sinf(x) * e_a1, ex = x / (1.0f + expf(-x));
                     const float val = fk < 2 ? sx + posv : fk == 2 ? ex : (s == 0 ? p1_bos : sx);
-                    const int g = fk < 2 ? pd_off_q(NB) + fb * 512 + 2 * j + fk : fk == 2 ? pd_off_qc(NB) + fb * 256 + j : pd_off_p1(NB) + fb * 256 + j;
-                    pd_publish<NB>(rsall, g, tag_now, val);
+                    const int gg = fk < 2 ? gQ + 2 * fjv + fk : fk == 2 ? gQC + fjv : gP1 + fjv;
+                    pd_publish<NG>(rsall, gg, tag_now, val);
                 }
                 rpar ^= 1;
             }
             PD_STAMP(3);
-            if (s < S && tid < 2 * NB) {                     // W_hh0 h0 from phase 4 of the previous step, for phase 3 (redC is valid since this phase's barrier)
+            if (s < S && tid < 2 * V) {                     // W_hh0 h0 from phase 4 of the previous step, for phase 3 (redC is valid since this phase's barrier)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) l0hh[g] = PD_SUM4(redC, RD, 12 * cb + 4 * cu + g);
+                for (int q = 0; q < 4; ++q) l0hh[q] = PD_SUM4(redC, RD, 12 * cb + 4 * cu + q);
             }
-            {   // deferred: the mel frame / stop logit of step s - 1, W_hh1 h1' for phase 4
-                float v[12 * NB];
+            {   // deferred: W_hh1 h1' for phase 4, the mel frame / stop logit of step s - 1
+                float v[12 * V];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < V; ++b) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl1h[c].y, hy[b].y, wl1h[c].x * hy[b].x);
-                    v[12 * b + 8] = fmaf(wfc.y, hy[b].y, wfc.x * hy[b].x);
+                    for (int c = 0; c < 8; ++c) v[12 * b + c] = fmaf(wl1h[b][c].y, hy.y, wl1h[b][c].x * hy.x);
+                    v[12 * b + 8] = fmaf(wfc[b].y, hy.y, wfc[b].x * hy.x);
                     v[12 * b + 9] = 0.f; v[12 * b + 10] = 0.f; v[12 * b + 11] = 0.f;
                 }
-                PD_WSUM(v, 12 * NB, redB, RD);
+                PD_WSUM(v, 12 * V, redB, RD);
             }
         }
         if (s == S) {                                        // the last mel frame
             __syncthreads();
-            if (tid < NB && j <= 80) {
+            if (tid < V && mjv <= 80) {
                 const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
-                if (j < 80) p.mel[((int64_t)tid * S + (S - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (S - 1)] = x + stopc;
+                if (mjv < 80) p.mel[((int64_t)g * S + (S - 1)) * 80 + mjv] = x; else p.stop[(int64_t)g * S + (S - 1)] = x + stopc;
             }
             break;
         }
         // ------------------------------------------------------------ phase 2
-        float2 xin[NB];                                      // this thread's pair of layer-0 inputs: cc (waves 0, 1) or o (waves 2, 3; prenet2 is added in phase 3)
-        uint4 ppre[NB];                                      // waves 2, 3: prenet2 requested ahead of the soft-max (published ~1.5 us earlier: it is usually there)
+        float2 xin;                                          // this thread's pair of layer-0 inputs: cc (waves 0, 1) or o (waves 2, 3; prenet2 is added in phase 3)
+        uint4 ppre;                                          // waves 2, 3: prenet2 requested ahead of the soft-max (published ~1.5 us earlier: it is usually there)
         {
-            float2 qv[NB]; float qcv[NB];
-            float4 pv[NB];
+            float2 qv; float qcv;
+            float4 pv;
             do {
-                bool ok = true;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const uint4 a = pd_load16(rs, pd_off_q(NB) + b * 512 + 2 * tid);
-                    const u64 c = pd_load8(rs, pd_off_qc(NB) + b * 256 + tid);
-                    ok &= a.y == tag_now && a.w == tag_now && (unsigned)(c >> 32) == tag_now;
-                    qv[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
-                    qcv[b] = __uint_as_float((unsigned)c);
-                    if (wave == 3) {                         // prenet1 of row b, k = 4 lane .. 4 lane + 3
-                        const uint4 x0 = pd_load16(rs, pd_off_p1(NB) + b * 256 + 4 * lane), x1 = pd_load16(rs, pd_off_p1(NB) + b * 256 + 4 * lane + 2);
-                        ok &= x0.y == tag_now && x0.w == tag_now && x1.y == tag_now && x1.w == tag_now;
-                        pv[b] = make_float4(__uint_as_float(x0.x), __uint_as_float(x0.z), __uint_as_float(x1.x), __uint_as_float(x1.z));
-                    }
+                const uint4 a = pd_load16(rs, gQ + 2 * tid);
+                const u64 c = pd_load8(rs, gQC + tid);
+                bool ok = a.y == tag_now && a.w == tag_now && (unsigned)(c >> 32) == tag_now;
+                qv = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                qcv = __uint_as_float((unsigned)c);
+                if (wave == 3) {                             // prenet1, k = 4 lane .. 4 lane + 3
+                    const uint4 x0 = pd_load16(rs, gP1 + 4 * lane), x1 = pd_load16(rs, gP1 + 4 * lane + 2);
+                    ok &= x0.y == tag_now && x0.w == tag_now && x1.y == tag_now && x1.w == tag_now;
+                    pv = make_float4(__uint_as_float(x0.x), __uint_as_float(x0.z), __uint_as_float(x1.x), __uint_as_float(x1.z));
                 }
                 if (!poll.retry(ok)) break;
             } while (true);
             if (poll.gave_up()) return;
             PD_STAMP(4);
-            if (wave == 3) {                                 // prenet2 column j: this wave's own sum, out at once
+            if (wave == 3) {                                 // prenet2, this workgroup's columns: the wave's own sums, out at once
                 float mine = 0.f;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const float t2 = pd_wave_sum(fmaf(wp2.w, pv[b].w, fmaf(wp2.z, pv[b].z, fmaf(wp2.y, pv[b].y, wp2.x * pv[b].x))));
+                for (int b = 0; b < V; ++b) {
+                    const float t2 = pd_wave_sum(fmaf(wp2[b].w, pv.w, fmaf(wp2[b].z, pv.z, fmaf(wp2[b].y, pv.y, wp2[b].x * pv.x))));
                     if (lane == b) mine = t2;
                 }
-                if (lane < NB) pd_publish<NB>(rsall, pd_off_p2(NB) + lane * 256 + j, tag_now, __sinf(mine + e_b2) * e_a2);
+                if (lane < V) pd_publish<NG>(rsall, gP2 + pjv, tag_now, __sinf(mine + e_b2) * e_a2);
             }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                *reinterpret_cast<float2*>(qs + b * 512 + 2 * tid) = make_float2(qv[b].x * tau, qv[b].y * tau);
-                qcs[b * 256 + tid] = qcv[b] * tau_c;
-            }
+            *reinterpret_cast<float2*>(qs + 2 * tid) = make_float2(qv.x * tau, qv.y * tau);
+            qcs[tid] = qcv * tau_c;
             __syncthreads();                                 // qs / qcs visible to the block (and phase 1's deferred sums in redB)
             PD_STAMP(5);
-            // logits: 8 threads per frame (keys in registers, q from LDS: the 8 frames of a wave read the same addresses), 16 threads per content frame
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            {   // logits: 8 threads per frame (keys in registers, q from LDS: the 8 frames of a wave read the same addresses), 16 threads per content frame
                 pd_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};     // two packed accumulators: v_pk_fma_f32, two products per instruction
-                const float* qr = qs + b * 512 + 4 * kp;
+                const float* qr = qs + 4 * kp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float4 qq = *reinterpret_cast<const float4*>(qr + 32 * i);
-                    float4 kk;
-                    if (b == 0) kk = kreg[i];
-                    else kk = kf < T ? *reinterpret_cast<const float4*>(Ks + (int64_t)kf * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    a01 = __builtin_elementwise_fma(pd_f2{qq.x, qq.y}, pd_f2{kk.x, kk.y}, a01);
-                    a23 = __builtin_elementwise_fma(pd_f2{qq.z, qq.w}, pd_f2{kk.z, kk.w}, a23);
+                    a01 = __builtin_elementwise_fma(pd_f2{qq.x, qq.y}, pd_f2{kreg[i].x, kreg[i].y}, a01);
+                    a23 = __builtin_elementwise_fma(pd_f2{qq.z, qq.w}, pd_f2{kreg[i].z, kreg[i].w}, a23);
                 }
                 float a = (a01.x + a01.y) + (a23.x + a23.y);
                 a += pd_dpp<0xB1>(a); a += pd_dpp<0x4E>(a); a += pd_dpp<0x141>(a);      // the 8 lanes of a frame (row_half_mirror)
-                if (kp == 0 && kf < T) sc[b * 48 + kf] = a;
+                if (kp == 0 && kf < T) sc[kf] = a;
                 float c0a = 0.f, c1a = 0.f, c2a = 0.f, c3a = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 qq = *reinterpret_cast<const float4*>(qcs + b * 256 + 4 * (cp + 16 * i));
-                    c0a = fmaf(qq.x, ckreg[b][i].x, c0a); c1a = fmaf(qq.y, ckreg[b][i].y, c1a); c2a = fmaf(qq.z, ckreg[b][i].z, c2a); c3a = fmaf(qq.w, ckreg[b][i].w, c3a);
+                    const float4 qq = *reinterpret_cast<const float4*>(qcs + 4 * (cp + 16 * i));
+                    c0a = fmaf(qq.x, ckreg[i].x, c0a); c1a = fmaf(qq.y, ckreg[i].y, c1a); c2a = fmaf(qq.z, ckreg[i].z, c2a); c3a = fmaf(qq.w, ckreg[i].w, c3a);
                 }
                 float ca = (c0a + c1a) + (c2a + c3a);
                 ca += pd_dpp<0xB1>(ca); ca += pd_dpp<0x4E>(ca); ca += pd_dpp<0x124>(ca); ca += pd_dpp<0x128>(ca);      // the 16 lanes of a content frame
-                if (cp == 0 && cf < M) sc[b * 48 + 32 + cf] = ca;
+                if (cp == 0 && cf < M) sc[32 + cf] = ca;
             }
             __syncthreads();
             PD_STAMP(6);
-            if (o_role) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) ppre[b] = pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
-            }
-            // every wave: softmax of its role's logits (lane = frame), then its threads' two columns of a @ V' / alpha @ value (decoder.py:414-419, 262-271)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            if (o_role) ppre = pd_load16(rs, gP2 + xc);
+            {   // every wave: softmax of its role's logits (lane = frame), then its threads' two columns of a @ V' / alpha @ value (decoder.py:414-419, 262-271)
                 const int n = o_role ? T : M;
                 const bool on = lane < n;
-                const float x = on ? sc[b * 48 + (o_role ? 0 : 32) + lane] : -INFINITY;
+                const float x = on ? sc[(o_role ? 0 : 32) + lane] : -INFINITY;
                 const float mx = pd_wave_max(x);
                 const float ex = on ? expf(x - mx) : 0.f;
                 const float aw = ex * __frcp_rn(pd_wave_sum(ex));
-                if (wave == 2 && j == b && on && p.attn) p.attn[((int64_t)b * S + s) * T + lane] = p.attn_logits ? x : aw;
+                if (wave == 2 && jl == 0 && on && p.attn) p.attn[((int64_t)g * S + s) * T + lane] = p.attn_logits ? x : aw;
+                // the wave's weights through LDS (lanes past n hold 0, value rows past T / m are 0): four frames per trip, no per-frame predicate
+                if (lane < 32) aws[wave * 32 + lane] = aw;
+                __builtin_amdgcn_wave_barrier();
+                const int n4 = (n + 3) & ~3;
                 float ox = 0.f, oy = 0.f, ox2 = 0.f, oy2 = 0.f;
-                {
-                    // the wave's weights through LDS (lanes past n hold 0, value rows past T / m are 0): four frames per trip, no per-frame predicate
-                    if (lane < 32) aws[wave * 32 + lane] = aw;
-                    __builtin_amdgcn_wave_barrier();
-                    const float* vr = vrow + (int64_t)b * VR * 256;
-                    const int n4 = (n + 3) & ~3;
 #pragma unroll 2
-                    for (int f = 0; f < n4; f += 4) {
-                        const float4 w4 = *reinterpret_cast<const float4*>(aws + wave * 32 + f);
-                        const float2 v0 = *reinterpret_cast<const float2*>(vr + f * 256), v1 = *reinterpret_cast<const float2*>(vr + (f + 1) * 256);
-                        const float2 v2 = *reinterpret_cast<const float2*>(vr + (f + 2) * 256), v3 = *reinterpret_cast<const float2*>(vr + (f + 3) * 256);
-                        ox = fmaf(w4.x, v0.x, ox); oy = fmaf(w4.x, v0.y, oy); ox2 = fmaf(w4.y, v1.x, ox2); oy2 = fmaf(w4.y, v1.y, oy2);
-                        ox = fmaf(w4.z, v2.x, ox); oy = fmaf(w4.z, v2.y, oy); ox2 = fmaf(w4.w, v3.x, ox2); oy2 = fmaf(w4.w, v3.y, oy2);
-                    }
-                    __builtin_amdgcn_wave_barrier();         // (the next clip's weights overwrite aws)
+                for (int f = 0; f < n4; f += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(aws + wave * 32 + f);
+                    const float2 v0 = *reinterpret_cast<const float2*>(vrow + f * 256), v1 = *reinterpret_cast<const float2*>(vrow + (f + 1) * 256);
+                    const float2 v2 = *reinterpret_cast<const float2*>(vrow + (f + 2) * 256), v3 = *reinterpret_cast<const float2*>(vrow + (f + 3) * 256);
+                    ox = fmaf(w4.x, v0.x, ox); oy = fmaf(w4.x, v0.y, oy); ox2 = fmaf(w4.y, v1.x, ox2); oy2 = fmaf(w4.y, v1.y, oy2);
+                    ox = fmaf(w4.z, v2.x, ox); oy = fmaf(w4.z, v2.y, oy); ox2 = fmaf(w4.w, v3.x, ox2); oy2 = fmaf(w4.w, v3.y, oy2);
                 }
-                xin[b] = make_float2(ox + ox2, oy + oy2);
+                xin = make_float2(ox + ox2, oy + oy2);
             }
             PD_STAMP(7);
         }
@@ -467,100 +457,89 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             if (o_role) {                                    // u = prenet + o (decoder.py:421): waves 2, 3 need prenet2 - first what was requested ahead
                 bool first = true;
                 do {
-                    bool ok = true;
-                    float2 pp[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const uint4 a = first ? ppre[b] : pd_load16(rs, pd_off_p2(NB) + b * 256 + xc);
-                        ok &= a.y == tag_now && a.w == tag_now;
-                        pp[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
-                    }
+                    const uint4 a = first ? ppre : pd_load16(rs, gP2 + xc);
+                    const bool ok = a.y == tag_now && a.w == tag_now;
                     first = false;
                     if (poll.retry(ok)) continue;            // stale: go around again
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) { xin[b].x += pp[b].x; xin[b].y += pp[b].y; }
+                    xin.x += __uint_as_float(a.x); xin.y += __uint_as_float(a.z);
                     break;
                 } while (true);
             }
             if (poll.gave_up()) return;
             PD_STAMP(8);
-            float v[8 * NB];
+            float v[8 * V];
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < V; ++b)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl0i[c].y, xin[b].y, wl0i[c].x * xin[b].x);
-            PD_WSUM(v, 8 * NB, red + rpar * 4 * RS, RS);
+                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl0i[b][c].y, xin.y, wl0i[b][c].x * xin.x);
+            PD_WSUM(v, 8 * V, red + rpar * 4 * RS, RS);
             __syncthreads();
             PD_STAMP(9);
-            if (tid < 2 * NB) {
+            if (tid < 2 * V) {
                 const float* r = red + rpar * 4 * RS;
                 const float gi = PD_SUM4(r, RS, 8 * cb + 4 * cu + 0) + l0hh[0] + e_bl0[0], gf = PD_SUM4(r, RS, 8 * cb + 4 * cu + 1) + l0hh[1] + e_bl0[1];
                 const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l0hh[2] + e_bl0[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l0hh[3] + e_bl0[3];
                 c0 = pd_sigmoid(gf) * c0 + pd_sigmoid(gi) * pd_tanh(gg);
                 const float hn = pd_sigmoid(go) * pd_tanh(c0);
-                pd_publish<NB>(rsall, pd_off_h0(NB) + cb * 512 + 2 * j + cu, tag_now, hn);
-                pd_publish<NB>(rsall, pd_off_c0(NB) + cb * 512 + 2 * j + cu, tag_now, c0);
+                pd_publish<NG>(rsall, gH0 + 2 * cjv + cu, tag_now, hn);
+                pd_publish<NG>(rsall, gC0 + 2 * cjv + cu, tag_now, c0);
             }
             rpar ^= 1;
             PD_STAMP(10);
             // while h0' / c0' cross the chip: phase 1's deferred sums (valid since phase 2's first barrier) - the mel frame / stop logit of step s - 1
             // (decoder.py:423-428) and W_hh1 h1 for phase 4
-            if (s > 0 && tid < NB && j <= 80) {
+            if (s > 0 && tid < V && mjv <= 80) {
                 const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
-                if (j < 80) p.mel[((int64_t)tid * S + (s - 1)) * 80 + j] = x; else p.stop[(int64_t)tid * S + (s - 1)] = x + stopc;
+                if (mjv < 80) p.mel[((int64_t)g * S + (s - 1)) * 80 + mjv] = x; else p.stop[(int64_t)g * S + (s - 1)] = x + stopc;
             }
-            if (tid < 2 * NB) {
+            if (tid < 2 * V) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) l1hh[g] = PD_SUM4(redB, RD, 12 * cb + 4 * cu + g);
+                for (int q = 0; q < 4; ++q) l1hh[q] = PD_SUM4(redB, RD, 12 * cb + 4 * cu + q);
             }
         }
         // ------------------------------------------------------------ phase 4: layer-1 cells; the h0 / c0 parts of the next step
         {
-            float2 hx[NB], cx[NB];
+            float2 hx, cx;
             do {
-                bool ok = true;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const uint4 a = pd_load16(rs, pd_off_h0(NB) + b * 512 + 2 * tid), c = pd_load16(rs, pd_off_c0(NB) + b * 512 + 2 * tid);
-                    ok &= a.y == tag_now && a.w == tag_now && c.y == tag_now && c.w == tag_now;
-                    hx[b] = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
-                    cx[b] = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
-                }
+                const uint4 a = pd_load16(rs, gH0 + 2 * tid), c = pd_load16(rs, gC0 + 2 * tid);
+                const bool ok = a.y == tag_now && a.w == tag_now && c.y == tag_now && c.w == tag_now;
+                hx = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+                cx = make_float2(__uint_as_float(c.x), __uint_as_float(c.z));
                 if (!poll.retry(ok)) break;
             } while (true);
             if (poll.gave_up()) return;
             PD_STAMP(11);
-            float v[8 * NB];
+            float v[8 * V];
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < V; ++b)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl1i[c].y, hx[b].y, wl1i[c].x * hx[b].x);
-            PD_WSUM(v, 8 * NB, red + rpar * 4 * RS, RS);
+                for (int c = 0; c < 8; ++c) v[8 * b + c] = fmaf(wl1i[b][c].y, hx.y, wl1i[b][c].x * hx.x);
+            PD_WSUM(v, 8 * V, red + rpar * 4 * RS, RS);
             __syncthreads();
             PD_STAMP(12);
-            if (tid < 2 * NB) {
+            if (tid < 2 * V) {
                 const float* r = red + rpar * 4 * RS;
                 const float gi = PD_SUM4(r, RS, 8 * cb + 4 * cu + 0) + l1hh[0] + e_bl1[0], gf = PD_SUM4(r, RS, 8 * cb + 4 * cu + 1) + l1hh[1] + e_bl1[1];
                 const float gg = PD_SUM4(r, RS, 8 * cb + 4 * cu + 2) + l1hh[2] + e_bl1[2], go = PD_SUM4(r, RS, 8 * cb + 4 * cu + 3) + l1hh[3] + e_bl1[3];
                 c1 = pd_sigmoid(gf) * c1 + pd_sigmoid(gi) * pd_tanh(gg);
                 const float hn = pd_sigmoid(go) * pd_tanh(c1);
-                pd_publish<NB>(rsall, pd_off_h1(NB) + cb * 512 + 2 * j + cu, tag_now, hn);
-                pd_publish<NB>(rsall, pd_off_c1(NB) + cb * 512 + 2 * j + cu, tag_now, c1);
+                pd_publish<NG>(rsall, gH1 + 2 * cjv + cu, tag_now, hn);
+                pd_publish<NG>(rsall, gC1 + 2 * cjv + cu, tag_now, c1);
             }
             rpar ^= 1;
             PD_STAMP(13);
             {   // deferred, for the next step: W_hh0 h0' (phase 3) and the h0 / c0 parts of q0, q1, qc (phase 1)
-                float w[12 * NB];
+                float w[12 * V];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < V; ++b) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) w[12 * b + c] = fmaf(wl0h[c].y, hx[b].y, wl0h[c].x * hx[b].x);
-                    w[12 * b + 8] = fmaf(wq0[0].y, hx[b].y, wq0[0].x * hx[b].x);
-                    w[12 * b + 9] = fmaf(wq0[1].y, hx[b].y, wq0[1].x * hx[b].x);
-                    w[12 * b + 10] = fmaf(wcq0.y, cx[b].y, wcq0.x * cx[b].x);
+                    for (int c = 0; c < 8; ++c) w[12 * b + c] = fmaf(wl0h[b][c].y, hx.y, wl0h[b][c].x * hx.x);
+                    w[12 * b + 8] = fmaf(wq0[b][0].y, hx.y, wq0[b][0].x * hx.x);
+                    w[12 * b + 9] = fmaf(wq0[b][1].y, hx.y, wq0[b][1].x * hx.x);
+                    w[12 * b + 10] = fmaf(wcq0[b].y, cx.y, wcq0[b].x * cx.x);
                     w[12 * b + 11] = 0.f;
                 }
-                PD_WSUM(w, 12 * NB, redC, RD);
+                PD_WSUM(w, 12 * V, redC, RD);
             }
         }
     }
@@ -582,7 +561,7 @@ int64_t pdecode_ws_bytes(int B) {
     return (int64_t)pd_rstride(nb) * 8 * PD_MAXREP + 256;
 }
 bool pdecode_supported(int B, int T, int m) {
-    return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM && pd_lds_floats(B, T, m) * 4 <= PD_LDS_MAX;
+    return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM && pd_lds_floats(2, T, m) * 4 <= PD_LDS_MAX;
 }
 
 // every persistent launch needs all 256 workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
@@ -596,7 +575,7 @@ static int g_pd_ts_step = 0;
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
-    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames whose values (and second clip's keys) fit the LDS");
+    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames whose values fit the LDS");
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(p.B), "persistent decode: exchange buffer too small");
     int nb = 1; while (nb < p.B) nb *= 2;
     std::lock_guard<std::mutex> lock(g_pd_mu);
@@ -617,15 +596,18 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(p.B), s));      // tags and the status word start at zero EVERY call
     L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
     ProfScope ps("decode_persistent", s);
-    const int lds = std::max(pd_lds_floats(nb, p.T, p.m) * 4, PD_LDS_MIN);
+    const int lds = std::max(pd_lds_floats(2, p.T, p.m) * 4, PD_LDS_MIN);
     static bool attr_set = false;
     if (!attr_set) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
         attr_set = true;
     }
-    if (nb == 1) hipLaunchKernelGGL(pdecode_kernel<1>, dim3(PD_WG), dim3(PD_NT), lds, s, q);
-    else hipLaunchKernelGGL(pdecode_kernel<2>, dim3(PD_WG), dim3(PD_NT), lds, s, q);
+    // 128 workgroups per clip, each standing for two of the one-per-CU layout: one clip leaves half the chip idle and is FASTER for it (7.7 against
+    // 9.7 us per step on 256 workgroups: an edge among 128 workgroups costs ~1.2 us, among 256 ~1.8; 64 workgroups of four: 12.2, the weights no
+    // longer fit the registers)
+    if (nb == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2), dim3(PD_NT), lds, s, q);
+    else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG), dim3(PD_NT), lds, s, q);
     hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
     L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));

@@ -21,8 +21,10 @@ for st in ([step] if S > step else [S // 2]):
     nm.decode_steps(state, B, T, S); torch.cuda.synchronize()
     native.check(L.l2s_op_pdecode_timeline(None, 0))
     t = ts.cpu().numpy().reshape(256, 16)[:, :14].astype(np.float64) * 0.01
+    t = t[t[:, 13] > 0]                                   # the workgroups of this launch (128 or 256)
+    print(f"{len(t)} workgroups")
     t -= t[:, 0].min()
-    print(f"persistent decode loop, B={B}, T={T}, S={S}: step {st}, us since the first workgroup entered the step (thread 0 of each of the 256 workgroups)")
+    print(f"persistent decode loop, B={B}, T={T}, S={S}: step {st}, us since the first workgroup entered the step (thread 0 of every workgroup)")
     print(f"{'stamp':22s} {'min':>7s} {'median':>7s} {'max':>7s}")
     for i, n in enumerate(names): print(f"{n:22s} {t[:, i].min():7.2f} {np.median(t[:, i]):7.2f} {t[:, i].max():7.2f}")
     d = np.diff(t, axis=1)
