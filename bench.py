@@ -495,9 +495,9 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
         finally:
-            nm.set_option("persist_decode", 2)
+            nm.set_option("persist_decode", 4)
         return sorted(ts[3:])[3] * 1e3
-    lat = {nb: (latency_ms(nb, 2), latency_ms(nb, 0)) for nb in (2, 1)} if world == 1 else None
+    lat = {nb: (latency_ms(nb, 4), latency_ms(nb, 0)) for nb in (2, 1)} if world == 1 else None
     train = train_leg() if (world == 1 and not args.skip_train_leg) else None
 
     if rank == 0:

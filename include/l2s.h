@@ -389,10 +389,10 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "train_bf16"        (0)  TRAINING entry points (encoder, prologue, post-net; forward and backward): GEMMs / Conv1d stacks round their operands to
  *                            bf16 (RNE) on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 results; the
  *                            recurrent loop, the Conv3d front-end, BatchNorm statistics, master weights and optimizer stay fp32
- *   "persist_decode"    (2)  the free-running decode loop (decoder.py:412-435) of a single-batch call with at most this many clips - 1 or 2, clips of
+ *   "persist_decode"    (4)  the free-running decode loop (decoder.py:412-435) of a single-batch call with at most this many clips - up to 4, clips of
  *                            <= 32 frames (demo.py runs one clip, BASELINE config 1 two) - as ONE persistent launch of 128 resident workgroups per clip that keep the
  *                            step weights in registers and exchange h / c / q / prenet as tagged 8-byte granules (pdecode.hip): 7.7 instead of 20.4 us per step at
- *                            one clip, 8.2 at two.  Another order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference); such
+ *                            one clip, 8.2 at two; three or four clips run as two such launches one after the other (l2s_inference 6.1 / 6.2 ms against 7.4).  Another order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference); such
  *                            launches are chained one after the other in a process (each needs the whole chip resident), a launch that cannot make
  *                            progress for 2 s gives up and poisons its outputs with NaN.  0 = always four launches per step; l2s_*_multi never uses it
  *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane (frames rounded to nearest even

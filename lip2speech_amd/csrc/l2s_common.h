@@ -70,9 +70,9 @@ struct Options {
     int frontend_x3 = 2;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel); 2 (default below): its
                                 //   two-output-frames-per-block form (frontend3d_x3p_kernel)
     int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
-    int persist = 2;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: 1 or 2 clips of
-                                //   <= 32 frames) as ONE persistent weight-stationary launch instead of four launches per step; 0 = never.  A latency form: one
-                                //   call owns the chip, such launches are chained one after the other; grouped calls (l2s_*_multi) never take it
+    int persist = 4;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: up to 4 clips
+                                //   of <= 32 frames, two per launch) as persistent weight-stationary launches instead of four launches per step; 0 = never.  A
+                                //   latency form: one call owns the chip, such launches are chained one after the other; grouped calls (l2s_*_multi) never take it
     int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
                                 //   voice tower with bf16 operands (fp32 accumulation); the recurrent loops, the fused ShuffleNet units and all statistics stay fp32
 };

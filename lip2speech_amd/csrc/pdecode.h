@@ -24,11 +24,12 @@ struct PDecP {
     u64* xch;                             // exchange granules (zeroed before the launch)
     unsigned* status;                     // [0]: set to 1 by a workgroup whose poll timed out (every workgroup then leaves)
     int attn_logits, B, T, m, S;
+    int b0;                               // set by launch_pdecode: first clip of THIS launch (clips go two at a time)
     unsigned long long* ts; int ts_step;  // measurement (tools/pdecode_timeline.py): [256 workgroups][16] stamps of step ts_step, or null
 };
 
 int64_t pdecode_ws_bytes(int B);                       // exchange granules + status word
-bool pdecode_supported(int B, int T, int m);            // <= 8 clips of <= 32 frames
+bool pdecode_supported(int B, int T, int m);            // <= 4 clips of <= 32 frames
 void pdecode_set_timeline(unsigned long long* ts, int step);      // non-null: thread 0 of every workgroup stamps the phases of that step
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s);      // xch / status are carved from ws
 

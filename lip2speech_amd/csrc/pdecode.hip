@@ -26,7 +26,7 @@ namespace l2s {
 
 constexpr int PD_WG = 256;                // workgroups = CUs
 constexpr int PD_NT = 256;                // threads per workgroup
-constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 2;
+constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 4;
 constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the 256 workgroups sit one per CU
 constexpr int PD_LDS_MAX = 159 * 1024;      // dynamic part
 // LDS of a workgroup, in floats: the fixed part, then its clip's projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
 
     constexpr int WPG = PD_WG / V;                          // workgroups per clip (the launch has NG * WPG of them)
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int g = j / WPG, jl = j - g * WPG;                // this workgroup's clip, its index among the clip's workgroups
+    const int g = j / WPG, jl = j - g * WPG;                // this workgroup's clip (of the launch's NG), its index among the clip's workgroups
+    const int gc = p.b0 + g;                                // ... the clip's row in the caller's batch
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, M = p.m, S = p.S;
     u64* const X = p.xch;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { e_bl0[q] = p.bl0[8 * cjv + 4 * cu + q]; e_bl1[q] = p.bl1[8 * cjv + 4 * cu + q]; }
     float c0 = 0.f, c1 = 0.f;                               // cell states of the cell threads (decoder.py:406: zeros)
-    const float stopc = p.stop_const[g];
+    const float stopc = p.stop_const[gc];
 
     // ---------------------------------------------------------------- the clip's keys / content keys into registers, its values into LDS
     const int kf = tid >> 3, kp = tid & 7;                  // attention logits: 8 threads per frame, 64 k each (k = 4 kp + 32 i + e)
@@ -244,14 +245,14 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     const float* const vrow = vs + (o_role ? 0 : T4 * 256) + xc;      // this thread's pair of columns in LDS, row pitch 256
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        kreg[i] = kf < T ? *reinterpret_cast<const float4*>(p.k + ((int64_t)g * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kreg[i] = kf < T ? *reinterpret_cast<const float4*>(p.k + ((int64_t)gc * T + kf) * 512 + 4 * kp + 32 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        ckreg[i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)g * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ckreg[i] = cf < M ? *reinterpret_cast<const float4*>(p.ckey + ((int64_t)gc * M + cf) * 256 + 4 * (cp + 16 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < T4 * 64; i += PD_NT)
-        *reinterpret_cast<float4*>(vs + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + (int64_t)g * T * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(vs + 4 * i) = i < T * 64 ? *reinterpret_cast<const float4*>(p.vp + (int64_t)gc * T * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < M4 * 64; i += PD_NT)
-        *reinterpret_cast<float4*>(vs + T4 * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + (int64_t)g * M * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(vs + T4 * 256 + 4 * i) = i < M * 64 ? *reinterpret_cast<const float4*>(p.cval + (int64_t)gc * M * 256 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
     // prenet1 of the BOS frame (step 0 has no previous h1; decoder.py:407,413): the finisher's column (fk = 3 uses it)
     float p1_bos;
     {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
     float l0hh[4] = {0.f, 0.f, 0.f, 0.f}, l1hh[4] = {0.f, 0.f, 0.f, 0.f};      // cell threads: W_hh0 h0 / W_hh1 h1 of their four gates
     {
         const int64_t hb = (int64_t)((p.B + 15) & ~15) * 512;
-        const float2 h = *reinterpret_cast<const float2*>(p.h_init + frag16_index(g, 2 * tid, 512));
+        const float2 h = *reinterpret_cast<const float2*>(p.h_init + frag16_index(gc, 2 * tid, 512));
         float v[12 * V];
 #pragma unroll
         for (int b = 0; b < V; ++b) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
         PD_WSUM(v, 12 * V, redC, RD);
         if (tid < 2 * V) {
             const int unit = 2 * cjv + cu;
-            pd_publish<NG>(rsall, gH1 + unit, 1u, p.h_init[hb + frag16_index(g, unit, 512)]);
+            pd_publish<NG>(rsall, gH1 + unit, 1u, p.h_init[hb + frag16_index(gc, unit, 512)]);
             pd_publish<NG>(rsall, gC1 + unit, 1u, 0.f);
         }
         __syncthreads();
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             __syncthreads();
             if (tid < V && mjv <= 80) {
                 const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
-                if (mjv < 80) p.mel[((int64_t)g * S + (S - 1)) * 80 + mjv] = x; else p.stop[(int64_t)g * S + (S - 1)] = x + stopc;
+                if (mjv < 80) p.mel[((int64_t)gc * S + (S - 1)) * 80 + mjv] = x; else p.stop[(int64_t)gc * S + (S - 1)] = x + stopc;
             }
             break;
         }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
                 const float mx = pd_wave_max(x);
                 const float ex = on ? expf(x - mx) : 0.f;
                 const float aw = ex * __frcp_rn(pd_wave_sum(ex));
-                if (wave == 2 && jl == 0 && on && p.attn) p.attn[((int64_t)g * S + s) * T + lane] = p.attn_logits ? x : aw;
+                if (wave == 2 && jl == 0 && on && p.attn) p.attn[((int64_t)gc * S + s) * T + lane] = p.attn_logits ? x : aw;
                 // the wave's weights through LDS (lanes past n hold 0, value rows past T / m are 0): four frames per trip, no per-frame predicate
                 if (lane < 32) aws[wave * 32 + lane] = aw;
                 __builtin_amdgcn_wave_barrier();
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
             // (decoder.py:423-428) and W_hh1 h1 for phase 4
             if (s > 0 && tid < V && mjv <= 80) {
                 const float x = PD_SUM4(redB, RD, 12 * tid + 8) + e_bfc;
-                if (mjv < 80) p.mel[((int64_t)g * S + (s - 1)) * 80 + mjv] = x; else p.stop[(int64_t)g * S + (s - 1)] = x + stopc;
+                if (mjv < 80) p.mel[((int64_t)gc * S + (s - 1)) * 80 + mjv] = x; else p.stop[(int64_t)gc * S + (s - 1)] = x + stopc;
             }
             if (tid < 2 * V) {
 #pragma unroll
@@ -556,10 +557,7 @@ __global__ void pdecode_guard_kernel(const unsigned* status, float* mel, float* 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_stop; i += gridDim.x * blockDim.x) stop[i] = nan;
 }
 
-int64_t pdecode_ws_bytes(int B) {
-    int nb = 1; while (nb < B) nb *= 2;
-    return (int64_t)pd_rstride(nb) * 8 * PD_MAXREP + 256;
-}
+int64_t pdecode_ws_bytes(int) { return (int64_t)pd_rstride(2) * 8 * PD_MAXREP + 256; }      // laid out for two clips per launch
 bool pdecode_supported(int B, int T, int m) {
     return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM && pd_lds_floats(2, T, m) * 4 <= PD_LDS_MAX;
 }
@@ -575,9 +573,8 @@ static int g_pd_ts_step = 0;
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
-    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 2 clips of <= 32 frames whose values fit the LDS");
-    L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(p.B), "persistent decode: exchange buffer too small");
-    int nb = 1; while (nb < p.B) nb *= 2;
+    L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 4 clips of <= 32 frames whose values fit the LDS");
+    L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(2), "persistent decode: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
     if (g_pd_cus < 0) {
         int dev = 0; hipDeviceProp_t prop;
@@ -588,14 +585,6 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
     }
     L2S_REQUIRE(g_pd_cus >= PD_WG, "persistent decode needs 256 compute units (one resident workgroup each)");
-    PDecP q = p;
-    q.xch = reinterpret_cast<u64*>(ws);
-    q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pd_rstride(nb) * 8 * PD_MAXREP);
-
-    q.ts = g_pd_ts; q.ts_step = g_pd_ts_step;
-    L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(p.B), s));      // tags and the status word start at zero EVERY call
-    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
-    ProfScope ps("decode_persistent", s);
     const int lds = std::max(pd_lds_floats(2, p.T, p.m) * 4, PD_LDS_MIN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -603,13 +592,25 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
         attr_set = true;
     }
-    // 128 workgroups per clip, each standing for two of the one-per-CU layout: one clip leaves half the chip idle and is FASTER for it (7.7 against
-    // 9.7 us per step on 256 workgroups: an edge among 128 workgroups costs ~1.2 us, among 256 ~1.8; 64 workgroups of four: 12.2, the weights no
-    // longer fit the registers)
-    if (nb == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2), dim3(PD_NT), lds, s, q);
-    else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG), dim3(PD_NT), lds, s, q);
-    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
-    L2S_CHECK_HIP(hipGetLastError());
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
+    ProfScope ps("decode_persistent", s);
+    // clips two at a time (three or four clips: two launches one after the other - still shorter than 300 x four launches)
+    for (int b0 = 0; b0 < p.B; b0 += 2) {
+        const int n = p.B - b0 >= 2 ? 2 : 1;
+        PDecP q = p;
+        q.b0 = b0;
+        q.xch = reinterpret_cast<u64*>(ws);
+        q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pd_rstride(2) * 8 * PD_MAXREP);
+        q.ts = g_pd_ts; q.ts_step = g_pd_ts_step;
+        L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pdecode_ws_bytes(2), s));      // tags and the status word start at zero EVERY launch
+        // 128 workgroups per clip, each standing for two of the one-per-CU layout: one clip leaves half the chip idle and is FASTER for it (7.7 against
+        // 9.7 us per step on 256 workgroups: an edge among 128 workgroups costs ~1.2 us, among 256 ~1.8; 64 workgroups of four: 12.2, the weights no
+        // longer fit the registers)
+        if (n == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2), dim3(PD_NT), lds, s, q);
+        else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG), dim3(PD_NT), lds, s, q);
+        hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
+        L2S_CHECK_HIP(hipGetLastError());
+    }
     L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
     return 0;
 }

@@ -28,7 +28,7 @@ def synth_sd():
 @pytest.fixture(scope="session", autouse=True)
 def _launch_path_by_default():
     """The suite pins the launch-per-phase decode loop unless a test asks otherwise: models created here start with "persist_decode" = 0 (the library's
-    default is 2: one or two clips take the persistent loop of pdecode.hip, which has its own tests, test_persistent_decode_*, on models that switch it on)."""
+    default is 4: up to four clips take the persistent loop of pdecode.hip, which has its own tests, test_persistent_decode_*, on models that switch it on)."""
     try:
         from lip2speech_amd import native
         native.set_option("persist_decode", 0)
