@@ -394,7 +394,7 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            step weights in registers and exchange h / c / q / prenet as tagged 8-byte granules (pdecode.hip): 7.7 instead of 20.4 us per step at
  *                            one clip, 8.2 at two; three or four clips run as two such launches one after the other (l2s_inference 6.1 / 6.2 ms against 7.4).  Another order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference); such
  *                            launches are chained one after the other in a process (each needs the whole chip resident), a launch that cannot make
- *                            progress for 2 s gives up and poisons its outputs with NaN.  0 = always four launches per step; l2s_*_multi never uses it
+ *                            progress for about a minute gives up and poisons its outputs with NaN.  0 = always four launches per step; l2s_*_multi never uses it
  *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane (frames rounded to nearest even
  *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
  *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every

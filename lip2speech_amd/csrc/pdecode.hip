@@ -122,10 +122,10 @@ __device__ __forceinline__ void pd_publish(__amdgpu_buffer_rsrc_t rsall, int gra
 }
 
 // One poll pass = every load of the phase issued, then every tag compared; repeated until the whole WAVE has fresh granules, so the wave stays
-// converged for the DPP reductions that follow.  A wave that has gone around PD_SPIN_LIMIT times (seconds) raises status[0] and leaves, and so, each on its
+// converged for the DPP reductions that follow.  A wave that has gone around PD_SPIN_LIMIT times (a minute or more) raises status[0] and leaves, and so, each on its
 // own count, does every other wave that waits for it.  (Two passes in flight half a round trip apart - register sets taking turns, one exit branch so that
 // the compiler waits for the older pass alone - were measured: 9.6-10.0 against 9.7 us per step; more polling is more contention, not a shorter edge.)
-constexpr unsigned PD_SPIN_LIMIT = 3000000u;
+constexpr unsigned PD_SPIN_LIMIT = 200000000u;      // >= a minute of polling: the loop cannot deadlock on its own (other streams' kernels only delay residency)
 struct PdPoll {
     unsigned* status; unsigned spins; bool dead;
     __device__ __forceinline__ PdPoll(unsigned* st) : status(st), spins(0), dead(false) {}
