@@ -555,8 +555,10 @@ __device__ __forceinline__ void skx_split8(const float4& a, const float4& b, skx
 // {4u + g} (four rows per half, their low column bits made distinct by the XOR) - neither side shares a bank.  The [16][17] layout cost every
 // write and every gate read a second LDS cycle (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the LSTM launches).
 __device__ __forceinline__ int sk_red_idx(int slot, int row, int col) { return slot * 256 + ((row ^ ((row >> 2) & 1)) << 4) + (col ^ ((row >> 1) & 3)); }
-template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false>
-__device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr) {
+template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false, bool TRAIN = false>
+__device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr,
+                                                 const SkinnyTrain* tr = nullptr) {
+    static_assert(!TRAIN || IS_LSTM, "the training stores of this form: the LSTM cell's tape (gates, new cell, dropped-out hidden state)");
     static_assert(NW == 8 || NW == 4, "eight waves, or four that each play two");
     static_assert(!X3 || (IS_LSTM && (LAY::NC / SK_WAVES) % 2 == 0), "the split-bf16 form: LSTM blocks, whole chunk pairs per slice");
     constexpr int VW = SK_WAVES / NW, NH = NW / 4;       // K slices per real wave; 256-thread epilogue teams
@@ -814,6 +816,14 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         p.h_out[frag16_index(b2, p.h_out_off + unit2, p.h_out_K)] = hn;
         if (p.h_seq) p.h_seq[(int64_t)b2 * p.ld_hseq + unit2] = hn;
         if (p.h_plain) p.h_plain[(int64_t)b2 * p.ld_hplain + unit2] = hn;
+        if constexpr (TRAIN) {      // the tape of the cell, the expressions of skinny_block<TRAIN>: same bits
+            if (tr->gates) {
+                float* gs = tr->gates + (int64_t)b2 * tr->ld_gates + unit2;
+                gs[0] = sigmoidf_(gi); gs[H] = sigmoidf_(gf); gs[2 * H] = tanhf(gg); gs[3 * H] = sigmoidf_(go);
+            }
+            if (tr->c_new) tr->c_new[(int64_t)b2 * tr->ld_c + unit2] = cn;
+            if (tr->h_drop) tr->h_drop[frag16_index(b2, unit2, tr->h_drop_K)] = tr->h_mask ? hn * tr->h_mask[(int64_t)b2 * tr->ld_hmask + unit2] : hn;
+        }
     }
     if constexpr (TIMED) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     L2S_STAMP(7);

@@ -286,6 +286,7 @@ static int postnet_train_bwd(l2s_model* m, const float* mel, const float* dmel_p
 // Stage 2: the autoregressive loop (decoder.py:353-375) - forward with a tape, then back-propagation through time.
 // =====================================================================================================================
 #include "skinny_dev.h"
+#include <cstdlib>
 namespace l2s {
 
 constexpr int TR_MAXC = 16;      // K <= 2048 for the backward products with the LSTM gate gradients
@@ -297,7 +298,35 @@ __global__ __launch_bounds__(512) void train_skinny_kernel(const SkinnyBatch bat
     const int g = blockIdx.z;
     skinny_block<true, TR_MAXC>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], &tb.t[g]);
 }
+// the forward LSTM cells on the inference path's four-wave straight-line blocks (one wave per SIMD, compile-time K layout, exact waits, buffer loads;
+// skinny_block_rcs<.., NW = 4, TRAIN>): per output element the arithmetic of the eight-wave general block, operation for operation - the same bits -
+// for the launch's two K layouts: [cc | p2 | a@v | h0] (K = 1536, phase-merged layer 0) and [h0' | h1] (K = 1024, layer 1)
+template <class LAY>
+__global__ __launch_bounds__(256, 1) void train_lstm_rc4_kernel(const SkinnyBatch batch, const TrainSkinnyBatch tb, int mts) {
+    __shared__ float red[SkRc<1, 1>::RED_FLOATS];
+    skinny_block_rcs<1, 1, LAY, 4, true, false, 4, false, true>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, nullptr, &tb.t[0]);
+}
 static int launch_train_skinny(const SkinnyBatch& b, const TrainSkinnyBatch& tb, hipStream_t s, const char* name) {
+    static const bool rc4 = !(getenv("L2S_TRAIN_RC4") && getenv("L2S_TRAIN_RC4")[0] == '0');      // L2S_TRAIN_RC4=0: the general eight-wave block (A/B)
+    if (rc4 && b.count == 1 && b.p[0].epi == SK_LSTM && !b.p[0].a_sum && !b.p[0].pre) {
+        const SkinnyP& p = b.p[0];
+        const int n0 = p.seg[0].nchunks, n1 = p.nseg > 1 ? p.seg[1].nchunks : 0, n2 = p.nseg > 2 ? p.seg[2].nchunks : 0, n3 = p.nseg > 3 ? p.seg[3].nchunks : 0;
+        const int mts1 = (p.B + 15) / 16;
+        SkinnyBatch bl = b;
+        for (int j = bl.p[0].nseg; j < 4; ++j) { bl.p[0].seg[j].nchunks = 0; bl.p[0].seg[j].a = bl.p[0].seg[0].a; }
+        if (n0 == 16 && n1 == 16 && n2 == 32 && n3 == 32) {
+            ProfScope ps(name, s);
+            hipLaunchKernelGGL((train_lstm_rc4_kernel<SegLay<16, 16, 32, 32>>), dim3(b.ntiles[0], mts1, 1), dim3(256), 0, s, bl, tb, mts1);
+            L2S_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+        if (n0 == 32 && n1 == 32 && n2 == 0 && n3 == 0) {
+            ProfScope ps(name, s);
+            hipLaunchKernelGGL((train_lstm_rc4_kernel<SegLay<32, 32, 0, 0>>), dim3(b.ntiles[0], mts1, 1), dim3(256), 0, s, bl, tb, mts1);
+            L2S_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     int maxt = 0, mts = 0;
     for (int i = 0; i < b.count; ++i) {
         const SkinnyP& p = b.p[i];
