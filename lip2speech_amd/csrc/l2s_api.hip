@@ -921,7 +921,8 @@ static int64_t prologue_ws_floats(int B, int T) {
     n += 8 * std::max((int64_t)B * m * 256, (int64_t)B * 512);   // split-K partial products
     for (int j = 1; j < 4; ++j) n += (int64_t)CT_KS[j] * B * L[j] * 512;   // per-tap partial products of Content.agg
     n += 8 * BT * 512;                                                      // split-K partial products of the two MultiHop bottlenecks
-    return n + 64 * 43;
+    if (B <= 2) n += pbilstm_ws_bytes() / 4 + 64;                           // exchange granules of the persistent BiLSTM
+    return n + 64 * 44;
 }
 static int64_t decode_ws_floats(int B) {
     int64_t Bp = pad16(B);
@@ -1066,6 +1067,9 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     for (int j = 1; j < 4; ++j) tap_floats += (int64_t)CT_KS[j] * B * L[j] * 512;
     float* tap_part = bp.f(tap_floats);
     float* bott_part = bp.f((int64_t)8 * BT * 512);
+    // one or two clips of a single-batch call: the BiLSTM recurrence as ONE persistent launch (pdecode.hip pbilstm_kernel; option "persist_decode")
+    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1 && pbilstm_supported(B, T) && pdecode_supported(B, T, mT);      // the envelope of the latency path
+    float* pbx = pbi ? bp.f(pbilstm_ws_bytes() / 4 + 64) : nullptr;
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
     // residual_bottleneck, site embeddings
@@ -1088,6 +1092,11 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
         if (m->opt.gemm_x3_dma) p.W3 = w.wih_cat3;
         if (launch_gemm1(p, s, "bilstm_input_gemm")) return 1;
     }
+    if (pbi) {
+        PBiP q{};
+        q.Whh0 = w.whh[0].W; q.Whh1 = w.whh[1].W; q.gin = gin; q.s_e = s_e; q.rnn = rnn; q.h_state = state + sl.h; q.cellcat = cellcat; q.B = B; q.T = T;
+        if (launch_pbilstm(q, pbx, pbilstm_ws_bytes(), s)) return 1;
+    } else {
     // recurrence: h0 = c0 = s_e for both directions (decoder.py:386-389)
     for (int d = 0; d < 2; ++d) {
         if (launch_to_frag(s_e, 512, B, 512, hf[d][0], 512, 0, 0, s)) return 1;
@@ -1118,6 +1127,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     // encoder_cell = E_C(cat(c_fwd, c_bwd))
     if (launch_from_frag(cf[0], 512, B, 512, cellcat, 1024, 0, s)) return 1;
     if (launch_from_frag(cf[1], 512, B, 512, cellcat, 1024, 512, s)) return 1;
+    }
     {
         GemmP p = gemm_plain(cellcat, 1024, w.e_c.W, state + sl.ecell, 512, B, 512, 1024);
         p.shift = w.e_c.shift;

@@ -28,6 +28,20 @@ struct PDecP {
     unsigned long long* ts; int ts_step;  // measurement (tools/pdecode_timeline.py): [256 workgroups][16] stamps of step ts_step, or null
 };
 
+// the prologue's BiLSTM recurrence in the same form (pbilstm_kernel)
+struct PBiP {
+    const float *Whh0, *Whh1;             // recurrent weights of the two directions, frag16 [2048][512], rows (unit, gate)
+    const float *gin;                     // [B][T][4096] input gates W_ih x + b_ih + b_hh: [direction][gate][unit]
+    const float *s_e;                     // [B][512] h0 = c0
+    float *rnn;                           // [B][T][1024] out: [forward | backward]
+    float *h_state;                       // frag16 [2][pad16(B)][512] out: final h (forward, backward)
+    float *cellcat;                       // [B][1024] out: final c (forward | backward)
+    u64* xch; unsigned* status;           // set by launch_pbilstm
+    int B, T;
+};
+int64_t pbilstm_ws_bytes();
+bool pbilstm_supported(int B, int T);                   // one or two clips
+int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s);
 int64_t pdecode_ws_bytes(int B);                       // exchange granules + status word
 bool pdecode_supported(int B, int T, int m);            // <= 4 clips of <= 32 frames
 void pdecode_set_timeline(unsigned long long* ts, int step);      // non-null: thread 0 of every workgroup stamps the phases of that step

@@ -18,6 +18,7 @@
 #include "l2s_common.h"
 #include "l2s_model.h"
 #include "pdecode.h"
+#include "skinny_dev.h"
 
 #include <algorithm>
 #include <mutex>
@@ -549,6 +550,90 @@ __global__ __launch_bounds__(PD_NT, 1) void pdecode_kernel(const PDecP p) {
 #undef PD_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------------
+// The decoder prologue's BiLSTM recurrence (decoder.py:386-389) of one or two clips in the same form: T dependent steps of one 2048 x 512 product per
+// direction were T launches at 6.9 us (+ ten launches of layout glue around them).  The chip is split between the 2 NB (direction, clip) pairs, 256 / (2 NB)
+// workgroups each; a workgroup owns 4 NB hidden units of its direction (16 NB gate columns, k = 2t, 2t + 1 per thread: 32 NB weight registers); h crosses the
+// group as tagged granules (ping-pong by step parity: a step reads and rewrites it), the input gates W_ih x + b come from the prologue's GEMM, the cell
+// state stays in the cell threads.  Outputs as the launch path leaves them: rnn_out (B, T, 1024), the final h of both directions as the decoder's initial
+// hidden state (frag16), the final c side by side for E_C.
+// ------------------------------------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int pb_granules(int NB) { return 2 * NB * 2 * 512; }      // [pair][parity][512]
+__host__ __device__ constexpr int pb_rstride(int NB) { return pb_granules(NB) + 520; }
+template <int NB>
+__global__ __launch_bounds__(PD_NT, 1) void pbilstm_kernel(const PBiP p) {
+    constexpr int NP = 2 * NB, WPG = PD_WG / NP, U = 512 / WPG, C = 4 * U;      // pairs, workgroups per pair, hidden units and gate columns per workgroup
+    __shared__ float red[2][4][C];
+    __shared__ float pad[PD_LDS_MIN / 4];                    // one workgroup per CU
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr = j / WPG, jl = j - pr * WPG, d = pr & 1, b = pr >> 1;      // this workgroup's (direction, clip), its index in the group
+    const int T = p.T;
+    if (tid == 0) pad[0] = 0.f;
+    u64* const X = p.xch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (int64_t)(j % PD_MAXREP) * pb_rstride(NB), 0, pb_granules(NB) * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsall = __builtin_amdgcn_make_buffer_rsrc(X, 0, PD_MAXREP * pb_rstride(NB) * 8, 0x00020000);
+    PdPoll poll(p.status);
+    const float* const Wd = d == 0 ? p.Whh0 : p.Whh1;
+    float2 w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = pd_w2(Wd, 32, C * jl + c, 2 * tid);      // packed rows are (unit, gate): a workgroup's units are C adjacent rows
+    const int cu = tid;                                      // cell thread (tid < U): unit U jl + cu
+    const int unit = U * jl + (cu < U ? cu : U - 1);
+    float cst = p.s_e[(int64_t)b * 512 + unit];              // h0 = c0 = the encoder-site embedding (decoder.py:386)
+    auto publish = [&](int par, unsigned tag, float v) {
+        pd_u2 x; x.x = __float_as_uint(v); x.y = tag;
+#pragma unroll
+        for (int r = 0; r < PD_MAXREP; ++r) __builtin_amdgcn_raw_buffer_store_b64(x, rsall, ((pr * 2 + par) * 512 + unit) * 8, r * pb_rstride(NB) * 8, 16);
+    };
+    if (tid < U) publish(0, 1u, cst);
+    int rpar = 0;
+    float hlast = cst;
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        // this step's input gates (bias folded in by the GEMM), requested before the poll
+        float pre[4];
+        if (tid < U) {
+            const float* g = p.gin + ((int64_t)b * T + t) * 4096 + d * 2048 + unit;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = g[q * 512];
+        }
+        float2 h;
+        do {
+            const uint4 a = pd_load16(rs, (pr * 2 + (s & 1)) * 512 + 2 * tid);
+            const bool ok = a.y == (unsigned)s + 1u && a.w == (unsigned)s + 1u;
+            h = make_float2(__uint_as_float(a.x), __uint_as_float(a.z));
+            if (!poll.retry(ok)) break;
+        } while (true);
+        if (poll.gave_up()) return;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = fmaf(w[c].y, h.y, w[c].x * h.x);
+        pd_wave_sum_multi<C>(v, lane);
+        if (lane < 4) {
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) red[rpar][wave][4 * i + lane] = v[i];
+        }
+        __syncthreads();
+        if (tid < U) {
+            float gsum[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gsum[q] = ((red[rpar][0][4 * cu + q] + red[rpar][1][4 * cu + q]) + (red[rpar][2][4 * cu + q] + red[rpar][3][4 * cu + q])) + pre[q];
+            cst = sigmoidf_(gsum[1]) * cst + sigmoidf_(gsum[0]) * tanhf(gsum[2]);
+            hlast = sigmoidf_(gsum[3]) * tanhf(cst);
+            publish((s + 1) & 1, (unsigned)s + 2u, hlast);
+            p.rnn[((int64_t)b * T + t) * 1024 + d * 512 + unit] = hlast;
+        }
+        rpar ^= 1;
+    }
+    if (tid < U) {      // finals: forward -> decoder layer 0, backward -> layer 1 (decoder.py:398-399); cells side by side for E_C
+        p.h_state[(int64_t)d * ((p.B + 15) & ~15) * 512 + frag16_index(b, unit, 512)] = hlast;
+        p.cellcat[(int64_t)b * 1024 + d * 512 + unit] = cst;
+    }
+}
+
+int64_t pbilstm_ws_bytes() { return (int64_t)pb_rstride(2) * 8 * PD_MAXREP + 256; }
+bool pbilstm_supported(int B, int T) { return B >= 1 && B <= 2 && T >= 1 && T <= 300; }
 // a launch whose workgroups gave up (a poll without progress for 2 s: the chip was not theirs) must not hand back plausible numbers
 __global__ void pdecode_guard_kernel(const unsigned* status, float* mel, float* stop, int n_mel, int n_stop) {
     if (__hip_atomic_load(status, PD_RLX) == 0u) return;
@@ -611,6 +696,35 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
         L2S_CHECK_HIP(hipGetLastError());
     }
+    L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    return 0;
+}
+
+int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
+    L2S_REQUIRE(pbilstm_supported(p.B, p.T), "persistent BiLSTM: one or two clips");
+    L2S_REQUIRE(ws && ws_bytes >= pbilstm_ws_bytes(), "persistent BiLSTM: exchange buffer too small");
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    if (g_pd_cus < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        L2S_CHECK_HIP(hipGetDevice(&dev));
+        L2S_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_pd_cus = prop.multiProcessorCount;
+        L2S_CHECK_HIP(hipEventCreateWithFlags(&g_pd_ev, hipEventDisableTiming));
+        L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    }
+    L2S_REQUIRE(g_pd_cus >= PD_WG, "persistent BiLSTM needs 256 compute units (one resident workgroup each)");
+    PBiP q = p;
+    q.xch = reinterpret_cast<u64*>(ws);
+    q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pb_rstride(2) * 8 * PD_MAXREP);
+    L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pbilstm_ws_bytes(), s));
+    // the frag16 state rows past B stay zero, as the launch path leaves them
+    L2S_CHECK_HIP(hipMemsetAsync(q.h_state, 0, sizeof(float) * 2 * ((p.B + 15) & ~15) * 512, s));
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
+    ProfScope ps("bilstm_persistent", s);
+    if (p.B == 1) hipLaunchKernelGGL(pbilstm_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    else hipLaunchKernelGGL(pbilstm_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
+    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, p.B * p.T * 1024, p.B * 1024);
+    L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
     return 0;
 }
