@@ -1068,7 +1068,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     float* tap_part = bp.f(tap_floats);
     float* bott_part = bp.f((int64_t)8 * BT * 512);
     // one or two clips of a single-batch call: the BiLSTM recurrence as ONE persistent launch (pdecode.hip pbilstm_kernel; option "persist_decode")
-    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1 && pbilstm_supported(B, T) && pdecode_supported(B, T, mT);      // the envelope of the latency path
+    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1 && pbilstm_supported(B, T) && pdecode_supported(B, T, mT) && pdecode_device_ok();      // the envelope of the latency path
     float* pbx = pbi ? bp.f(pbilstm_ws_bytes() / 4 + 64) : nullptr;
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
@@ -1337,7 +1337,7 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
     if (!teacher && fold && m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1) {      // the latency form: one launch for the whole loop
         const Weights& w = m->w;
         StateLayout sl = state_layout(B, T);
-        if (pdecode_supported(B, T, sl.m) && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) {
+        if (pdecode_supported(B, T, sl.m) && pdecode_device_ok() && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) {
             PDecP p{};
             p.Wq = w.q.W; p.bq = w.q.bias; p.aq = w.q.actw;
             p.Wcq = w.cq.W; p.bcq = w.cq.bias;

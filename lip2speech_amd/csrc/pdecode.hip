@@ -657,6 +657,17 @@ static int g_pd_ts_step = 0;
 
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
+// the persistent forms need 256 compute units on the current device (a partitioned MI355X shows fewer): callers fall back to the launch path otherwise
+bool pdecode_device_ok() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        cus = prop.multiProcessorCount;
+    }
+    return cus >= PD_WG;
+}
+
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 4 clips of <= 32 frames whose values fit the LDS");
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(2), "persistent decode: exchange buffer too small");
