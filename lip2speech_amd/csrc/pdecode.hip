@@ -25,16 +25,16 @@
 
 namespace l2s {
 
-constexpr int PD_WG = 256;                // workgroups = CUs
+constexpr int PD_WG = 256;                // workgroups of a full launch = compute units (128 per clip)
 constexpr int PD_NT = 256;                // threads per workgroup
 constexpr int PD_MAXT = 32, PD_MAXM = 16, PD_MAXB = 4;
-constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the 256 workgroups sit one per CU
-constexpr int PD_LDS_MAX = 159 * 1024;      // dynamic part
+constexpr int PD_LDS_MIN = 84 * 1024;     // at least 84 KB of LDS per workgroup: more than half of a CU's, so the workgroups sit one per CU
+constexpr int PD_LDS_MAX = 159 * 1024;    // most dynamic LDS a launch may ask for (a few static bytes ride along)
 // LDS of a workgroup, in floats: the fixed part, then its clip's projected values V' [T4][256] and content values [m4][256] (T4, m4 = T, m rounded up to 4;
 // the rows past T / m are zero)
 __host__ __device__ constexpr int pd_lds_fixed(int V) { return 512 + 256 + 48 + 2 * 4 * 8 * V + 2 * 4 * 12 * V + 4 * 32; }
 __host__ __device__ inline int pd_lds_floats(int V, int T, int m) { return pd_lds_fixed(V) + (((T + 3) & ~3) + ((m + 3) & ~3)) * 256; }
-// granule arrays, in u64 units per row count NB: [h0 | h1 | c0 | c1 | q: NB x 512 each][qc, p1, o, cc, p2: NB x 256 each]
+// granule arrays of one replica, in u64 units, for NB clips: [h0 | h1 | c0 | c1 | q: NB x 512 each][qc, p1, p2: NB x 256 each]
 __host__ __device__ constexpr int pd_off_h0(int NB) { return 0; }
 __host__ __device__ constexpr int pd_off_h1(int NB) { return NB * 512; }
 __host__ __device__ constexpr int pd_off_c0(int NB) { return 2 * NB * 512; }
@@ -42,9 +42,7 @@ __host__ __device__ constexpr int pd_off_c1(int NB) { return 3 * NB * 512; }
 __host__ __device__ constexpr int pd_off_q(int NB) { return 4 * NB * 512; }
 __host__ __device__ constexpr int pd_off_qc(int NB) { return 5 * NB * 512; }
 __host__ __device__ constexpr int pd_off_p1(int NB) { return pd_off_qc(NB) + NB * 256; }
-__host__ __device__ constexpr int pd_off_o(int NB) { return pd_off_p1(NB) + NB * 256; }
-__host__ __device__ constexpr int pd_off_cc(int NB) { return pd_off_o(NB) + NB * 256; }
-__host__ __device__ constexpr int pd_off_p2(int NB) { return pd_off_cc(NB) + NB * 256; }
+__host__ __device__ constexpr int pd_off_p2(int NB) { return pd_off_p1(NB) + NB * 256; }
 __host__ __device__ constexpr int pd_granules(int NB) { return pd_off_p2(NB) + NB * 256; }
 constexpr int PD_MAXREP = 8;
 __host__ __device__ constexpr int pd_rstride(int NB) { return pd_granules(NB) + 520; }      // replicas 4 KB + 64 B off a power-of-two pitch
