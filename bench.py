@@ -13,7 +13,8 @@ N*K*B*S / max-over-ranks(time).
 
 The K steps of a rank are independent batches.  One pass is a chain of ~1 500 dependent launches whose 1 200 step kernels are
 latency-bound at 32 rows, so the steps are advanced `--group` (default 8) batches per launch chain (`l2s_inference_multi`: the G batches
-are rows of the same launches, on one weight blob) with `--inflight` (default 2) chains in flight, each on its own HIP stream from its
+are rows of the same launches, on one weight blob) with `--inflight` chains in flight (default: two, or three
+where that cuts the K steps into fuller launches - `InflightPool.chains_for`), each on its own HIP stream from its
 own host thread (lip2speech_amd.parallel.InflightPool).  Every step is still one full pass over one B=32 batch and every batch's
 results are bit-identical to `l2s_inference` on it alone (tests/test_gpu_parity.py); `one_batch_at_a_time` in the JSON line is the same K
 steps as K sequential `l2s_inference` calls, `one_chain_at_a_time` the same with one chain, `latency` what one group takes alone.
@@ -345,7 +346,8 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
     ap.add_argument("--skip-train-leg", action="store_true", help="inference mode: leave the train_step_B8 leg out of the line (profiler runs)")
     ap.add_argument("--group", type=int, default=8, help="independent B=32 batches advanced per launch chain (l2s_inference_multi, 1..8); 1 = one batch per chain")
-    ap.add_argument("--inflight", type=int, default=2, help="launch chains in flight per GPU (HIP streams + host threads); 1 = strictly sequential chains "
+    ap.add_argument("--inflight", type=int, default=None, help="launch chains in flight per GPU (HIP streams + host threads); default: InflightPool.chains_for(steps, group) "
+                    "- two, or three where K steps cut into fuller launches that way (20 steps: 7 + 7 + 6 instead of 4 x 5); 1 = strictly sequential chains "
                     "(measured at 8 batches per chain: 1 chain 4.78 ms per batch, 2 chains 4.30, 3 chains 4.22-4.33; their relative phase does not matter)")
     ap.add_argument("--bf16", action="store_true", help="--mode train: bf16 operands in the GEMMs / Conv1d stacks of encoder, prologue and post-net "
                     "(option train_bf16; BASELINE.json configs[2] names bf16), fp32 accumulation / master weights / recurrent loop")
@@ -383,7 +385,8 @@ def main():
     from lip2speech_amd.parallel import InflightPool
     sd = synth.synth_state_dict()
     tensors = {k: v.cuda() for k, v in sd.items()}
-    G, NI = max(1, min(8, args.group)), max(1, args.inflight)
+    G = max(1, min(8, args.group))
+    NI = max(1, args.inflight) if args.inflight is not None else InflightPool.chains_for(args.steps, G)
     pool = InflightPool(tensors, list(sd.keys()), n_inflight=NI, group=G)
     nm = pool.model
     # every slot of every chain gets its own batch (different clips, embeddings and noise): concurrent passes share nothing but the weights

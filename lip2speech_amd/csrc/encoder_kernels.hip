@@ -1114,12 +1114,341 @@ static int launch_s1_inst(const ShuffleS1P& p, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ fused units on the bf16 matrix cores
+// The pointwise convs of the fused units through the exact three-way split of the dense kernels (x = hi + mid + lo, six bf16 products per fp32
+// product, fp32 accumulation: `v_mfma_f32_16x16x32_bf16`, 96 clk per 16x16x32 where `v_mfma_f32_16x16x4_f32` takes 256).  An activation is split ONCE,
+// by the thread that writes it to LDS (three bf16 planes, rows of KP32 * 2 + 32 bytes: 32 x odd, conflict-free for the operand's ds_read_b128 lane
+// groups), not once per column tile by the waves that read it; the weights arrive pre-split in operand order (su_planes_kernel: [column tile][32-k chunk]
+// [plane][lane] 16 bytes, derived on the device from the packed [N][K] matrix at load and after every refresh).  The planes (6 bytes per value) and
+// the fp32 map the depthwise conv reads (4 bytes) never live at the same time - a GEMM holds its accumulators across the barrier in front of its
+// in-place epilogue, the depthwise holds its outputs across the barrier in front of its stores - so ONE region of 3 planes serves both and two
+// blocks still share a CU (69-78 KB).
+typedef __bf16 su_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int su_pad32(int v) { return (v + 31) / 32 * 32; }
+constexpr int su_pitch(int kp32) { return kp32 * 2 + 32; }                  // bytes per plane row
+// two adjacent k as {lo16 = even k, hi16 = odd k} in each of the three planes
+__device__ __forceinline__ void su_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned xa = __float_as_uint(a), xb = __float_as_uint(b);
+    const float ra = a - __uint_as_float(xa & 0xFFFF0000u), rb = b - __uint_as_float(xb & 0xFFFF0000u);                                  // exact
+    const float qa = ra - __uint_as_float(__float_as_uint(ra) & 0xFFFF0000u), qb = rb - __uint_as_float(__float_as_uint(rb) & 0xFFFF0000u);   // exact, <= 8 bits
+    hi = __builtin_amdgcn_perm(xb, xa, 0x07060302u);
+    mid = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x07060302u);
+}
+
+// weights [N][K] fp32 -> operand planes: out[((nt * NCH + ch) * 3 + plane) * 64 + lane] (16 bytes) = bf16 plane of W[nt * 16 + (lane & 15)][ch * 32 + 8 * (lane >> 4) + 0..7]
+__global__ __launch_bounds__(256) void su_planes_kernel(const float* __restrict__ W, int N, int K, int NT, int NCH, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NT * NCH * 64) return;
+    const int lane = idx & 63, ch = (idx >> 6) % NCH, nt = (idx >> 6) / NCH;
+    const int n = nt * 16 + (lane & 15), k0 = ch * 32 + 8 * (lane >> 4);
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = k0 + 2 * e;
+        const float a = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f, b = (n < N && k + 1 < K) ? W[(int64_t)n * K + k + 1] : 0.f;
+        su_split2(a, b, h[e], m[e], l[e]);
+    }
+    uint4* o = out + ((int64_t)(nt * NCH + ch) * 3) * 64 + lane;
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[64] = make_uint4(m[0], m[1], m[2], m[3]);
+    o[128] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+int64_t su_planes_bytes(int N, int K) { return (int64_t)((N + 15) / 16) * (su_pad32(K) / 32) * 3 * 1024; }
+int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s) {
+    const int NT = (N + 15) / 16, NCH = su_pad32(K) / 32;
+    ProfScope ps("shuffle_unit_weight_planes", s);
+    hipLaunchKernelGGL(su_planes_kernel, dim3((NT * NCH * 64 + 255) / 256), dim3(256), 0, s, W, N, K, NT, NCH, reinterpret_cast<uint4*>(out));
+    L2S_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[m][n] = relu((A[m][:] . W[n][:]) * scale[n] + shift[n]) for all 16-row tiles of the block: A from the three bf16 planes at `pl` (rows of PITCH
+// bytes, planes PLANE bytes apart), the result as fp32 rows of LDA floats at the SAME address (accumulators held across the barrier).  Work items as
+// su_gemm.  A column tile's weight chunks are requested BD at a time (all of them up to K = 128; three in flight beyond).
+template <class GM, int NCH, int PITCH, int PLANE, int LDA>
+__device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const uint4* __restrict__ Wp,
+                                           const float* __restrict__ scale, const float* __restrict__ shift) {
+    constexpr int G = GM::G, IT = GM::IT, NT = GM::NT, BD = NCH <= 4 ? NCH : 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    float* const buf = reinterpret_cast<float*>(pl);
+    f32x4 acc[IT][G];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = wave + 8 * it;
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[it][j] = {0.f, 0.f, 0.f, 0.f};
+        if (item < GM::ITEMS) {
+            const int nt = item % NT, mg = item / NT;
+            const int mt0 = min(mg * G, GM::MT - G);
+            const uint4* wb = Wp + (int64_t)nt * NCH * 192 + lane;
+            const unsigned char* ab = pl + (mt0 * 16 + li) * PITCH + 16 * lg;
+            uint4 b[BD][3];
+#pragma unroll
+            for (int c = 0; c < BD; ++c) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[c][q] = wb[(c * 3 + q) * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int sl = c % BD;
+                const su_bf16x8 bh = __builtin_bit_cast(su_bf16x8, b[sl][0]), bm = __builtin_bit_cast(su_bf16x8, b[sl][1]), bl = __builtin_bit_cast(su_bf16x8, b[sl][2]);
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const unsigned char* ap = ab + j * 16 * PITCH + 64 * c;
+                    const su_bf16x8 ah = *reinterpret_cast<const su_bf16x8*>(ap), am = *reinterpret_cast<const su_bf16x8*>(ap + PLANE),
+                                    al = *reinterpret_cast<const su_bf16x8*>(ap + 2 * PLANE);
+                    f32x4 a = acc[it][j];      // smallest partial products first
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
+                    acc[it][j] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later chunks from being hoisted (VGPRs)
+                if (c + BD < NCH) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[sl][q] = wb[((c + BD) * 3 + q) * 64];
+                }
+            }
+        }
+    }
+    __syncthreads();                                     // every wave has read its operand rows
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = wave + 8 * it;
+        if (item < GM::ITEMS) {
+            const int nt = item % NT, mg = item / NT;
+            const int mt0 = min(mg * G, GM::MT - G);
+            const int n = nt * 16 + li;
+            if (n < GM::N) {
+                const float sc = scale[n], sh = shift[n];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[it][j][r] * sc + sh;
+                        buf[((mt0 + j) * 16 + 4 * lg + r) * LDA + n] = v > 0.f ? v : 0.f;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int H, int HALF, int F>
+struct S1XGeo {
+    static constexpr int HH = H * H, C = 2 * HALF, KP = su_pad16(HALF), LDA = KP + 4, PX = F * HH;
+    static constexpr int MT = (PX + 15) / 16, ROWS = MT * 16;
+    static constexpr int KP32 = su_pad32(HALF), NCH = KP32 / 32, PITCH = su_pitch(KP32), PLANE = ROWS * PITCH;
+    static constexpr int NPAIR = HALF / 2, KPAIR = KP32 / 2;               // channel pairs of a branch: real, and with the K padding
+    static constexpr int PPI = KPAIR <= 32 ? 2 : 1;                        // pixels per wave instruction of the input phase
+    static constexpr int QIT = PPI == 2 ? 1 : KPAIR / 64, PPW = (PX + 8 * PPI - 1) / (8 * PPI);
+    using GM = SuGemm<HALF, KP / 16, MT>;
+    static constexpr size_t SMEM = 3 * (size_t)PLANE > (size_t)ROWS * LDA * 4 ? 3 * (size_t)PLANE : (size_t)ROWS * LDA * 4;
+    static_assert(HALF % 2 == 0 && (PPI == 2 || KPAIR % 64 == 0), "channel pairs; a pixel's pairs fill whole wave instructions");
+};
+
+template <int H, int HALF, int F, bool TIMED>
+__global__ __launch_bounds__(512, 4) void shuffle_s1x_kernel(const ShuffleS1P p, unsigned long long* __restrict__ ts) {
+    using Q = S1XGeo<H, HALF, F>;
+    constexpr int HH = Q::HH, C = Q::C, LDA = Q::LDA, PPW = Q::PPW, QIT = Q::QIT, PPI = Q::PPI, PITCH = Q::PITCH, PLANE = Q::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float su_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SU_STAMP(0);
+    const int f0 = blockIdx.x * F;
+    const int Mv = min(F, p.NF - f0) * HH;                // valid pixel rows of this block
+    float* buf = su_smem;
+    unsigned char* const pl = reinterpret_cast<unsigned char*>(su_smem);
+    const float* xb = p.x + (int64_t)f0 * HH * C;
+    float* ob = p.out + (int64_t)f0 * HH * C;
+
+    // phase 0: the block's whole input in one round of 8-byte loads: a lane takes channel PAIR q of both halves of pixel m - the passthrough pair stays
+    // in registers, the branch pair is split and goes to the three planes as one 4-byte store each (pairs past HALF: zeros - the K padding)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, Mv * C * 4, 0x00020000);
+    const int sub = PPI == 2 ? lane >> 5 : 0;
+    typedef unsigned su_u2 __attribute__((ext_vector_type(2)));
+    float2 xr[PPW][QIT];
+    su_u2 br[PPW][QIT];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int soff = (wave + 8 * i) * PPI * C * 4;
+#pragma unroll
+        for (int j = 0; j < QIT; ++j) {
+            const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+            const int voff = q < Q::NPAIR ? (sub * C + 2 * q) * 4 : 0x7ffffff0;      // past the end: reads 0
+            const su_u2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+            br[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, q < Q::NPAIR ? voff + HALF * 4 : 0x7ffffff0, soff, 0);
+            xr[i][j] = make_float2(__uint_as_float(a.x), __uint_as_float(a.y));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int m = (wave + 8 * i) * PPI + sub;
+#pragma unroll
+        for (int j = 0; j < QIT; ++j) {
+            const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+            unsigned hi, mid, lo;
+            su_split2(__uint_as_float(br[i][j].x), __uint_as_float(br[i][j].y), hi, mid, lo);
+            if (m < Q::ROWS) {
+                unsigned* d = reinterpret_cast<unsigned*>(pl + m * PITCH + q * 4);
+                d[0] = hi; d[PLANE / 4] = mid; d[2 * (PLANE / 4)] = lo;
+            }
+        }
+    }
+    SU_STAMP(1);                                          // input landed, LDS written
+    __syncthreads();
+    SU_STAMP(2);
+    // phase 1: pw1 + BN + ReLU: planes -> fp32 map
+    su_gemm_x3<typename Q::GM, Q::NCH, PITCH, PLANE, LDA>(pl, reinterpret_cast<const uint4*>(p.w1p), p.s1, p.b1);
+    SU_STAMP(3);
+    // phase 2: depthwise 3x3 (pad 1) + BN over the fp32 map, the sliding window of shuffle_s1_kernel (same taps, same order); its outputs go back as planes
+    constexpr bool PAIRS = HALF > 64;
+    constexpr int NROW = F * H, RPW = (NROW + 7) / 8;
+    typedef float su_f2 __attribute__((ext_vector_type(2)));
+    using DV = std::conditional_t<PAIRS, su_f2, float>;
+    constexpr int DW = PAIRS ? 2 : 1;                         // channels per lane
+    constexpr int CHD = Q::KP32 / (64 * DW);                  // channel passes (over the padded width: the pad lanes write zeros)
+    DV dv[CHD][RPW][H];
+    const DV zero = DV{};
+#pragma unroll
+    for (int jc = 0; jc < CHD; ++jc) {
+        const int c = min(DW * lane + 64 * DW * jc, HALF - DW);
+        DV wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const DV*>(p.wd + t * HALF + c);
+        const DV sd = *reinterpret_cast<const DV*>(p.sd + c), bd = *reinterpret_cast<const DV*>(p.bd + c);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int R = wave + 8 * r;                       // wave-uniform
+            if (R * H < Mv) {
+                const int y = R % H;
+                const bool up = y > 0, dn = y < H - 1;
+                const float* rm = buf + (R * H) * LDA + c;    // this row; the rows above / below (or this one again, under zero weights)
+                const float* ru = rm - (up ? H * LDA : 0);
+                const float* rd = rm + (dn ? H * LDA : 0);
+                DV wu[3], wdn[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { wu[k] = up ? wk[k] : zero; wdn[k] = dn ? wk[6 + k] : zero; }
+                DV a0 = zero, a1 = zero, a2 = zero;
+                DV b0 = *reinterpret_cast<const DV*>(ru), b1 = *reinterpret_cast<const DV*>(rm), b2 = *reinterpret_cast<const DV*>(rd);
+                DV c0 = zero, c1 = zero, c2 = zero;
+                if constexpr (H > 1) { c0 = *reinterpret_cast<const DV*>(ru + LDA); c1 = *reinterpret_cast<const DV*>(rm + LDA); c2 = *reinterpret_cast<const DV*>(rd + LDA); }
+#pragma unroll
+                for (int x = 0; x < H; ++x) {
+                    DV acc = zero;
+                    if (x > 0) acc = __builtin_elementwise_fma(a0, wu[0], acc);
+                    acc = __builtin_elementwise_fma(b0, wu[1], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c0, wu[2], acc);
+                    if (x > 0) acc = __builtin_elementwise_fma(a1, wk[3], acc);
+                    acc = __builtin_elementwise_fma(b1, wk[4], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c1, wk[5], acc);
+                    if (x > 0) acc = __builtin_elementwise_fma(a2, wdn[0], acc);
+                    acc = __builtin_elementwise_fma(b2, wdn[1], acc);
+                    if (x < H - 1) acc = __builtin_elementwise_fma(c2, wdn[2], acc);
+                    dv[jc][r][x] = acc * sd + bd;
+                    a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+                    if (x + 2 < H) {
+                        c0 = *reinterpret_cast<const DV*>(ru + (x + 2) * LDA); c1 = *reinterpret_cast<const DV*>(rm + (x + 2) * LDA);
+                        c2 = *reinterpret_cast<const DV*>(rd + (x + 2) * LDA);
+                    }
+                }
+            }
+        }
+    }
+    SU_STAMP(4);                                          // depthwise taps computed
+    __syncthreads();
+#pragma unroll
+    for (int jc = 0; jc < CHD; ++jc) {
+        const int c = DW * lane + 64 * DW * jc;           // < KP32: every lane writes (zeros in the K padding)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int R = wave + 8 * r;
+            if (R * H < Mv) {
+#pragma unroll
+                for (int x = 0; x < H; ++x) {
+                    unsigned char* d = pl + (R * H + x) * PITCH + c * 2;
+                    if constexpr (PAIRS) {
+                        unsigned hi, mid, lo;
+                        su_split2(c < HALF ? dv[jc][r][x][0] : 0.f, c < HALF ? dv[jc][r][x][1] : 0.f, hi, mid, lo);
+                        *reinterpret_cast<unsigned*>(d) = hi; *reinterpret_cast<unsigned*>(d + PLANE) = mid; *reinterpret_cast<unsigned*>(d + 2 * PLANE) = lo;
+                    } else {
+                        const float v = c < HALF ? dv[jc][r][x] : 0.f;
+                        const float r1 = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+                        const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                        *reinterpret_cast<unsigned short*>(d) = (unsigned short)(__float_as_uint(v) >> 16);
+                        *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)(__float_as_uint(r1) >> 16);
+                        *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SU_STAMP(5);
+    // phase 3: pw2 + BN + ReLU: planes -> fp32 map
+    su_gemm_x3<typename Q::GM, Q::NCH, PITCH, PLANE, LDA>(pl, reinterpret_cast<const uint4*>(p.w2p), p.s2, p.b2);
+    SU_STAMP(6);
+    // phase 4: channel_shuffle store: out[2k] = x1[k] (register), out[2k+1] = branch[k] (LDS): a lane's pair as one 16-byte store
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int m = (wave + 8 * i) * PPI + sub;
+#pragma unroll
+        for (int j = 0; j < QIT; ++j) {
+            const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+            if (m < Mv && q < Q::NPAIR) {
+                const float2 bv = *reinterpret_cast<const float2*>(buf + m * LDA + 2 * q);
+                *reinterpret_cast<float4*>(ob + (int64_t)m * C + 4 * q) = make_float4(xr[i][j].x, bv.x, xr[i][j].y, bv.y);
+            }
+        }
+    }
+    if (TIMED) {
+        __builtin_amdgcn_s_waitcnt(0);                    // stores drained
+        SU_STAMP(7);
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (threadIdx.x == 0) { ts[blockIdx.x * 10 + 8] = hw; ts[blockIdx.x * 10 + 9] = xcc; }
+    }
+}
+
+template <int H, int HALF, int F>
+static int launch_s1x_inst(const ShuffleS1P& p, hipStream_t s) {
+    using Q = S1XGeo<H, HALF, F>;
+    static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1x_kernel<H, HALF, F, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1x_kernel<H, HALF, F, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        attr_set = true;
+    }
+    if (g_su_ts && g_su_ts_h == H) hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, true>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, g_su_ts);
+    else hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    return 0;
+}
+
 // frames per block (measured, profiles/r01_fused_units_pmc.txt): 1 at 12x12 / 11x11, 2 at 6x6 and 3x3
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s) {
     L2S_REQUIRE(p.Kpad == su_pad16(p.half), "shuffle_s1: weight fragments are packed for K = pad16(half)");
     ProfScope ps(p.h >= 11 ? "shuffle_unit_s1_fused_h12" : p.h == 6 ? "shuffle_unit_s1_fused_h6" : "shuffle_unit_s1_fused_h3", s);
     int rc = 1;
-    if (p.h == 12 && p.half == 58) rc = launch_s1_inst<12, 58, 1>(p, s);
+    if (p.w1p && p.w2p) {      // the pointwise convs on the bf16 matrix cores (option "trunk_x3"): same frames per block
+        if (p.h == 12 && p.half == 58) rc = launch_s1x_inst<12, 58, 1>(p, s);
+        else if (p.h == 11 && p.half == 58) rc = launch_s1x_inst<11, 58, 1>(p, s);
+        else if (p.h == 6 && p.half == 116) rc = launch_s1x_inst<6, 116, 2>(p, s);
+        else if (p.h == 3 && p.half == 232) rc = p.NF >= 2048 ? launch_s1x_inst<3, 232, 5>(p, s) : launch_s1x_inst<3, 232, 2>(p, s);
+        else set_error("shuffle_s1: unsupported unit geometry");
+    }
+    else if (p.h == 12 && p.half == 58) rc = launch_s1_inst<12, 58, 1>(p, s);
     else if (p.h == 11 && p.half == 58) rc = launch_s1_inst<11, 58, 1>(p, s);      // 88x88 crops
     // frames per block: with many frames in the launch (grouped batches) more frames share one pass over the unit's weights, which every block
     // streams from L2 (3x3 stage: 2 x 215 KB per block against 2 x 9 pixels of work) and the 16-row tiles fill better (18 of 32 rows -> 45 of 48):

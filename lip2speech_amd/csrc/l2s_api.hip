@@ -27,7 +27,7 @@ static Options g_default_opt;          // process defaults: what l2s_model_creat
 int set_option_field(Options& o, const char* name, int value) {
     struct { const char* name; int Options::*field; } table[] = {
         {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
-        {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"refresh_map", &Options::refresh_map},
+        {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"trunk_x3", &Options::trunk_x3}, {"refresh_map", &Options::refresh_map},
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3}, {"gemm_x3_dma", &Options::gemm_x3_dma},
         {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
@@ -621,6 +621,32 @@ static int derive_gemm_planes(l2s_model* m, hipStream_t s) {
     return 0;
 }
 
+// bf16 operand planes of the fused ShuffleNet units' pointwise convs (option "trunk_x3"): derived on the device from the packed [N][K] matrices,
+// after every pack and every device-side refresh
+static int derive_unit_planes(l2s_model* m, hipStream_t s) {
+    Weights& w = m->w;
+    for (UnitW& U : w.unit) { U.pw1_p3 = nullptr; U.pw2_p3 = nullptr; U.b1_p3 = nullptr; }
+    if (!m->has_enc) return 0;
+    struct Item { const float* W; int N, K; const void** slot; };
+    std::vector<Item> items;
+    for (UnitW& U : w.unit) {
+        const int pw1_in = U.stride2 ? U.cin : U.half;
+        items.push_back({U.pw1.W, U.half, pw1_in, &U.pw1_p3});
+        items.push_back({U.pw2.W, U.half, U.half, &U.pw2_p3});
+        if (U.stride2) items.push_back({U.b1_pw.W, U.half, U.cin, &U.b1_p3});
+    }
+    int64_t total = 0;
+    for (const Item& it : items) { if (!it.W) return 0; total += su_planes_bytes(it.N, it.K); }
+    if (!m->unit_planes) L2S_CHECK_HIP(hipMalloc(&m->unit_planes, total));
+    char* base = reinterpret_cast<char*>(m->unit_planes);
+    for (const Item& it : items) {
+        if (launch_su_planes(it.W, it.N, it.K, base, s)) return 1;
+        *it.slot = base;
+        base += su_planes_bytes(it.N, it.K);
+    }
+    return 0;
+}
+
 static int pack_model(l2s_model* m, hipStream_t stream) {
     Packer P{m};
     bool want_enc = false, want_dec = false, want_spk = false;
@@ -645,6 +671,8 @@ static int pack_model(l2s_model* m, hipStream_t stream) {
     if (derive_lstm_planes(m, stream)) return 1;
     if (m->gemm_planes) { (void)hipFree(m->gemm_planes); m->gemm_planes = nullptr; }
     if (derive_gemm_planes(m, stream)) return 1;
+    if (m->unit_planes) { (void)hipFree(m->unit_planes); m->unit_planes = nullptr; }
+    if (derive_unit_planes(m, stream)) return 1;
     return 0;
 }
 
@@ -864,6 +892,7 @@ static int refresh_weights(l2s_model* m, hipStream_t s) {
     }
     if (m->lstm_planes && derive_lstm_planes(m, s)) return 1;      // the LSTM weights' bf16 planes are splits of the old weights too
     if (m->gemm_planes && derive_gemm_planes(m, s)) return 1;
+    if (m->unit_planes && derive_unit_planes(m, s)) return 1;
     m->folded_valid = false;        // W_p1 W_out and W_ih W_ap are products of the old parameters ...
     if (remerge_step_weights(m, s)) return 1;      // ... rebuilt here when the decoder's tensors are bound (then the 4-launch step stays valid)
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -994,6 +1023,7 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
             sp.F = h >= 11 ? 1 : 2;                            // informational: fixed by the kernel instance
+            if (m->opt.trunk_x3) { sp.w1p = U.pw1_p3; sp.w2p = U.pw2_p3; }      // pointwise convs on the bf16 matrix cores (exact split)
             if (launch_shuffle_s1(sp, s)) return 1;
         } else {
             const int64_t px = (int64_t)NF * h * h;
@@ -1535,6 +1565,7 @@ int l2s_model_destroy(l2s_model* m) {
     if (m->merge_scratch) (void)hipFree(m->merge_scratch);
     if (m->lstm_planes) (void)hipFree(m->lstm_planes);
     if (m->gemm_planes) (void)hipFree(m->gemm_planes);
+    if (m->unit_planes) (void)hipFree(m->unit_planes);
     delete m;
     return 0;
 }

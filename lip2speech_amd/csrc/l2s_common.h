@@ -47,6 +47,8 @@ struct Options {
     int overlap_postnet = 0;    // "overlap_postnet": windowed post-net on a second stream under the decode loop
     int fuse_trunk = 1;         // "fuse_trunk": stride-1 ShuffleNet units as one fused kernel each
     int fuse_s2 = 1;            // "fuse_s2": stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk)
+    int trunk_x3 = 1;           // "trunk_x3": the fused units' pointwise convs on the bf16 matrix cores through the exact three-way split (activations split once where
+                                //             they are written to LDS, weights as pre-split operand planes); 0 = the f32-MFMA units
     int refresh_map = 0;        // "refresh_map": l2s_model_finalize also builds the device-side refresh map (training)
     int skinny_static = 0;      // "skinny_static": compile-time K-segment layouts in the batch-row kernels
     int skinny_sized = 1;       // "skinny_sized": batch-row instances sized for the launch's longest K
@@ -259,7 +261,10 @@ struct ShuffleS1P {
     const float* wd; const float* sd; const float* bd;       // dw: [9][half], BN scale/shift
     const float* w2f; const float* s2; const float* b2;      // pw2
     int NF, h, half, Kpad, F;
+    const void* w1p; const void* w2p;                        // pw1 / pw2 as pre-split bf16 operand planes (launch_su_planes) or null: both set -> the split-bf16 unit
 };
+int64_t su_planes_bytes(int N, int K);
+int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s);      // [N][K] fp32 -> [ceil(N/16)][pad32(K)/32][3 planes][64 lanes] 16 bytes
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s);
 void shuffle_set_timeline(unsigned long long* ts, int h);     // non-null: launch the stamped measurement build (tools/fused_unit_timeline.py)
 // fused stride-2 ShuffleNet unit (encoder_kernels.hip): banch1 (dw s2 -> pw) and banch2 (pw -> dw s2 -> pw) of one strip of Ro

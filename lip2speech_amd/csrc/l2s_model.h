@@ -39,6 +39,7 @@ struct UnitW {
     ConvW pw1; DwW dw; ConvW pw2;      // banch2
     const float* pw1_frag = nullptr; const float* pw2_frag = nullptr; int kpad = 0;   // fused units: frag16 [pad16(half)][K]; kpad = pad16(half)
     const float* b1_frag = nullptr; int kin = 0;                                      // stride-2 units: banch1 pw, and pw1, have K = kin = pad16(cin)
+    const void* pw1_p3 = nullptr; const void* pw2_p3 = nullptr; const void* b1_p3 = nullptr;   // the same as bf16 operand planes (launch_su_planes; option "trunk_x3")
 };
 struct SkW { const float* W = nullptr; const float* bias = nullptr; const float* actw = nullptr; int N = 0, K = 0, tiles = 0; const void* W3 = nullptr; };      // W3: bf16 planes (split-bf16 LSTM blocks)
 
@@ -105,6 +106,7 @@ struct l2s_model {
     bool planes_valid = true;                                 // the front-end's bf16 operand planes (w3 / w1) match the current parameters
     float* merge_scratch = nullptr;                           // device: the two products of the device-side re-merge (l2s_train_refresh_weights)
     void* gemm_planes = nullptr;                              // device: bf16 planes of the post-net's Conv1d weights, the BiLSTM input matrix and conv_last (option "gemm_x3_dma"); rebuilt like lstm_planes
+    void* unit_planes = nullptr;                              // device: bf16 operand planes of the fused ShuffleNet units' pointwise convs (option "trunk_x3"); rebuilt like lstm_planes
     void* lstm_planes = nullptr;                              // device: bf16 planes of the decoder LSTM weights (split-bf16 LSTM blocks, option "lstm_x3"); rebuilt
                                                               //   from the packed fp32 fragments after every pack / device-side refresh
     // training: BatchNorm layers normalise with batch statistics and update their running statistics (nn.Module.train()); off = running statistics

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(PD_NT, 1) void pbilstm_kernel(const PBiP p) {
 
 int64_t pbilstm_ws_bytes() { return (int64_t)pb_rstride(2) * 8 * PD_MAXREP + 256; }
 bool pbilstm_supported(int B, int T) { return B >= 1 && B <= 2 && T >= 1 && T <= 300; }
-// a launch whose workgroups gave up (a poll without progress for 2 s: the chip was not theirs) must not hand back plausible numbers
+// a launch whose workgroups gave up (PD_SPIN_LIMIT polls without progress - a minute or more: the chip was not theirs) must not hand back plausible numbers
 __global__ void pdecode_guard_kernel(const unsigned* status, float* mel, float* stop, int n_mel, int n_stop) {
     if (__hip_atomic_load(status, PD_RLX) == 0u) return;
     const float nan = __uint_as_float(0x7fc00000u);
@@ -645,48 +645,56 @@ bool pdecode_supported(int B, int T, int m) {
     return B >= 1 && B <= PD_MAXB && T >= 1 && T <= PD_MAXT && m >= 1 && m <= PD_MAXM && pd_lds_floats(2, T, m) * 4 <= PD_LDS_MAX;
 }
 
-// every persistent launch needs all 256 workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
-// wait for the other half for ever, so they are chained through one event (a launch waits for the previous persistent launch of the process)
+// every persistent launch needs all its workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
+// wait for the other half for ever, so they are chained through one event per device (a launch waits for the previous persistent launch on its device)
+struct PdDevice {
+    bool init = false, attr = false;
+    int cus = 0;
+    hipEvent_t ev = nullptr;
+};
+constexpr int PD_MAX_DEVICES = 64;
 static std::mutex g_pd_mu;
-static hipEvent_t g_pd_ev = nullptr;
-static int g_pd_cus = -1;
+static PdDevice g_pd_dev[PD_MAX_DEVICES];
 static unsigned long long* g_pd_ts = nullptr;
 static int g_pd_ts_step = 0;
 
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
 
+// the current device's entry (g_pd_mu held); nullptr when the device cannot be queried
+static PdDevice* pd_device_locked() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PD_MAX_DEVICES) return nullptr;
+    PdDevice& d = g_pd_dev[dev];
+    if (!d.init) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        d.cus = prop.multiProcessorCount;
+        d.init = true;
+    }
+    return &d;
+}
+
 // the persistent forms need 256 compute units on the current device (a partitioned MI355X shows fewer): callers fall back to the launch path otherwise
 bool pdecode_device_ok() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-        cus = prop.multiProcessorCount;
-    }
-    return cus >= PD_WG;
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    const PdDevice* d = pd_device_locked();
+    return d && d->cus >= PD_WG;
 }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(pdecode_supported(p.B, p.T, p.m), "persistent decode: <= 4 clips of <= 32 frames whose values fit the LDS");
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(2), "persistent decode: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
-    if (g_pd_cus < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        L2S_CHECK_HIP(hipGetDevice(&dev));
-        L2S_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_pd_cus = prop.multiProcessorCount;
-        L2S_CHECK_HIP(hipEventCreateWithFlags(&g_pd_ev, hipEventDisableTiming));
-        L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
-    }
-    L2S_REQUIRE(g_pd_cus >= PD_WG, "persistent decode needs 256 compute units (one resident workgroup each)");
+    PdDevice* const dv = pd_device_locked();
+    L2S_REQUIRE(dv && dv->cus >= PD_WG, "persistent decode needs 256 compute units (one resident workgroup each)");
     const int lds = std::max(pd_lds_floats(2, p.T, p.m) * 4, PD_LDS_MIN);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!dv->attr) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
-        attr_set = true;
+        dv->attr = true;
     }
-    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, dv->ev, 0));      // a never-recorded event is complete
     ProfScope ps("decode_persistent", s);
     // clips two at a time (three or four clips: two launches one after the other - still shorter than 300 x four launches)
     for (int b0 = 0; b0 < p.B; b0 += 2) {
@@ -705,7 +713,7 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
         L2S_CHECK_HIP(hipGetLastError());
     }
-    L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
     return 0;
 }
 
@@ -713,28 +721,21 @@ int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(pbilstm_supported(p.B, p.T), "persistent BiLSTM: one or two clips");
     L2S_REQUIRE(ws && ws_bytes >= pbilstm_ws_bytes(), "persistent BiLSTM: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
-    if (g_pd_cus < 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        L2S_CHECK_HIP(hipGetDevice(&dev));
-        L2S_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_pd_cus = prop.multiProcessorCount;
-        L2S_CHECK_HIP(hipEventCreateWithFlags(&g_pd_ev, hipEventDisableTiming));
-        L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
-    }
-    L2S_REQUIRE(g_pd_cus >= PD_WG, "persistent BiLSTM needs 256 compute units (one resident workgroup each)");
+    PdDevice* const dv = pd_device_locked();
+    L2S_REQUIRE(dv && dv->cus >= PD_WG, "persistent BiLSTM needs 256 compute units (one resident workgroup each)");
     PBiP q = p;
     q.xch = reinterpret_cast<u64*>(ws);
     q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pb_rstride(2) * 8 * PD_MAXREP);
     L2S_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)pbilstm_ws_bytes(), s));
     // the frag16 state rows past B stay zero, as the launch path leaves them
     L2S_CHECK_HIP(hipMemsetAsync(q.h_state, 0, sizeof(float) * 2 * ((p.B + 15) & ~15) * 512, s));
-    L2S_CHECK_HIP(hipStreamWaitEvent(s, g_pd_ev, 0));
+    L2S_CHECK_HIP(hipStreamWaitEvent(s, dv->ev, 0));
     ProfScope ps("bilstm_persistent", s);
     if (p.B == 1) hipLaunchKernelGGL(pbilstm_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
     else hipLaunchKernelGGL(pbilstm_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
     hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, p.B * p.T * 1024, p.B * 1024);
     L2S_CHECK_HIP(hipGetLastError());
-    L2S_CHECK_HIP(hipEventRecord(g_pd_ev, s));
+    L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
     return 0;
 }
 

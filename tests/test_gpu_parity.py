@@ -153,6 +153,18 @@ def test_encoder_other_geometries(nm, synth_sd, hw, B, T):
     assert pc.maxdiff(feat, ref) < 2e-5
 
 
+@pytest.mark.parametrize("hw,B,T", [(96, 2, 29), (88, 1, 3), (96, 1, 5)])
+def test_encoder_trunk_f32_units(nm, synth_sd, hw, B, T):
+    """option trunk_x3 = 0: the fused ShuffleNet units with f32-MFMA pointwise convs (the default runs them on the bf16 matrix cores through the exact
+    three-way split).  Both against the oracle, and against each other at rounding level - another kernel really ran."""
+    own = pc.fresh_native_model(synth_sd, trunk_x3=0)
+    v = synth.synth_video(B, T, hw, hw, tag=f"trunk{hw}_{B}_{T}")
+    feat = own.encoder_fwd(v.cuda())
+    assert pc.maxdiff(feat, orc.encoder_forward(synth_sd, v)) < 2e-5
+    d = pc.maxdiff(feat, nm.encoder_fwd(v.cuda()))
+    assert 0 < d < 2e-6
+
+
 def test_prologue_matches_oracle(nm):
     g, _, emb = pc.lrw2_inputs()
     B, T = 2, 29

@@ -29,6 +29,7 @@ RUNS = {
     "time_frontend.py": ([], {}),
     "time_group.py": ([], {"G": "1", "NT": "1"}),
     "time_latency.py": ([], {"ROWS": "2", "REPS": "1", "S": "20"}),
+    "time_trunk.py": ([], {"B": "32"}),
     "time_step_phases.py": (["1"], {}),
     "time_vocoder.py": ([], {"N": "32", "ITERS": "4"}),
     "train_stages.py": ([], {}),
