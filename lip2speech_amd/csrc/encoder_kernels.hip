@@ -1478,7 +1478,8 @@ struct S2Geo {
 // depthwise 3x3 / stride 2 / pad 1 (+BN) from an LDS tile of input rows (tile row 0 = frame row iy0) to an LDS tile of output
 // pixels; lanes = channels, waves = output pixels. Frame borders are skipped, not read: the padding is of THIS map (for banch2
 // that is relu(bn(pw1(x))), whose value on a zero pixel is not zero).
-template <int H, int HO, int LDA, int CN>
+// PITCH > 0: the outputs go to `dst` as three bf16 planes (rows of PITCH bytes, planes PLANE bytes apart; the split-bf16 units) instead of fp32 rows.
+template <int H, int HO, int LDA, int CN, int PITCH = 0, int PLANE = 0>
 __device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* __restrict__ dst, int iy0, int outv,
                                          const float* __restrict__ w9, const float* __restrict__ sc, const float* __restrict__ sh) {
     const int lane = threadIdx.x & 63;
@@ -1509,7 +1510,15 @@ __device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* _
                             acc = __builtin_elementwise_fma(v, in ? wk[ky * 3 + kx] : zero2, acc);
                         }
                     }
-                    *reinterpret_cast<su_f2*>(dst + m * LDA + c) = acc * s + b;
+                    const su_f2 o = acc * s + b;
+                    if constexpr (PITCH > 0) {
+                        unsigned hi, mid, lo;
+                        su_split2(o[0], o[1], hi, mid, lo);
+                        unsigned char* d = reinterpret_cast<unsigned char*>(dst) + m * PITCH + c * 2;
+                        *reinterpret_cast<unsigned*>(d) = hi; *reinterpret_cast<unsigned*>(d + PLANE) = mid; *reinterpret_cast<unsigned*>(d + 2 * PLANE) = lo;
+                    } else {
+                        *reinterpret_cast<su_f2*>(dst + m * LDA + c) = o;
+                    }
                 }
             }
         }
@@ -1536,7 +1545,17 @@ __device__ __forceinline__ void su_dw_s2(const float* __restrict__ src, float* _
                         acc = fmaf(src[(in ? r * H + ix : (2 * oyl + 1) * H + 2 * ox) * LDA + c], in ? wk[ky * 3 + kx] : 0.f, acc);
                     }
                 }
-                dst[m * LDA + c] = acc * s + b;
+                const float o = acc * s + b;
+                if constexpr (PITCH > 0) {
+                    const float r1 = o - __uint_as_float(__float_as_uint(o) & 0xFFFF0000u);
+                    const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                    unsigned char* d = reinterpret_cast<unsigned char*>(dst) + m * PITCH + c * 2;
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)(__float_as_uint(o) >> 16);
+                    *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)(__float_as_uint(r1) >> 16);
+                    *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)(__float_as_uint(r2) >> 16);
+                } else {
+                    dst[m * LDA + c] = o;
+                }
             }
         }
     }
@@ -1632,6 +1651,144 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p, 
     if (TIMED) { __builtin_amdgcn_s_waitcnt(0); S2_STAMP(8); }
 }
 
+// The stride-2 unit with its three pointwise convs on the bf16 matrix cores (used for stage 3; stage 4's unit streams 3 x 223 KB of weights per 36-pixel
+// block and is bound by them - as planes they would be 1.5x the bytes).  The input tile is needed twice: as fp32 by banch1's depthwise, as planes by
+// pw1 - the threads keep the float4s they loaded and write the planes over the fp32 tile once the depthwise has read it.  Both depthwise convs write
+// their outputs as planes; every GEMM leaves fp32 rows in place of its operand planes.
+template <int H, int CIN, int HALF, int RO>
+struct S2XGeo {
+    using B = S2Geo<H, CIN, HALF, RO>;
+    static constexpr int HO = B::HO, LDA = B::LDA, MTI = B::MTI, MTO = B::MTO, RX = B::RIN * H;
+    static constexpr int KI32 = su_pad32(CIN), KH32 = su_pad32(HALF), PIN = su_pitch(KI32), PH = su_pitch(KH32);
+    static constexpr int XPLANE = RX * PIN, D1PLANE = MTO * 16 * PIN, D2PLANE = MTO * 16 * PH;      // X: valid tile rows only (the last tile's other rows read on into the next plane: garbage rows nobody reads)
+    static constexpr int XBYTES = 3 * XPLANE > MTI * 16 * LDA * 4 ? 3 * XPLANE : MTI * 16 * LDA * 4;
+    static constexpr size_t SMEM = (size_t)XBYTES + 3 * D1PLANE + 3 * D2PLANE;
+    static_assert(3 * D1PLANE >= MTO * 16 * LDA * 4 && 3 * D2PLANE >= MTO * 16 * LDA * 4, "a GEMM's fp32 rows fit in place of its operand planes");
+    static_assert(XBYTES % 16 == 0 && D1PLANE % 16 == 0, "16-byte aligned regions");
+    using G1 = SuGemm<HALF, 1, MTI>;
+    using G2 = SuGemm<HALF, 1, MTO>;
+};
+
+template <int H, int CIN, int HALF, int RO, bool TIMED>
+__global__ __launch_bounds__(512, 4) void shuffle_s2x_kernel(const ShuffleS2P p, unsigned long long* __restrict__ ts) {
+    using Q = S2XGeo<H, CIN, HALF, RO>;
+    constexpr int HO = Q::HO, LDA = Q::LDA, CIN4 = CIN / 4, PIN = Q::PIN, PH = Q::PH;
+    extern __shared__ __attribute__((aligned(16))) float su_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y;
+    const int oy0 = blockIdx.x * RO;
+    const int ro = min(RO, HO - oy0);
+    const int iy0 = 2 * oy0 - 1;                           // frame row of tile row 0
+    const int outv = ro * HO;                              // valid output pixels of this block
+    float* X = su_smem;
+    unsigned char* const XP = reinterpret_cast<unsigned char*>(su_smem);
+    unsigned char* const D1P = XP + Q::XBYTES;
+    unsigned char* const D2P = D1P + 3 * Q::D1PLANE;
+    float* D1 = reinterpret_cast<float*>(D1P);
+    float* D2 = reinterpret_cast<float*>(D2P);
+    S2_STAMP(0);
+
+    const int iy_lo = max(iy0, 0), iy_hi = min(iy0 + 2 * ro + 1, H);
+    const int n4 = (iy_hi - iy_lo) * (H * CIN4);
+    const int row0 = (iy_lo - iy0) * H;                    // first tile row inside the frame
+    const float4* src4 = reinterpret_cast<const float4*>(p.x + ((int64_t)f * H + iy_lo) * (H * CIN));
+    float* xt = X + row0 * LDA;
+    constexpr int NLD = (Q::RX * CIN4 + 511) / 512;
+    float4 xin[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        xin[i] = idx < n4 ? src4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the output-resolution operand planes start as zeros: their K padding must be, and their unused rows must not hold NaN patterns
+    for (int idx = tid; idx < (3 * Q::D1PLANE + 3 * Q::D2PLANE) / 16; idx += 512) reinterpret_cast<uint4*>(D1P)[idx] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        if (idx < n4) {
+            const int px = idx / CIN4, c4 = idx - px * CIN4;
+            *reinterpret_cast<float4*>(xt + px * LDA + 4 * c4) = xin[i];
+        }
+    }
+    S2_STAMP(1);
+    __syncthreads();
+    S2_STAMP(2);
+    // banch1: depthwise s2 + BN of x -> D1 planes
+    su_dw_s2<H, HO, LDA, CIN, PIN, Q::D1PLANE>(X, D1, iy0, outv, p.wd1, p.sd1, p.bd1);
+    __syncthreads();                                       // the fp32 tile has been read: its planes take its place
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 512 * i;
+        if (idx < n4) {
+            const int px = idx / CIN4, c4 = idx - px * CIN4;
+            unsigned h0, m0, l0, h1, m1, l1;
+            su_split2(xin[i].x, xin[i].y, h0, m0, l0);
+            su_split2(xin[i].z, xin[i].w, h1, m1, l1);
+            unsigned char* d = XP + (row0 + px) * PIN + c4 * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + Q::XPLANE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * Q::XPLANE) = make_uint2(l0, l1);
+        }
+    }
+    if constexpr (Q::KI32 > CIN) {                         // the K padding of the input planes
+        constexpr int PS = (Q::KI32 - CIN) / 4;
+        for (int idx = tid; idx < Q::RX * PS; idx += 512) {
+            const int m = idx / PS, k4 = idx - m * PS;
+            unsigned char* d = XP + m * PIN + (CIN4 + k4) * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(d + Q::XPLANE) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(d + 2 * Q::XPLANE) = make_uint2(0u, 0u);
+        }
+    }
+    S2_STAMP(3);
+    __syncthreads();
+    // banch2: pw1 + BN + ReLU at full resolution: planes -> fp32 tile
+    su_gemm_x3<typename Q::G1, Q::KI32 / 32, PIN, Q::XPLANE, LDA>(XP, reinterpret_cast<const uint4*>(p.w1p), p.s1, p.b1);
+    S2_STAMP(4);
+    // banch2: depthwise s2 + BN -> D2 planes
+    su_dw_s2<H, HO, LDA, HALF, PH, Q::D2PLANE>(X, D2, iy0, outv, p.wd, p.sd, p.bd);
+    __syncthreads();
+    S2_STAMP(5);
+    // the two output-resolution pointwise convs + BN + ReLU: planes -> fp32 rows in place
+    su_gemm_x3<typename Q::G2, Q::KI32 / 32, PIN, Q::D1PLANE, LDA>(D1P, reinterpret_cast<const uint4*>(p.wb1p), p.sb1, p.bb1);
+    S2_STAMP(6);
+    su_gemm_x3<typename Q::G2, Q::KH32 / 32, PH, Q::D2PLANE, LDA>(D2P, reinterpret_cast<const uint4*>(p.w2p), p.s2, p.b2);
+    S2_STAMP(7);
+    // channel_shuffle store: out[2k] = banch1[k], out[2k+1] = banch2[k]
+    float* ob = p.out + ((int64_t)f * HO + oy0) * (HO * 2 * HALF);
+    for (int m = wave; m < outv; m += 8) {
+#pragma unroll
+        for (int jc = 0; jc < (HALF + 63) / 64; ++jc) {
+            const int c = lane + 64 * jc;
+            if (c < HALF) {
+                float2 o;
+                o.x = D1[m * LDA + c];
+                o.y = D2[m * LDA + c];
+                *reinterpret_cast<float2*>(ob + m * (2 * HALF) + 2 * c) = o;
+            }
+        }
+    }
+    if (TIMED) { __builtin_amdgcn_s_waitcnt(0); S2_STAMP(8); }
+}
+
+template <int H, int CIN, int HALF, int RO>
+static int launch_s2x_inst(const ShuffleS2P& p, hipStream_t s) {
+    using Q = S2XGeo<H, CIN, HALF, RO>;
+    static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2x_kernel<H, CIN, HALF, RO, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2x_kernel<H, CIN, HALF, RO, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        attr_set = true;
+    }
+    if (g_su_ts && g_su_ts_h == -H) hipLaunchKernelGGL((shuffle_s2x_kernel<H, CIN, HALF, RO, true>), dim3(Q::B::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, g_su_ts);
+    else hipLaunchKernelGGL((shuffle_s2x_kernel<H, CIN, HALF, RO, false>), dim3(Q::B::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    return 0;
+}
+
 template <int H, int CIN, int HALF, int RO>
 static int launch_s2_inst(const ShuffleS2P& p, hipStream_t s) {
     using Q = S2Geo<H, CIN, HALF, RO>;
@@ -1656,7 +1813,14 @@ int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s) {
     L2S_REQUIRE((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0, "shuffle_s2 input must be 16-byte aligned");
     ProfScope ps(p.cin == 24 ? "shuffle_unit_s2_fused_st2" : p.cin == 116 ? "shuffle_unit_s2_fused_st3" : "shuffle_unit_s2_fused_st4", s);
     int rc = 1;
-    if (p.h == 24 && p.cin == 24 && p.half == 58) rc = launch_s2_inst<24, 24, 58, 2>(p, s);
+    // stage 3 on the bf16 matrix cores (option "trunk_x3").  Stage 2 (K = 24: the matrix pipe is 38 % of the f32 unit) is SLOWER that way - 715 against 681 us
+    // per 256 clips, the second copy of the input tile and its extra barrier cost more than the MFMAs save - and stage 4 is bound by its weight stream
+    const bool x3 = p.w1p && p.w2p && p.wb1p && p.cin == 116;
+    if (x3 && p.h == 24 && p.cin == 24 && p.half == 58) rc = launch_s2x_inst<24, 24, 58, 2>(p, s);
+    else if (x3 && p.h == 22 && p.cin == 24 && p.half == 58) rc = launch_s2x_inst<22, 24, 58, 2>(p, s);
+    else if (x3 && p.h == 12 && p.cin == 116 && p.half == 116) rc = launch_s2x_inst<12, 116, 116, 2>(p, s);
+    else if (x3 && p.h == 11 && p.cin == 116 && p.half == 116) rc = launch_s2x_inst<11, 116, 116, 2>(p, s);
+    else if (p.h == 24 && p.cin == 24 && p.half == 58) rc = launch_s2_inst<24, 24, 58, 2>(p, s);
     else if (p.h == 22 && p.cin == 24 && p.half == 58) rc = launch_s2_inst<22, 24, 58, 2>(p, s);      // 88x88 crops
     else if (p.h == 12 && p.cin == 116 && p.half == 116) rc = launch_s2_inst<12, 116, 116, 2>(p, s);
     else if (p.h == 11 && p.cin == 116 && p.half == 116) rc = launch_s2_inst<11, 116, 116, 2>(p, s);

@@ -1002,6 +1002,7 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
             sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
             sp.NF = NF; sp.h = h; sp.ho = (h + 1) / 2; sp.cin = U.cin; sp.half = half; sp.Kin = U.kin; sp.Kh = U.kpad;
             sp.Ro = U.cin == 232 ? 3 : 2;                      // informational: fixed by the kernel instance
+            if (m->opt.trunk_x3) { sp.wb1p = U.b1_p3; sp.w1p = U.pw1_p3; sp.w2p = U.pw2_p3; }
             if (launch_shuffle_s2(sp, s)) return 1;
             h = sp.ho;
         } else if (U.stride2) {

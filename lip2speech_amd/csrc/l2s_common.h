@@ -277,6 +277,7 @@ struct ShuffleS2P {
     const float* wd; const float* sd; const float* bd;       // banch2 dw: [9][half]
     const float* w2f; const float* s2; const float* b2;      // banch2 pw2: frag16 [pad16(half)][Kh]
     int NF, h, ho, cin, half, Kin, Kh, Ro;
+    const void* wb1p; const void* w1p; const void* w2p;      // the three pointwise weights as pre-split bf16 operand planes (launch_su_planes) or null
 };
 int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s);
 // out[r*ldo + off_o + c*cs_o] = in[r*ldi + off_i + c]

@@ -23,8 +23,10 @@ for x3 in (0, 1):
     print(f"trunk_x3={x3}: encoder {e0.elapsed_time(e1) / 5:.3f} ms per {B} clips")
     native.profile_enable(True); native.profile_reset()
     nm.encoder_fwd(v); torch.cuda.synchronize()
+    tot = 0.0
     for name, n, ms in native.profile_read():
-        if "shuffle" in name: print(f"    {name:36s} {ms * 1e3 / max(n, 1):8.1f} us x {n}")
+        if "shuffle" in name: print(f"    {name:36s} {ms * 1e3 / max(n, 1):8.1f} us x {n}"); tot += ms
+    print(f"    all 16 units: {tot:.3f} ms")
     native.profile_enable(False)
 d = (feats[0] - feats[1]).abs()
 print(f"features x3 vs f32 units: max |d| {d.max().item():.3e}, mean {d.mean().item():.3e} (unit-norm rows of 768)")
