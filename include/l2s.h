@@ -364,6 +364,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            registers, 66 VGPRs, three blocks per CU instead of two: +2 % with four batches in flight, -0.4 % one at a time;
  *                            1 = one round trip; 3 = no further gain.  "skinny_split8" (1): the same for the K <= 1024 instance (no gain)
  *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
+ *   "trunk_x3"          (1)  the fused units' pointwise convs on the bf16 matrix cores through the exact three-way split (activations split once where
+ *                            they are written to LDS, weights as pre-split operand planes: stride-1 units and stage 3's stride-2 unit); 0 = f32 MFMA
  *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
  *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
 /* l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.

@@ -1169,7 +1169,7 @@ int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s) {
 template <class GM, int NCH, int PITCH, int PLANE, int LDA>
 __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const uint4* __restrict__ Wp,
                                            const float* __restrict__ scale, const float* __restrict__ shift) {
-    constexpr int G = GM::G, IT = GM::IT, NT = GM::NT, BD = NCH <= 4 ? NCH : 3;
+    constexpr int G = GM::G, IT = GM::IT, NT = GM::NT, BD = NCH <= 4 ? NCH : 3;      // (two chunks in flight at K = 128: 3 % slower)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const
                     const unsigned char* ap = ab + j * 16 * PITCH + 64 * c;
                     const su_bf16x8 ah = *reinterpret_cast<const su_bf16x8*>(ap), am = *reinterpret_cast<const su_bf16x8*>(ap + PLANE),
                                     al = *reinterpret_cast<const su_bf16x8*>(ap + 2 * PLANE);
-                    f32x4 a = acc[it][j];      // smallest partial products first
+                    f32x4 a = acc[it][j];      // smallest partial products first (term-major over two, three or all row tiles: no faster)
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
@@ -1209,7 +1209,7 @@ __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
                     acc[it][j] = a;
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later chunks from being hoisted (VGPRs)
+                __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later chunks from being hoisted (VGPRs; without it: 3 % slower)
                 if (c + BD < NCH) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) b[sl][q] = wb[((c + BD) * 3 + q) * 64];
