@@ -5,7 +5,7 @@ set -u
 R=$PWD; O=$R/gpurun_out/prof_r4; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() { timeout 500 "$@" < /dev/null > /tmp/prof.log 2>&1 || tail -3 /tmp/prof.log; }
 rm -rf /tmp/p_bench; run rocprofv3 --kernel-trace --stats -d /tmp/p_bench -o b -- python $R/bench.py --steps 64 --warmup 16 --skip-cpu-baseline
-python $R/tools/rocprof_summary.py $(find /tmp/p_bench -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --steps 64 --warmup 16 --skip-cpu-baseline (round 3: 8 batches per launch chain, 2 chains in flight, B=32, T=29, S=300)" > $O/r04_kernel_stats.md
+python $R/tools/rocprof_summary.py $(find /tmp/p_bench -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --steps 64 --warmup 16 --skip-cpu-baseline (round 4: 8 batches per launch chain, 2 chains in flight, B=32, T=29, S=300)" > $O/r04_kernel_stats.md
 rm -rf /tmp/p_tr; run rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o t -- python $R/tools/prof_decode.py
 python $R/tools/rocprof_summary.py $(find /tmp/p_tr -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python tools/prof_decode.py (decode loop only, 256 rows per launch, 3 x 300 steps)" > $O/r04_kernel_stats_decode256.md
 for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do n=$(echo $set | cut -d' ' -f1); rm -rf /tmp/p_$n; run rocprofv3 --pmc $set -d /tmp/p_$n -o c -- python $R/tools/prof_decode.py; done
