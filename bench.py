@@ -71,13 +71,24 @@ def kernel_model(name, rows=B):
         "frontend3d_conv_bn_prelu_pool": (2 * 1178.6e6 * R, (R * 3 * T * HW * HW + R * T * 24 * 24 * 24 + 17640) * w4),
         "postnet_conv_gemm": (2 * 4.34e6 * S * R / 5, (R * S * (80 + 512 * 4 * 2 + 80) + 4.35e6) * w4 / 5),
     }
+    # fused ShuffleNet units (shufflenetv2.py:42-104), one launch over R*T frames: the unit's MACs (two / three 1x1 convs + 3x3 depthwise) and its
+    # map read once + written once + its weights
+    NF = R * T
+    for tag, hh, half in (("h12", 144, 58), ("h6", 36, 116), ("h3", 9, 232)):       # stride-1: x2 -> pw -> dw -> pw, x1 passes through
+        table["shuffle_unit_s1_fused_" + tag] = (2 * NF * hh * (2 * half * half + 9 * half), (NF * hh * 2 * half * 2 + 2 * half * half + 15 * half) * w4)
+    for tag, h, cin, half in (("st2", 24, 24, 58), ("st3", 12, 116, 116), ("st4", 6, 232, 232)):      # stride-2: (dw s2 -> pw) and (pw -> dw s2 -> pw)
+        ho = h // 2
+        table["shuffle_unit_s2_fused_" + tag] = (2 * NF * (ho * ho * (9 * cin + cin * half + 9 * half + half * half) + h * h * cin * half),
+                                                 (NF * (h * h * cin + ho * ho * 2 * half) + 2 * cin * half + half * half + 9 * cin + 15 * half) * w4)
     return table.get(name)
 
 
 # which matrix pipe a kernel of the path runs on: "bf16x3" = the bf16 matrix cores through the exact three-way split (six
 # bf16 MFMAs per fp32 product: ceiling 2 500 / 6 = 416.7 TFLOP/s fp32-equivalent); "f32" = v_mfma_f32_*_f32 (157.3 TFLOP/s)
 KERNEL_PIPE = {"step_lstm_cell": "bf16x3", "postnet_conv_gemm": "bf16x3", "frontend3d_conv_bn_prelu_pool": "bf16x3",
-               "step_prenet1_q_cq_fc": "f32", "step_fc_out_stop": "f32", "step_attention_proj": "f32"}
+               "step_prenet1_q_cq_fc": "f32", "step_fc_out_stop": "f32", "step_attention_proj": "f32",
+               "shuffle_unit_s1_fused_h12": "bf16x3", "shuffle_unit_s1_fused_h6": "bf16x3", "shuffle_unit_s1_fused_h3": "bf16x3", "shuffle_unit_s2_fused_st3": "bf16x3",
+               "shuffle_unit_s2_fused_st2": "f32", "shuffle_unit_s2_fused_st4": "f32"}
 
 
 def mfma_roof(name, flops, avg_s):
@@ -562,7 +573,7 @@ def main():
         others = []
         for oname, olaunches, oms in prof[1:]:
             om = kernel_model(oname, rows)
-            if not om or len(others) >= 5:
+            if not om or len(others) >= 11:
                 continue
             oavg = oms / olaunches * 1e-3
             oflops, obytes = om

@@ -635,7 +635,10 @@ static bool x3_wide(const GemmBatch& b) {
         narrow += (int64_t)((p.M + XM - 1) / XM) * ((p.N + XN - 1) / XN);
     }
     if (b.p[0].x3 & 2) return true;                           // forced (operator tests): the wide tile wherever it fits
-    const double cost_w = (double)((wide + 255) / 256) * (b.count > 1 ? 2.0 : 1.7), cost_n = (double)((narrow + 255) / 256);
+    bool dma = true;
+    for (int i = 0; i < b.count; ++i) dma = dma && b.p[i].W3 && b.p[i].ldw == 0;
+    // grouped launches whose members all bring weight planes (the MultiHop convs): the DMA form's K step is 2 013 clk against 2 x 1 320
+    const double cost_w = (double)((wide + 255) / 256) * (b.count > 1 ? (dma ? 1.6 : 2.0) : 1.7), cost_n = (double)((narrow + 255) / 256);
     return cost_w < cost_n;
 }
 

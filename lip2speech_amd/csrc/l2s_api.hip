@@ -600,12 +600,15 @@ static int derive_gemm_planes(l2s_model* m, hipStream_t s) {
     Weights& w = m->w;
     for (int i = 0; i < 5; ++i) w.post[i].W3 = nullptr;
     w.wih_cat3 = nullptr; w.conv_last.W3 = nullptr;
+    for (int kv = 0; kv < 2; ++kv) for (int j = 0; j < 4; ++j) w.mh_branch[kv][j].W3 = nullptr;
     struct Item { const float* W; int N, K; const void** slot; };
     std::vector<Item> items;
     if (m->has_dec) {
         const int Ks[4] = {5 * NM, 5 * 512, 5 * 512, 5 * 512};
         for (int i = 0; i < 4; ++i) items.push_back({w.post[i].W, 512, Ks[i], &w.post[i].W3});
         items.push_back({w.wih_cat, 4096, 1024, &w.wih_cat3});
+        for (int kv = 0; kv < 2; ++kv)
+            for (int j = 0; j < 4; ++j) items.push_back({w.mh_branch[kv][j].W, 512, 512 * MH_KS[j], &w.mh_branch[kv][j].W3});      // the eight MultiHop convs (k = 1, 3, 7, 11; K and V)
     }
     if (m->has_enc) items.push_back({w.conv_last.W, LAST_CH, STAGE_CH[3], &w.conv_last.W3});
     int64_t total = 0;
@@ -1184,6 +1187,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
                 gb.p[g++] = conv_gemm(cat, 4608, B, T, 512, w.mh_branch[kv][j], 512, MH_KS[j], 1, MH_KS[j] / 2,
                                       cat + 512 + (kv * 4 + j) * 512, 4608, ACT_SILU);
         gb.count = 8;
+        if (!m->opt.gemm_x3_dma) for (int i = 0; i < 8; ++i) gb.p[i].W3 = nullptr;
         if (launch_gemm(gb, s, "multihop_conv_gemm")) return 1;
         GemmBatch bb{};
         for (int kv = 0; kv < 2; ++kv) {
