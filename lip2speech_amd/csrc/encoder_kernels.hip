@@ -1168,7 +1168,7 @@ int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s) {
 // su_gemm.  A column tile's weight chunks are requested BD at a time (all of them up to K = 128; three in flight beyond).
 template <class GM, int NCH, int PITCH, int PLANE, int LDA>
 __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const uint4* __restrict__ Wp,
-                                           const float* __restrict__ scale, const float* __restrict__ shift) {
+                                           const float* __restrict__ scale, const float* __restrict__ shift, int mrows = 1 << 30) {
     constexpr int G = GM::G, IT = GM::IT, NT = GM::NT, BD = NCH <= 4 ? NCH : 3;      // (two chunks in flight at K = 128: 3 % slower)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1232,7 +1232,8 @@ __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[it][j][r] * sc + sh;
-                        buf[((mt0 + j) * 16 + 4 * lg + r) * LDA + n] = v > 0.f ? v : 0.f;
+                        const int row = (mt0 + j) * 16 + 4 * lg + r;
+                        if (row < mrows) buf[row * LDA + n] = v > 0.f ? v : 0.f;      // mrows: the rows the region was sized for (the tile's other rows are nobody's)
                     }
                 }
             }
@@ -1651,7 +1652,7 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2_kernel(const ShuffleS2P p, 
     if (TIMED) { __builtin_amdgcn_s_waitcnt(0); S2_STAMP(8); }
 }
 
-// The stride-2 unit with its three pointwise convs on the bf16 matrix cores (used for stage 3; stage 4's unit streams 3 x 223 KB of weights per 36-pixel
+// The stride-2 unit with its three pointwise convs on the bf16 matrix cores (stages 2 and 3; stage 4's unit streams 3 x 223 KB of weights per 36-pixel
 // block and is bound by them - as planes they would be 1.5x the bytes).  The input tile is needed twice: as fp32 by banch1's depthwise, as planes by
 // pw1 - the threads keep the float4s they loaded and write the planes over the fp32 tile once the depthwise has read it.  Both depthwise convs write
 // their outputs as planes; every GEMM leaves fp32 rows in place of its operand planes.
@@ -1660,11 +1661,14 @@ struct S2XGeo {
     using B = S2Geo<H, CIN, HALF, RO>;
     static constexpr int HO = B::HO, LDA = B::LDA, MTI = B::MTI, MTO = B::MTO, RX = B::RIN * H;
     static constexpr int KI32 = su_pad32(CIN), KH32 = su_pad32(HALF), PIN = su_pitch(KI32), PH = su_pitch(KH32);
-    static constexpr int XPLANE = RX * PIN, D1PLANE = MTO * 16 * PIN, D2PLANE = MTO * 16 * PH;      // X: valid tile rows only (the last tile's other rows read on into the next plane: garbage rows nobody reads)
+    static constexpr int RV = RO * HO;                     // output pixels of a block: the rows the output-resolution regions are sized for
+    // valid rows only: a tile's other rows are read on into whatever follows (garbage rows nobody reads) and never written (su_gemm_x3's row limit)
+    static constexpr int XPLANE = RX * PIN, D1PLANE = RV * PIN, D2PLANE = RV * PH;
     static constexpr int XBYTES = 3 * XPLANE > MTI * 16 * LDA * 4 ? 3 * XPLANE : MTI * 16 * LDA * 4;
-    static constexpr size_t SMEM = (size_t)XBYTES + 3 * D1PLANE + 3 * D2PLANE;
-    static_assert(3 * D1PLANE >= MTO * 16 * LDA * 4 && 3 * D2PLANE >= MTO * 16 * LDA * 4, "a GEMM's fp32 rows fit in place of its operand planes");
-    static_assert(XBYTES % 16 == 0 && D1PLANE % 16 == 0, "16-byte aligned regions");
+    static constexpr int TAIL = (MTO * 16 - RV) * PIN + 16;      // the last region's over-read stays inside the allocation
+    static constexpr size_t SMEM = (size_t)XBYTES + 3 * D2PLANE + 3 * D1PLANE + TAIL;      // [X | D2 | D1 | tail]: stage 2 fits three blocks per CU (54 016 B)
+    static_assert(3 * D1PLANE >= RV * LDA * 4 && 3 * D2PLANE >= RV * LDA * 4, "a GEMM's fp32 rows fit in place of its operand planes");
+    static_assert(XBYTES % 16 == 0 && D1PLANE % 16 == 0 && D2PLANE % 16 == 0 && TAIL % 16 == 0, "16-byte aligned regions");
     using G1 = SuGemm<HALF, 1, MTI>;
     using G2 = SuGemm<HALF, 1, MTO>;
 };
@@ -1683,8 +1687,8 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2x_kernel(const ShuffleS2P p,
     const int outv = ro * HO;                              // valid output pixels of this block
     float* X = su_smem;
     unsigned char* const XP = reinterpret_cast<unsigned char*>(su_smem);
-    unsigned char* const D1P = XP + Q::XBYTES;
-    unsigned char* const D2P = D1P + 3 * Q::D1PLANE;
+    unsigned char* const D2P = XP + Q::XBYTES;
+    unsigned char* const D1P = D2P + 3 * Q::D2PLANE;
     float* D1 = reinterpret_cast<float*>(D1P);
     float* D2 = reinterpret_cast<float*>(D2P);
     S2_STAMP(0);
@@ -1702,7 +1706,7 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2x_kernel(const ShuffleS2P p,
         xin[i] = idx < n4 ? src4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // the output-resolution operand planes start as zeros: their K padding must be, and their unused rows must not hold NaN patterns
-    for (int idx = tid; idx < (3 * Q::D1PLANE + 3 * Q::D2PLANE) / 16; idx += 512) reinterpret_cast<uint4*>(D1P)[idx] = make_uint4(0u, 0u, 0u, 0u);
+    for (int idx = tid; idx < (3 * Q::D1PLANE + 3 * Q::D2PLANE + Q::TAIL) / 16; idx += 512) reinterpret_cast<uint4*>(D2P)[idx] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int idx = tid + 512 * i;
@@ -1751,9 +1755,9 @@ __global__ __launch_bounds__(512, 4) void shuffle_s2x_kernel(const ShuffleS2P p,
     __syncthreads();
     S2_STAMP(5);
     // the two output-resolution pointwise convs + BN + ReLU: planes -> fp32 rows in place
-    su_gemm_x3<typename Q::G2, Q::KI32 / 32, PIN, Q::D1PLANE, LDA>(D1P, reinterpret_cast<const uint4*>(p.wb1p), p.sb1, p.bb1);
+    su_gemm_x3<typename Q::G2, Q::KI32 / 32, PIN, Q::D1PLANE, LDA>(D1P, reinterpret_cast<const uint4*>(p.wb1p), p.sb1, p.bb1, Q::RV);
     S2_STAMP(6);
-    su_gemm_x3<typename Q::G2, Q::KH32 / 32, PH, Q::D2PLANE, LDA>(D2P, reinterpret_cast<const uint4*>(p.w2p), p.s2, p.b2);
+    su_gemm_x3<typename Q::G2, Q::KH32 / 32, PH, Q::D2PLANE, LDA>(D2P, reinterpret_cast<const uint4*>(p.w2p), p.s2, p.b2, Q::RV);
     S2_STAMP(7);
     // channel_shuffle store: out[2k] = banch1[k], out[2k+1] = banch2[k]
     float* ob = p.out + ((int64_t)f * HO + oy0) * (HO * 2 * HALF);
@@ -1813,9 +1817,10 @@ int launch_shuffle_s2(const ShuffleS2P& p, hipStream_t s) {
     L2S_REQUIRE((reinterpret_cast<uintptr_t>(p.x) & 15u) == 0, "shuffle_s2 input must be 16-byte aligned");
     ProfScope ps(p.cin == 24 ? "shuffle_unit_s2_fused_st2" : p.cin == 116 ? "shuffle_unit_s2_fused_st3" : "shuffle_unit_s2_fused_st4", s);
     int rc = 1;
-    // stage 3 on the bf16 matrix cores (option "trunk_x3").  Stage 2 (K = 24: the matrix pipe is 38 % of the f32 unit) is SLOWER that way - 715 against 681 us
-    // per 256 clips, the second copy of the input tile and its extra barrier cost more than the MFMAs save - and stage 4 is bound by its weight stream
-    const bool x3 = p.w1p && p.w2p && p.wb1p && p.cin == 116;
+    // stages 2 and 3 on the bf16 matrix cores (option "trunk_x3").  Stage 2 (K = 24: the matrix pipe is 38 % of the f32 unit) only pays with its regions sized
+    // for the valid rows - 54 KB, three blocks per CU like the f32 unit: 676 -> 652 us per 256 clips (with full 16-row tiles, two blocks per CU: 715); stage 4 is
+    // bound by its weight stream (planes would be 1.5x the bytes) and stays on f32 MFMA
+    const bool x3 = p.w1p && p.w2p && p.wb1p && p.cin != 232;
     if (x3 && p.h == 24 && p.cin == 24 && p.half == 58) rc = launch_s2x_inst<24, 24, 58, 2>(p, s);
     else if (x3 && p.h == 22 && p.cin == 24 && p.half == 58) rc = launch_s2x_inst<22, 24, 58, 2>(p, s);
     else if (x3 && p.h == 12 && p.cin == 116 && p.half == 116) rc = launch_s2x_inst<12, 116, 116, 2>(p, s);

@@ -10,7 +10,7 @@ sd = {k: v for k, v in synth.synth_state_dict().items() if k.startswith("encoder
 B = int(os.environ.get("B", 256))
 v = synth.synth_video(32, 29, tag="bench").cuda().repeat(max(1, B // 32), 1, 1, 1, 1)[:B]
 feats = {}
-for x3 in (0, 1):
+for x3 in ((1, 0) if os.environ.get("REVERSE") else (0, 1)):
     nm = native.NativeModel(); nm.load({k: v_.cuda() for k, v_ in sd.items()}, list(sd.keys()))
     nm.set_option("trunk_x3", x3)
     for _ in range(3): f = nm.encoder_fwd(v)
