@@ -395,8 +395,11 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            <= 32 frames (demo.py runs one clip, BASELINE config 1 two) - as ONE persistent launch of 128 resident workgroups per clip that keep the
  *                            step weights in registers and exchange h / c / q / prenet as tagged 8-byte granules (pdecode.hip): 7.7 instead of 20.4 us per step at
  *                            one clip, 8.2 at two; three or four clips run as two such launches one after the other (l2s_inference 6.1 / 6.2 ms against 7.4).  Another order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference); such
- *                            launches are chained one after the other in a process (each needs the whole chip resident), a launch that cannot make
- *                            progress for about a minute gives up and poisons its outputs with NaN.  0 = always four launches per step; l2s_*_multi never uses it
+ *                            launches are chained one after the other in a process (each needs the whole chip resident); the form is only taken where
+ *                            l2s_persist_available() says every workgroup can be resident (otherwise the launch path runs, same entry points); a launch that
+ *                            makes no progress for 2 s gives up, overwrites mel / stop / attention with NaN and counts in l2s_persist_timeouts(); the next
+ *                            persistent-eligible call fails once with that error and later ones take the launch path.  0 = always four launches per step;
+ *                            l2s_*_multi never uses it
  *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane (frames rounded to nearest even
  *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
  *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every
@@ -412,6 +415,13 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            flight; 2 / 4 = that many chunks per batch, two in flight, for every shape; 15 = 4x2 with five one-chunk batches in flight */
 int l2s_set_option(const char* name, int value);
 int l2s_model_set_option(l2s_model* m, const char* name, int value);
+/* The persistent forms (option "persist_decode") spin on other workgroups and need all of them resident at once.  l2s_persist_available: 1 where that
+ * holds on the current device - 256 compute units, no compute-unit mask in the environment (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), one workgroup of every
+ * persistent kernel fits a compute unit (occupancy query), and no persistent launch of this process has timed out - else 0: calls inside the
+ * envelope then take the launch-per-phase path.  l2s_persist_timeouts: how many persistent launches of this process gave up (2 s without progress) and had
+ * their outputs overwritten with NaN; read from pinned host memory, no synchronize - a host checks it after it has synchronized with the stream. */
+int l2s_persist_available(void);
+int l2s_persist_timeouts(void);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */
 int l2s_profile_enable(int on);

@@ -81,6 +81,7 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
     import time
     from .datasets.spectrograms import MelSpec2Audio
     from .hparams import create_hparams
+    from . import native
     from .metrics import estoi_device, stoi
     hp = create_hparams()
     fs = sampling_rate or hp.sampling_rate
@@ -99,7 +100,7 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
             pred_dev = vocoder(torch.cat([m for _, m in pending], dim=0), rows_per_call=pending[0][1].shape[0])
         else:
             pred_dev = torch.cat([vocoder(m) for _, m in pending], dim=0)
-        n = min(min(a.shape[1] for a, _ in pending), pred_dev.shape[1])
+        n = min(min(a.shape[1] for a, _ in pending), pred_dev.shape[1])      # the device branch only (all audio lengths equal there)
         on_device = metric != "host" and pred_dev.is_cuda and all(a.shape[1] == pending[0][0].shape[1] for a, _ in pending) and \
             -(-n * 10000 // fs) <= 16512
         if metric == "hip" and not on_device:
@@ -109,15 +110,17 @@ def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", ma
             t2 = time.perf_counter()
             gt_dev = torch.cat([a[:, :n] for a, _ in pending], dim=0).to(pred_dev.device, non_blocking=True).float().contiguous()
             scores.extend(float(v) for v in estoi_device(gt_dev, pred_dev[:, :n].contiguous(), fs).cpu())
+            native.check_persist_timeouts()
             row = gt_dev.shape[0]
         else:
             pred = pred_dev.cpu().numpy()
             t2 = time.perf_counter()
             row = 0
-            for audios, m in pending:
+            for audios, m in pending:      # per loader batch, like the reference's loop: a batch's score does not depend on which batches share its group
                 gt = audios.numpy() if not audios.is_cuda else audios.cpu().numpy()
+                n_b = min(gt.shape[1], pred.shape[1])
                 for i in range(gt.shape[0]):
-                    scores.append(stoi(gt[i, :n], pred[row + i, :n], fs, extended=True))
+                    scores.append(stoi(gt[i, :n_b], pred[row + i, :n_b], fs, extended=True))
                 row += gt.shape[0]
         t3 = time.perf_counter()
         t["vocoder_s"] += t2 - t1

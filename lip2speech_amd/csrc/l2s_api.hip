@@ -1102,7 +1102,7 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     float* tap_part = bp.f(tap_floats);
     float* bott_part = bp.f((int64_t)8 * BT * 512);
     // one or two clips of a single-batch call: the BiLSTM recurrence as ONE persistent launch (pdecode.hip pbilstm_kernel; option "persist_decode")
-    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1 && pbilstm_supported(B, T) && pdecode_supported(B, T, mT) && pdecode_device_ok();      // the envelope of the latency path
+    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && !grouped_entry() && pbilstm_supported(B, T) && pdecode_supported(B, T, mT) && pdecode_device_ok();      // the envelope of the latency path
     float* pbx = pbi ? bp.f(pbilstm_ws_bytes() / 4 + 64) : nullptr;
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
@@ -1369,7 +1369,7 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
                       float* mel, float* stop, float* attn, int attn_logits, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(S >= 1 && S <= L2S_MAX_STEPS, "S must be in [1, 300] (positional table)");
     const bool fold = m->opt.fold != 0 && m->folded_valid;
-    if (!teacher && fold && m->opt.persist > 0 && B <= m->opt.persist && gemm_x3_group() == 1) {      // the latency form: one launch for the whole loop
+    if (!teacher && fold && m->opt.persist > 0 && B <= m->opt.persist && !grouped_entry()) {      // the latency form: one launch for the whole loop
         const Weights& w = m->w;
         StateLayout sl = state_layout(B, T);
         if (pdecode_supported(B, T, sl.m) && pdecode_device_ok() && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) {
@@ -1995,6 +1995,8 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_flat_timeline(void* ts_dev) { skinny_set_flat_timeline((unsigned long long*)ts_dev); return 0; }
+int l2s_persist_available(void) { return pdecode_device_ok() ? 1 : 0; }
+int l2s_persist_timeouts(void) { return pdecode_timeouts(); }
 int l2s_op_pdecode_timeline(void* ts_dev, int step) { pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block) { gemm_x3_set_timeline((unsigned long long*)ts_dev, block); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }

@@ -133,7 +133,12 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 int& gemm_x3_mode();                     // thread-local
 int& gemm_x3_group();                    // thread-local: batches per launch chain (1 outside l2s_inference_multi)
 struct X3Scope { int prev; explicit X3Scope(int on) : prev(gemm_x3_mode()) { gemm_x3_mode() = on; } ~X3Scope() { gemm_x3_mode() = prev; } };
-struct X3Group { int prev; explicit X3Group(int g) : prev(gemm_x3_group()) { gemm_x3_group() = g; } ~X3Group() { gemm_x3_group() = prev; } };
+bool& grouped_entry();                  // thread-local: inside an l2s_*_multi call, whatever G (such calls never take the persistent latency forms)
+struct X3Group {
+    int prev; bool prev_grouped;
+    explicit X3Group(int g) : prev(gemm_x3_group()), prev_grouped(grouped_entry()) { gemm_x3_group() = g; grouped_entry() = true; }
+    ~X3Group() { gemm_x3_group() = prev; grouped_entry() = prev_grouped; }
+};
 // bf16-operand mode of the TRAINING GEMMs (forward gemm_nt.hip and backward gemm_bwd.hip; option "train_bf16"): operands rounded to bf16
 // (RNE) while they are staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results.  Thread-local, opened by the l2s_train_*
 // entry points; the recurrent loop, the front-end conv, BatchNorm statistics and every elementwise kernel stay fp32.

@@ -42,7 +42,8 @@ struct PBiP {
 int64_t pbilstm_ws_bytes();
 bool pbilstm_supported(int B, int T);                   // one or two clips
 int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s);
-bool pdecode_device_ok();                               // 256 compute units on the current device
+bool pdecode_device_ok();                               // every workgroup of a persistent launch can be resident: 256 compute units, none masked, kernels fit, no timed-out launch so far
+int pdecode_timeouts();                                 // persistent launches of this process whose workgroups gave up (outputs NaN)
 int64_t pdecode_ws_bytes(int B);                       // exchange granules + status word
 bool pdecode_supported(int B, int T, int m);            // <= 4 clips of <= 32 frames
 void pdecode_set_timeline(unsigned long long* ts, int step);      // non-null: thread 0 of every workgroup stamps the phases of that step

@@ -21,6 +21,7 @@
 #include "skinny_dev.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace l2s {
@@ -121,16 +122,23 @@ __device__ __forceinline__ void pd_publish(__amdgpu_buffer_rsrc_t rsall, int gra
 }
 
 // One poll pass = every load of the phase issued, then every tag compared; repeated until the whole WAVE has fresh granules, so the wave stays
-// converged for the DPP reductions that follow.  A wave that has gone around PD_SPIN_LIMIT times (a minute or more) raises status[0] and leaves, and so, each on its
-// own count, does every other wave that waits for it.  (Two passes in flight half a round trip apart - register sets taking turns, one exit branch so that
-// the compiler waits for the older pass alone - were measured: 9.6-10.0 against 9.7 us per step; more polling is more contention, not a shorter edge.)
-constexpr unsigned PD_SPIN_LIMIT = 200000000u;      // >= a minute of polling: the loop cannot deadlock on its own (other streams' kernels only delay residency)
+// converged for the DPP reductions that follow.  A wave whose polls have made no progress for PD_GIVE_UP_TICKS of the 100 MHz wall clock (~2 s: the
+// workgroups it waits for are not resident - a CU-masked or shared device; other streams' kernels delay residency by milliseconds, not seconds) raises
+// status[0] and leaves, and so, each on its own clock, does every other wave that waits for it.  The clock is read every 256th failed pass only (the
+// first read starts the budget), so a pass that succeeds - the normal case: a few passes per edge - never pays for it.  (Two passes in flight half a
+// round trip apart - register sets taking turns, one exit branch so that the compiler waits for the older pass alone - were measured: 9.6-10.0 against
+// 9.7 us per step; more polling is more contention, not a shorter edge.)
+constexpr unsigned long long PD_GIVE_UP_TICKS = 200000000ull;      // 2 s of wall_clock64() without a fresh granule
 struct PdPoll {
-    unsigned* status; unsigned spins; bool dead;
-    __device__ __forceinline__ PdPoll(unsigned* st) : status(st), spins(0), dead(false) {}
+    unsigned* status; unsigned spins; bool dead; unsigned long long t0;
+    __device__ __forceinline__ PdPoll(unsigned* st) : status(st), spins(0), dead(false), t0(0) {}
     __device__ __forceinline__ bool retry(bool ok) {         // true: go around again
         if (__all(ok)) { spins = 0; return false; }
-        if (++spins > PD_SPIN_LIMIT) { dead = true; return false; }
+        if ((++spins & 255u) == 0u) {
+            const unsigned long long now = wall_clock64();
+            if (spins == 256u) t0 = now;
+            else if (now - t0 > PD_GIVE_UP_TICKS) { dead = true; return false; }
+        }
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         return true;
@@ -632,12 +640,16 @@ __global__ __launch_bounds__(PD_NT, 1) void pbilstm_kernel(const PBiP p) {
 
 int64_t pbilstm_ws_bytes() { return (int64_t)pb_rstride(2) * 8 * PD_MAXREP + 256; }
 bool pbilstm_supported(int B, int T) { return B >= 1 && B <= 2 && T >= 1 && T <= 300; }
-// a launch whose workgroups gave up (PD_SPIN_LIMIT polls without progress - a minute or more: the chip was not theirs) must not hand back plausible numbers
-__global__ void pdecode_guard_kernel(const unsigned* status, float* mel, float* stop, int n_mel, int n_stop) {
+// a launch whose workgroups gave up (no fresh granule for PD_GIVE_UP_TICKS: the chip was not theirs) must not hand back plausible numbers: every output
+// of the launch is overwritten with NaN and the process-wide count of such launches (pinned host memory, readable without a synchronize:
+// l2s_persist_timeouts) goes up by one - the next persistent launch of the process then fails with an error instead of queueing behind a wedged device
+__global__ void pdecode_guard_kernel(const unsigned* status, float* a, float* b, float* c, int na, int nb, int nc, unsigned* timeouts) {
     if (__hip_atomic_load(status, PD_RLX) == 0u) return;
     const float nan = __uint_as_float(0x7fc00000u);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mel; i += gridDim.x * blockDim.x) mel[i] = nan;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_stop; i += gridDim.x * blockDim.x) stop[i] = nan;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) a[i] = nan;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) b[i] = nan;
+    if (c) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) c[i] = nan;
+    if (timeouts && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int64_t pdecode_ws_bytes(int) { return (int64_t)pd_rstride(2) * 8 * PD_MAXREP + 256; }      // laid out for two clips per launch
@@ -650,6 +662,7 @@ bool pdecode_supported(int B, int T, int m) {
 struct PdDevice {
     bool init = false, attr = false;
     int cus = 0;
+    bool resident = false;        // every persistent kernel fits one workgroup per compute unit AND nothing in the environment takes compute units away
     hipEvent_t ev = nullptr;
 };
 constexpr int PD_MAX_DEVICES = 64;
@@ -657,8 +670,21 @@ static std::mutex g_pd_mu;
 static PdDevice g_pd_dev[PD_MAX_DEVICES];
 static unsigned long long* g_pd_ts = nullptr;
 static int g_pd_ts_step = 0;
+static unsigned* g_pd_timeouts = nullptr;      // pinned, device-visible: launches whose workgroups gave up (pdecode_guard_kernel)
+static unsigned g_pd_timeouts_seen = 0;        // ... of which a launcher has already reported
 
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
+
+int pdecode_timeouts() {
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    return g_pd_timeouts ? (int)__atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) : 0;
+}
+
+template <typename K>
+static bool pd_fits(K kernel, int lds) {
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, PD_NT, (size_t)lds) == hipSuccess && nb >= 1;
+}
 
 // the current device's entry (g_pd_mu held); nullptr when the device cannot be queried
 static PdDevice* pd_device_locked() {
@@ -669,17 +695,48 @@ static PdDevice* pd_device_locked() {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!g_pd_timeouts) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&g_pd_timeouts), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) g_pd_timeouts = nullptr;
+            else *g_pd_timeouts = 0u;
+        }
         d.cus = prop.multiProcessorCount;
+        // Co-residency, checked up front: the workgroups spin on each other, so a launch is only made where all of them can be resident at once -
+        // 256 compute units, one workgroup of every persistent kernel fits a compute unit at the largest LDS request (the occupancy query), and no
+        // compute-unit mask in the environment (the device then still reports 256 but hands out fewer).  What cannot be seen from here - another
+        // process on the device - is bounded by the kernels' own 2 s give-up and reported through the guard kernel.
+        const bool masked = std::getenv("HSA_CU_MASK") || std::getenv("ROC_GLOBAL_CU_MASK") || std::getenv("HSA_CU_MASK_SKIP_INIT");
+        bool fits = d.cus >= PD_WG && !masked && g_pd_timeouts;
+        if (fits) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
+            d.attr = true;
+            fits = pd_fits(pdecode_kernel<1, 2>, PD_LDS_MAX) && pd_fits(pdecode_kernel<2, 2>, PD_LDS_MAX) && pd_fits(pbilstm_kernel<1>, 0) && pd_fits(pbilstm_kernel<2>, 0);
+        }
+        d.resident = fits;
         d.init = true;
     }
     return &d;
 }
 
-// the persistent forms need 256 compute units on the current device (a partitioned MI355X shows fewer): callers fall back to the launch path otherwise
+// the persistent forms need every workgroup resident at once (above): callers fall back to the launch path where that cannot be promised, and after a
+// launch of this process has timed out (the device is evidently shared)
 bool pdecode_device_ok() {
     std::lock_guard<std::mutex> lock(g_pd_mu);
     const PdDevice* d = pd_device_locked();
-    return d && d->cus >= PD_WG;
+    return d && d->resident && __atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) == 0u;
+}
+
+// g_pd_mu held.  A timed-out launch is reported ONCE as an error by the next launcher (its outputs are NaN already); pdecode_device_ok() is false from
+// then on, so the callers' next calls take the launch path.
+static int pd_report_timeouts_locked() {
+    const unsigned n = g_pd_timeouts ? __atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) : 0u;
+    if (n != g_pd_timeouts_seen) {
+        g_pd_timeouts_seen = n;
+        set_error("an earlier persistent launch gave up after 2 s without progress (its workgroups were not all resident: shared or CU-masked device); "
+                  "its outputs were overwritten with NaN; further calls take the launch-per-phase path");
+        return 1;
+    }
+    return 0;
 }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -687,13 +744,9 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(2), "persistent decode: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
     PdDevice* const dv = pd_device_locked();
-    L2S_REQUIRE(dv && dv->cus >= PD_WG, "persistent decode needs 256 compute units (one resident workgroup each)");
+    L2S_REQUIRE(dv && dv->resident, "persistent decode needs 256 compute units, one resident workgroup each (none masked)");
+    if (pd_report_timeouts_locked()) return 1;
     const int lds = std::max(pd_lds_floats(2, p.T, p.m) * 4, PD_LDS_MIN);
-    if (!dv->attr) {
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
-        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX));
-        dv->attr = true;
-    }
     L2S_CHECK_HIP(hipStreamWaitEvent(s, dv->ev, 0));      // a never-recorded event is complete
     ProfScope ps("decode_persistent", s);
     // clips two at a time (three or four clips: two launches one after the other - still shorter than 300 x four launches)
@@ -710,7 +763,7 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         // longer fit the registers)
         if (n == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2), dim3(PD_NT), lds, s, q);
         else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG), dim3(PD_NT), lds, s, q);
-        hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.B * q.S * 80, q.B * q.S);
+        hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.attn, q.B * q.S * 80, q.B * q.S, q.attn ? q.B * q.S * q.T : 0, g_pd_timeouts);
         L2S_CHECK_HIP(hipGetLastError());
     }
     L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
@@ -722,7 +775,8 @@ int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(ws && ws_bytes >= pbilstm_ws_bytes(), "persistent BiLSTM: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
     PdDevice* const dv = pd_device_locked();
-    L2S_REQUIRE(dv && dv->cus >= PD_WG, "persistent BiLSTM needs 256 compute units (one resident workgroup each)");
+    L2S_REQUIRE(dv && dv->resident, "persistent BiLSTM needs 256 compute units, one resident workgroup each (none masked)");
+    if (pd_report_timeouts_locked()) return 1;
     PBiP q = p;
     q.xch = reinterpret_cast<u64*>(ws);
     q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pb_rstride(2) * 8 * PD_MAXREP);
@@ -733,7 +787,7 @@ int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     ProfScope ps("bilstm_persistent", s);
     if (p.B == 1) hipLaunchKernelGGL(pbilstm_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
     else hipLaunchKernelGGL(pbilstm_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
-    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, p.B * p.T * 1024, p.B * 1024);
+    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, q.h_state, p.B * p.T * 1024, p.B * 1024, 2 * ((p.B + 15) & ~15) * 512, g_pd_timeouts);
     L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
     return 0;

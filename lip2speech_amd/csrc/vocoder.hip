@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void griffin_lim_kernel(const GriffinP p) 
 
 // =====================================================================================================================================
 // ESTOI (pystoi 0.3.3 stoi(x, y, fs, extended=True) as restated in lip2speech_amd/metrics.py), one block per clip:
-//   resample_poly(., 10000 / g, fs / g) with the caller's polyphase FIR -> drop the frames of the clean signal more than 40 dB below its
+//   resample_poly(., 10000 / g, fs / g) with the caller's polyphase FIR (pystoi's resample_oct window) -> drop the frames of the clean signal more than 40 dB below its
 //   loudest frame (256-sample hann frames, hop 128) from both signals and overlap-add the rest -> 512-point spectra of 256-sample frames ->
 //   15 one-third octave bands -> every run of 30 frames: rows and columns normalised to zero mean / unit norm -> mean correlation.
 // The work per clip is small (two signals x ~93 frames x 257 bins): the spectra are direct sums against a 512-entry twiddle table.
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(1024) void estoi_kernel(const EstoiP p) {
     }
     __syncthreads();
     // ---- silent-frame removal: energies of the clean signal's windowed frames
-    const int nf = nr >= ES_FRAME ? 1 + (nr - ES_FRAME) / ES_HOP : 0;
+    // pystoi 0.3.3 frames with range(0, len - framelen, hop): ceil((len - framelen) / hop) frames - the one ending on the last sample is not taken
+    const int nf = nr > ES_FRAME ? (nr - ES_FRAME + ES_HOP - 1) / ES_HOP : 0;
     {
         const int wv = tid >> 6, ln = tid & 63;
         for (int f = wv; f < nf; f += 16) {
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(1024) void estoi_kernel(const EstoiP p) {
         }
     __syncthreads();
     // ---- power spectra of the bins the bands use (direct sums against the twiddle table), then the band magnitudes
-    const int nf2 = len2 >= ES_FRAME ? 1 + (len2 - ES_FRAME) / ES_HOP : 0;
+    const int nf2 = len2 > ES_FRAME ? (len2 - ES_FRAME + ES_HOP - 1) / ES_HOP : 0;      // = nk - 1: the same rule on the overlap-added signal
     if (nf2 < ES_SEG) { if (tid == 0) p.score[clip] = 1e-5f; return; }      // pystoi: not enough frames -> 1e-5 (with a warning)
     const int k_lo = p.band_lo[0], k_hi = p.band_hi[ES_BANDS - 1], nkb = k_hi - k_lo;
     for (int item = tid; item < 2 * nf2 * nkb; item += 1024) {

@@ -1,7 +1,16 @@
 """ESTOI, the score `evaluate.py` reports (reference: /root/reference/evaluate.py:41-45 calls ``pystoi.stoi(clean, pred, fs,
-extended=True)``).  pystoi (0.3.3) is a third-party package that is not installed here; its published algorithm (Jensen & Taal 2016;
-pystoi/stoi.py, pystoi/utils.py) is restated below on numpy/scipy - PARITY UNPINNED.  Host-side, like the
-reference: the score is computed on numpy waveforms after the vocoder.
+extended=True)``).  pystoi (pinned 0.3.3, requirements.txt:6) is a third-party package that is not installed here; its published
+algorithm (Jensen & Taal 2016; pystoi/stoi.py, pystoi/utils.py) is restated below on numpy/scipy - PARITY UNPINNED (SURVEY.md §8(f)
+row 4).  Host-side, like the reference: the score is computed on numpy waveforms after the vocoder.
+
+Two details of 0.3.3 that a textbook STOI does not share and that this file follows:
+* framing (`remove_silent_frames`, `stft` in pystoi/utils.py) iterates ``range(0, len(x) - framelen, hop)``: the frame that would END
+  exactly at the last sample is NOT taken, i.e. ceil((len - framelen) / hop) frames.  After the overlap-add of k kept frames the
+  signal is (k - 1) hop + framelen long - always such a case - so the spectra have k - 1 frames, and "fewer than 30 frames -> 1e-5"
+  triggers at k <= 30 kept frames;
+* resampling to 10 kHz is `resample_oct`: scipy's resample_poly with pystoi's own Octave-compatible Kaiser-windowed sinc
+  (`_resample_window_oct`: 60 dB rejection, cut-off 1 / (2 max(p, q)), transition a tenth of it), normalised to unit sum - not
+  resample_poly's default firwin(kaiser 5.0).
 """
 from __future__ import annotations
 
@@ -33,8 +42,13 @@ def thirdoct(fs: int, nfft: int, num_bands: int, min_freq: float):
     return obm, cf
 
 
+def n_frames(n: int, framelen: int, hop: int) -> int:
+    """len(range(0, n - framelen, hop)): pystoi 0.3.3's frame count (the frame ending on the last sample is dropped)."""
+    return -(-(n - framelen) // hop) if n > framelen else 0
+
+
 def _frames(x: np.ndarray, framelen: int, hop: int, window: np.ndarray) -> np.ndarray:
-    n = 1 + (len(x) - framelen) // hop if len(x) >= framelen else 0
+    n = n_frames(len(x), framelen, hop)
     idx = np.arange(framelen)[None, :] + hop * np.arange(n)[:, None]
     return x[idx] * window[None, :]
 
@@ -55,6 +69,32 @@ def remove_silent_frames(x: np.ndarray, y: np.ndarray, dyn_range: float, framele
         xo[i * hop: i * hop + framelen] += xf[i]
         yo[i * hop: i * hop + framelen] += yf[i]
     return xo, yo
+
+
+def resample_window_oct(p: int, q: int) -> np.ndarray:
+    """pystoi/utils.py `_resample_window_oct` (a port of Octave's `resample`): Kaiser-windowed sinc, NOT normalised."""
+    g = int(np.gcd(int(p), int(q)))
+    p, q = int(p) // g, int(q) // g
+    log10_rejection = -3.0
+    stopband_cutoff_f = 1.0 / (2 * max(p, q))
+    roll_off_width = stopband_cutoff_f / 10
+    rejection_db = -20 * log10_rejection
+    half = int(np.ceil((rejection_db - 8) / (28.714 * roll_off_width)))
+    t = np.arange(-half, half + 1)
+    ideal = 2 * p * stopband_cutoff_f * np.sinc(2 * stopband_cutoff_f * t)
+    if 21 <= rejection_db <= 50:
+        beta = 0.5842 * (rejection_db - 21) ** 0.4 + 0.07886 * (rejection_db - 21)
+    elif rejection_db > 50:
+        beta = 0.1102 * (rejection_db - 8.7)
+    else:
+        beta = 0.0
+    return np.kaiser(2 * half + 1, beta) * ideal
+
+
+def resample_oct(x: np.ndarray, p: int, q: int) -> np.ndarray:
+    """pystoi/utils.py `resample_oct`: resample_poly with the window above normalised to unit sum."""
+    h = resample_window_oct(p, q)
+    return resample_poly(x, p, q, window=h / np.sum(h))
 
 
 def _stft(x: np.ndarray, win_size: int, fft_size: int, overlap: int = 2) -> np.ndarray:
@@ -78,8 +118,7 @@ def stoi(x, y, fs_sig: int, extended: bool = False) -> float:
     if x.shape != y.shape:
         raise Exception("x and y should have the same length, found {} and {}".format(x.shape, y.shape))
     if fs_sig != FS:
-        g = np.gcd(FS, fs_sig)
-        x, y = resample_poly(x, FS // g, fs_sig // g), resample_poly(y, FS // g, fs_sig // g)
+        x, y = resample_oct(x, FS, fs_sig), resample_oct(y, FS, fs_sig)
     x, y = remove_silent_frames(x, y, DYN_RANGE, N_FRAME, N_FRAME // 2)
     xs, ys = _stft(x, N_FRAME, NFFT).T, _stft(y, N_FRAME, NFFT).T          # (freq, frames)
     if xs.shape[-1] < N:
@@ -106,19 +145,19 @@ def stoi(x, y, fs_sig: int, extended: bool = False) -> float:
 
 # ---------------------------------------------------------------------------------------------------------------- on the device (l2s_estoi)
 def resample_poly_plan(n_in: int, up: int, down: int):
-    """What scipy.signal.resample_poly(x, up, down) (default Kaiser-5 window, zero-padded ends) computes before it filters: the FIR it
-    designs - scaled by `up`, with its leading / trailing zero pads - the number of leading outputs it drops and its output length.
-    Returns (h float64, up, down, n_pre_remove, n_out) with up / down reduced, or (None, 1, 1, 0, n_in) when there is nothing to do."""
-    from scipy.signal import firwin
+    """What `resample_oct(x, up, down)` = scipy.signal.resample_poly(x, up, down, window=h / sum(h)) computes before it filters: the FIR
+    (pystoi's Octave-compatible window, unit sum, scaled by `up`) with the leading / trailing zero pads resample_poly adds, the number of
+    leading outputs it drops and its output length.  Returns (h float64, up, down, n_pre_remove, n_out) with up / down reduced, or
+    (None, 1, 1, 0, n_in) when there is nothing to do."""
     g = int(np.gcd(int(up), int(down)))
     up, down = int(up) // g, int(down) // g
     if up == down == 1:
         return None, 1, 1, 0, n_in
     n_out = n_in * up
     n_out = n_out // down + bool(n_out % down)
-    max_rate = max(up, down)
-    half_len = 10 * max_rate
-    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    w = resample_window_oct(up, down)
+    h = w / np.sum(w) * up
+    half_len = (len(h) - 1) // 2
     n_pre_pad = down - half_len % down
     n_post_pad = 0
     n_pre_remove = (half_len + n_pre_pad) // down

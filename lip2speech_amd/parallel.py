@@ -102,6 +102,8 @@ class InflightPool:
         """Cut `run` into consecutive groups of at most `group` items whose count is a multiple of `chains` (when the run is long enough)
         and whose sizes differ by at most one."""
         k = len(run)
+        if k == 0:
+            return []
         n = min(k, chains * -(-k // (chains * group)))
         base, extra = divmod(k, n)
         out, pos = [], 0
@@ -117,6 +119,8 @@ class InflightPool:
         most rows per launch (the decode loop's launches cost nearly the same at 160 rows as at 256), the smaller count on a tie - a third
         chain only overlaps launch gaps the second one already fills.  20 batches in groups of up to 8: three chains (7 + 7 + 6 rows of
         batches per launch) rather than two (four groups of 5): measured 2.96 against 2.85 M mel-frames/s; 192 batches: two (3.17 against 3.08)."""
+        if k <= 0:
+            return 1
         best, best_rows = 1, 0.0
         for c in range(2, max(2, max_chains) + 1):
             n = len(InflightPool.balanced_groups(list(range(k)), group, c))
@@ -216,11 +220,10 @@ class InflightPool:
                                 out[idx[0]] = fn(self.model, batches[idx[0]])
                                 continue
                             grp = [batches[i] for i in idx]
-                        if len(idx) == 1:
-                            out[idx[0]] = self.model.inference(*grp[0], S=S, want_attn=want_attn)
-                        else:
-                            for i, r in zip(idx, self.model.inference_multi(grp, S=S, want_attn=want_attn)):
-                                out[i] = r
+                        # ONE arithmetic whatever the group size: a one-batch tail group takes the grouped entry too (l2s_inference_multi never
+                        # takes the persistent latency form, which sums in another order), so a batch's bits do not depend on how the stream was cut
+                        for i, r in zip(idx, self.model.inference_multi(grp, S=S, want_attn=want_attn)):
+                            out[i] = r
             except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
                 errors.append(e)
 
@@ -249,9 +252,7 @@ class InflightPool:
             self.stats[j0["entry"] + "_groups"] += 1
             self.stats[j0["entry"] + "_batches"] += len(jobs)
             self.stats["max_group"] = max(self.stats["max_group"], len(jobs))
-        if j0["entry"] == "inference":
-            if len(jobs) == 1:
-                return [self.model.inference(j0["video"], j0["emb"], j0["gumbel"], S=j0["S"], want_attn=j0.get("want_attn", False))]
+        if j0["entry"] == "inference":      # also for a one-job group: the pool's results do not depend on the group size (see map)
             return self.model.inference_multi([(j["video"], j["emb"], j["gumbel"]) for j in jobs], S=j0["S"], want_attn=j0.get("want_attn", False))
         if j0["entry"] == "forward":
             return self.model.forward_eval_multi([(j["video"], j["emb"], j["gumbel"], j.get("teacher")) for j in jobs], j0["S"], teacher_mask=j0.get("mask"))

@@ -36,6 +36,29 @@ def native_model(sd=None):
     return _models["m"]
 
 
+SHIPPED_PERSIST = 4          # the library's own default of "persist_decode" (l2s_common.h Options::persist); tests/conftest.py pins 0 for the suite
+
+
+def shipped_model(sd=None):
+    """The cached NativeModel with the options the library SHIPS with (persist_decode = 4: one to four clips of <= 32 frames take the persistent
+    decode loop and, at one or two clips, the persistent BiLSTM) - what a caller of l2s_inference gets who sets no option."""
+    if "shipped" not in _models:
+        _models["shipped"] = fresh_native_model(sd, persist_decode=SHIPPED_PERSIST)
+    return _models["shipped"]
+
+
+class process_default:
+    """with process_default("persist_decode", 4): models created inside (get_network(...) too) start with that option value."""
+    def __init__(self, name, value, restore=0):
+        self.name, self.value, self.restore = name, value, restore
+
+    def __enter__(self):
+        native.set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        native.set_option(self.name, self.restore)
+
+
 def fresh_native_model(sd=None, **options):
     """A NativeModel of its own (not the cached one) with run-time options set BEFORE the weights are packed - options are per model."""
     sd = synth.synth_state_dict() if sd is None else sd

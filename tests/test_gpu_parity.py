@@ -20,6 +20,20 @@ def nm(synth_sd):
     return pc.native_model(synth_sd)
 
 
+@pytest.fixture(params=["launch", "shipped"])
+def nm_both(request, synth_sd):
+    """Both arithmetic routes of a small single-batch call: "launch" = the suite's pinned launch-per-phase loop (persist_decode = 0), "shipped" = the
+    options the library ships with (persist_decode = 4: persistent decode loop for <= 4 clips of <= 32 frames, persistent BiLSTM for <= 2 clips)."""
+    return pc.native_model(synth_sd) if request.param == "launch" else pc.shipped_model(synth_sd)
+
+
+@pytest.fixture(params=[0, pc.SHIPPED_PERSIST], ids=["launch", "shipped"])
+def persist_default(request):
+    """The process default of "persist_decode" while the test runs (models the test creates - get_network too - start with it)."""
+    with pc.process_default("persist_decode", request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("M,N,K,act", [(64, 64, 32, 0), (100, 70, 36, 1), (928, 512, 1024, 2), (37, 501, 256, 3),
                                        (130, 58, 58, 1), (9, 80, 2560, 0), (1, 1, 4, 0)])
 def test_gemm_operator(M, N, K, act):
@@ -165,7 +179,8 @@ def test_encoder_trunk_f32_units(nm, synth_sd, hw, B, T):
     assert 0 < d < 2e-6
 
 
-def test_prologue_matches_oracle(nm):
+def test_prologue_matches_oracle(nm_both):
+    nm = nm_both
     g, _, emb = pc.lrw2_inputs()
     B, T = 2, 29
     vis = native.build_visual(g["feat"].cuda(), emb.cuda())
@@ -184,8 +199,9 @@ def test_prologue_matches_oracle(nm):
     assert pc.maxdiff(dis, pc.golden("forward_lrw_b2_s77.npz")["content_dis"]) < 1e-6
 
 
-def test_inference_matches_reference_golden(nm):
+def test_inference_matches_reference_golden(nm_both):
     """The headline parity gate: Lip2Speech.inference, S=300, identical Gumbel noise."""
+    nm = nm_both
     g, video, emb = pc.lrw2_inputs()
     mel_post, lengths, attn = nm.inference(video.cuda(), emb.cuda(), g["gumbel"].cuda(), S=300, want_attn=True)
     assert pc.maxdiff(mel_post, g["mel_post"]) < MEL_TOL
@@ -445,13 +461,14 @@ def test_full_size_matches_reference_golden(nm):
 
 @pytest.mark.parametrize("B,T,HW,S", [(1, 7, 96, 3), (3, 75, 88, 5), (17, 8, 96, 4), (33, 29, 96, 6), (2, 13, 88, 300), (11, 16, 96, 4),
                                       (3, 59, 88, 24), (19, 14, 88, 38)])
-def test_shapes_against_oracle(nm, synth_sd, B, T, HW, S):
+def test_shapes_against_oracle(nm_both, synth_sd, B, T, HW, S):
     """Shapes off the benchmark's grid (tools/fuzz_parity.py draws more): tile remainders of every kernel, the shortest and the longest
     clips, both crop sizes, batches that are not multiples of the 16-row tile."""
     tag = f"fz{B}_{T}_{HW}_{S}"
     v = synth.synth_video(B, T, HW, HW, tag=tag)
     e = synth.synth_speaker_embedding(B, tag=tag)
     g = synth.synth_gumbel(B * native.min_T(T), tag=tag)
+    nm = nm_both
     mel, ln, at = nm.inference(v.cuda(), e.cuda(), g.cuda(), S=S, want_attn=True)
     with torch.no_grad():
         omel, oln, oat = orc.inference(synth_sd, v, e, g, S=S)
@@ -463,7 +480,7 @@ def test_shapes_against_oracle(nm, synth_sd, B, T, HW, S):
     assert torch.equal(amax[sure], oamax[sure])
 
 
-def test_model_api_inference(synth_sd):
+def test_model_api_inference(synth_sd, persist_default):
     """Through the boundary the reference's callers use: get_network('test').inference(...) (demo.py:82-86)."""
     from model.model import get_network
     g, video, emb = pc.lrw2_inputs()
@@ -495,7 +512,7 @@ def test_model_api_inference(synth_sd):
     ("forward_grid_b2_t75_s188.npz", 2, 75, 188, "grid2"),      # variable-T: min_T = 10
     ("forward_pad_b2_t50_s128.npz", 2, 50, 128, "pad2"),        # zero-padded clip: lengths are ignored
 ])
-def test_forward_eval_matches_reference_golden(synth_sd, name, B, T, S, tag):
+def test_forward_eval_matches_reference_golden(synth_sd, persist_default, name, B, T, S, tag):
     """evaluate.py:38 semantics: net(...,tf_ratio=1) in eval mode -> list of 7."""
     from model.model import get_network
     g = pc.golden(name)
@@ -521,8 +538,9 @@ def test_forward_eval_matches_reference_golden(synth_sd, name, B, T, S, tag):
     assert pc.maxdiff(out[5], g["content_dis"]) < 1e-6
 
 
-def test_teacher_forced_steps(nm):
+def test_teacher_forced_steps(nm_both):
     """Scheduled sampling made explicit: the reference's own torch.rand draws, replayed as a step mask."""
+    nm = nm_both
     g = pc.golden("forward_lrw_b2_s77_tf05.npz")
     base, video, emb = pc.lrw2_inputs()
     B, T, S = 2, 29, 77
@@ -558,8 +576,9 @@ def test_full_batch_rows_are_independent(nm):
     assert torch.equal(len_p, lengths[perm.cuda()])
 
 
-def test_edge_shapes(nm, synth_sd):
+def test_edge_shapes(nm_both, synth_sd):
     """B=1, the shortest clip the reference accepts (T=7: the stride-7 content branch), S=1, and B not a multiple of 16."""
+    nm = nm_both
     for B, T, S in [(1, 7, 1), (3, 12, 5), (17, 9, 3)]:
         video = synth.synth_video(B, T, tag=f"edge{B}")
         emb = synth.synth_speaker_embedding(B, tag=f"edge{B}")
@@ -687,6 +706,19 @@ def test_inflight_pool_is_bit_identical_to_sequential(synth_sd):
             torch.cuda.synchronize()
             for g, w in zip(got, want):
                 assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    # the options the library ships with (persist_decode = 4; B = 4, T = 29 is inside the latency envelope): the pool's bits still do not depend on
+    # how the list was cut - a one-batch group takes the grouped entry like any other (l2s_*_multi never takes the persistent form), so every
+    # result equals the launch path's; the direct single-batch call is the latency form, another order of the same sums
+    shipped = pc.shipped_model(synth_sd)
+    for n_inflight, group in ((3, 1), (2, 3), (1, 8)):
+        got = InflightPool(model=shipped, n_inflight=n_inflight, group=group).map(batches, S=S, want_attn=True)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    if native.persist_available():
+        direct = shipped.inference(*batches[0], S=S, want_attn=True)
+        assert not torch.equal(direct[0], want[0][0]) and pc.maxdiff(direct[0], want[0][0]) < 5e-4
+    assert InflightPool.chains_for(0, 8) == 1 and InflightPool.balanced_groups([], 8, 2) == []
     with pytest.raises(ValueError):
         InflightPool({k: v.cuda() for k, v in synth_sd.items()}, n_inflight=5)
     # host-resident batches prepared on the worker's stream (uint8 clips -> device normalise) and then grouped: same results
@@ -854,7 +886,7 @@ def test_forward_many_matches_forward_per_batch(synth_sd):
 
 
 @pytest.mark.gpu
-def test_stop_bookkeeping_matches_reference_golden(synth_sd):
+def test_stop_bookkeeping_matches_reference_golden(synth_sd, persist_default):
     """decoder.py:429-435 pinned against the reference where it is not trivial (tests/golden/make_stop_goldens.py: the checkpoint differs only
     in the stop layer; the reference's first crossings spread over 13..286 and three clips of the B=32 batch never stop -> 300; at B=2 one clip
     stops at 183, the other never): int64 equality of `output_lengths` through `l2s_inference` AND `l2s_inference_multi`, the stop logits
@@ -915,7 +947,7 @@ def test_persistent_decode_matches_reference_golden(synth_sd, nm):
     feat = nm.encoder_fwd(args[0]); vis = native.build_visual(feat, args[1]); state, _ = nm.decoder_prologue(vis, args[1], args[2])
     pa = own.decode_steps(state, 2, 29, 60, attn_logits=True)
     pb = nm.decode_steps(state, 2, 29, 60, attn_logits=True)
-    assert not torch.equal(pa[0], pb[0]) and pc.maxdiff(pa[0], pb[0]) < 2e-4 and pc.maxdiff(pa[1], pb[1]) < 2e-4
+    assert torch.equal(pa[0], pb[0]) != native.persist_available() and pc.maxdiff(pa[0], pb[0]) < 2e-4 and pc.maxdiff(pa[1], pb[1]) < 2e-4
     assert pc.maxdiff(pa[2], pb[2]) / pb[2].abs().max().item() < 1e-5
     gs = pc.golden("stop_lrw_b2.npz")
     sd = dict(synth_sd)
@@ -941,7 +973,8 @@ def test_persistent_decode_shapes_against_launch_path(synth_sd, nm, B, T, HW, S)
     a = own.inference(video, emb, gum, S=S, want_attn=True)
     b = nm.inference(video, emb, gum, S=S, want_attn=True)
     assert torch.isfinite(a[0]).all()
-    assert not torch.equal(a[0], b[0])                     # (it did take the other route)
+    assert torch.equal(a[0], b[0]) != native.persist_available()      # it did take the other route - wherever the device allows it (l2s_persist_available)
+    assert native.persist_timeouts() == 0
     assert pc.maxdiff(a[0], b[0]) < 5e-4 and torch.equal(a[1], b[1]) and pc.maxdiff(a[2], b[2]) < 5e-4
     if B == 1 and S == 300:
         v3 = synth.synth_video(5, 8, tag="pd5").cuda(); e3 = synth.synth_speaker_embedding(5, tag="pd5").cuda(); g3 = synth.synth_gumbel(5 * native.min_T(8), tag="pd5").cuda()

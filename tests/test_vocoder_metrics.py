@@ -28,6 +28,32 @@ def speechlike(n=16000 * 2, fs=16000, seed=0):
     return ((0.05 * voiced + x) * syll * 0.1).astype(np.float64)
 
 
+def test_estoi_frame_rule_of_pystoi_033_by_hand():
+    """pystoi 0.3.3 frames with range(0, len - framelen, hop) in remove_silent_frames AND stft: the frame ending on the last sample is not
+    taken.  Hand-computed at 10 kHz (no resampler), stationary noise (no frame is silent), framelen 256, hop 128:
+      len 4096 = 256 + 30 * 128 -> 30 frames kept -> overlap-add (30 - 1) * 128 + 256 = 3968 -> spectra of 29 frames < 30 -> 1e-5
+      len 4224 = 256 + 31 * 128 -> 31 kept -> 4096 samples -> 30 frames = exactly one segment -> x against x scores 1
+      len 4225 -> ceil(3969 / 128) = 32 kept -> 4224 -> 31 frames -> two segments."""
+    assert [metrics.n_frames(n, 256, 128) for n in (256, 257, 384, 385, 4096, 4224, 4225)] == [0, 1, 1, 2, 30, 31, 32]
+    x = np.random.default_rng(11).standard_normal(4225)
+    assert len(metrics.remove_silent_frames(x[:4096], x[:4096], 40, 256, 128)[0]) == 3968
+    assert metrics._stft(np.zeros(3968), 256, 512).shape[0] == 29
+    assert metrics.stoi(x[:4096], x[:4096], 10000, extended=True) == 1e-5
+    assert abs(metrics.stoi(x[:4224], x[:4224], 10000, extended=True) - 1.0) < 1e-9
+    assert abs(metrics.stoi(x, x, 10000, extended=True) - 1.0) < 1e-9
+
+
+@pytest.mark.gpu
+def test_estoi_kernel_frame_rule_by_hand():
+    """The same hand-computed cases through `l2s_estoi`: 4096 samples at 10 kHz -> 1e-5 (29 frames), 4224 -> one segment, score 1."""
+    x = torch.from_numpy(np.random.default_rng(11).standard_normal((3, 4225)).astype(np.float32)).cuda()
+    assert np.allclose(metrics.estoi_device(x[:, :4096].contiguous(), x[:, :4096].contiguous(), 10000).cpu().numpy(), 1e-5)
+    assert np.abs(metrics.estoi_device(x[:, :4224].contiguous(), x[:, :4224].contiguous(), 10000).cpu().numpy() - 1.0).max() < 1e-4
+    y = x + 0.5 * torch.roll(x, 1, 0)
+    want = np.array([metrics.stoi(x[i].cpu().numpy().astype(np.float64), y[i].cpu().numpy().astype(np.float64), 10000, extended=True) for i in range(3)])
+    assert np.abs(metrics.estoi_device(x, y.contiguous(), 10000).cpu().numpy() - want).max() < 1e-4
+
+
 def test_estoi_properties():
     x = speechlike()
     rng = np.random.default_rng(1)
@@ -124,14 +150,17 @@ def test_inverse_mel_device_stopping_rule_and_grouped_calls():
 
 
 def test_resample_plan_and_band_edges_reproduce_scipy_and_thirdoct():
-    """The host-side constants handed to `l2s_estoi`: the polyphase FIR / offsets of scipy.signal.resample_poly (the kernel computes
-    out[n] = sum_i x[i] h[(n + n_pre_remove) down - i up]) and the one-third octave band edges."""
-    from scipy.signal import resample_poly
+    """The host-side constants handed to `l2s_estoi`: the polyphase FIR / offsets of pystoi's `resample_oct` = scipy.signal.resample_poly
+    with pystoi's Octave-compatible window (the kernel computes out[n] = sum_i x[i] h[(n + n_pre_remove) down - i up]) and the one-third
+    octave band edges."""
     rng = np.random.default_rng(5)
+    # the window itself, by hand for 16 kHz -> 10 kHz (p, q = 5, 8): cut-off 1/16, transition 1/160, 60 dB -> half length ceil(52 / (28.714 / 160)) = 290
+    w = metrics.resample_window_oct(10000, 16000)
+    assert len(w) == 2 * 290 + 1 and np.argmax(w) == 290 and abs(w[290] - 2 * 5 / 16) < 1e-12 and np.allclose(w, w[::-1])
     for n_in, fs in ((19456, 16000), (4001, 16000), (3000, 22050), (5000, 8000)):
         x = rng.standard_normal(n_in)
         h, up, down, n_pre, n_out = metrics.resample_poly_plan(n_in, metrics.FS, fs)
-        want = resample_poly(x, up, down)
+        want = metrics.resample_oct(x, metrics.FS, fs)
         assert len(want) == n_out
         got = np.zeros(n_out)
         for n in range(0, n_out, 7):                     # every 7th output, by the kernel's formula
