@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: 192 inference passes (0.9 s) / 20 training steps")
     ap.add_argument("--warmup", type=int, default=None, help="default: 16 / 3")
     ap.add_argument("--skip-cpu-baseline", action="store_true", help="for profiler runs")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="run-time option of the library (include/l2s.h) set as the process "
+                    "default before any model is created - A/B runs; the line records them under config.options")
     ap.add_argument("--skip-train-leg", action="store_true", help="inference mode: leave the train_step_B8 leg out of the line (profiler runs)")
     ap.add_argument("--group", type=int, default=8, help="independent B=32 batches advanced per launch chain (l2s_inference_multi, 1..8); 1 = one batch per chain")
     ap.add_argument("--inflight", type=int, default=None, help="launch chains in flight per GPU (HIP streams + host threads); default: InflightPool.chains_for(steps, group) "
@@ -394,6 +396,8 @@ def main():
 
     # replicated weights, per-rank shard of clips (no exchange step on the inference path)
     from lip2speech_amd.parallel import InflightPool
+    for kv in args.opt:
+        native.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     sd = synth.synth_state_dict()
     tensors = {k: v.cuda() for k, v in sd.items()}
     G = max(1, min(8, args.group))
@@ -598,7 +602,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LRW single-word, batch=32 per step, 29x96x96 RGB mouth crops, S=300 decode steps, speaker embedding "
                                    "supplied (encoding=voice), random-init weights; every step is one full pass over one B=32 batch",
-                       "batch_per_step": B, "frames": T, "decode_steps": S, "parallelism": f"dp{world} (clip sharding, no collective)",
+                       "batch_per_step": B, "frames": T, "decode_steps": S, "options": list(args.opt), "parallelism": f"dp{world} (clip sharding, no collective)",
                        "batches_per_launch_chain": G, "launch_chains_in_flight_per_gpu": NI, "distinct_batches_per_gpu": n_distinct,
                        "collective_backend": backend, "ranks": world},
             "warmup_extra_steps_until_steady": extra,

@@ -379,12 +379,18 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "gemm_x3_dma"       (1)  the constant weights that meet the split-bf16 kernel's 128x256x16 tile (post-net layers 0-3, BiLSTM input matrix, conv_last) reach
  *                            it as pre-split bf16 planes (derived on the device at load / refresh, 6 bytes per weight) by LDS-DMA instead of load + split +
  *                            LDS store in its staging waves; same bits; 0 = off
- *   "lstm_x3"           (2)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
+ *   "lstm_x3"           (3)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
  *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
- *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks (same bits), 0 = f32 MFMAs
- *                            (other bits, rounding-level)
- *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows: 1 = at up to
- *                            128 rows per launch, 2 = always, 0 = never (one-column loads, 120 registers); same bits
+ *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks, 3 = eight-wave blocks except
+ *                            the 4x2 blocks of launches with >= 208 rows, which run as FOUR waves of <= 256 registers - half a compute unit, each wave
+ *                            playing its two K slices one after the other on one accumulator set - so that kernels of other launch chains run beside
+ *                            them on the same CUs (1 / 2 / 3: same bits); 0 = f32 MFMAs (other bits, rounding-level)
+ *   "flat_half"         (1)  the step's first launch (flat grid of per-group block shapes, >= 128 rows) on four-wave 2x1 / 2x2 blocks of <= 153 registers
+ *                            and 39 KB of LDS, up to 512 per launch (two or three per CU) instead of eight-wave blocks that sit alone on their CU; same bits
+ *   "half_min_mts"      (13) with "lstm_x3" = 3: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on (13 = where the 4x2 shape is
+ *                            chosen anyway); same bits
+ *   "attn_lds"          (2)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows (74 registers:
+ *                            three blocks per CU): 1 = at up to 128 rows per launch, 2 = always, 0 = never (one-column loads, 120 registers); same bits
  *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path: 2 = two consecutive output
  *                            frames per block (every input frame staged once for both, their 2 x 24 channels as three 16-wide MFMA tiles), 1 = one frame per
  *                            block (32-wide tiles), 0 = f32 MFMA kernel

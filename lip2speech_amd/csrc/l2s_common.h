@@ -57,9 +57,15 @@ struct Options {
     int rc_shape = 0;           // "skinny_rc": register-blocked batch-row blocks for >= 64 rows: 0 = by tile count, 11 = never, 21 / 22 / 42 = force RT x CT
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
     int gemm_x3_dma = 1;        // "gemm_x3_dma": constant Conv1d / Linear weights of the split-bf16 GEMMs as pre-split planes fetched by LDS-DMA (ConvW::W3)
-    int lstm_x3 = 2;            // "lstm_x3": the decode step's LSTM launches on the bf16 matrix cores (exact three-way split, pre-split weight planes): 2 = eight-wave
-                                //   blocks (default), 1 = four-wave blocks (same bits), 0 = the f32 MFMA form
-    int attn_lds = 1;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
+    int lstm_x3 = 3;            // "lstm_x3": the decode step's LSTM launches on the bf16 matrix cores (exact three-way split, pre-split weight planes): 2 = eight-wave
+                                //   blocks, 1 = four-wave blocks, 3 (default) = as 2, but the 4x2 blocks (>= 208 rows) as four-wave blocks of at most 256 registers - half
+                                //   a compute unit, so that kernels of other launch chains run beside them (all the same bits), 0 = the f32 MFMA form
+    int half_min_mts = 13;      // "half_min_mts": with "lstm_x3" = 3 an LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on (13: where 4x2
+                                //   blocks give >= 224 blocks anyway; lower: 4x2 half blocks instead of 2x2 eight-wave blocks at fewer rows); same bits
+    int flat_half = 1;          // "flat_half": the flat first phase of the step on four-wave 2x1 / 2x2 blocks (at most 153 registers, 39 KB of LDS: two or
+                                //   three per CU, up to 512 per launch) instead of eight-wave blocks that sit alone on their CU - so that other chains'
+                                //   kernels run beside them; same bits
+    int attn_lds = 2;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
                                 //   1 = at up to 128 rows per launch, 2 = always, 0 = never
     int hoist_vproj = 2;        // "hoist_vproj": the phase-merged step reads o = a @ V' with V' = V W_ap^T + b_ap computed once in the prologue: 2 = LSTM0 on
                                 //   [content | prenet + o | h0] (K = 1024, the sum formed by the operand loader: the reference's own u = prenet + o), 1 = on

@@ -90,6 +90,16 @@ __global__ __launch_bounds__(256, 1) void skinny_rc4x_kernel(const SkinnyBatch b
     const int g = blockIdx.z;
     skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 4, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
 }
+// Half a compute unit per block (option "lstm_x3" = 3): four waves of at most 256 registers - each wave plays its two K slices one after the other
+// on ONE set of accumulators (skinny_block_rcs<.., SEQ>: same partial sums, same bits as the other forms) - so that two blocks share a CU: of one
+// launch (more than 256 blocks) or of two launch chains on different streams, whose kernels then OVERLAP instead of queueing (a block alone leaves
+// its CU's load path and matrix pipe idle two thirds of its lifetime: first-operand latency, reduction, store drain, launch boundary)
+template <int RT, int CT, int LAYID, int DEPTH>
+__global__ __launch_bounds__(256, 2) void skinny_rc4h_kernel(const SkinnyBatch batch, int mts) {
+    __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
+    const int g = blockIdx.z;
+    skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 4, true, false, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+}
 template <int RT, int CT, int LAYID, int DEPTH>
 __global__ __launch_bounds__(512, 1) void skinny_rc8x_kernel(const SkinnyBatch batch, int mts) {      // the same on eight waves: the two waves of a SIMD alternate split VALU and MFMAs
     __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
@@ -126,7 +136,16 @@ int launch_skx_planes(const float* Wf, int ntiles, int K, void* out, hipStream_t
 template <int RT, int CT, int DEPTH>
 static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s, int x3 = 0) {
     const dim3 grid((maxt + CT - 1) / CT, (mts + RT - 1) / RT, bl.count), blk(256);
-    if (kind == 2 && x3 == 2 && (lay == 1 || lay == 2 || lay == 6)) {
+    constexpr int HD = 3;       // operand slots in flight of the half-CU 4x2 form (four: its 256 registers spill)
+    if constexpr (RT * CT >= 8) {       // the half-CU form exists for the 4x2 block; the smaller shapes already leave room beside them
+        if (kind == 2 && x3 == 3 && (lay == 1 || lay == 2 || lay == 6)) {
+            if (lay == 1) hipLaunchKernelGGL((skinny_rc4h_kernel<RT, CT, 1, HD>), grid, blk, 0, s, bl, mts);
+            else if (lay == 2) hipLaunchKernelGGL((skinny_rc4h_kernel<RT, CT, 2, HD>), grid, blk, 0, s, bl, mts);
+            else hipLaunchKernelGGL((skinny_rc4h_kernel<RT, CT, 6, HD>), grid, blk, 0, s, bl, mts);
+            return true;
+        }
+    }
+    if (kind == 2 && x3 >= 2 && (lay == 1 || lay == 2 || lay == 6)) {
         if (lay == 1) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 1, DEPTH>), grid, dim3(512), 0, s, bl, mts);      // the BiLSTM recurrence (K = 512)
         else if (lay == 2) hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 2, DEPTH>), grid, dim3(512), 0, s, bl, mts);
         else hipLaunchKernelGGL((skinny_rc8x_kernel<RT, CT, 6, DEPTH>), grid, dim3(512), 0, s, bl, mts);
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
 // measurements of tools/time_step_phases.py as bytes / 36.5 GB/s (what one block streams through its CU's vector-memory path) plus its MFMA
 // work at 350 GFLOP/s per CU (not overlapped: a 4x2 block of a K = 512 group has twice the matrix work of a 2x1 block of a K = 1024 group with
 // the same bytes, and lasts longer).  Returns 0 when nothing fits (then the uniform grid runs), else S8 * 100 + S4.
-static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl) {
+static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl, bool half = false) {
     static const int S8[2] = {21, 22}, S4[3] = {21, 22, 42};
     const int n = bl.count;
     auto shape_of = [&](int g, int s8, int s4) { return bl.p[g].K > 512 ? s8 : s4; };
@@ -273,6 +292,7 @@ static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl) {
     int64_t best_sum = 0;
     for (int s8 : S8)
         for (int s4 : S4) {
+            if (half && s4 == 42) continue;      // the 4x2 four-wave block needs 291 registers: not a half-CU block
             int blocks = 0; double mx = 0; int64_t sum = 0;
             for (int g = 0; g < n; ++g) {
                 const int sh = shape_of(g, s8, s4);
@@ -353,13 +373,15 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     const int cls = !o.skinny_sized ? 12 : maxk <= 512 ? 4 : maxk <= 1024 ? 8 : 12;
     // many batch rows: register-blocked blocks, the largest shape that still gives the chip one block per CU
     int shape = (bl.count > 1 && o.rc_shape_multi) ? o.rc_shape_multi : o.rc_shape;
+    bool n_lstm_all = o.rc_jb == 0;       // every group an LSTM cell with pre-split planes: the launch can take the half-CU 4x2 form
+    for (int i = 0; i < bl.count; ++i) n_lstm_all = n_lstm_all && bl.p[i].epi == SK_LSTM && bl.p[i].W3;
     if (shape == 0) {
         shape = 11;
         if (mts >= 4) {
             auto blocks = [&](int rt, int ct) { int n = 0; for (int i = 0; i < bl.count; ++i) n += (bl.ntiles[i] + ct - 1) / ct; return n * ((mts + rt - 1) / rt); };
             // (a 4x4 block - 33 % fewer operand bytes per tile - is MFMA-bound at 30.4 us per block: 512 rows in 31.9 us against 33.0 us with 4x2
             //  blocks in two rounds, and 256 accumulator + operand registers with spills; not kept)
-            if (blocks(4, 2) >= 224) shape = 42;
+            if (blocks(4, 2) >= 224 || (o.lstm_x3 == 3 && o.half_min_mts > 0 && mts >= o.half_min_mts && n_lstm_all)) shape = 42;
             else if (blocks(2, 2) >= 224) shape = 22;
             else if (blocks(2, 1) >= 224) shape = 21;
         }
@@ -377,10 +399,11 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
     if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024 && rc_kind == 1) {      // a forced block shape wins; LSTM groups (the BiLSTM's two directions) keep the uniform grid of four-wave blocks
         SkinnyFlat fl{};
-        const int plan = plan_flat(bl, mts, 256, fl);
+        const bool half = o.flat_half != 0;
+        const int plan = plan_flat(bl, mts, half ? 512 : 256, fl, half);
         // 0 = general blocks, 1 = straight-line eight-wave blocks (default: 12.4 us at 256 rows against 12.9 general), 2 = straight-line four-wave
         // blocks ("skinny_rc_jb" = 44: 14.9 us - these blocks move 262 KB for 3.4 us of matrix work; eight waves keep more loads in flight)
-        int stat = o.rc_jb == 0 || o.rc_jb == 28 ? 1 : o.rc_jb == 44 ? 2 : 0;
+        int stat = half ? 2 : o.rc_jb == 0 || o.rc_jb == 28 ? 1 : o.rc_jb == 44 ? 2 : 0;
         for (int i = 0; i < bl.count; ++i) if (!(skinny_layout_of(bl.p[i]) == (bl.p[i].K > 512 ? 2 : 1) && bl.p[i].epi != SK_LSTM)) stat = 0;
         if (plan) {
             switch (plan) {

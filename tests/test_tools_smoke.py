@@ -13,6 +13,7 @@ TOOLS = os.path.join(ROOT, "tools")
 RUNS = {
     "attn_l2_probe.py": ([], {"ROWS": "32"}),
     "attn_timeline.py": ([], {"ROWS": "32"}),
+    "coresident_probe.py": (["1"], {"PAIRS": "10", "REP": "1"}),
     "flat_timeline.py": ([], {}),
     "fused_unit_timeline.py": ([], {"B": "32"}),
     "gemm_x3_timeline.py": (["1024", "512", "512"], {}),
@@ -40,7 +41,7 @@ SYNTAX_ONLY = ["pmc_decode_json.py", "pmc_read.py", "rocprof_summary.py"]
 
 def test_tools_inventory_is_what_the_readme_lists():
     have = sorted(f for f in os.listdir(TOOLS) if f.endswith((".py", ".sh")))
-    want = sorted(list(RUNS) + SYNTAX_ONLY + ["attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r4.sh"])
+    want = sorted(list(RUNS) + SYNTAX_ONLY + ["ab_bench.sh", "attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r4.sh"])
     assert have == want, (set(have) ^ set(want))
     readme = open(os.path.join(TOOLS, "README.md")).read()
     for f in have + ["membw/membw.hip", "persist/persist_probe.hip"]:

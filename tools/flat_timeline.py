@@ -7,7 +7,8 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()
-nm = native.NativeModel(); nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
+nm = native.NativeModel(); nm.set_option("flat_half", 0)      # the stamped build is the eight-wave form's (one block per CU)
+nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))
 G = 8
 batches = [(synth.synth_video(32, 29, tag=f"b{i}").cuda(), synth.synth_speaker_embedding(32, tag=f"b{i}").cuda(), synth.synth_gumbel(32 * 4, tag=f"b{i}").cuda()) for i in range(G)]
 nm.inference_multi(batches, S=4); torch.cuda.synchronize()
