@@ -13,17 +13,18 @@ N*K*B*S / max-over-ranks(time).
 
 The K steps of a rank are independent batches.  One pass is a chain of ~1 500 dependent launches whose 1 200 step kernels are
 latency-bound at 32 rows, so the steps are advanced `--group` (default 8) batches per launch chain (`l2s_inference_multi`: the G batches
-are rows of the same launches, on one weight blob) with `--inflight` chains in flight (default: two, or three
-where that cuts the K steps into fuller launches - `InflightPool.chains_for`), each on its own HIP stream from its
-own host thread (lip2speech_amd.parallel.InflightPool).  Every step is still one full pass over one B=32 batch and every batch's
+are rows of the same launches, on one weight blob) with `--inflight` chains in flight (default: three - the step kernels' blocks take
+half a compute unit, so launches of different chains run side by side on the CUs; `InflightPool.chains_for`), each on its own HIP
+stream from its own host thread (lip2speech_amd.parallel.InflightPool).  Every step is still one full pass over one B=32 batch and every batch's
 results are bit-identical to `l2s_inference` on it alone (tests/test_gpu_parity.py); `one_batch_at_a_time` in the JSON line is the same K
 steps as K sequential `l2s_inference` calls, `one_chain_at_a_time` the same with one chain, `latency` what one group takes alone.
 Each stream needs a hardware queue: GPU_MAX_HW_QUEUES is raised to 8 below, before the HIP runtime starts (the secondary figures
 use four chains).
 
 The JSON line also carries
-  roofline     for the kernel with the largest share of GPU time, timed live with HIP events on the launch stream
-               in a separate profiled pass (l2s_profile_*), against its algorithmic FLOPs / bytes;
+  roofline     for the kernel with the largest share of GPU time (HIP events per launch in a separate profiled pass, l2s_profile_*),
+               against its algorithmic FLOPs / bytes: `frac` from what the chip spends per launch with the chains of the timed
+               region in flight, `frac_one_chain` from the duration of a launch that has the chip to itself;
   cpu_baseline the CPU oracle (oracle/l2s_oracle.py, "port" of the reference math, verified against the imported
                reference) timed on this host's cores on the same workload (rank 0, N=1 only).
 """
@@ -538,6 +539,34 @@ def main():
             avg_s = nm.lstm_cell_chain_us(rows, 300) * 1e-6
             roof["timing"] = "one HIP-event pair around a chain of 600 launches (300 x {layer 0, layer 1}) on the launch stream"
         roof["avg_us"] = avg_s * 1e6
+        one_chain_s = avg_s
+        if name == "step_lstm_cell" and NI > 1:
+            # The timed region keeps NI launch chains in flight and the step kernels' blocks take half a compute unit, so LSTM launches of different
+            # chains run side by side on the CUs: what the chip spends per launch is the wall time of NI such chains at once / (NI x launches).
+            import threading
+            def chains_at_once(n_pairs=300):
+                bar = threading.Barrier(NI + 1)
+                def work(i):
+                    torch.cuda.set_device(local_rank)
+                    with torch.cuda.stream(pool.streams[i]):
+                        bar.wait()
+                        nm.lstm_cell_chain_us(rows, n_pairs)
+                        pool.streams[i].synchronize()
+                th = [threading.Thread(target=work, args=(i,)) for i in range(NI)]
+                for t_ in th: t_.start()
+                torch.cuda.synchronize()
+                bar.wait()
+                t0_ = time.perf_counter()
+                for t_ in th: t_.join()
+                return (time.perf_counter() - t0_) / (NI * (2 * n_pairs + 16))      # the chain op runs 8 warm-up pairs first
+            chains_at_once(50)
+            avg_s = min(chains_at_once() for _ in range(3))
+            roof["avg_us_one_chain"] = one_chain_s * 1e6
+            roof["avg_us"] = avg_s * 1e6
+            roof["chains_at_once"] = NI
+            roof["timing"] = (f"wall time of {NI} chains of 616 launches (layer 0 / layer 1 alternating) at once on the pool's {NI} streams / ({NI} x 616): what the "
+                              "chip spends per launch with the chains the timed region keeps in flight; avg_us_one_chain = one HIP-event pair around one "
+                              "such chain alone on its stream (what rocprofv3 reports as the kernel's duration)")
         model = kernel_model(name, rows)
         if model:
             flops, nbytes = model
@@ -550,18 +579,23 @@ def main():
             roof["algorithmic_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
             roof["arithmetic_intensity"] = ai
+            if one_chain_s != avg_s and roof["bound"] == "mfma":
+                roof["frac_one_chain"] = roof["frac"] * avg_s / one_chain_s
             ex = executed_flops(name, rows)
             if ex and roof["bound"] == "mfma":
                 roof["executed_flops"] = ex
                 roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj, which the value "
                                 "projection hoisted into the prologue no longer executes per step) / measured duration / the ceiling of the pipe the "
                                 "kernel runs on (bf16 matrix cores, six products per fp32 product: 416.7 TFLOP/s fp32-equivalent); frac_fp32_equiv is the "
-                                "same rate against the fp32 matrix peak of 157.3 TFLOP/s (the data's dtype; rounds 1-3 quoted that one)")
+                                "same rate against the fp32 matrix peak of 157.3 TFLOP/s (the data's dtype; rounds 1-3 quoted that one); frac_one_chain: "
+                                "against the duration of a launch that has the chip to itself (rounds 1-4 quoted that one: 0.238 in round 4) - since round 5 "
+                                "the blocks of the step kernels take half a compute unit and launches of different chains overlap, so a launch's own "
+                                "duration no longer is what the chip spends on it")
         # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
         # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
         roof["traffic"] = None
         try:
-            pmc_file = next(f for f in ("r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k = pmc["kernels"].get(name)
             if k and pmc.get("rows_per_launch") == rows:
@@ -570,7 +604,7 @@ def main():
                 roof["l2_hit_rate_offline"] = k.get("l2_hit_rate")
                 if k.get("avg_us_rocprofv3"):
                     roof["avg_us_rocprofv3_offline"] = k["avg_us_rocprofv3"]
-                    roof["frac_at_rocprofv3_duration"] = roof["frac"] * roof["avg_us"] / k["avg_us_rocprofv3"]
+                    roof["frac_at_rocprofv3_duration"] = roof["frac"] * roof["avg_us"] / k["avg_us_rocprofv3"]      # one chain under the profiler: compare with frac_one_chain
         except (OSError, KeyError, ValueError, StopIteration):
             pass
         # the other kernels with a closed-form cost model, same pass (per-launch HIP-event brackets: us-scale kernels carry ~1.8 us of it)

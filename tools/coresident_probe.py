@@ -1,6 +1,6 @@
 """Do the kernels of several launch chains overlap on the chip when a block takes half a compute unit?
 
-Two measurements, each for the default block forms (every step kernel's blocks sit alone on their CU: "lstm_x3" = 2, "flat_half" = 0) and the half-CU
+Two measurements, each for the default block forms (every step kernel's blocks sit alone on their CU: "lstm_x3" = 2, "flat_half" = 0, "attn_lds" = 1: round 4's) and the half-CU
 forms ("lstm_x3" = 3: four-wave LSTM blocks of <= 256 registers; "flat_half" = 1: four-wave first-phase blocks of <= 153 registers):
   * LSTM launches alone: n chains of 600 launches (l2s_op_lstm_cell_chain, 256 rows) at once on n streams;
   * the whole decode loop: n chains of l2s_decode_steps (S = 300, G x 32 rows each, prepared state) at once.
@@ -17,6 +17,9 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ROWS, T, S = 32 * G, 29, 300
 N = int(os.environ.get("PAIRS", "300"))
 REP = int(os.environ.get("REP", "3"))
+CHAINS = [int(c) for c in os.environ.get("CHAINS", "1,2,3,4").split(",")]      # e.g. CHAINS=3 MODE=decode FORMS=half under rocprofv3
+MODE = os.environ.get("MODE", "lstm,decode").split(",")
+FORMS = os.environ.get("FORMS", "default,half").split(",")
 sd = synth.synth_state_dict()
 tensors = {k: v.cuda() for k, v in sd.items()}
 
@@ -42,7 +45,9 @@ def together(n, fn):
     return time.perf_counter() - t0
 
 
-for name, opts in (("default blocks ", {}), ("half-CU blocks ", {"lstm_x3": 3, "flat_half": 1})):
+for name, opts in (("default blocks ", {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}), ("half-CU blocks ", {"lstm_x3": 3, "flat_half": 1, "attn_lds": 2})):
+    if name.split("-")[0].split()[0] not in FORMS:
+        continue
     nm = native.NativeModel()
     nm.set_option("persist_decode", 0)
     nm.set_option("use_graph", 0)
@@ -52,11 +57,14 @@ for name, opts in (("default blocks ", {}), ("half-CU blocks ", {"lstm_x3": 3, "
     # ---- LSTM launches alone
     nm.lstm_cell_chain_us(ROWS, 20)
     line = f"{name} LSTM launches, {ROWS} rows:"
-    for n in (1, 2, 3, 4):
+    for n in (CHAINS if "lstm" in MODE else []):
         w = min(together(n, lambda i: nm.lstm_cell_chain_us(ROWS, N)) for _ in range(REP))
         per = w * 1e6 / (2 * N + 16)
         line += f"  {n} chain(s): {per:6.2f} us per launch of a chain, {per / n:5.2f} for the chip;"
-    print(line, flush=True)
+    if "lstm" in MODE:
+        print(line, flush=True)
+    if "decode" not in MODE and "attn" not in MODE:
+        continue
     # ---- the whole decode loop
     states = []
     for i in range(4):
@@ -66,10 +74,24 @@ for name, opts in (("default blocks ", {}), ("half-CU blocks ", {"lstm_x3": 3, "
         states.append(st)
         del v, feat
     torch.cuda.synchronize()
+    if "attn" in MODE:      # the attention launch alone (l2s_op_step_attn_chain: same K / V / content state every launch, zero queries)
+        L = native.lib()
+        wss = [torch.empty(64 << 20, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        NA = 2 * N
+        def attn_chain(i):
+            native.check(L.l2s_op_step_attn_chain(nm._h, states[i].data_ptr(), ROWS, T, NA, wss[i].data_ptr(), wss[i].numel(), torch.cuda.current_stream().cuda_stream))
+        attn_chain(0); torch.cuda.synchronize()
+        line = f"{name} attention launches, {ROWS} rows:"
+        for n in CHAINS:
+            w = min(together(n, attn_chain) for _ in range(REP))
+            per = w * 1e6 / NA
+            line += f"  {n} chain(s): {per:6.2f} us per launch of a chain, {per / n:5.2f} for the chip;"
+        print(line, flush=True)
     nm.decode_steps(states[0], ROWS, T, S, want_attn=False)
     line = f"{name} decode loop,   {ROWS} rows:"
-    for n in (1, 2, 3, 4):
+    for n in (CHAINS if "decode" in MODE else []):
         w = min(together(n, lambda i: nm.decode_steps(states[i], ROWS, T, S, want_attn=False)) for _ in range(REP))
         per = w * 1e6 / S
         line += f"  {n} chain(s): {per:6.2f} us per step of a chain, {per / n:5.2f} for the chip;"
-    print(line, flush=True)
+    if "decode" in MODE:
+        print(line, flush=True)
