@@ -36,12 +36,12 @@ RUNS = {
     "time_vocoder.py": ([], {"N": "32", "ITERS": "4"}),
     "train_stages.py": ([], {}),
 }
-SYNTAX_ONLY = ["pmc_decode_json.py", "pmc_read.py", "rocprof_summary.py"]
+SYNTAX_ONLY = ["pmc_decode_json.py", "pmc_read.py", "rocprof_concurrency.py", "rocprof_summary.py"]
 
 
 def test_tools_inventory_is_what_the_readme_lists():
     have = sorted(f for f in os.listdir(TOOLS) if f.endswith((".py", ".sh")))
-    want = sorted(list(RUNS) + SYNTAX_ONLY + ["ab_bench.sh", "attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r4.sh"])
+    want = sorted(list(RUNS) + SYNTAX_ONLY + ["ab_bench.sh", "attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r5.sh", "profile_r5_chains.sh"])
     assert have == want, (set(have) ^ set(want))
     readme = open(os.path.join(TOOLS, "README.md")).read()
     for f in have + ["membw/membw.hip", "persist/persist_probe.hip"]:

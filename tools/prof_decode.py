@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Run only the decode loop (prologue once, then REPS x 300 steps over ROWS clips; ROWS = 32 x batches per launch chain, default 256) - for
 rocprofv3 counter passes.
--> profiles/rNN_kernel_stats_decode256.md, rNN_pmc_decode.json (through tools/profile_r4.sh)"""
+-> profiles/rNN_kernel_stats_decode256.md, rNN_pmc_decode.json (through tools/profile_r5.sh)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,4 +22,4 @@ state, _ = nm.decoder_prologue(native.build_visual(feat, emb), emb, gum)
 for _ in range(int(os.environ.get("REPS", "3"))):
     nm.decode_steps(state, B, T, S, want_attn=False)
 torch.cuda.synchronize()
-print(f"decode loop: {B} rows, S={S}, done (run under rocprofv3: tools/profile_r4.sh)")
+print(f"decode loop: {B} rows, S={S}, done (run under rocprofv3: tools/profile_r5.sh)")
