@@ -25,7 +25,7 @@ def demo_clip(net, batch, speaker_encoder=None, speaker_embedding: Optional[torc
 
 
 def demo_clips(net, batches: Iterable, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda",
-               group: int = 8, n_inflight: int = 2):
+               group: int = 8, n_inflight: int = 3):
     """demo.py:60-90 over a whole loader: per clip the speaker embedding from the VOICE tower (``--encoding voice``) or a supplied one,
     ``net.inference(..., return_attention_map=True)``, truncation to ``output_lengths[0]``.  The clips are advanced ``group`` per launch
     chain with ``n_inflight`` chains on the GPU (``Lip2Speech.inference_many``); yields ``(mel, lengths, attention)`` per clip, in order."""
@@ -60,7 +60,7 @@ def _evaluate_outputs(net, batches: Iterable, speaker_encoder, device, group: in
         yield kept.pop(0), out
 
 
-def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda", group: int = 8, n_inflight: int = 2) -> List[torch.Tensor]:
+def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda", group: int = 8, n_inflight: int = 3) -> List[torch.Tensor]:
     """Post-net mels of ``net(..., tf_ratio=1)[1]`` for every collated batch (``train_collate_fn_pad`` layout; evaluate.py:32-38), ``group``
     loader batches per launch chain (``l2s_forward_eval_multi``), ``n_inflight`` chains in flight."""
     was_training = net.training
@@ -72,7 +72,7 @@ def evaluate_mels(net, batches: Iterable, speaker_encoder=None, device="cuda", g
 
 
 def evaluate_net(net, batches: Iterable, speaker_encoder=None, device="cuda", max_iters: int = 256, sampling_rate: int = None,
-                 group: int = 8, n_inflight: int = 2, timings: Optional[dict] = None, vocoder_backend: str = "auto", metric: str = "auto") -> float:
+                 group: int = 8, n_inflight: int = 3, timings: Optional[dict] = None, vocoder_backend: str = "auto", metric: str = "auto") -> float:
     """Mean ESTOI of the vocoded predictions against the ground-truth audio (reference: evaluate.py:22-51): `net(..., tf_ratio=1)[1]`
     -> `MelSpec2Audio` (InverseMelScale + Griffin-Lim, `max_iters` each) -> `stoi(gt, pred, fs, extended=True)` per clip.  Vocoder and
     metric are restatements of third-party algorithms (parity unpinned); the mels come from the HIP path, `group` loader batches per launch

@@ -212,7 +212,7 @@ class Lip2Speech(NativeBacked):
                 "finish": (lambda o: (o[0], o[1], o[2])) if return_attention_map else (lambda o: (o[0], o[1]))}
 
     # ------------------------------------------------------------------ loader-driven callers: G batches per launch chain, chains in flight
-    def pool(self, group: int = 8, n_inflight: int = 2):
+    def pool(self, group: int = 8, n_inflight: int = 3):
         """The `parallel.InflightPool` of this model's weight blob (cached per shape of concurrency)."""
         from ..parallel import InflightPool
         nm = self.native_model()
@@ -234,7 +234,7 @@ class Lip2Speech(NativeBacked):
             return item[:-1], item[-1]
         return item, {}
 
-    def inference_many(self, calls, group: int = 8, n_inflight: int = 2):
+    def inference_many(self, calls, group: int = 8, n_inflight: int = 3):
         """`inference` over a stream of batches - the loop of demo.py:60-90 - with `group` batches advanced per launch chain
         (`l2s_inference_multi`) and `n_inflight` chains on the GPU at once.  `calls` is any iterable (e.g. a generator over a DataLoader) of
         argument tuples `(video_frames, face_frames[, speaker_embedding[, return_attention_map[, gumbel_noise]]])`, optionally ending in a
@@ -244,7 +244,7 @@ class Lip2Speech(NativeBacked):
         prep = lambda item: (lambda a, k: self._inference_job(*a, **k))(*self._call(item))      # noqa: E731
         return self.pool(group, n_inflight).imap(calls, prep)
 
-    def forward_many(self, calls, group: int = 8, n_inflight: int = 2):
+    def forward_many(self, calls, group: int = 8, n_inflight: int = 3):
         """Eval-mode `forward` over a stream of batches - the loop of evaluate.py:22-51 (`net(..., tf_ratio=1)` per DataLoader batch) - on the
         grouped path (`l2s_forward_eval_multi`).  `calls`: iterable of `forward`'s argument tuples `(video_frames, face_frames, audio_frames,
         melspecs, video_lengths, audio_lengths, melspec_lengths, tf_ratio)`, optionally ending in a dict (`speaker_embedding=`,

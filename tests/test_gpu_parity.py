@@ -386,6 +386,34 @@ def test_runtime_options_keep_parity(synth_sd, nm, opts, exact):
     assert pc.maxdiff(out[1], gf["mel_post"]) < MEL_TOL
 
 
+@pytest.mark.parametrize("rows", [256, 224, 208, 512])
+def test_half_cu_block_forms_same_bits(synth_sd, nm, rows):
+    """Round 5: at >= 208 rows per launch the step's LSTM launches run on four-wave blocks of half a compute unit (a wave plays its two K slices one after
+    the other on one accumulator set, option "lstm_x3" = 3), the first phase on four-wave 2x1 / 2x2 blocks ("flat_half") and the attention always in its
+    74-register form ("attn_lds" = 2), so that launch chains overlap on the CUs.  Every partial sum is the one the round-4 block forms compute: the decode
+    loop's mel frames, stop logits and attention logits are the same bits (and rows 0-1, the golden clips, stay inside the reference's gate)."""
+    T, S = 29, 12
+    g, video2, emb2 = pc.lrw2_inputs()
+    reps = rows // 2
+    video = video2.repeat(reps, 1, 1, 1, 1).clone(); emb = emb2.repeat(reps, 1).clone(); gum = g["gumbel"].view(2, 4, -1).repeat(reps, 1, 1).reshape(rows * 4, -1).clone()
+    video[2:] += 0.01 * torch.randn(video[2:].shape, generator=torch.Generator().manual_seed(rows))      # other clips than the golden pair
+    feat = nm.encoder_fwd(video.cuda())
+    vis = native.build_visual(feat, emb.cuda())
+    outs = []
+    for opts in ({}, {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}, {"lstm_x3": 1, "flat_half": 0}, {"lstm_x3": 3, "flat_half": 1, "attn_lds": 2, "half_min_mts": 8}):
+        own = pc.fresh_native_model(synth_sd, **opts)
+        state, _ = own.decoder_prologue(vis, emb.cuda(), gum.cuda())
+        mel, stop, attn = own.decode_steps(state, rows, T, S, attn_logits=True)
+        outs.append((mel.clone(), stop.clone(), attn.clone()))
+        del own
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    post, cf = nm.postnet(outs[0][0], want_cf=True)
+    assert torch.isfinite(post).all()
+    ref = nm.inference(video2.cuda(), emb2.cuda(), g["gumbel"].cuda(), S=S)
+    assert pc.maxdiff(post[:2], ref[0]) < 1e-4
+
+
 @pytest.mark.parametrize("B,S", [(32, 300), (256, 77), (40, 123)])
 def test_postnet_weight_planes_by_dma_same_bits(synth_sd, nm, B, S):
     """The post-net's Conv1d weights as pre-split bf16 planes fetched by LDS-DMA (option "gemm_x3_dma", default) against the staging waves' own load +
