@@ -660,7 +660,7 @@ bool pdecode_supported(int B, int T, int m) {
 // every persistent launch needs all its workgroups resident at once: two of them in flight on different streams could each hold half of the chip and
 // wait for the other half for ever, so they are chained through one event per device (a launch waits for the previous persistent launch on its device)
 struct PdDevice {
-    bool init = false, attr = false;
+    bool init = false;
     int cus = 0;
     bool resident = false;        // every persistent kernel fits one workgroup per compute unit AND nothing in the environment takes compute units away
     hipEvent_t ev = nullptr;
@@ -709,7 +709,6 @@ static PdDevice* pd_device_locked() {
         if (fits) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
-            d.attr = true;
             fits = pd_fits(pdecode_kernel<1, 2>, PD_LDS_MAX) && pd_fits(pdecode_kernel<2, 2>, PD_LDS_MAX) && pd_fits(pbilstm_kernel<1>, 0) && pd_fits(pbilstm_kernel<2>, 0);
         }
         d.resident = fits;
@@ -761,8 +760,11 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         // 128 workgroups per clip, each standing for two of the one-per-CU layout: one clip leaves half the chip idle and is FASTER for it (7.7 against
         // 9.7 us per step on 256 workgroups: an edge among 128 workgroups costs ~1.2 us, among 256 ~1.8; 64 workgroups of four: 12.2, the weights no
         // longer fit the registers)
-        if (n == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2), dim3(PD_NT), lds, s, q);
-        else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG), dim3(PD_NT), lds, s, q);
+        // test hook (tests/test_persist_timeout.py, its own process): one workgroup short, so that the others wait for granules that never come and the
+        // give-up path runs - 2 s, NaN outputs, l2s_persist_timeouts() = 1
+        static const int starve = std::getenv("L2S_TEST_PDECODE_STARVE") ? 1 : 0;
+        if (n == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2 - starve), dim3(PD_NT), lds, s, q);
+        else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG - starve), dim3(PD_NT), lds, s, q);
         hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.attn, q.B * q.S * 80, q.B * q.S, q.attn ? q.B * q.S * q.T : 0, g_pd_timeouts);
         L2S_CHECK_HIP(hipGetLastError());
     }

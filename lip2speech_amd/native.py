@@ -615,12 +615,18 @@ def persist_timeouts() -> int:
     return int(lib().l2s_persist_timeouts())
 
 
+_timeouts_reported = 0
+
+
 def check_persist_timeouts() -> None:
-    """For a host that has just synchronized with the stream: raise if a persistent launch timed out (instead of handing NaNs on)."""
+    """For a host that has just synchronized with the stream: raise if a persistent launch timed out since the last check (instead of handing its
+    NaNs on).  Later persistent-eligible calls take the launch path (l2s_persist_available() is 0 from then on), so the error is raised once."""
+    global _timeouts_reported
     n = persist_timeouts()
-    if n:
-        raise RuntimeError(f"{n} persistent decode launch(es) gave up after 2 s without progress (shared or CU-masked device): outputs are NaN; "
-                           f"set option persist_decode=0 or free the device")
+    if n > _timeouts_reported:
+        new, _timeouts_reported = n - _timeouts_reported, n
+        raise RuntimeError(f"{new} persistent decode launch(es) gave up after 2 s without progress (shared or CU-masked device): their outputs are NaN; "
+                           f"later calls take the launch-per-phase path (or set option persist_decode=0)")
 
 
 def op_conv1d_bwd(dZ, X, Wp, taps=1, stride=1, pad=0, want_dx=True):
