@@ -548,6 +548,7 @@ def main():
                 bar = threading.Barrier(NI + 1)
                 def work(i):
                     torch.cuda.set_device(local_rank)
+                    native.set_thread_chains(NI)
                     with torch.cuda.stream(pool.streams[i]):
                         bar.wait()
                         nm.lstm_cell_chain_us(rows, n_pairs)

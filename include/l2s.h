@@ -379,6 +379,8 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "gemm_x3_dma"       (1)  the constant weights that meet the split-bf16 kernel's 128x256x16 tile (post-net layers 0-3, BiLSTM input matrix, conv_last) reach
  *                            it as pre-split bf16 planes (derived on the device at load / refresh, 6 bytes per weight) by LDS-DMA instead of load + split +
  *                            LDS store in its staging waves; same bits; 0 = off
+ *   (the three options below that choose half-CU block forms - "lstm_x3" = 3, "flat_half" = 1, "attn_lds" = 1 - act when the calling thread has announced
+ *    two or more chains in flight, l2s_set_thread_chains; "flat_half" = 2 / "attn_lds" = 2 force them)
  *   "lstm_x3"           (3)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
  *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
  *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks, 3 = eight-wave blocks except
@@ -389,8 +391,9 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *                            and 39 KB of LDS, up to 512 per launch (two or three per CU) instead of eight-wave blocks that sit alone on their CU; same bits
  *   "half_min_mts"      (13) with "lstm_x3" = 3: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on (13 = where the 4x2 shape is
  *                            chosen anyway); same bits
- *   "attn_lds"          (2)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows (74 registers:
- *                            three blocks per CU): 1 = at up to 128 rows per launch, 2 = always, 0 = never (one-column loads, 120 registers); same bits
+ *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows (74 registers:
+ *                            three blocks per CU): 1 = at up to 128 rows per launch and whenever chains overlap, 2 = always, 0 = never (one-column loads,
+ *                            120 registers); same bits
  *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path: 2 = two consecutive output
  *                            frames per block (every input frame staged once for both, their 2 x 24 channels as three 16-wide MFMA tiles), 1 = one frame per
  *                            block (32-wide tiles), 0 = f32 MFMA kernel
@@ -428,6 +431,11 @@ int l2s_model_set_option(l2s_model* m, const char* name, int value);
  * their outputs overwritten with NaN; read from pinned host memory, no synchronize - a host checks it after it has synchronized with the stream. */
 int l2s_persist_available(void);
 int l2s_persist_timeouts(void);
+/* How many launch chains the CALLER keeps in flight on the device, for the calling host thread (default 1): a scheduling hint, never arithmetic.  With
+ * n >= 2 the step kernels of this thread's calls take blocks of half a compute unit (options "lstm_x3" = 3, "flat_half", "attn_lds"), so that kernels of
+ * the other chains run beside them on the same CUs - 33.6 -> 27-28 us per decode step for the chip at 256 rows with three chains; with n = 1 they keep the
+ * blocks that fill a CU, which are 3-4 % faster when the chain has the chip to itself.  lip2speech_amd.parallel.InflightPool sets it in its worker threads. */
+int l2s_set_thread_chains(int n);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */
 int l2s_profile_enable(int on);

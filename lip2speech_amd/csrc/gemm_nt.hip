@@ -299,6 +299,7 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 int& gemm_x3_mode() { static thread_local int mode = 0; return mode; }
 int& gemm_x3_group() { static thread_local int group = 1; return group; }
 bool& grouped_entry() { static thread_local bool grouped = false; return grouped; }
+int& chains_hint() { static thread_local int chains = 1; return chains; }
 int& gemm_bf16_mode() { static thread_local int mode = 0; return mode; }
 
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }

@@ -1995,6 +1995,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_flat_timeline(void* ts_dev) { skinny_set_flat_timeline((unsigned long long*)ts_dev); return 0; }
+int l2s_set_thread_chains(int n) { chains_hint() = n < 1 ? 1 : n; return 0; }
 int l2s_persist_available(void) { return pdecode_device_ok() ? 1 : 0; }
 int l2s_persist_timeouts(void) { return pdecode_timeouts(); }
 int l2s_op_pdecode_timeline(void* ts_dev, int step) { pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }

@@ -65,7 +65,7 @@ struct Options {
     int flat_half = 1;          // "flat_half": the flat first phase of the step on four-wave 2x1 / 2x2 blocks (at most 153 registers, 39 KB of LDS: two or
                                 //   three per CU, up to 512 per launch) instead of eight-wave blocks that sit alone on their CU - so that other chains'
                                 //   kernels run beside them; same bits
-    int attn_lds = 2;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
+    int attn_lds = 1;           // "attn_lds": the step's attention blocks fetch keys / projected values by buffer loads, the values as 16-byte rows through LDS:
                                 //   1 = at up to 128 rows per launch, 2 = always, 0 = never
     int hoist_vproj = 2;        // "hoist_vproj": the phase-merged step reads o = a @ V' with V' = V W_ap^T + b_ap computed once in the prologue: 2 = LSTM0 on
                                 //   [content | prenet + o | h0] (K = 1024, the sum formed by the operand loader: the reference's own u = prenet + o), 1 = on
@@ -139,6 +139,7 @@ GemmP gemm_plain(const float* A, int lda, const float* W, float* C, int ldc, int
 int& gemm_x3_mode();                     // thread-local
 int& gemm_x3_group();                    // thread-local: batches per launch chain (1 outside l2s_inference_multi)
 struct X3Scope { int prev; explicit X3Scope(int on) : prev(gemm_x3_mode()) { gemm_x3_mode() = on; } ~X3Scope() { gemm_x3_mode() = prev; } };
+int& chains_hint();                     // thread-local: launch chains the CALLER keeps in flight on the device (l2s_set_thread_chains; 1 = this thread's calls have the chip to themselves)
 bool& grouped_entry();                  // thread-local: inside an l2s_*_multi call, whatever G (such calls never take the persistent latency forms)
 struct X3Group {
     int prev; bool prev_grouped;

@@ -381,7 +381,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
             auto blocks = [&](int rt, int ct) { int n = 0; for (int i = 0; i < bl.count; ++i) n += (bl.ntiles[i] + ct - 1) / ct; return n * ((mts + rt - 1) / rt); };
             // (a 4x4 block - 33 % fewer operand bytes per tile - is MFMA-bound at 30.4 us per block: 512 rows in 31.9 us against 33.0 us with 4x2
             //  blocks in two rounds, and 256 accumulator + operand registers with spills; not kept)
-            if (blocks(4, 2) >= 224 || (o.lstm_x3 == 3 && o.half_min_mts > 0 && mts >= o.half_min_mts && n_lstm_all)) shape = 42;
+            if (blocks(4, 2) >= 224 || (o.lstm_x3 == 3 && chains_hint() >= 2 && o.half_min_mts > 0 && mts >= o.half_min_mts && n_lstm_all)) shape = 42;
             else if (blocks(2, 2) >= 224) shape = 22;
             else if (blocks(2, 1) >= 224) shape = 21;
         }
@@ -393,13 +393,18 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     int n_lstm = 0;
     for (int i = 0; i < bl.count; ++i) n_lstm += bl.p[i].epi == SK_LSTM ? 1 : 0;
     const int rc_kind = n_lstm == bl.count ? 2 : n_lstm == 0 ? 1 : 0;
-    int x3 = (o.rc_jb == 0 && rc_kind == 2 && (rc_lay == 1 || rc_lay == 2 || rc_lay == 6)) ? o.lstm_x3 : 0;      // LSTM launches on the bf16 matrix cores (1: four waves, 2: eight)
+    // Block forms by how many launch chains the caller keeps in flight (l2s_set_thread_chains): with two or more, blocks of half a compute unit, so
+    // that kernels of different chains run side by side on the CUs; a chain that has the chip to itself keeps the eight-wave blocks (3-4 % faster
+    // alone).  Same bits either way.
+    const bool overlap = chains_hint() >= 2;
+    int x3 = (o.rc_jb == 0 && rc_kind == 2 && (rc_lay == 1 || rc_lay == 2 || rc_lay == 6)) ? o.lstm_x3 : 0;      // LSTM launches on the bf16 matrix cores (1: four waves, 2: eight, 3: half-CU 4x2 blocks when chains overlap)
+    if (x3 == 3 && !overlap) x3 = 2;
     for (int i = 0; i < bl.count; ++i) if (!bl.p[i].W3) x3 = 0;
     // several groups, >= 128 rows (below that the 1x1 / 2x1 uniform grids with two blocks per CU are faster, tools/time_step_phases.py): per-group
     // block shapes in one flat grid of at most one block per CU ("skinny_flat", default on)
     if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024 && rc_kind == 1) {      // a forced block shape wins; LSTM groups (the BiLSTM's two directions) keep the uniform grid of four-wave blocks
         SkinnyFlat fl{};
-        const bool half = o.flat_half != 0;
+        const bool half = o.flat_half != 0 && (o.flat_half >= 2 || chains_hint() >= 2);
         const int plan = plan_flat(bl, mts, half ? 512 : 256, fl, half);
         // 0 = general blocks, 1 = straight-line eight-wave blocks (default: 12.4 us at 256 rows against 12.9 general), 2 = straight-line four-wave
         // blocks ("skinny_rc_jb" = 44: 14.9 us - these blocks move 262 KB for 3.4 us of matrix work; eight waves keep more loads in flight)
@@ -505,8 +510,9 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     sb.mts = (at.B + 15) / 16;
     ProfScope ps("step_attention_prenet2", s);
     // projected values of a short clip fetched as 16-byte rows through LDS (attention_block<.., VLDS>): faster alone and at up to 128 rows per launch
-    // (32 rows: 8.64 against 8.85 us inside the step), not at 256 (11.2 against 10.6 us event-bracketed, the pass 0.06 ms longer): option 1 = by rows, 2 = always
-    const bool vl = lds_values && (lds_values >= 2 || at.B <= 128) && at.vp != nullptr && at.T <= 32;
+    // (32 rows: 8.64 against 8.85 us inside the step), not at 256 (11.2 against 10.6 us event-bracketed, the pass 0.06 ms longer) - unless the caller keeps several
+    // chains in flight: three 74-register blocks per CU leave room for other chains' kernels (+1.4 % at three chains): option 1 = by rows and chains, 2 = always
+    const bool vl = lds_values && (lds_values >= 2 || at.B <= 128 || chains_hint() >= 2) && at.vp != nullptr && at.T <= 32;
     if (g_attn_ts && vl) hipLaunchKernelGGL(step_attn_timed_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb, g_attn_ts);
     else if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     else hipLaunchKernelGGL(step_attn_kernel<false>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
     "l2s_min_T", "l2s_workspace_bytes", "l2s_state_floats", "l2s_state_offset",
     "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
-    "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_persist_available", "l2s_persist_timeouts", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
+    "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_persist_available", "l2s_persist_timeouts", "l2s_set_thread_chains", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_inverse_mel_workspace_bytes", "l2s_inverse_mel", "l2s_griffin_lim_workspace_bytes", "l2s_griffin_lim", "l2s_estoi_workspace_bytes", "l2s_estoi",
     "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_pdecode_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
@@ -603,6 +603,12 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
 def set_option(name: str, value: int) -> None:
     """Process DEFAULT of a run-time option: copied into models created afterwards (`NativeModel.set_option` changes one model)."""
     check(lib().l2s_set_option(name.encode(), int(value)))
+
+
+def set_thread_chains(n: int) -> None:
+    """Tell the library how many launch chains the caller keeps in flight, for the calling host thread (include/l2s.h l2s_set_thread_chains): with
+    two or more the step kernels take half-CU block forms so that chains overlap on the CUs.  A scheduling hint - results are the same bits."""
+    check(lib().l2s_set_thread_chains(int(n)))
 
 
 def persist_available() -> bool:

@@ -148,6 +148,7 @@ class InflightPool:
         group right before it launches the current one, so the copies and the normalise kernel travel under that chain's own compute as well
         as the others' (staged on the compute stream they cost the chain 4 ms per group of eight).  With it `shape_of(batch)` must give the
         (B,3,T,H,W) shape the batch will have (groups are formed before preparation)."""
+        from . import native
         shape = (lambda b: tuple(shape_of(b))) if shape_of is not None else (lambda b: tuple(b[0].shape))
         items: List[List[int]] = []
         if fn is not None or self.group == 1:
@@ -196,9 +197,12 @@ class InflightPool:
                         t.record_stream(compute_stream)
             return grp, ev
 
+        n_workers = min(self.n_inflight, max(1, len(items)))
+
         def worker(w: int):
             try:
                 torch.cuda.set_device(self.device)
+                native.set_thread_chains(n_workers)        # this thread's chain shares the chip with n_workers - 1 others: half-CU block forms
                 with torch.cuda.stream(self.streams[w]):
                     self.streams[w].wait_event(ready)
                     staged = None
@@ -228,7 +232,7 @@ class InflightPool:
             except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(min(self.n_inflight, max(1, len(items))))]
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(n_workers)]
         for t in threads:
             t.start()
         for t in threads:
@@ -271,6 +275,7 @@ class InflightPool:
         (host RNG draws inside `prepare` - the scheduled-sampling `torch.rand(1)`s - are consumed exactly as a sequential loop consumes them);
         `prepare` runs on the pool's copy stream, so its host-to-device copies and the voice tower travel under the chains' compute.  A worker
         keeps at most `depth` groups enqueued and the pool runs at most `depth + 1` rounds ahead of the consumer."""
+        from . import native
         it = iter(items)
         caller_stream = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
@@ -314,6 +319,7 @@ class InflightPool:
         def worker(w: int):
             try:
                 torch.cuda.set_device(self.device)
+                native.set_thread_chains(self.n_inflight)
                 stream = self.streams[w]
                 enq = collections.deque()
                 with torch.cuda.stream(stream):

@@ -393,6 +393,14 @@ def test_half_cu_block_forms_same_bits(synth_sd, nm, rows):
     74-register form ("attn_lds" = 2), so that launch chains overlap on the CUs.  Every partial sum is the one the round-4 block forms compute: the decode
     loop's mel frames, stop logits and attention logits are the same bits (and rows 0-1, the golden clips, stay inside the reference's gate)."""
     T, S = 29, 12
+    native.set_thread_chains(3)            # the half-CU forms are what a caller with several chains in flight gets (InflightPool's worker threads)
+    try:
+        _half_cu_forms_same_bits(synth_sd, nm, rows, T, S)
+    finally:
+        native.set_thread_chains(1)
+
+
+def _half_cu_forms_same_bits(synth_sd, nm, rows, T, S):
     g, video2, emb2 = pc.lrw2_inputs()
     reps = rows // 2
     video = video2.repeat(reps, 1, 1, 1, 1).clone(); emb = emb2.repeat(reps, 1).clone(); gum = g["gumbel"].view(2, 4, -1).repeat(reps, 1, 1).reshape(rows * 4, -1).clone()
@@ -400,7 +408,7 @@ def test_half_cu_block_forms_same_bits(synth_sd, nm, rows):
     feat = nm.encoder_fwd(video.cuda())
     vis = native.build_visual(feat, emb.cuda())
     outs = []
-    for opts in ({}, {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}, {"lstm_x3": 1, "flat_half": 0}, {"lstm_x3": 3, "flat_half": 1, "attn_lds": 2, "half_min_mts": 8}):
+    for opts in ({}, {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}, {"lstm_x3": 1, "flat_half": 0}, {"lstm_x3": 3, "flat_half": 2, "attn_lds": 2, "half_min_mts": 8}):
         own = pc.fresh_native_model(synth_sd, **opts)
         state, _ = own.decoder_prologue(vis, emb.cuda(), gum.cuda())
         mel, stop, attn = own.decode_steps(state, rows, T, S, attn_logits=True)

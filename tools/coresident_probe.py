@@ -31,6 +31,7 @@ def together(n, fn):
 
     def work(i):
         torch.cuda.set_device(0)
+        native.set_thread_chains(HINT)   # 1: the blocks of a chain that has the chip to itself (round 4's forms), 2: the half-CU forms - whatever n, also for the one-chain column
         with torch.cuda.stream(streams[i]):
             bar.wait()
             fn(i)
@@ -45,9 +46,11 @@ def together(n, fn):
     return time.perf_counter() - t0
 
 
-for name, opts in (("default blocks ", {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}), ("half-CU blocks ", {"lstm_x3": 3, "flat_half": 1, "attn_lds": 2})):
+HINT = 1
+for name, opts in (("default blocks ", {"lstm_x3": 2, "flat_half": 0, "attn_lds": 1}), ("half-CU blocks ", {"lstm_x3": 3, "flat_half": 2, "attn_lds": 2})):
     if name.split("-")[0].split()[0] not in FORMS:
         continue
+    HINT = 1 if name.startswith("default") else 2
     nm = native.NativeModel()
     nm.set_option("persist_decode", 0)
     nm.set_option("use_graph", 0)
