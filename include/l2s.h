@@ -384,13 +384,13 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
  *   "lstm_x3"           (3)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
  *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
  *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks, 3 = eight-wave blocks except
- *                            the 4x2 blocks of launches with >= 208 rows, which run as FOUR waves of <= 256 registers - half a compute unit, each wave
+ *                            the 4x2 blocks of launches with >= 192 rows, which run as FOUR waves of <= 256 registers - half a compute unit, each wave
  *                            playing its two K slices one after the other on one accumulator set - so that kernels of other launch chains run beside
  *                            them on the same CUs (1 / 2 / 3: same bits); 0 = f32 MFMAs (other bits, rounding-level)
  *   "flat_half"         (1)  the step's first launch (flat grid of per-group block shapes, >= 128 rows) on four-wave 2x1 / 2x2 blocks of <= 153 registers
  *                            and 39 KB of LDS, up to 512 per launch (two or three per CU) instead of eight-wave blocks that sit alone on their CU; same bits
- *   "half_min_mts"      (13) with "lstm_x3" = 3: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on (13 = where the 4x2 shape is
- *                            chosen anyway); same bits
+ *   "half_min_mts"      (12) with "lstm_x3" = 3 and chains overlapping: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on
+ *                            (13 = where the 4x2 shape is chosen anyway; 12 = also the 192-row launches of a six-batch group); same bits
  *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows (74 registers:
  *                            three blocks per CU): 1 = at up to 128 rows per launch and whenever chains overlap, 2 = always, 0 = never (one-column loads,
  *                            120 registers); same bits

@@ -58,10 +58,12 @@ struct Options {
     int rc_jb = 0;              // "skinny_rc_jb": operand batching of the register-blocked blocks: 0 = 4x2 blocks one chunk per batch and four batches in flight, smaller shapes two chunks per batch and two in flight; 2 / 4 = that many chunks per batch, two in flight, every shape; 15 = 4x2 with five in flight
     int gemm_x3_dma = 1;        // "gemm_x3_dma": constant Conv1d / Linear weights of the split-bf16 GEMMs as pre-split planes fetched by LDS-DMA (ConvW::W3)
     int lstm_x3 = 3;            // "lstm_x3": the decode step's LSTM launches on the bf16 matrix cores (exact three-way split, pre-split weight planes): 2 = eight-wave
-                                //   blocks, 1 = four-wave blocks, 3 (default) = as 2, but the 4x2 blocks (>= 208 rows) as four-wave blocks of at most 256 registers - half
+                                //   blocks, 1 = four-wave blocks, 3 (default) = as 2, but the 4x2 blocks (>= 192 rows) as four-wave blocks of at most 256 registers - half
                                 //   a compute unit, so that kernels of other launch chains run beside them (all the same bits), 0 = the f32 MFMA form
-    int half_min_mts = 13;      // "half_min_mts": with "lstm_x3" = 3 an LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on (13: where 4x2
-                                //   blocks give >= 224 blocks anyway; lower: 4x2 half blocks instead of 2x2 eight-wave blocks at fewer rows); same bits
+    int half_min_mts = 12;      // "half_min_mts": with "lstm_x3" = 3 and chains overlapping, an LSTM launch takes the half-CU 4x2 form from this many 16-row tiles
+                                //   on (13: where 4x2 blocks give >= 224 blocks anyway; 12: also the 192-row launches of a six-batch group, whose 384 2x2
+                                //   eight-wave blocks otherwise fill every CU for two rounds - the driver's 20-step command cuts into 7 + 7 + 6 batches:
+                                //   3.14-3.18 -> 3.21-3.29 M in three A/B pairs; 8: no better there, worse at 128 / 160 rows); same bits
     int flat_half = 1;          // "flat_half": the flat first phase of the step on four-wave 2x1 / 2x2 blocks (at most 153 registers, 39 KB of LDS: two or
                                 //   three per CU, up to 512 per launch) instead of eight-wave blocks that sit alone on their CU - so that other chains'
                                 //   kernels run beside them; same bits

@@ -56,6 +56,9 @@ for name, opts in (("default blocks ", {"lstm_x3": 2, "flat_half": 0, "attn_lds"
     nm.set_option("use_graph", 0)
     for k, v in opts.items():
         nm.set_option(k, v)
+    for kv in os.environ.get("L2S_OPT", "").split(","):      # extra options on top, e.g. L2S_OPT=half_min_mts=8
+        if kv:
+            nm.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     nm.load(tensors, list(sd.keys()))
     # ---- LSTM launches alone
     nm.lstm_cell_chain_us(ROWS, 20)
