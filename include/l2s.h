@@ -296,145 +296,56 @@ int l2s_train_encoder_fwd(l2s_model* m, const float* video, int B, int T, int H,
 int l2s_train_encoder_bwd(l2s_model* m, const float* video, int B, int T, int H, int W, const float* dfeat, int ld_dfeat, float* tape, void* ws, int64_t ws_bytes,
                           void* stream);
 
-/* ---- operator-level entry points (used by the parity tests and by bench.py's kernel timing) -------- */
-/* C[M,N] = act((A[M,K] @ Wt[N,K]^T) * scale[N] + shift[N]);  act: 0 none, 1 relu, 2 silu, 3 sin(x)*actw[n] */
-int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw,
-                float* C, int M, int N, int K, int act, void* stream);
-/* Conv1d over channel-last sequences as an implicit GEMM: X (B,Tin,Cin), Wp (Cout, taps*Cin) with
- * k = tap*Cin + ci, out (B,Tout,Cout), Tout = (Tin + 2*pad - taps)/stride + 1 */
-int l2s_op_conv1d(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw,
-                  float* out, int B, int Tin, int Cin, int Cout, int taps, int stride, int pad, int act,
-                  void* stream);
-/* the same two operators with flags: bit 0 = run on the split-bf16 kernel (fp32 operands split into 3 bf16 planes, six bf16 MFMAs per
- * K step; eligible shapes only - otherwise the f32 kernel runs); bit 1 = bf16 operands (round to nearest even on the way into LDS, one
- * bf16 MFMA per K step, fp32 accumulation); bit 2 (with bit 0) = the split-bf16 kernel's 128x128x32 tile instead of its default 128x256x16 one
- * (same bits out; kept for A/B timing); bit 3 (with bit 0) = the weight operand as pre-split bf16 planes fetched by LDS-DMA - what a model with
- * "gemm_x3_dma" runs in its post-net - derived per call into scratch memory the library owns (N % 256 == 0, K % 16 == 0, else ignored; same bits out) */
-int l2s_op_gemm_ex(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
-                   int K, int act, int flags, void* stream);
-int l2s_op_conv1d_ex(const float* X, const float* Wp, const float* scale, const float* shift, const float* actw, float* out, int B,
-                     int Tin, int Cin, int Cout, int taps, int stride, int pad, int act, int flags, void* stream);
-/* backward of l2s_op_conv1d (no scale/shift/activation): dZ (B,Tout,Cout), X (B,Tin,Cin), Wp (Cout, taps*Cin) ->
- * dX (B,Tin,Cin) (stride 1 only; may be NULL) and dWp (Cout, taps*Cin) (may be NULL) */
-int l2s_op_conv1d_bwd(const float* dZ, const float* X, const float* Wp, float* dX, float* dWp, int B, int Tin, int Cin, int Cout, int taps,
-                      int stride, int pad, void* stream);
-/* fused Conv3d(3->24,5x7x7,s(1,2,2),p(2,3,3)) + BN + PReLU + MaxPool(1,3,3)/s(1,2,2)/p(0,1,1) of the model:
- * video dev (B,3,T,H,W) -> out dev (B*T, H/4, W/4, 24) channel-last */
-int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W, float* out, void* stream);
-/* average duration (us) of the decoder LSTM-cell kernel over a chain of n_pairs x {layer 0, layer 1} launches bracketed by ONE pair
- * of HIP events on `stream` (bench.py's roofline figure; synchronises) */
-int l2s_op_lstm_cell_chain(l2s_model* m, int B, int n_pairs, void* ws, int64_t ws_bytes, void* stream, double* avg_us);
-/* launch-floor probe: n dependent launches of an empty kernel (kind 0) or of a kernel in which each of `blocks` 512-thread
- * blocks streams n_per_block x 8 KiB from `in` (kind 1) - the cost model of a latency-bound decode phase (tools/launch_floor.py) */
-int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream);
-/* measurement: with ts_dev != NULL every batch-row ("skinny") launch runs a stamped build of the same kernel - thread 0 of each block
- * writes 8 x 64-bit 100 MHz wall-clock stamps (entry, parameters in SGPRs, loads issued, first operands landed, MFMAs done, after the
- * reduction barrier, after the gate barrier, stores drained) to ts_dev[block*8 ..]; NULL restores the production kernel */
-int l2s_op_skinny_timeline(void* ts_dev);
-/* the same for the attention blocks of the step's second launch: 8 x uint64 per block (entry, requests issued, q visible, logits, after the barrier,
-   weights visible, stored) of the 100 MHz wall clock.  tools/attn_timeline.py */
-int l2s_op_attn_timeline(void* ts_dev);
-/* and for the step's first launch (the flat grid of per-group block shapes, at >= 128 rows): 8 stamps per block as for l2s_op_skinny_timeline; the last
-   such launch leaves its stamps.  tools/flat_timeline.py */
-int l2s_op_flat_timeline(void* ts_dev);
-/* persistent decode loop (option "persist_decode"): ts_dev = [256 workgroups][16] uint64 stamps of step `step` (100 MHz clock), or NULL to stop */
-int l2s_op_pdecode_timeline(void* ts_dev, int step);
-/* measurement build of the split-bf16 GEMM: lane 0 of each of the eight waves of block `block` stamps the shader clock per K tile
-   ([12 waves][96 K tiles][8 slots] uint64); NULL switches it off again.  tools/gemm_x3_timeline.py */
-int l2s_op_gemm_x3_timeline(void* ts_dev, int block);
-/* measurement: the same for the fused stride-1 ShuffleNet units of spatial size h (12, 6 or 3; the last such launch leaves its stamps) - 10 x 64-bit words per block to ts_dev[block*10 ..]: 8 stamps (entry,
- * input in LDS, after the barrier, pw1 done, depthwise taps done, depthwise written, pw2 done, stores drained), HW_ID, XCC_ID.  h = -24 / -12 / -6: the
- * stride-2 unit whose INPUT map is that size (9 stamps: entry, input issued, after the barrier, banch1 depthwise, banch2 pw1, banch2 depthwise, banch1 pw,
- * banch2 pw2, stores drained; block = frame * strips + strip).  ([wave][96 K tiles][8 slots] for the GEMM hook above.) */
-int l2s_op_fused_unit_timeline(void* ts_dev, int h);
-/* measurement: n back-to-back launches of the decode step's attention kernel alone on the state of l2s_decoder_prologue (zero queries): whether a
- * clip's K / V survive in its XCD's L2 between launches when nothing else runs in between (tools/attn_l2_probe.py; workspace: l2s_workspace_bytes) */
-int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launches, void* ws, int64_t ws_bytes, void* stream);
-/* the same chain issued alternately on two streams (two independent dependency chains): does a second chain hide the launch floor? */
-int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream_a, void* stream_b);
-/* run-time options (A/B switches kept for measurement; defaults are the fastest measured):
- *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and W_ih*attention_proj; 0 = literal 6-phase step
- *   "use_graph"         (0)  replay the decode loop from a captured hipGraph
- *   "fuse_trunk"        (1)  stride-1 ShuffleNet units as one fused kernel each; 0 = pw/dw/pw/copy launches
- *   "skinny_static"     (0)  compile-time K-segment layouts in the batch-row kernels: the load-issue phase of a block 1.9 -> 1.2 us,
- *                            23.6 -> 23.1 us per step one batch at a time, but 3 % slower with four batches in flight
- *   "skinny_sized"      (1)  batch-row kernel instances sized for the launch's longest K (48 / 80 / 118 VGPRs for K <= 512 / 1024 / 1536:
- *                            4 / 3 / 2 blocks per CU); 0 = the K <= 1536 instance everywhere
- *   "skinny_split"      (2)  K <= 1536 batch-row launches (LSTM layer 0) fetch their operands in this many batches: 2 = half the operand
- *                            registers, 66 VGPRs, three blocks per CU instead of two: +2 % with four batches in flight, -0.4 % one at a time;
- *                            1 = one round trip; 3 = no further gain.  "skinny_split8" (1): the same for the K <= 1024 instance (no gain)
- *   "fuse_s2"           (1)  stride-2 ShuffleNet units as one fused kernel each (needs fuse_trunk); 0 = dw/pw + pw/dw/pw launches
- *   "trunk_x3"          (1)  the fused units' pointwise convs on the bf16 matrix cores through the exact three-way split (activations split once where
- *                            they are written to LDS, weights as pre-split operand planes: stride-1 units and stage 3's stride-2 unit); 0 = f32 MFMA
- *   "overlap_postnet"   (0)  l2s_inference: windowed post-net on a second stream under the decode loop
- *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training) */
-/* l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.
+/* ---- run-time options ------------------------------------------------------------------------------------------------------------
+ * l2s_set_option changes the PROCESS DEFAULTS: what l2s_model_create copies into a new model.  l2s_model_set_option changes one model.
  * Launch sequences only ever read their own model's copy, so a thread that flips a switch cannot disturb batches other threads have in
  * flight on other models.  Several host threads may also drive ONE model at once (lip2speech_amd.parallel.InflightPool: chains in flight on
  * one weight blob): the blob is read-only, every workspace is its caller's, the per-model side stream / events / graph cache behind
- * "overlap_postnet" and "use_graph" are serialised by a per-model mutex (those chains enqueue one after the other), and the l2s_profile_*
- * accumulators are guarded - only changing an option of a model WHILE other threads run batches on it is the caller's race.
- *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the split-bf16 kernel (x = hi + mid + lo exactly, six bf16 MFMAs per K step of 16
- *                            instead of eight f32 MFMAs of K = 2: 6/16 of the f32 matrix time) where the shapes are eligible; 0 = f32 MFMA kernel
- *   "gemm_x3_dma"       (1)  the constant weights that meet the split-bf16 kernel's 128x256x16 tile (post-net layers 0-3, BiLSTM input matrix, conv_last) reach
- *                            it as pre-split bf16 planes (derived on the device at load / refresh, 6 bytes per weight) by LDS-DMA instead of load + split +
- *                            LDS store in its staging waves; same bits; 0 = off
- *   (the three options below that choose half-CU block forms - "lstm_x3" = 3, "flat_half" = 1, "attn_lds" = 1 - act when the calling thread has announced
- *    two or more chains in flight, l2s_set_thread_chains; "flat_half" = 2 / "attn_lds" = 2 force them)
- *   "lstm_x3"           (3)  the decode step's two LSTM launches on the BF16 matrix cores by the exact three-way split of the dense kernels (fp32 operands:
- *                            activations split by the wave that loads them, weights as pre-split planes derived on the device at load / refresh; six bf16
- *                            MFMAs per pair of 16-k chunks, fp32 accumulation): 2 = eight-wave blocks, 1 = four-wave blocks, 3 = eight-wave blocks except
- *                            the 4x2 blocks of launches with >= 192 rows, which run as FOUR waves of <= 256 registers - half a compute unit, each wave
- *                            playing its two K slices one after the other on one accumulator set - so that kernels of other launch chains run beside
- *                            them on the same CUs (1 / 2 / 3: same bits); 0 = f32 MFMAs (other bits, rounding-level)
- *   "flat_half"         (1)  the step's first launch (flat grid of per-group block shapes, >= 128 rows) on four-wave 2x1 / 2x2 blocks of <= 153 registers
- *                            and 39 KB of LDS, up to 512 per launch (two or three per CU) instead of eight-wave blocks that sit alone on their CU; same bits
- *   "half_min_mts"      (12) with "lstm_x3" = 3 and chains overlapping: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on
- *                            (13 = where the 4x2 shape is chosen anyway; 12 = also the 192-row launches of a six-batch group); same bits
- *   "attn_lds"          (1)  the step's attention blocks with buffer loads and the projected values staged through LDS as 16-byte rows (74 registers:
- *                            three blocks per CU): 1 = at up to 128 rows per launch and whenever chains overlap, 2 = always, 0 = never (one-column loads,
- *                            120 registers); same bits
- *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the split-bf16 matrix path: 2 = two consecutive output
- *                            frames per block (every input frame staged once for both, their 2 x 24 channels as three 16-wide MFMA tiles), 1 = one frame per
- *                            block (32-wide tiles), 0 = f32 MFMA kernel
- *   "train_bf16"        (0)  TRAINING entry points (encoder, prologue, post-net; forward and backward): GEMMs / Conv1d stacks round their operands to
- *                            bf16 (RNE) on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 results; the
- *                            recurrent loop, the Conv3d front-end, BatchNorm statistics, master weights and optimizer stay fp32
+ * "use_graph" are serialised by a per-model mutex, and the l2s_profile_* accumulators are guarded - only changing an option of a model WHILE
+ * other threads run batches on it is the caller's race.  An unknown name is an error.  The options of the product library choose WHAT is
+ * computed (precision leg, semantics) or a documented mode; the switches that only choose between block forms of the same arithmetic
+ * (measured and rejected forms, kept for A/B timing) exist in the diagnostic build alone: include/l2s_diag.h.
  *   "persist_decode"    (4)  the free-running decode loop (decoder.py:412-435) of a single-batch call with at most this many clips - up to 4, clips of
- *                            <= 32 frames (demo.py runs one clip, BASELINE config 1 two) - as ONE persistent launch of 128 resident workgroups per clip that keep the
- *                            step weights in registers and exchange h / c / q / prenet as tagged 8-byte granules (pdecode.hip): 7.7 instead of 20.4 us per step at
- *                            one clip, 8.2 at two; three or four clips run as two such launches one after the other (l2s_inference 6.1 / 6.2 ms against 7.4).  Another order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference); such
- *                            launches are chained one after the other in a process (each needs the whole chip resident); the form is only taken where
- *                            l2s_persist_available() says every workgroup can be resident (otherwise the launch path runs, same entry points); a launch that
- *                            makes no progress for 2 s gives up, overwrites mel / stop / attention with NaN and counts in l2s_persist_timeouts(); the next
- *                            persistent-eligible call fails once with that error and later ones take the launch path.  0 = always four launches per step;
- *                            l2s_*_multi never uses it
- *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane (frames rounded to nearest even
- *                            while staged, weights pre-rounded by l2s_model_finalize), GEMMs / Conv1d stacks of encoder, prologue, post-net and voice
- *                            tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the fused ShuffleNet units and every
- *                            activation in HBM stay fp32.  Outside the 1e-3 fp32 gate by construction (mel: 5e-3 mean, 4e-2 max absolute deviation)
- *   "hoist_vproj"       (1)  the phase-merged step with attention_proj (decoder.py:420) applied to the VALUES once per clip in the prologue
- *                            (V' = V W_ap^T + b_ap; the attention weights sum to one, so a @ V' = attention_proj(a @ v)): the step's attention reads 256
- *                            instead of 512 value columns and LSTM layer 0 runs K = 1280 instead of 1536; 0 = a @ v through the pre-multiplied W_ih W_ap
- *   "skinny_flat"       (1)  batch-row launches that carry several GEMM groups (the step's first phase) at >= 64 rows: every group gets its own
- *                            block shape, all groups together at most one block per CU, one flat grid, longest blocks first; 0 = one shape for all groups
- *   "skinny_rc"         (0)  batch-row kernels at >= 64 rows: 0 = the largest register-blocked shape that still gives one block per CU,
- *                            11 = 1x1 blocks only, 21 / 22 / 42 = force RT x CT tiles;  "skinny_rc_jb" (0): operand batching of those blocks - 0 = 4x2 blocks one chunk per
- *                            batch with four batches in flight (20.2 -> 19.4 us per LSTM launch at 256 rows), smaller shapes two chunks per batch with two in
- *                            flight; 2 / 4 = that many chunks per batch, two in flight, for every shape; 15 = 4x2 with five one-chunk batches in flight */
+ *                            <= 32 frames (demo.py runs one clip, BASELINE config 1 two) - as ONE persistent launch of 128 resident workgroups per clip
+ *                            that keep the step weights in registers and exchange h / c / q / prenet as tagged 8-byte granules (pdecode.hip): 7.7 instead
+ *                            of 20.4 us per step at one clip, 8.2 at two; three or four clips run as two such launches one after the other.  Another
+ *                            order of the same fp32 sums (within 5e-4 of the launch path, < 1e-3 of the reference).  The form is only taken where
+ *                            l2s_persist_available() says every workgroup can be resident; a launch that makes no progress for 2 s gives up,
+ *                            overwrites mel / stop / attention with NaN and counts in l2s_persist_timeouts(); the NEXT persistent-eligible call on that
+ *                            device fails once with that error, later ones take the launch path until the option is set to a positive value again
+ *                            (which re-arms the device).  0 = always four launches per step; l2s_*_multi never uses it
+ *   "use_graph"         (0)  replay the decode loop from a captured hipGraph (BASELINE config 4's streaming decoder; slower than plain launches
+ *                            on this runtime at every size measured, so off by default)
+ *   "fold_step_weights" (1)  4-launch step with pre-multiplied prenet1*fc_out and attention_proj hoisted onto the values; 0 = the literal 6-phase
+ *                            step of decoder.py:412-429 (what a model runs after l2s_train_refresh_weights until its merged weights are rebuilt)
+ *   "refresh_map"       (0)  l2s_model_finalize also builds the map l2s_train_refresh_weights needs (training)
+ *   "infer_bf16"        (0)  the bf16 leg of the INFERENCE / evaluate entry points: the front-end conv on one bf16 plane, GEMMs / Conv1d stacks of
+ *                            encoder, prologue, post-net and voice tower with bf16 operands and fp32 accumulation; the decode loop, the BiLSTM, the
+ *                            fused ShuffleNet units and every activation in HBM stay fp32.  Outside the 1e-3 fp32 gate by construction
+ *   "train_bf16"        (0)  TRAINING entry points (encoder, prologue, post-net; forward and backward): GEMMs / Conv1d stacks round their operands to
+ *                            bf16 (RNE) on the way into LDS, fp32 accumulation and results; the recurrent loop, the Conv3d front-end, BatchNorm
+ *                            statistics, master weights and optimizer stay fp32
+ *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the bf16 matrix cores through the EXACT three-way split (x = hi + mid + lo, six bf16
+ *                            MFMAs per K step of 16 instead of eight f32 MFMAs of K = 2) where the shapes are eligible; 0 = the f32 MFMA kernel
+ *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the same split-bf16 path: 2 = two consecutive
+ *                            output frames per block, 1 = one frame per block, 0 = the f32 MFMA kernel
+ *   "trunk_x3"          (1)  the fused ShuffleNet units' pointwise convs on the split-bf16 path; 0 = f32 MFMA
+ *   "lstm_x3"           (3)  the decode step's two LSTM launches on the split-bf16 path (1 / 2 / 3: four-wave / eight-wave / half-CU block forms of the
+ *                            same arithmetic, same bits - 3 picks by l2s_set_thread_chains); 0 = f32 MFMAs (other bits, rounding-level) */
 int l2s_set_option(const char* name, int value);
 int l2s_model_set_option(l2s_model* m, const char* name, int value);
 /* The persistent forms (option "persist_decode") spin on other workgroups and need all of them resident at once.  l2s_persist_available: 1 where that
  * holds on the current device - 256 compute units, no compute-unit mask in the environment (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), one workgroup of every
- * persistent kernel fits a compute unit (occupancy query), and no persistent launch of this process has timed out - else 0: calls inside the
- * envelope then take the launch-per-phase path.  l2s_persist_timeouts: how many persistent launches of this process gave up (2 s without progress) and had
- * their outputs overwritten with NaN; read from pinned host memory, no synchronize - a host checks it after it has synchronized with the stream. */
+ * persistent kernel fits a compute unit (occupancy query), and no persistent launch on this device has timed out since it was last armed - else 0: calls
+ * inside the envelope then take the launch-per-phase path.  l2s_persist_timeouts: how many persistent launches of this process gave up (2 s without
+ * progress) and had their outputs overwritten with NaN; read from pinned host memory, no synchronize - meaningful after the host has synchronized with
+ * the stream.  The library itself reports a time-out through the next persistent-eligible call on that device (it fails once; l2s_last_error). */
 int l2s_persist_available(void);
 int l2s_persist_timeouts(void);
 /* How many launch chains the CALLER keeps in flight on the device, for the calling host thread (default 1): a scheduling hint, never arithmetic.  With
- * n >= 2 the step kernels of this thread's calls take blocks of half a compute unit (options "lstm_x3" = 3, "flat_half", "attn_lds"), so that kernels of
- * the other chains run beside them on the same CUs - 33.6 -> 27-28 us per decode step for the chip at 256 rows with three chains; with n = 1 they keep the
- * blocks that fill a CU, which are 3-4 % faster when the chain has the chip to itself.  lip2speech_amd.parallel.InflightPool sets it in its worker threads. */
+ * n >= 2 the step kernels of this thread's calls take blocks of half a compute unit, so that kernels of the other chains run beside them on the same
+ * CUs - 33.6 -> 27-28 us per decode step for the chip at 256 rows with three chains; with n = 1 they keep the blocks that fill a CU, which are 3-4 %
+ * faster when the chain has the chip to itself.  lip2speech_amd.parallel.InflightPool sets it in its worker threads. */
 int l2s_set_thread_chains(int n);
 /* per-kernel timing: when enabled every launch is bracketed by HIP events on its stream; read back with
  * l2s_profile_get (which synchronises the events it reads).  Off by default. */

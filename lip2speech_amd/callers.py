@@ -18,10 +18,22 @@ from typing import Iterable, List, Optional
 
 import torch
 
+from . import native
+
 
 def demo_clip(net, batch, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda"):
-    """``batch`` = one item of ``DataLoader(ds, batch_size=1, collate_fn=test_collate_fn_pad)`` (one iteration of demo.py:60-90)."""
-    return list(demo_clips(net, [batch], speaker_encoder=speaker_encoder, speaker_embedding=speaker_embedding, device=device, group=1, n_inflight=1))[0]
+    """``batch`` = one item of ``DataLoader(ds, batch_size=1, collate_fn=test_collate_fn_pad)`` (one iteration of demo.py:60-90): the direct
+    ``net.inference`` call, which for one clip takes the library's latency form (the decode loop as one persistent launch, option "persist_decode") -
+    a single clip has no grouping to stay consistent with; ``demo_clips`` streams a whole loader through the grouped path instead."""
+    if speaker_embedding is None and speaker_encoder is None:
+        raise ValueError("pass a SpeakerEncoder (voice route) or a speaker_embedding")
+    (videos, _), (audios, _), _, face_crops, _ = batch
+    with torch.no_grad():
+        emb = speaker_embedding if speaker_embedding is not None else speaker_encoder.inference(audios.to(device, non_blocking=True))
+        mel, lengths, attn = net.inference(videos.to(device, non_blocking=True), face_crops, speaker_embedding=emb, return_attention_map=True)
+    n = int(lengths[0])                                  # synchronises: a timed-out persistent launch is reported here, not handed on as NaN
+    native.check_persist_timeouts()
+    return mel[:1, :, :n], lengths, attn[:, :n]
 
 
 def demo_clips(net, batches: Iterable, speaker_encoder=None, speaker_embedding: Optional[torch.Tensor] = None, device="cuda",

@@ -930,9 +930,11 @@ struct S1Geo {
 
 // measurement hook (tools/fused_unit_timeline.py): non-null -> the stamped build; thread 0 of every block writes 8 x 64-bit stamps
 // of the 100 MHz wall clock plus its XCC / CU id
+#ifdef L2S_DIAG      // libl2s_diag.so only (include/l2s_diag.h l2s_op_fused_unit_timeline); the product launches TIMED = false and never instantiates the stamped builds
 static unsigned long long* g_su_ts = nullptr;
 static int g_su_ts_h = 0;                                 // stamp only the units of this spatial size
 void shuffle_set_timeline(unsigned long long* ts, int h) { g_su_ts = ts; g_su_ts_h = h; }
+#endif
 #define SU_STAMP(k) do { if (TIMED && threadIdx.x == 0) ts[blockIdx.x * 10 + (k)] = wall_clock64(); } while (0)
 
 template <int H, int HALF, int F, bool TIMED>
@@ -1105,12 +1107,17 @@ static int launch_s1_inst(const ShuffleS1P& p, hipStream_t s) {
     if (!attr_set) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<H, HALF, F, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#ifdef L2S_DIAG
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1_kernel<H, HALF, F, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#endif
         attr_set = true;
     }
+#ifdef L2S_DIAG
     if (g_su_ts && g_su_ts_h == H) hipLaunchKernelGGL((shuffle_s1_kernel<H, HALF, F, true>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, g_su_ts);
-    else hipLaunchKernelGGL((shuffle_s1_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    else
+#endif
+    hipLaunchKernelGGL((shuffle_s1_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 
@@ -1428,12 +1435,17 @@ static int launch_s1x_inst(const ShuffleS1P& p, hipStream_t s) {
     if (!attr_set) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1x_kernel<H, HALF, F, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#ifdef L2S_DIAG
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1x_kernel<H, HALF, F, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#endif
         attr_set = true;
     }
+#ifdef L2S_DIAG
     if (g_su_ts && g_su_ts_h == H) hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, true>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, g_su_ts);
-    else hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    else
+#endif
+    hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 
@@ -1784,12 +1796,17 @@ static int launch_s2x_inst(const ShuffleS2P& p, hipStream_t s) {
     if (!attr_set) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2x_kernel<H, CIN, HALF, RO, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#ifdef L2S_DIAG
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2x_kernel<H, CIN, HALF, RO, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#endif
         attr_set = true;
     }
+#ifdef L2S_DIAG
     if (g_su_ts && g_su_ts_h == -H) hipLaunchKernelGGL((shuffle_s2x_kernel<H, CIN, HALF, RO, true>), dim3(Q::B::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, g_su_ts);
-    else hipLaunchKernelGGL((shuffle_s2x_kernel<H, CIN, HALF, RO, false>), dim3(Q::B::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    else
+#endif
+    hipLaunchKernelGGL((shuffle_s2x_kernel<H, CIN, HALF, RO, false>), dim3(Q::B::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 
@@ -1801,13 +1818,18 @@ static int launch_s2_inst(const ShuffleS2P& p, hipStream_t s) {
     if (!attr_set) {
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#ifdef L2S_DIAG
         L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s2_kernel<H, CIN, HALF, RO, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+#endif
         attr_set = true;
     }
     // measurement hook: l2s_op_fused_unit_timeline(ts, -H) stamps the stride-2 unit whose INPUT is H x H
+#ifdef L2S_DIAG
     if (g_su_ts && g_su_ts_h == -H) hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO, true>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, g_su_ts);
-    else hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO, false>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    else
+#endif
+    hipLaunchKernelGGL((shuffle_s2_kernel<H, CIN, HALF, RO, false>), dim3(Q::STRIPS, p.NF), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
     return 0;
 }
 

@@ -617,9 +617,11 @@ bool gemm_x3_eligible(const GemmBatch& b) {
     return tiles >= (b.count > 1 ? 150 : 100) || (b.p[0].x3 & 2);
 }
 
+#ifdef L2S_DIAG      // the stamped measurement builds exist in libl2s_diag.so only (include/l2s_diag.h l2s_op_gemm_x3_timeline)
 static unsigned long long* g_x3_ts = nullptr;
 static int g_x3_stamp_block = 0;
 void gemm_x3_set_timeline(unsigned long long* ts, int block) { g_x3_ts = ts; g_x3_stamp_block = block; }
+#endif
 
 // Which tile: both give the same bits, so the choice is free per launch.  The wide tile needs N, K, Cin and the A split to fit its uniform K steps, and
 // it pays when the launch runs in fewer "rounds" of 256 blocks x tile time: a wide tile takes ~1.7x a narrow one for twice the work (2 250 against
@@ -683,6 +685,7 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
         L2S_CHECK_HIP(attr);
         static const hipError_t attr_d = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_D);
         L2S_CHECK_HIP(attr_d);
+#ifdef L2S_DIAG
         if (g_x3_ts) {
             static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             L2S_CHECK_HIP(attr_t);
@@ -690,7 +693,9 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
             L2S_CHECK_HIP(attr_td);
             if (dma) hipLaunchKernelGGL((gemm_x3w_kernel<true, true>), grid, dim3(WTHREADS), LDS_BYTES_D, s, b, g_x3_ts, g_x3_stamp_block);
             else hipLaunchKernelGGL((gemm_x3w_kernel<true, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
-        } else if (dma) {
+        } else
+#endif
+        if (dma) {
             hipLaunchKernelGGL((gemm_x3w_kernel<false, true>), grid, dim3(WTHREADS), LDS_BYTES_D, s, b, (unsigned long long*)nullptr, 0);
         } else {
             hipLaunchKernelGGL((gemm_x3w_kernel<false, false>), grid, dim3(WTHREADS), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
@@ -702,11 +707,14 @@ int launch_gemm_x3(const GemmBatch& b, hipStream_t s, const char* name) {
     constexpr int LDS_BYTES = 2 * 6 * XPLANE;              // 122 880: two operand stages (one block per CU)
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     L2S_CHECK_HIP(attr);
+#ifdef L2S_DIAG
     if (g_x3_ts) {
         static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         L2S_CHECK_HIP(attr_t);
         hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(512), LDS_BYTES, s, b, g_x3_ts, g_x3_stamp_block);
-    } else {
+    } else
+#endif
+    {
         hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(512), LDS_BYTES, s, b, (unsigned long long*)nullptr, 0);
     }
     L2S_CHECK_HIP(hipGetLastError());

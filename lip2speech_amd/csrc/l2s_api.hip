@@ -2,6 +2,9 @@
 // the visual encoder, decoder prologue, decode loop and post-net.  Host code only orchestrates; all
 // arithmetic is in the kernels of gemm_nt.hip / encoder_kernels.hip / skinny.hip / decoder_kernels.hip.
 #include "../../include/l2s.h"
+#ifdef L2S_DIAG
+#include "../../include/l2s_diag.h"
+#endif
 #include "l2s_common.h"
 #include "l2s_model.h"
 #include "pdecode.h"
@@ -25,15 +28,25 @@ void set_error(const std::string& msg) { g_err = msg; }
 // ------------------------------------------------------------------------------------------------ options
 static Options g_default_opt;          // process defaults: what l2s_model_create copies into a new model (l2s_set_option)
 int set_option_field(Options& o, const char* name, int value) {
-    struct { const char* name; int Options::*field; } table[] = {
-        {"fold_step_weights", &Options::fold}, {"use_graph", &Options::graph}, {"overlap_postnet", &Options::overlap_postnet},
-        {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2}, {"trunk_x3", &Options::trunk_x3}, {"refresh_map", &Options::refresh_map},
-        {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
-        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi}, {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"lstm_x3", &Options::lstm_x3}, {"flat_half", &Options::flat_half}, {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma},
-        {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3}, {"train_bf16", &Options::train_bf16},
-        {"infer_bf16", &Options::infer_bf16}, {"persist_decode", &Options::persist}};
-    for (auto& t : table)
+    struct Row { const char* name; int Options::*field; };
+    // what the product library (include/l2s.h) offers: precision legs, semantics, documented modes
+    static const Row product[] = {
+        {"persist_decode", &Options::persist}, {"use_graph", &Options::graph}, {"fold_step_weights", &Options::fold}, {"refresh_map", &Options::refresh_map},
+        {"infer_bf16", &Options::infer_bf16}, {"train_bf16", &Options::train_bf16}, {"gemm_x3", &Options::gemm_x3}, {"frontend_x3", &Options::frontend_x3},
+        {"trunk_x3", &Options::trunk_x3}, {"lstm_x3", &Options::lstm_x3}};
+    for (auto& t : product)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
+#ifdef L2S_DIAG
+    // block-form A/B switches of the same arithmetic (include/l2s_diag.h): libl2s_diag.so only
+    static const Row diag[] = {
+        {"overlap_postnet", &Options::overlap_postnet}, {"fuse_trunk", &Options::fuse_trunk}, {"fuse_s2", &Options::fuse_s2},
+        {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
+        {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
+        {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"flat_half", &Options::flat_half},
+        {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma}, {"flat_xcd", &Options::flat_xcd}, {"attn_skip0", &Options::attn_skip0}};
+    for (auto& t : diag)
+        if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
+#endif
     return 1;
 }
 
@@ -1102,7 +1115,10 @@ static int prologue_run(l2s_model* m, const float* vis, const float* emb, const 
     float* tap_part = bp.f(tap_floats);
     float* bott_part = bp.f((int64_t)8 * BT * 512);
     // one or two clips of a single-batch call: the BiLSTM recurrence as ONE persistent launch (pdecode.hip pbilstm_kernel; option "persist_decode")
-    const bool pbi = m->opt.persist > 0 && B <= m->opt.persist && !grouped_entry() && pbilstm_supported(B, T) && pdecode_supported(B, T, mT) && pdecode_device_ok();      // the envelope of the latency path
+    // (the envelope of the latency path; a persistent launch that timed out since the last call fails THIS call once: pdecode_gate)
+    const int pgate = (m->opt.persist > 0 && B <= m->opt.persist && !grouped_entry() && pbilstm_supported(B, T) && pdecode_supported(B, T, mT)) ? pdecode_gate() : 0;
+    if (pgate < 0) return 1;
+    const bool pbi = pgate > 0;
     float* pbx = pbi ? bp.f(pbilstm_ws_bytes() / 4 + 64) : nullptr;
     L2S_REQUIRE(!bp.overflow, "prologue workspace too small");
 
@@ -1372,7 +1388,9 @@ static int decode_run(l2s_model* m, float* state, int B, int T, int S, const flo
     if (!teacher && fold && m->opt.persist > 0 && B <= m->opt.persist && !grouped_entry()) {      // the latency form: one launch for the whole loop
         const Weights& w = m->w;
         StateLayout sl = state_layout(B, T);
-        if (pdecode_supported(B, T, sl.m) && pdecode_device_ok() && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) {
+        const int pgate = (pdecode_supported(B, T, sl.m) && w.vproj.W && w.pre1f.W && w.lstm0.W && w.lstm1.W) ? pdecode_gate() : 0;
+        if (pgate < 0) return 1;      // an earlier persistent launch on this device gave up (its outputs are NaN): reported here, once
+        if (pgate > 0) {
             PDecP p{};
             p.Wq = w.q.W; p.bq = w.q.bias; p.aq = w.q.actw;
             p.Wcq = w.cq.W; p.bcq = w.cq.bias;
@@ -1825,6 +1843,7 @@ int l2s_forward_eval_multi(l2s_model* m, int G, const float* const* video, const
 }
 
 // ---- operator-level entry points
+#ifdef L2S_DIAG      // operator-level test hooks: libl2s_diag.so (include/l2s_diag.h)
 int l2s_op_gemm(const float* A, const float* Wt, const float* scale, const float* shift, const float* actw, float* C, int M, int N,
                 int K, int act, void* stream) {
     GemmP p = gemm_plain(A, K, Wt, C, N, M, N, K);
@@ -1891,6 +1910,8 @@ int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W
     return launch_frontend(fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }
 
+#endif
+
 int l2s_train_set_bn(l2s_model* m, int batch_stats, float momentum) {
     L2S_REQUIRE(m != nullptr && momentum >= 0.f && momentum <= 1.f, "bad arguments");
     m->bn_batch = batch_stats != 0;
@@ -1906,14 +1927,17 @@ int l2s_train_refresh_weights(l2s_model* m, void* stream) {
 int l2s_set_option(const char* name, int value) {
     L2S_REQUIRE(name != nullptr, "null option name");
     if (set_option_field(g_default_opt, name, value)) { set_error(std::string("unknown option ") + name); return 1; }
+    if (!std::strcmp(name, "persist_decode") && value > 0) pdecode_rearm();
     return 0;
 }
 int l2s_model_set_option(l2s_model* m, const char* name, int value) {
     L2S_REQUIRE(m != nullptr && name != nullptr, "bad arguments");
     if (set_option_field(m->opt, name, value)) { set_error(std::string("unknown option ") + name); return 1; }
+    if (!std::strcmp(name, "persist_decode") && value > 0) pdecode_rearm();      // asking for the persistent forms (again) forgives the device's earlier time-outs
     return 0;
 }
 
+#ifdef L2S_DIAG      // chain microbenches, timelines, probes: libl2s_diag.so (include/l2s_diag.h)
 // Average duration of the decoder LSTM-cell kernel (the kernel with the largest share of GPU time) measured with ONE pair of HIP
 // events around a chain of n_pairs x {layer 0 (K=1536), layer 1 (K=1024)} launches on `stream` - the same launches the decode loop
 // issues, on zeroed state.  Per-launch event brackets (l2s_profile_*) add ~1.8 us to a 6 us kernel; this does not.  Synchronises.
@@ -1995,12 +2019,13 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
 int l2s_op_skinny_timeline(void* ts_dev) { skinny_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_attn_timeline(void* ts_dev) { attn_set_timeline((unsigned long long*)ts_dev); return 0; }
 int l2s_op_flat_timeline(void* ts_dev) { skinny_set_flat_timeline((unsigned long long*)ts_dev); return 0; }
-int l2s_set_thread_chains(int n) { chains_hint() = n < 1 ? 1 : n; return 0; }
-int l2s_persist_available(void) { return pdecode_device_ok() ? 1 : 0; }
-int l2s_persist_timeouts(void) { return pdecode_timeouts(); }
 int l2s_op_pdecode_timeline(void* ts_dev, int step) { pdecode_set_timeline((unsigned long long*)ts_dev, step); return 0; }
 int l2s_op_gemm_x3_timeline(void* ts_dev, int block) { gemm_x3_set_timeline((unsigned long long*)ts_dev, block); return 0; }
 int l2s_op_fused_unit_timeline(void* ts_dev, int h) { shuffle_set_timeline((unsigned long long*)ts_dev, h); return 0; }
+int l2s_op_stamp_log(void* log_dev, int64_t capacity) {
+    L2S_REQUIRE(set_stamp_log((unsigned long long*)log_dev, (long long)capacity) == 0, "stamp log: hipMemcpyToSymbol failed");
+    return 0;
+}
 
 int l2s_op_launch_chain(int kind, int n_launches, int blocks, int n_per_block, const float* in, float* out, void* stream) {
     for (int i = 0; i < n_launches; ++i)
@@ -2015,6 +2040,11 @@ int l2s_op_launch_chain2(int kind, int n_launches, int blocks, int n_per_block, 
     }
     return 0;
 }
+#endif      // L2S_DIAG
+
+int l2s_set_thread_chains(int n) { chains_hint() = n < 1 ? 1 : n; return 0; }
+int l2s_persist_available(void) { return pdecode_device_ok() ? 1 : 0; }
+int l2s_persist_timeouts(void) { return pdecode_timeouts(); }
 
 int l2s_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 int l2s_profile_reset(void) { prof_drain(); g_prof.clear(); g_prof_idx.clear(); return 0; }

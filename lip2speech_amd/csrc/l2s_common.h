@@ -83,6 +83,8 @@ struct Options {
     int persist = 4;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: up to 4 clips
                                 //   of <= 32 frames, two per launch) as persistent weight-stationary launches instead of four launches per step; 0 = never.  A
                                 //   latency form: one call owns the chip, such launches are chained one after the other; grouped calls (l2s_*_multi) never take it
+    int flat_xcd = 0;           // "flat_xcd" (diagnostic A/B): the flat first phase's block -> tile map XCD-affine (an XCD = one row half x one column quarter of a group)
+    int attn_skip0 = 0;         // "attn_skip0" (diagnostic A/B): the attention blocks fetch a frame's projected values only when its soft-max weight is not exactly zero
     int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
                                 //   voice tower with bf16 operands (fp32 accumulation); the recurrent loops, the fused ShuffleNet units and all statistics stay fp32
 };
@@ -363,7 +365,9 @@ void attn_set_timeline(unsigned long long* ts);        // non-null: the stamped 
 void skinny_set_flat_timeline(unsigned long long* ts);   // non-null: the stamped build of the step's flat first phase (tools/flat_timeline.py)
 void skinny_set_timeline(unsigned long long* ts);      // non-null: launch the stamped measurement build (tools/skinny_timeline.py)
 
-int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);
+int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* out, hipStream_t s);      // libl2s_diag.so only, like every *_set_timeline above
+void skinny_set_flat_timeline(unsigned long long* ts);
+int set_stamp_log(unsigned long long* log, long long cap);      // the block-stamp log of the step kernels (skinny.hip; libl2s_diag.so only)
 
 // ---------------------------------------------------------------- decoder helper kernels (decoder_kernels.hip)
 struct AttnP {

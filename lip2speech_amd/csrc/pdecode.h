@@ -43,6 +43,8 @@ int64_t pbilstm_ws_bytes();
 bool pbilstm_supported(int B, int T);                   // one or two clips
 int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s);
 bool pdecode_device_ok();                               // every workgroup of a persistent launch can be resident: 256 compute units, none masked, kernels fit, no timed-out launch so far
+int pdecode_gate();                                     // per call of a persistent-eligible entry: 1 = persistent form, 0 = launch path, -1 = an earlier launch timed out: fail this call once (error set)
+void pdecode_rearm();                                   // option "persist_decode" > 0 was set: forgive the current device's time-outs so far
 int pdecode_timeouts();                                 // persistent launches of this process whose workgroups gave up (outputs NaN)
 int64_t pdecode_ws_bytes(int B);                       // exchange granules + status word
 bool pdecode_supported(int B, int T, int m);            // <= 4 clips of <= 32 frames

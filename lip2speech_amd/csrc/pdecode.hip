@@ -664,20 +664,25 @@ struct PdDevice {
     int cus = 0;
     bool resident = false;        // every persistent kernel fits one workgroup per compute unit AND nothing in the environment takes compute units away
     hipEvent_t ev = nullptr;
+    unsigned* timeouts = nullptr; // pinned, device-visible word of THIS device: its launches whose workgroups gave up (pdecode_guard_kernel)
+    unsigned seen = 0;            // ... of which the gate has already reported (pdecode_gate)
+    unsigned armed_at = 0;        // the count when the persistent forms were last (re-)armed on this device: they are off while *timeouts != armed_at
 };
 constexpr int PD_MAX_DEVICES = 64;
 static std::mutex g_pd_mu;
 static PdDevice g_pd_dev[PD_MAX_DEVICES];
 static unsigned long long* g_pd_ts = nullptr;
 static int g_pd_ts_step = 0;
-static unsigned* g_pd_timeouts = nullptr;      // pinned, device-visible: launches whose workgroups gave up (pdecode_guard_kernel)
-static unsigned g_pd_timeouts_seen = 0;        // ... of which a launcher has already reported
 
+#ifdef L2S_DIAG
 void pdecode_set_timeline(unsigned long long* ts, int step) { g_pd_ts = ts; g_pd_ts_step = step; }
+#endif
 
-int pdecode_timeouts() {
+int pdecode_timeouts() {      // process-wide: the sum over the devices this process has used
     std::lock_guard<std::mutex> lock(g_pd_mu);
-    return g_pd_timeouts ? (int)__atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) : 0;
+    unsigned n = 0;
+    for (const PdDevice& d : g_pd_dev) if (d.timeouts) n += __atomic_load_n(d.timeouts, __ATOMIC_RELAXED);
+    return (int)n;
 }
 
 template <typename K>
@@ -695,17 +700,15 @@ static PdDevice* pd_device_locked() {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (!g_pd_timeouts) {
-            if (hipHostMalloc(reinterpret_cast<void**>(&g_pd_timeouts), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) g_pd_timeouts = nullptr;
-            else *g_pd_timeouts = 0u;
-        }
+        if (hipHostMalloc(reinterpret_cast<void**>(&d.timeouts), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) d.timeouts = nullptr;
+        else *d.timeouts = 0u;
         d.cus = prop.multiProcessorCount;
         // Co-residency, checked up front: the workgroups spin on each other, so a launch is only made where all of them can be resident at once -
         // 256 compute units, one workgroup of every persistent kernel fits a compute unit at the largest LDS request (the occupancy query), and no
         // compute-unit mask in the environment (the device then still reports 256 but hands out fewer).  What cannot be seen from here - another
         // process on the device - is bounded by the kernels' own 2 s give-up and reported through the guard kernel.
-        const bool masked = std::getenv("HSA_CU_MASK") || std::getenv("ROC_GLOBAL_CU_MASK") || std::getenv("HSA_CU_MASK_SKIP_INIT");
-        bool fits = d.cus >= PD_WG && !masked && g_pd_timeouts;
+        const bool masked = std::getenv("HSA_CU_MASK") || std::getenv("ROC_GLOBAL_CU_MASK");
+        bool fits = d.cus >= PD_WG && !masked && d.timeouts;
         if (fits) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pdecode_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX);
@@ -718,24 +721,37 @@ static PdDevice* pd_device_locked() {
 }
 
 // the persistent forms need every workgroup resident at once (above): callers fall back to the launch path where that cannot be promised, and after a
-// launch of this process has timed out (the device is evidently shared)
+// launch on this device has timed out (the device is evidently shared) - per device, until the caller re-arms it (pdecode_rearm)
+static bool pd_armed(const PdDevice* d) { return d && d->resident && __atomic_load_n(d->timeouts, __ATOMIC_RELAXED) == d->armed_at; }
 bool pdecode_device_ok() {
     std::lock_guard<std::mutex> lock(g_pd_mu);
-    const PdDevice* d = pd_device_locked();
-    return d && d->resident && __atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) == 0u;
+    return pd_armed(pd_device_locked());
 }
 
-// g_pd_mu held.  A timed-out launch is reported ONCE as an error by the next launcher (its outputs are NaN already); pdecode_device_ok() is false from
-// then on, so the callers' next calls take the launch path.
-static int pd_report_timeouts_locked() {
-    const unsigned n = g_pd_timeouts ? __atomic_load_n(g_pd_timeouts, __ATOMIC_RELAXED) : 0u;
-    if (n != g_pd_timeouts_seen) {
-        g_pd_timeouts_seen = n;
-        set_error("an earlier persistent launch gave up after 2 s without progress (its workgroups were not all resident: shared or CU-masked device); "
-                  "its outputs were overwritten with NaN; further calls take the launch-per-phase path");
-        return 1;
+// The gate every persistent-eligible call goes through (decode_run / prologue_run): 1 = take the persistent form, 0 = take the launch path, -1 = a
+// persistent launch on this device gave up since the last call through the gate - its outputs are NaN - and THIS call fails once with that error
+// (l2s_last_error); the calls after it take the launch path until the device is re-armed.  The count sits in pinned host memory and is written by
+// the guard kernel at the end of the timed-out launch, so a caller that has synchronized with that launch is certain to see it here.
+int pdecode_gate() {
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    PdDevice* const d = pd_device_locked();
+    if (!d || !d->resident) return 0;
+    const unsigned n = __atomic_load_n(d->timeouts, __ATOMIC_RELAXED);
+    if (n != d->seen) {
+        d->seen = n;
+        set_error("an earlier persistent launch on this device gave up after 2 s without progress (its workgroups were not all resident: shared or CU-masked "
+                  "device); its outputs were overwritten with NaN; further calls take the launch-per-phase path (re-arm: set option persist_decode again)");
+        return -1;
     }
-    return 0;
+    return n == d->armed_at ? 1 : 0;
+}
+
+// option "persist_decode" set to a positive value: the caller asks for the persistent forms (again) - the current device's time-outs so far are
+// forgiven (a transient co-tenant need not switch the latency path off for the rest of the process); the process-wide count keeps counting
+void pdecode_rearm() {
+    std::lock_guard<std::mutex> lock(g_pd_mu);
+    PdDevice* const d = pd_device_locked();
+    if (d && d->timeouts) d->armed_at = __atomic_load_n(d->timeouts, __ATOMIC_RELAXED);      // `seen` stays: a time-out nobody has been told about is still reported by the gate
 }
 
 int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -743,8 +759,7 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(ws && ws_bytes >= pdecode_ws_bytes(2), "persistent decode: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
     PdDevice* const dv = pd_device_locked();
-    L2S_REQUIRE(dv && dv->resident, "persistent decode needs 256 compute units, one resident workgroup each (none masked)");
-    if (pd_report_timeouts_locked()) return 1;
+    L2S_REQUIRE(pd_armed(dv), "persistent decode needs 256 compute units, one resident workgroup each (none masked), and no timed-out launch since the device was armed");
     const int lds = std::max(pd_lds_floats(2, p.T, p.m) * 4, PD_LDS_MIN);
     L2S_CHECK_HIP(hipStreamWaitEvent(s, dv->ev, 0));      // a never-recorded event is complete
     ProfScope ps("decode_persistent", s);
@@ -760,12 +775,16 @@ int launch_pdecode(const PDecP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
         // 128 workgroups per clip, each standing for two of the one-per-CU layout: one clip leaves half the chip idle and is FASTER for it (7.7 against
         // 9.7 us per step on 256 workgroups: an edge among 128 workgroups costs ~1.2 us, among 256 ~1.8; 64 workgroups of four: 12.2, the weights no
         // longer fit the registers)
-        // test hook (tests/test_persist_timeout.py, its own process): one workgroup short, so that the others wait for granules that never come and the
-        // give-up path runs - 2 s, NaN outputs, l2s_persist_timeouts() = 1
+        // test hook, diagnostic build only (libl2s_diag.so; tests/test_persist_timeout.py, its own process): one workgroup short, so that the others wait
+        // for granules that never come and the give-up path runs - 2 s, NaN outputs, l2s_persist_timeouts() = 1
+#ifdef L2S_DIAG
         static const int starve = std::getenv("L2S_TEST_PDECODE_STARVE") ? 1 : 0;
+#else
+        constexpr int starve = 0;
+#endif
         if (n == 1) hipLaunchKernelGGL((pdecode_kernel<1, 2>), dim3(PD_WG / 2 - starve), dim3(PD_NT), lds, s, q);
         else hipLaunchKernelGGL((pdecode_kernel<2, 2>), dim3(PD_WG - starve), dim3(PD_NT), lds, s, q);
-        hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.attn, q.B * q.S * 80, q.B * q.S, q.attn ? q.B * q.S * q.T : 0, g_pd_timeouts);
+        hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.mel, q.stop, q.attn, q.B * q.S * 80, q.B * q.S, q.attn ? q.B * q.S * q.T : 0, dv->timeouts);
         L2S_CHECK_HIP(hipGetLastError());
     }
     L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
@@ -777,8 +796,7 @@ int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     L2S_REQUIRE(ws && ws_bytes >= pbilstm_ws_bytes(), "persistent BiLSTM: exchange buffer too small");
     std::lock_guard<std::mutex> lock(g_pd_mu);
     PdDevice* const dv = pd_device_locked();
-    L2S_REQUIRE(dv && dv->resident, "persistent BiLSTM needs 256 compute units, one resident workgroup each (none masked)");
-    if (pd_report_timeouts_locked()) return 1;
+    L2S_REQUIRE(pd_armed(dv), "persistent BiLSTM needs 256 compute units, one resident workgroup each (none masked), and no timed-out launch since the device was armed");
     PBiP q = p;
     q.xch = reinterpret_cast<u64*>(ws);
     q.status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (int64_t)pb_rstride(2) * 8 * PD_MAXREP);
@@ -789,7 +807,7 @@ int launch_pbilstm(const PBiP& p, void* ws, int64_t ws_bytes, hipStream_t s) {
     ProfScope ps("bilstm_persistent", s);
     if (p.B == 1) hipLaunchKernelGGL(pbilstm_kernel<1>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
     else hipLaunchKernelGGL(pbilstm_kernel<2>, dim3(PD_WG), dim3(PD_NT), 0, s, q);
-    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, q.h_state, p.B * p.T * 1024, p.B * 1024, 2 * ((p.B + 15) & ~15) * 512, g_pd_timeouts);
+    hipLaunchKernelGGL(pdecode_guard_kernel, dim3(8), dim3(256), 0, s, q.status, q.rnn, q.cellcat, q.h_state, p.B * p.T * 1024, p.B * 1024, 2 * ((p.B + 15) & ~15) * 512, dv->timeouts);
     L2S_CHECK_HIP(hipGetLastError());
     L2S_CHECK_HIP(hipEventRecord(dv->ev, s));
     return 0;

@@ -16,6 +16,41 @@
 
 namespace l2s {
 
+// ---- block-stamp log (libl2s_diag.so only; include/l2s_diag.h l2s_op_stamp_log): thread 0 of every block of the decode step's kernels appends
+// {entry, exit, tag} on the 100 MHz constant clock - the overlap proof of profiles/ that does not depend on the host's clock or on the profiler
+#ifdef L2S_DIAG
+__device__ unsigned long long* d_stamp_log = nullptr;
+__device__ unsigned long long d_stamp_cap = 0;
+struct BlockStamp {
+    unsigned long long t0 = 0;
+    unsigned long long* log = nullptr;
+    __device__ __forceinline__ void begin() { log = d_stamp_log; if (log && threadIdx.x == 0) t0 = wall_clock64(); }
+    __device__ __forceinline__ void end(unsigned kind, const void* key) {
+        if (!log) return;
+        __syncthreads();                                   // the block's last wave is through (its stores may still drain)
+        if (threadIdx.x == 0) {
+            const unsigned long long t1 = wall_clock64();
+            const unsigned long long slot = atomicAdd(log, 1ull);
+            if (slot < d_stamp_cap) {
+                unsigned long long* r = log + 1 + 3 * slot;
+                r[0] = t0; r[1] = t1; r[2] = ((unsigned long long)kind << 60) | ((unsigned long long)(uintptr_t)key & 0xFFFFFFFFFFFFull);
+            }
+        }
+    }
+};
+int set_stamp_log(unsigned long long* log, long long cap) {
+    const unsigned long long c = cap > 0 ? (unsigned long long)cap : 0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_stamp_cap), &c, sizeof(c)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_stamp_log), &log, sizeof(log)) != hipSuccess) return 1;
+    return 0;
+}
+#define L2S_BLOCK_STAMP_BEGIN() BlockStamp bs_; bs_.begin()
+#define L2S_BLOCK_STAMP_END(kind, key) bs_.end(kind, key)
+#else
+#define L2S_BLOCK_STAMP_BEGIN() do {} while (0)
+#define L2S_BLOCK_STAMP_END(kind, key) do {} while (0)
+#endif
+
 // segment layouts with their own instance (chunks of 16 columns per segment): the decode step's and the BiLSTM's operand shapes
 //   1: [32]            K = 512   fc_out+stop, prenet1∘fc_out, BiLSTM / speaker LSTM recurrences
 //   2: [32 | 32]       K = 1024  LSTM1 on [h0' | h1], Q on [h0 | h1], content Q on [c0 | c1]
@@ -98,13 +133,17 @@ template <int RT, int CT, int LAYID, int DEPTH>
 __global__ __launch_bounds__(256, 2) void skinny_rc4h_kernel(const SkinnyBatch batch, int mts) {
     __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
     const int g = blockIdx.z;
+    L2S_BLOCK_STAMP_BEGIN();
     skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 4, true, false, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+    L2S_BLOCK_STAMP_END(1u, batch.p[g].c_out);
 }
 template <int RT, int CT, int LAYID, int DEPTH>
 __global__ __launch_bounds__(512, 1) void skinny_rc8x_kernel(const SkinnyBatch batch, int mts) {      // the same on eight waves: the two waves of a SIMD alternate split VALU and MFMAs
     __shared__ float red[SkRc<RT, CT>::RED_FLOATS];
     const int g = blockIdx.z;
+    L2S_BLOCK_STAMP_BEGIN();
     skinny_block_rcs<RT, CT, typename SkLay<LAYID>::T, DEPTH, true, false, 8, true>(batch.p[g], blockIdx.x, blockIdx.y, red, batch.ntiles[g], mts);
+    L2S_BLOCK_STAMP_END(1u, batch.p[g].c_out);
 }
 // weight planes of the split-bf16 LSTM blocks from the packed fp32 fragments ([tile][chunk][lane] float4): chunk pair ip of K slice s = chunks
 // (s + 16 ip, s + 16 ip + 8); out[tile][s][ip][plane][lane] = 8 bf16 (the lane's quad of the first chunk, then of the second)
@@ -171,6 +210,7 @@ static bool launch_rc4(const SkinnyBatch& bl, int lay, int kind, int maxt, int m
     } else return false;
     return true;
 }
+#ifdef L2S_DIAG
 // measurement build of the 4x2 LSTM form: thread 0 of every block stamps its phases (8 x 64-bit per block, tools/skinny_timeline.py ROWS=256)
 template <int LAYID, bool X3 = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 1) void skinny_rcs_timed_kernel(const SkinnyBatch batch, int mts, unsigned long long* ts) {
@@ -178,6 +218,7 @@ __global__ __launch_bounds__(64 * NW, 1) void skinny_rcs_timed_kernel(const Skin
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     skinny_block_rcs<4, 2, typename SkLay<LAYID>::T, 4, true, true, NW, X3>(batch.p[0], blockIdx.x, blockIdx.y, red, batch.ntiles[0], mts, ts + (int64_t)blk * 8);
 }
+#endif
 // lay: the K layout every group shares; kind: 2 = every group is an LSTM cell, 1 = none is
 template <int RT, int CT, int DEPTH>
 static bool launch_rcs(const SkinnyBatch& bl, int lay, int kind, int maxt, int mts, hipStream_t s) {
@@ -264,6 +305,7 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
     const int local = b - fl.first[k], nc = fl.ncol[k];
     const int tp = local % nc, mg = local / nc;
     const SkinnyP& p = batch.p[g];
+    L2S_BLOCK_STAMP_BEGIN();
     if constexpr (STATIC == 2) {  // every wide group is [h | h] (K = 1024), every narrow one [h] (K = 512): straight-line four-wave blocks (256 threads)
         if (fl.wide[k]) skinny_block_rcs<R8, C8, SegLay<32, 32, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
         else skinny_block_rcs<R4, C4, SegLay<32, 0, 0, 0>, 4, false, false, 4>(p, tp, mg, red, batch.ntiles[g], mts);
@@ -275,6 +317,7 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
         if (fl.wide[k]) skinny_block_rc<R8, C8, 8, 2>(p, tp, mg, red, batch.ntiles[g], mts);
         else skinny_block_rc<R4, C4, 4, 2>(p, tp, mg, red, batch.ntiles[g], mts);
     }
+    L2S_BLOCK_STAMP_END(2u, batch.p[0].out);
 }
 // choose the pair of shapes: at most `cap` blocks in total (one per CU) and the shortest longest block.  A block's time is modelled from the
 // measurements of tools/time_step_phases.py as bytes / 36.5 GB/s (what one block streams through its CU's vector-memory path) plus its MFMA
@@ -315,18 +358,23 @@ static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl, bo
     for (int k = n; k <= SKINNY_MAX_GROUP; ++k) fl.first[k] = pos;
     return best8 * 100 + best4;
 }
+#ifdef L2S_DIAG
 static unsigned long long* g_flat_ts = nullptr;
 void skinny_set_flat_timeline(unsigned long long* ts) { g_flat_ts = ts; }
+#endif
 template <int S8, int S4>
 static void launch_flat(const SkinnyBatch& bl, const SkinnyFlat& fl, int mts, hipStream_t s, int stat) {
+#ifdef L2S_DIAG
     if (g_flat_ts && stat == 1) {
         if constexpr (S8 == 22 && S4 == 42) { hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1, true>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, g_flat_ts); return; }
     }
+#endif
     if (stat == 2) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 2>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(256), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
     else if (stat == 1) hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 1>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL((skinny_flat_kernel<S8, S4, 0>), dim3(fl.first[SKINNY_MAX_GROUP]), dim3(512), 0, s, bl, fl, mts, (unsigned long long*)nullptr);
 }
 
+#ifdef L2S_DIAG
 // measurement build of the same kernel: every block's thread 0 stamps its phases (8 stamps per block, block index = (z*gridDim.y + y)*gridDim.x + x)
 __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch batch, unsigned long long* ts) {
     __shared__ float red[SK_RED_FLOATS];
@@ -337,11 +385,18 @@ __global__ __launch_bounds__(512) void skinny_kernel_timed(const SkinnyBatch bat
     else if (p.layout == 2) skinny_block<false, 8, true, SegLay<32, 32, 0, 0>>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
     else skinny_block<false, SK_MAXC, true>(p, blockIdx.x, blockIdx.y, red, batch.ntiles[g], nullptr, ts + (int64_t)blk * 8);
 }
+#endif
+#ifdef L2S_DIAG
 static unsigned long long* g_skinny_ts = nullptr;
+#else
+static constexpr unsigned long long* g_skinny_ts = nullptr;      // the product never launches a stamped build
+#endif
 // options (l2s_common.h Options): "skinny_static" = compile-time segment layouts: +2 % one batch at a time (23.6 -> 23.1 us/step), -3 % with four
 // batches in flight (1.60 -> 1.56 M mel-frames/s), off by default; "skinny_sized" = instances sized for the launch's longest K;
 // "skinny_split" / "skinny_split8" = operand loads of the K <= 1536 / K <= 1024 instance in this many batches
+#ifdef L2S_DIAG
 void skinny_set_timeline(unsigned long long* ts) { g_skinny_ts = ts; }
+#endif
 
 static bool skinny_shape_known(int shape) { return shape == 0 || shape == 11 || shape == 21 || shape == 22 || shape == 42; }
 // a forced "skinny_rc" / "skinny_rc_multi" outside {11, 21, 22, 42} falls through to skinny_kernel<cls>, which knows nothing of SkinnyP::a_sum: the
@@ -428,6 +483,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
                     "skinny: a summed segment needs the straight-line LSTM blocks (shape 11 / 21 / 22 / 42, default operand batching)");
     bool any_sum = false;
     for (int i = 0; i < bl.count; ++i) any_sum = any_sum || bl.p[i].a_sum;
+#ifdef L2S_DIAG
     if (g_skinny_ts && shape == 42 && bl.count == 1 && rc_kind == 2 && (rc_lay == 2 || rc_lay == 3)) {
         const dim3 grid((maxt + 1) / 2, (mts + 3) / 4, 1);
         if (rc_lay == 3) hipLaunchKernelGGL(skinny_rcs_timed_kernel<3>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
@@ -436,7 +492,9 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
         else hipLaunchKernelGGL(skinny_rcs_timed_kernel<2>, grid, dim3(256), 0, s, bl, mts, g_skinny_ts);
     }
     else if (g_skinny_ts) hipLaunchKernelGGL(skinny_kernel_timed, dim3(maxt, mts, b.count), dim3(512), 0, s, bl, g_skinny_ts);
-    else if (shape == 11 && o.rc_jb == 0 && rc_lay && rc_kind && launch_rc4<1, 1, 4>(bl, rc_lay, rc_kind, maxt, mts, s, x3)) {}      // 16 x 16 tiles, four waves
+    else
+#endif
+    if (shape == 11 && o.rc_jb == 0 && rc_lay && rc_kind && launch_rc4<1, 1, 4>(bl, rc_lay, rc_kind, maxt, mts, s, x3)) {}      // 16 x 16 tiles, four waves
     else if (shape == 42) launch_rc<4, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
     else if (shape == 22) launch_rc<2, 2>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
     else if (shape == 21) launch_rc<2, 1>(bl, cls, maxt, mts, s, o.rc_jb, rc_lay, rc_kind, x3);
@@ -472,6 +530,7 @@ __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
     const int nb = sb.at.B, ptiles = sb.pre2_tiles;
     L2S_PIN_S("s"(nb), "s"(ptiles));
     const int bid = blockIdx.x;
+    L2S_BLOCK_STAMP_BEGIN();
     if (bid < nb) {
         attention_block<false, false, VL>(sb.at, bid, sm);
     } else if (bid < 2 * nb) {
@@ -481,8 +540,10 @@ __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
         const int tile = j % ptiles, mt = j / ptiles;
         skinny_block<false, ATT_PRE2_MAXC>(sb.pre2, tile, mt, sm);       // K = 256: the 12-chunk instance would set this kernel's VGPR count
     }
+    L2S_BLOCK_STAMP_END(3u, sb.at.q);
 }
 
+#ifdef L2S_DIAG
 // measurement build (tools/attn_timeline.py): thread 0 of every attention block stamps the 100 MHz wall clock at seven points
 __global__ __launch_bounds__(512) void step_attn_timed_kernel(const StepB sb, unsigned long long* ts) {
     __shared__ __attribute__((aligned(16))) float sm[(ATT_SM_FLOATS + ATT_VLDS_FLOATS) > SK_RED_FLOATS ? (ATT_SM_FLOATS + ATT_VLDS_FLOATS) : SK_RED_FLOATS];
@@ -500,6 +561,7 @@ __global__ __launch_bounds__(512) void step_attn_timed_kernel(const StepB sb, un
 static unsigned long long* g_attn_ts = nullptr;
 void attn_set_timeline(unsigned long long* ts) { g_attn_ts = ts; }
 
+#endif
 int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values) {
     L2S_REQUIRE(at.T <= ATT_MAXT && at.m <= 16, "attention sizes");
     L2S_REQUIRE(pre2.K <= 16 * SK_WAVES * ATT_PRE2_MAXC, "prenet layer 2 is a 256-wide layer");
@@ -513,13 +575,17 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     // (32 rows: 8.64 against 8.85 us inside the step), not at 256 (11.2 against 10.6 us event-bracketed, the pass 0.06 ms longer) - unless the caller keeps several
     // chains in flight: three 74-register blocks per CU leave room for other chains' kernels (+1.4 % at three chains): option 1 = by rows and chains, 2 = always
     const bool vl = lds_values && (lds_values >= 2 || at.B <= 128 || chains_hint() >= 2) && at.vp != nullptr && at.T <= 32;
+#ifdef L2S_DIAG
     if (g_attn_ts && vl) hipLaunchKernelGGL(step_attn_timed_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb, g_attn_ts);
-    else if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    else
+#endif
+    if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     else hipLaunchKernelGGL(step_attn_kernel<false>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+#ifdef L2S_DIAG
 // ---- launch-floor probes (tools/launch_floor.py): chains of dependent launches shaped like a decode phase
 __global__ __launch_bounds__(512) void probe_empty_kernel(float* out) {
     if (threadIdx.x == 1023) out[0] = 0.f;
@@ -549,5 +615,7 @@ int launch_probe(int kind, int blocks, int n_per_block, const float* in, float* 
     L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+#endif
 
 }  // namespace l2s

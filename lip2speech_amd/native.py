@@ -18,9 +18,13 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("L2S_LIB") or os.path.join(_HERE, "csrc", "libl2s_hip.so")   # L2S_LIB: A/B another build of the same ABI
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libl2s_diag.so")      # the diagnostic build (include/l2s_diag.h): tools/ and the operator tests only
+# L2S_LIB: another build of the same ABI - tools/ point it at the diagnostic library ("diag" = DIAG_LIB_PATH), whose ABI is a superset
+LIB_PATH = os.environ.get("L2S_LIB") or os.path.join(_HERE, "csrc", "libl2s_hip.so")
+if LIB_PATH == "diag":
+    LIB_PATH = DIAG_LIB_PATH
 
-# every symbol include/l2s.h declares; tests check the built library exports all of them
+# every symbol include/l2s.h declares; tests check the built library exports all of them (and the product library nothing else)
 ABI_SYMBOLS = (
     "l2s_abi_version", "l2s_last_error",
     "l2s_model_create", "l2s_model_set_tensor", "l2s_model_finalize", "l2s_model_destroy",
@@ -28,7 +32,7 @@ ABI_SYMBOLS = (
     "l2s_encoder_fwd", "l2s_normalise_pad_frames", "l2s_build_visual", "l2s_decoder_prologue", "l2s_decode_steps", "l2s_postnet",
     "l2s_output_lengths", "l2s_inference", "l2s_inference_multi", "l2s_workspace_bytes_multi", "l2s_forward_eval", "l2s_forward_eval_multi", "l2s_model_set_option", "l2s_persist_available", "l2s_persist_timeouts", "l2s_set_thread_chains", "l2s_speaker_workspace_bytes", "l2s_speaker_encoder_fwd",
     "l2s_inverse_mel_workspace_bytes", "l2s_inverse_mel", "l2s_griffin_lim_workspace_bytes", "l2s_griffin_lim", "l2s_estoi_workspace_bytes", "l2s_estoi",
-    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_set_option", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_pdecode_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain",
+    "l2s_set_option",
     "l2s_train_scratch_bytes", "l2s_loss", "l2s_grad_norm", "l2s_adamw_amsgrad_step",
     "l2s_train_steps_tape_floats", "l2s_train_steps_weights_floats", "l2s_train_steps_ws_bytes", "l2s_train_steps_pack_weights",
     "l2s_train_steps_fwd", "l2s_train_steps_bwd",
@@ -37,24 +41,57 @@ ABI_SYMBOLS = (
     "l2s_train_bind", "l2s_train_postnet_tape_floats", "l2s_train_postnet_ws_bytes", "l2s_train_postnet_fwd", "l2s_train_postnet_bwd",
     "l2s_profile_enable", "l2s_profile_reset", "l2s_profile_count", "l2s_profile_get",
 )
+# what include/l2s_diag.h adds: exported by libl2s_diag.so only
+DIAG_SYMBOLS = (
+    "l2s_op_gemm", "l2s_op_conv1d", "l2s_op_gemm_ex", "l2s_op_conv1d_ex", "l2s_op_conv1d_bwd", "l2s_op_frontend", "l2s_op_launch_chain", "l2s_op_launch_chain2", "l2s_op_skinny_timeline", "l2s_op_attn_timeline", "l2s_op_flat_timeline", "l2s_op_pdecode_timeline", "l2s_op_gemm_x3_timeline", "l2s_op_fused_unit_timeline", "l2s_op_lstm_cell_chain", "l2s_op_step_attn_chain", "l2s_op_stamp_log",
+)
+
+# run-time options only the diagnostic build accepts (block-form A/B switches of the same arithmetic, include/l2s_diag.h)
+DIAG_OPTIONS = frozenset(("overlap_postnet", "fuse_trunk", "fuse_s2", "skinny_static", "skinny_sized", "skinny_split", "skinny_split8", "skinny_rc", "skinny_rc_jb",
+                          "skinny_rc_multi", "skinny_flat", "hoist_vproj", "attn_lds", "flat_half", "half_min_mts", "gemm_x3_dma", "flat_xcd", "attn_skip0"))
 
 ST_K, ST_V, ST_CKEY, ST_CVAL, ST_ECELL, ST_H, ST_C, ST_ENC, ST_STOPC = range(9)
 
 _lib = None
+_diag = None
+_process_defaults: Dict[str, int] = {}
 _vp, _i, _i64, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+
+
+def _load(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"native library not built: {path} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C lip2speech_amd/csrc` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the Lip2Speech hot path.")
+    L = ctypes.CDLL(path)
+    _bind(L)
+    if hasattr(L, "l2s_op_gemm"):
+        _bind_diag(L)
+    return L
 
 
 def lib() -> ctypes.CDLL:
     """Load the native library (once).  Fails loudly - the HIP path is the only path."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"native library not built: {LIB_PATH} is missing. Build it with "
-            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C lip2speech_amd/csrc` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the Lip2Speech hot path.")
-    L = ctypes.CDLL(LIB_PATH)
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def diag() -> ctypes.CDLL:
+    """The diagnostic build (libl2s_diag.so, include/l2s_diag.h): the product ABI plus operator-level hooks, chain microbenches, stamped kernel builds
+    and the block-form A/B options.  Loaded on demand by tools/ and the operator tests - never by the package's own callers."""
+    global _diag
+    if _diag is None:
+        _diag = lib() if hasattr(lib(), "l2s_op_gemm") else _load(DIAG_LIB_PATH)
+        if _diag is not _lib:
+            for name, value in _process_defaults.items():      # the process defaults set so far hold for models of either library
+                check(_diag.l2s_set_option(name.encode(), value), _diag)
+    return _diag
+
+
+def _bind(L: ctypes.CDLL) -> None:
     L.l2s_last_error.restype = ctypes.c_char_p
     L.l2s_abi_version.restype = _i
     L.l2s_model_create.argtypes = [ctypes.POINTER(_vp)]
@@ -86,23 +123,7 @@ def lib() -> ctypes.CDLL:
     L.l2s_forward_eval_multi.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp,
                                          _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp, _i64, _vp]
     L.l2s_model_set_option.argtypes = [_vp, ctypes.c_char_p, _i]
-    L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
-    L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
-    L.l2s_op_gemm_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]
-    L.l2s_op_conv1d_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
-    L.l2s_op_conv1d_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]
-    L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
     L.l2s_set_option.argtypes = [ctypes.c_char_p, _i]
-    L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
-    L.l2s_op_skinny_timeline.argtypes = [_vp]
-    L.l2s_op_attn_timeline.argtypes = [_vp]
-    L.l2s_op_flat_timeline.argtypes = [_vp]
-    L.l2s_op_pdecode_timeline.argtypes = [_vp, ctypes.c_int]
-    L.l2s_op_gemm_x3_timeline.argtypes = [_vp, ctypes.c_int]
-    L.l2s_op_fused_unit_timeline.argtypes = [_vp, _i]
-    L.l2s_op_launch_chain2.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp, _vp]
-    L.l2s_op_step_attn_chain.argtypes = [_vp, _fp, _i, _i, _i, _vp, _i64, _vp]
-    L.l2s_op_lstm_cell_chain.argtypes = [_vp, _i, _i, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_double)]
     L.l2s_train_bind.argtypes = [_vp, ctypes.c_char_p, _fp, _fp]
     L.l2s_train_postnet_tape_floats.argtypes = [_i, _i]
     L.l2s_train_postnet_tape_floats.restype = _i64
@@ -148,13 +169,35 @@ def lib() -> ctypes.CDLL:
     L.l2s_estoi.argtypes = [_fp, _fp, _i, _i, _fp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _fp, _vp, _i64, _vp]
     L.l2s_profile_enable.argtypes = [_i]
     L.l2s_profile_get.argtypes = [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]
-    _lib = L
-    return L
 
 
-def check(rc: int) -> None:
+def _bind_diag(L: ctypes.CDLL) -> None:
+    L.l2s_op_gemm.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_gemm_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d_ex.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_conv1d_bwd.argtypes = [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]
+    L.l2s_op_frontend.argtypes = [_vp, _fp, _i, _i, _i, _i, _fp, _vp]
+    L.l2s_op_launch_chain.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp]
+    L.l2s_op_skinny_timeline.argtypes = [_vp]
+    L.l2s_op_attn_timeline.argtypes = [_vp]
+    L.l2s_op_flat_timeline.argtypes = [_vp]
+    L.l2s_op_pdecode_timeline.argtypes = [_vp, ctypes.c_int]
+    L.l2s_op_gemm_x3_timeline.argtypes = [_vp, ctypes.c_int]
+    L.l2s_op_fused_unit_timeline.argtypes = [_vp, _i]
+    L.l2s_op_launch_chain2.argtypes = [_i, _i, _i, _i, _fp, _fp, _vp, _vp]
+    L.l2s_op_step_attn_chain.argtypes = [_vp, _fp, _i, _i, _i, _vp, _i64, _vp]
+    L.l2s_op_lstm_cell_chain.argtypes = [_vp, _i, _i, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_double)]
+    L.l2s_op_stamp_log.argtypes = [_vp, _i64]
+
+
+def check(rc: int, L: Optional[ctypes.CDLL] = None) -> None:
     if rc != 0:
-        raise RuntimeError("libl2s_hip: " + lib().l2s_last_error().decode("utf-8", "replace"))
+        raise RuntimeError("libl2s_hip: " + (L or lib()).l2s_last_error().decode("utf-8", "replace"))
+
+
+def _dcheck(rc: int) -> None:
+    check(rc, diag())
 
 
 def _stream() -> int:
@@ -181,37 +224,41 @@ def min_T(T: int) -> int:
 class NativeModel:
     """Owns an ``l2s_model`` (the packed device weight blob)."""
 
-    def __init__(self):
+    def __init__(self, library: Optional[ctypes.CDLL] = None):
+        self._L = library or lib()        # every call of this model goes to ONE library: the product, or the diagnostic build (tests of the A/B options, tools)
         self._h = _vp()
-        check(lib().l2s_model_create(ctypes.byref(self._h)))
+        self._check(self._L.l2s_model_create(ctypes.byref(self._h)), self._L)
         self._tls = threading.local()      # the workspace is per host thread: several threads may run batches on ONE model (one weight blob)
         self.calls = collections.Counter()  # whole-path entry points used, by C-ABI name (tests assert which route a caller took)
 
+    def _check(self, rc: int) -> None:
+        check(rc, self._L)
+
     def set_option(self, name: str, value: int) -> None:
         """Run-time option of THIS model (include/l2s.h "run-time options"); `native.set_option` changes the defaults of models created later."""
-        check(lib().l2s_model_set_option(self._h, name.encode(), int(value)))
+        self._check(self._L.l2s_model_set_option(self._h, name.encode(), int(value)))
 
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                lib().l2s_model_destroy(self._h)
+                self._L.l2s_model_destroy(self._h)
         except Exception:
             pass
 
     def load(self, tensors: Dict[str, torch.Tensor], keys: Iterable[str]) -> None:
         """Hand the checkpoint tensors named ``keys`` (reference key names) to the library and pack them."""
-        L = lib()
+        L = self._L
         for key in keys:
             t = tensors[key]
             if not t.is_floating_point():
                 continue                                   # num_batches_tracked: not used in eval arithmetic
             a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
-            check(L.l2s_model_set_tensor(self._h, key.encode(), a.ctypes.data_as(_vp), a.size))
-        check(L.l2s_model_finalize(self._h, _stream()))
+            self._check(L.l2s_model_set_tensor(self._h, key.encode(), a.ctypes.data_as(_vp), a.size))
+        self._check(L.l2s_model_finalize(self._h, _stream()))
 
     # ------------------------------------------------------------------ workspace (caller-owned, cached)
     def workspace(self, B: int, T: int, H: int, W: int, S: int, device, G: int = 0) -> torch.Tensor:
-        need = int(lib().l2s_workspace_bytes_multi(G, B, T, H, W, S)) if G else int(lib().l2s_workspace_bytes(B, T, H, W, S))
+        need = int(self._L.l2s_workspace_bytes_multi(G, B, T, H, W, S)) if G else int(self._L.l2s_workspace_bytes(B, T, H, W, S))
         ws = getattr(self._tls, "ws", None)
         if ws is None or ws.numel() < need or ws.device != device:
             ws = self._tls.ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -224,7 +271,7 @@ class NativeModel:
         assert C == 3, "frames are (B,3,T,H,W) RGB"
         feat = torch.empty(B, T, 768, dtype=torch.float32, device=video.device)
         ws = self.workspace(B, T, H, W, 1, video.device)
-        check(lib().l2s_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(feat), _ptr(ws), ws.numel(), _stream()))
+        self._check(self._L.l2s_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(feat), _ptr(ws), ws.numel(), _stream()))
         return feat
 
     def decoder_prologue(self, vis: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, want_dis: bool = True):
@@ -233,10 +280,10 @@ class NativeModel:
         assert C == 1024 and emb.shape == (B, 256)
         m = min_T(T)
         assert m == 0 or gumbel.shape == (B * m, 501), f"gumbel noise must be {(B * m, 501)}"
-        state = torch.zeros(int(lib().l2s_state_floats(B, T)), dtype=torch.float32, device=vis.device)
+        state = torch.zeros(int(self._L.l2s_state_floats(B, T)), dtype=torch.float32, device=vis.device)
         dis = torch.empty(B * m, 501, dtype=torch.float32, device=vis.device) if want_dis else None
         ws = self.workspace(B, T, 96, 96, 1, vis.device)
-        check(lib().l2s_decoder_prologue(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis),
+        self._check(self._L.l2s_decoder_prologue(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis),
                                          _ptr(ws), ws.numel(), _stream()))
         return state, dis
 
@@ -256,7 +303,7 @@ class NativeModel:
         else:
             teacher = None
         ws = self.workspace(B, T, 96, 96, S, dev)
-        check(lib().l2s_decode_steps(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_buf, _ptr(mel), _ptr(stop),
+        self._check(self._L.l2s_decode_steps(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_buf, _ptr(mel), _ptr(stop),
                                      _ptr(attn), 1 if attn_logits else 0, _ptr(ws), ws.numel(), _stream()))
         return mel, stop, attn
 
@@ -267,7 +314,7 @@ class NativeModel:
         out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
         cf = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device) if want_cf else None
         ws = self.workspace(B, 29, 96, 96, S, mel.device)
-        check(lib().l2s_postnet(self._h, _ptr(mel), B, S, _ptr(out), _ptr(cf), _ptr(ws), ws.numel(), _stream()))
+        self._check(self._L.l2s_postnet(self._h, _ptr(mel), B, S, _ptr(out), _ptr(cf), _ptr(ws), ws.numel(), _stream()))
         return out, cf
 
     def forward_eval(self, video: torch.Tensor, emb: torch.Tensor, gumbel: torch.Tensor, S: int, teacher: Optional[torch.Tensor] = None,
@@ -307,11 +354,11 @@ class NativeModel:
         self.calls["l2s_forward_eval" if G == 1 else "l2s_forward_eval_multi"] += 1
         if G == 1:
             ws = self.workspace(B, T, H, W, S, dev)
-            check(lib().l2s_forward_eval(self._h, _ptr(vids[0]), _ptr(embs[0]), _ptr(gums[0]), B, T, H, W, S, _ptr(teach[0]) if teach else None, mask_buf,
+            self._check(self._L.l2s_forward_eval(self._h, _ptr(vids[0]), _ptr(embs[0]), _ptr(gums[0]), B, T, H, W, S, _ptr(teach[0]) if teach else None, mask_buf,
                                          _ptr(mel_cf), _ptr(mel_post), _ptr(stop), _ptr(attn), _ptr(dis), _ptr(ws), ws.numel(), _stream()))
         else:
             ws = self.workspace(B, T, H, W, S, dev, G=G)
-            check(lib().l2s_forward_eval_multi(self._h, G, arr(vids), arr(embs), arr(gums), arr(teach) if teach else None, mask_buf, B, T, H, W, S,
+            self._check(self._L.l2s_forward_eval_multi(self._h, G, arr(vids), arr(embs), arr(gums), arr(teach) if teach else None, mask_buf, B, T, H, W, S,
                                                _ptr(mel_cf), _ptr(mel_post), _ptr(stop), _ptr(attn), _ptr(dis), _ptr(ws), ws.numel(), _stream()))
         return [(mel_cf[g * B:(g + 1) * B], mel_post[g * B:(g + 1) * B], stop[g * B:(g + 1) * B], attn[g * B:(g + 1) * B],
                  dis[g * B * m:(g + 1) * B * m]) for g in range(G)]
@@ -335,7 +382,7 @@ class NativeModel:
         attn = torch.empty(B, S, T, dtype=torch.float32, device=video.device) if want_attn else None
         self.calls["l2s_inference"] += 1
         ws = self.workspace(B, T, H, W, S, video.device)
-        check(lib().l2s_inference(self._h, _ptr(video), _ptr(emb), _ptr(gumbel), B, T, H, W, S, _ptr(mel_post),
+        self._check(self._L.l2s_inference(self._h, _ptr(video), _ptr(emb), _ptr(gumbel), B, T, H, W, S, _ptr(mel_post),
                                   _ptr(lengths), _ptr(attn), _ptr(ws), ws.numel(), _stream()))
         return mel_post, lengths, attn
 
@@ -357,7 +404,7 @@ class NativeModel:
         self.calls["l2s_inference_multi"] += 1
         ws = self.workspace(B, T, H, W, S, dev, G=G)
         arr = lambda ts: (_vp * G)(*[t.data_ptr() for t in ts])      # noqa: E731
-        check(lib().l2s_inference_multi(self._h, G, arr(vids), arr(embs), arr(gums), B, T, H, W, S, _ptr(mel_post), _ptr(lengths), _ptr(attn),
+        self._check(self._L.l2s_inference_multi(self._h, G, arr(vids), arr(embs), arr(gums), B, T, H, W, S, _ptr(mel_post), _ptr(lengths), _ptr(attn),
                                         _ptr(ws), ws.numel(), _stream()))
         return [(mel_post[g * B:(g + 1) * B], lengths[g * B:(g + 1) * B], attn[g * B:(g + 1) * B] if want_attn else None) for g in range(G)]
 
@@ -365,8 +412,8 @@ class NativeModel:
         audio = _f32(audio)
         B, N = audio.shape
         emb = torch.empty(B, 256, dtype=torch.float32, device=audio.device)
-        ws = torch.empty(int(lib().l2s_speaker_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
-        check(lib().l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
+        ws = torch.empty(int(self._L.l2s_speaker_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
+        self._check(self._L.l2s_speaker_encoder_fwd(self._h, _ptr(audio), B, N, _ptr(emb), _ptr(ws), ws.numel(), _stream()))
         return emb
 
     # ------------------------------------------------------------------ training (forward with tapes + backward)
@@ -377,34 +424,34 @@ class NativeModel:
             if not p.is_floating_point():
                 continue
             g = grads.get(key)
-            check(lib().l2s_train_bind(self._h, key.encode(), _ptr(p), _ptr(g) if g is not None else None))
+            self._check(self._L.l2s_train_bind(self._h, key.encode(), _ptr(p), _ptr(g) if g is not None else None))
 
     def train_set_bn(self, batch_stats: bool, momentum: float = 0.1) -> None:
         """BatchNorm of the training entry points: batch statistics + running-stat updates (nn.Module.train()) or running statistics."""
-        check(lib().l2s_train_set_bn(self._h, 1 if batch_stats else 0, float(momentum)))
+        self._check(self._L.l2s_train_set_bn(self._h, 1 if batch_stats else 0, float(momentum)))
 
     def train_refresh_weights(self) -> None:
         """Device-side re-pack of the weight blob from the bound tensors (needs self.set_option('refresh_map', 1) before load())."""
-        check(lib().l2s_train_refresh_weights(self._h, _stream()))
+        self._check(self._L.l2s_train_refresh_weights(self._h, _stream()))
 
     def train_postnet_fwd(self, mel: torch.Tensor, drop: Optional[torch.Tensor] = None):
         """Post-net forward with a tape: mel (B,S,80) -> (mel_post (B,80,S), tape).  drop: packed dropout multipliers (postnet_drop_pack)."""
         mel = _f32(mel)
         B, S, _ = mel.shape
-        L = lib()
+        L = self._L
         tape = torch.zeros(int(L.l2s_train_postnet_tape_floats(B, S)), dtype=torch.float32, device=mel.device)
         out = torch.empty(B, 80, S, dtype=torch.float32, device=mel.device)
-        check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _ptr(drop), _stream()))
+        self._check(L.l2s_train_postnet_fwd(self._h, _ptr(mel), B, S, _ptr(tape), _ptr(out), _ptr(drop), _stream()))
         return out, tape
 
     def train_postnet_bwd(self, mel: torch.Tensor, dmel_post: torch.Tensor, tape: torch.Tensor, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Post-net backward: dmel_post (B,80,S) -> dmel (B,S,80) (residual path included); parameter gradients into the bound slots."""
         mel, dmel_post = _f32(mel), _f32(dmel_post)
         B, S, _ = mel.shape
-        L = lib()
+        L = self._L
         dmel = torch.zeros_like(mel)
         ws = torch.empty(int(L.l2s_train_postnet_ws_bytes(B, S)), dtype=torch.uint8, device=mel.device)
-        check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(drop), _ptr(ws), ws.numel(), _stream()))
+        self._check(L.l2s_train_postnet_bwd(self._h, _ptr(mel), _ptr(dmel_post), B, S, _ptr(tape), _ptr(dmel), _ptr(drop), _ptr(ws), ws.numel(), _stream()))
         return dmel
 
     def train_postnet(self, mel: torch.Tensor, dmel_post: torch.Tensor, drop: Optional[torch.Tensor] = None):
@@ -414,9 +461,9 @@ class NativeModel:
 
     def train_pack_weights(self, device) -> torch.Tensor:
         """Transposed step / prologue weights for the backward GEMMs, packed on the device from the bound parameters."""
-        L = lib()
+        L = self._L
         wbuf = torch.empty(int(L.l2s_train_steps_weights_floats()), dtype=torch.float32, device=device)
-        check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
+        self._check(L.l2s_train_steps_pack_weights(self._h, _ptr(wbuf), _stream()))
         return wbuf
 
     def train_steps_fwd(self, state, B, T, S, teacher=None, teacher_mask=None, drop=None):
@@ -427,7 +474,7 @@ class NativeModel:
         assert dp is None or tuple(dp.shape) == (S, B, 256)
         assert da is None or tuple(da.shape) == (S, B, T)
         assert dr is None or tuple(dr.shape) == (S, B, 512)
-        L, dev = lib(), state.device
+        L, dev = self._L, state.device
         tape = torch.zeros(int(L.l2s_train_steps_tape_floats(B, S)), dtype=torch.float32, device=dev)
         ws = torch.empty(int(L.l2s_train_steps_ws_bytes(B, S)), dtype=torch.uint8, device=dev)
         mel = torch.empty(B, S, 80, dtype=torch.float32, device=dev)
@@ -439,7 +486,7 @@ class NativeModel:
             mask_np = np.ascontiguousarray(np.asarray(teacher_mask, dtype=np.uint8))
             mask_dev = torch.from_numpy(mask_np).to(dev)
             mask_ptr = mask_np.ctypes.data_as(_vp)
-        check(L.l2s_train_steps_fwd(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_ptr, _ptr(mask_dev) if mask_dev is not None else None,
+        self._check(L.l2s_train_steps_fwd(self._h, _ptr(state), B, T, S, _ptr(teacher), mask_ptr, _ptr(mask_dev) if mask_dev is not None else None,
                                     _ptr(tape), _ptr(mel), _ptr(stop), _ptr(logits), _ptr(dp), _ptr(da), _ptr(dr), _ptr(ws), ws.numel(), _stream()))
         ctx = dict(state=state, B=B, T=T, S=S, tape=tape, ws=ws, logits=logits, mask_np=mask_np, mask_ptr=mask_ptr, teacher=teacher, mask_dev=mask_dev,
                    drop=(dp, da, dr))
@@ -447,7 +494,7 @@ class NativeModel:
 
     def train_steps_bwd(self, ctx, dmel, dstop, wbuf=None):
         """BPTT through the loop: dmel (B,S,80), dstop (B,S) -> gradients of the prologue state; parameter gradients into the bound slots."""
-        L, state = lib(), ctx["state"]
+        L, state = self._L, ctx["state"]
         B, T, S, dev = ctx["B"], ctx["T"], ctx["S"], state.device
         m = min_T(T)
         out = {"dk": torch.empty(B, T, 512, device=dev), "dv": torch.empty(B, T, 512, device=dev), "dckey": torch.empty(B, m, 256, device=dev),
@@ -455,7 +502,7 @@ class NativeModel:
         if wbuf is None:
             wbuf = self.train_pack_weights(dev)
         ws = ctx["ws"]
-        check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, ctx["mask_ptr"], _ptr(ctx["tape"]), _ptr(ctx["logits"]), _ptr(_f32(dmel)), _ptr(_f32(dstop)),
+        self._check(L.l2s_train_steps_bwd(self._h, _ptr(state), B, T, S, ctx["mask_ptr"], _ptr(ctx["tape"]), _ptr(ctx["logits"]), _ptr(_f32(dmel)), _ptr(_f32(dstop)),
                                     _ptr(wbuf), _ptr(out["dk"]), _ptr(out["dv"]), _ptr(out["dckey"]), _ptr(out["dcval"]), _ptr(out["dh_init"]), _ptr(out["de_c"]),
                                     _ptr(ctx["drop"][0]), _ptr(ctx["drop"][1]), _ptr(ctx["drop"][2]), _ptr(ws), ws.numel(), _stream()))
         return out
@@ -469,32 +516,32 @@ class NativeModel:
         """Encoder forward with a tape.  Returns (vis (B,T,1024) or None, feat (B,T,768), tape)."""
         video = _f32(video)
         B, _, T, H, W = video.shape
-        L, dev = lib(), video.device
+        L, dev = self._L, video.device
         tape = torch.empty(int(L.l2s_train_encoder_tape_floats(B, T, H)), dtype=torch.float32, device=dev)
         feat = torch.empty(B, T, 768, dtype=torch.float32, device=dev)
         vis = torch.empty(B, T, 1024, dtype=torch.float32, device=dev) if emb is not None else None
-        check(L.l2s_train_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(_f32(emb)) if emb is not None else None, _ptr(vis), _ptr(feat), _ptr(tape), _stream()))
+        self._check(L.l2s_train_encoder_fwd(self._h, _ptr(video), B, T, H, W, _ptr(_f32(emb)) if emb is not None else None, _ptr(vis), _ptr(feat), _ptr(tape), _stream()))
         return vis, feat, tape
 
     def train_encoder_bwd(self, video, dfeat, tape) -> None:
         """Encoder backward: dfeat (B,T,>=768) (e.g. dvis, row stride 1024); parameter gradients land in the bound slots."""
         video = _f32(video)
         B, _, T, H, W = video.shape
-        L = lib()
+        L = self._L
         assert dfeat.is_cuda and dfeat.dtype == torch.float32 and dfeat.stride(-1) == 1 and dfeat.stride(0) == T * dfeat.stride(1)
         ws = torch.empty(int(L.l2s_train_encoder_ws_bytes(B, T, H)), dtype=torch.uint8, device=video.device)
-        check(L.l2s_train_encoder_bwd(self._h, _ptr(video), B, T, H, W, dfeat.data_ptr(), int(dfeat.stride(1)), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
+        self._check(L.l2s_train_encoder_bwd(self._h, _ptr(video), B, T, H, W, dfeat.data_ptr(), int(dfeat.stride(1)), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
 
     def train_prologue_fwd(self, vis, emb, gumbel):
         """Prologue forward with a tape (stage 3).  Returns (state, content_dis, tape)."""
         vis, emb, gumbel = _f32(vis), _f32(emb), _f32(gumbel)
         B, T, _ = vis.shape
-        L, dev = lib(), vis.device
+        L, dev = self._L, vis.device
         state = torch.zeros(int(L.l2s_state_floats(B, T)), dtype=torch.float32, device=dev)
         dis = torch.empty(B * min_T(T), 501, dtype=torch.float32, device=dev)
         tape = torch.zeros(int(L.l2s_train_prologue_tape_floats(B, T)), dtype=torch.float32, device=dev)
         ws = torch.empty(int(L.l2s_train_prologue_ws_bytes(B, T)), dtype=torch.uint8, device=dev)
-        check(L.l2s_train_prologue_fwd(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
+        self._check(L.l2s_train_prologue_fwd(self._h, _ptr(vis), _ptr(emb), _ptr(gumbel), B, T, _ptr(state), _ptr(dis), _ptr(tape), _ptr(ws), ws.numel(), _stream()))
         return state, dis, tape
 
     def train_prologue_bwd(self, vis, emb, state, tape, g, dcontent_dis=None, wbuf=None):
@@ -502,14 +549,14 @@ class NativeModel:
         parameter gradients land in the bound slots."""
         vis, emb = _f32(vis), _f32(emb)
         B, T, _ = vis.shape
-        L, dev = lib(), vis.device
+        L, dev = self._L, vis.device
         if wbuf is None:
             wbuf = self.train_pack_weights(dev)
         ws = torch.empty(int(L.l2s_train_prologue_ws_bytes(B, T)), dtype=torch.uint8, device=dev)
         dvis = torch.empty(B, T, 1024, dtype=torch.float32, device=dev)
         gg = {k: _f32(v) for k, v in g.items()}
         dd = _f32(dcontent_dis) if dcontent_dis is not None else None
-        check(L.l2s_train_prologue_bwd(self._h, _ptr(vis), _ptr(emb), B, T, _ptr(state), _ptr(tape), _ptr(wbuf), _ptr(gg["dk"]), _ptr(gg["dv"]),
+        self._check(L.l2s_train_prologue_bwd(self._h, _ptr(vis), _ptr(emb), B, T, _ptr(state), _ptr(tape), _ptr(wbuf), _ptr(gg["dk"]), _ptr(gg["dv"]),
                                        _ptr(gg["dckey"]), _ptr(gg["dcval"]), _ptr(gg["dh_init"]), _ptr(gg["de_c"]), _ptr(dd), _ptr(dvis),
                                        _ptr(ws), ws.numel(), _stream()))
         return dvis
@@ -518,14 +565,16 @@ class NativeModel:
         """Average duration of the decoder LSTM-cell kernel, one HIP-event pair around 2*n_pairs chained launches."""
         ws = self.workspace(B, 29, 96, 96, 300, torch.device("cuda", torch.cuda.current_device()))
         out = ctypes.c_double()
-        check(lib().l2s_op_lstm_cell_chain(self._h, B, n_pairs, _ptr(ws), ws.numel(), _stream(), ctypes.byref(out)))
+        D = diag()                          # diagnostic library; the model handle may come from either library
+        check(D.l2s_op_lstm_cell_chain(self._h, B, n_pairs, _ptr(ws), ws.numel(), _stream(), ctypes.byref(out)), D)
         return float(out.value)
 
     def op_frontend(self, video: torch.Tensor) -> torch.Tensor:
         video = _f32(video)
         B, _, T, H, W = video.shape
         out = torch.empty(B * T, H // 4, W // 4, 24, dtype=torch.float32, device=video.device)
-        check(lib().l2s_op_frontend(self._h, _ptr(video), B, T, H, W, _ptr(out), _stream()))
+        D = diag()
+        check(D.l2s_op_frontend(self._h, _ptr(video), B, T, H, W, _ptr(out), _stream()), D)
         return out
 
 
@@ -583,7 +632,7 @@ def op_gemm(A, Wt, scale=None, shift=None, actw=None, act: int = 0, x3: bool = F
     M, K = A.shape
     N = Wt.shape[0]
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    check(lib().l2s_op_gemm_ex(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0) | (8 if x3_dma else 0), _stream()))
+    _dcheck(diag().l2s_op_gemm_ex(_ptr(A), _ptr(Wt), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(C), M, N, K, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0) | (8 if x3_dma else 0), _stream()))
     return C
 
 
@@ -595,20 +644,28 @@ def op_conv1d(X, Wp, scale=None, shift=None, actw=None, taps=1, stride=1, pad=0,
     Cout = Wp.shape[0]
     Tout = (Tin + 2 * pad - taps) // stride + 1
     out = torch.empty(B, Tout, Cout, dtype=torch.float32, device=X.device)
-    check(lib().l2s_op_conv1d_ex(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
+    _dcheck(diag().l2s_op_conv1d_ex(_ptr(X), _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(actw), _ptr(out), B, Tin, Cin, Cout,
                                  taps, stride, pad, act, (1 if x3 else 0) | (2 if bf16 else 0) | (4 if x3_narrow else 0) | (8 if x3_dma else 0), _stream()))
     return out
 
 
 def set_option(name: str, value: int) -> None:
     """Process DEFAULT of a run-time option: copied into models created afterwards (`NativeModel.set_option` changes one model)."""
+    if name in DIAG_OPTIONS:
+        _dcheck(diag().l2s_set_option(name.encode(), int(value)))      # a diagnostic switch: a default of diagnostic-library models only
+        return
     check(lib().l2s_set_option(name.encode(), int(value)))
+    _process_defaults[name] = int(value)
+    if _diag is not None and _diag is not _lib:
+        check(_diag.l2s_set_option(name.encode(), int(value)), _diag)
 
 
 def set_thread_chains(n: int) -> None:
     """Tell the library how many launch chains the caller keeps in flight, for the calling host thread (include/l2s.h l2s_set_thread_chains): with
     two or more the step kernels take half-CU block forms so that chains overlap on the CUs.  A scheduling hint - results are the same bits."""
     check(lib().l2s_set_thread_chains(int(n)))
+    if _diag is not None and _diag is not _lib:      # the hint is thread-local state of each library
+        check(_diag.l2s_set_thread_chains(int(n)), _diag)
 
 
 def persist_available() -> bool:
@@ -642,7 +699,7 @@ def op_conv1d_bwd(dZ, X, Wp, taps=1, stride=1, pad=0, want_dx=True):
     Cout = Wp.shape[0]
     dX = torch.empty_like(X) if want_dx else None
     dW = torch.empty_like(Wp)
-    check(lib().l2s_op_conv1d_bwd(_ptr(dZ), _ptr(X), _ptr(Wp), _ptr(dX), _ptr(dW), B, Tin, Cin, Cout, taps, stride, pad, _stream()))
+    _dcheck(diag().l2s_op_conv1d_bwd(_ptr(dZ), _ptr(X), _ptr(Wp), _ptr(dX), _ptr(dW), B, Tin, Cin, Cout, taps, stride, pad, _stream()))
     return dX, dW
 
 

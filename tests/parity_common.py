@@ -59,10 +59,14 @@ class process_default:
         native.set_option(self.name, self.restore)
 
 
-def fresh_native_model(sd=None, **options):
-    """A NativeModel of its own (not the cached one) with run-time options set BEFORE the weights are packed - options are per model."""
+def fresh_native_model(sd=None, diag=None, **options):
+    """A NativeModel of its own (not the cached one) with run-time options set BEFORE the weights are packed - options are per model.
+    diag: bind the model to the diagnostic build (libl2s_diag.so: the block-form A/B switches of include/l2s_diag.h exist there only);
+    default: exactly when one of `options` is such a switch."""
     sd = synth.synth_state_dict() if sd is None else sd
-    nm = native.NativeModel()
+    if diag is None:
+        diag = any(k in native.DIAG_OPTIONS for k in options)
+    nm = native.NativeModel(native.diag() if diag else None)
     for k, v in options.items():
         nm.set_option(k, v)
     nm.load({k: v.cuda() for k, v in sd.items()}, list(sd.keys()))

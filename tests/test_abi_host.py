@@ -14,19 +14,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def built_lib():
     from lip2speech_amd import native
-    if not os.path.exists(native.LIB_PATH):
+    if not (os.path.exists(native.LIB_PATH) and os.path.exists(native.DIAG_LIB_PATH)):
         subprocess.run(["make", "-C", os.path.join(ROOT, "lip2speech_amd", "csrc"), "-j", "8"], check=True)
     return ctypes.CDLL(native.LIB_PATH)
 
 
+def _declared(header_path):
+    """names declared as functions in a header: `l2s_name(` at the start of a declaration (comments mention other names)"""
+    text = re.sub(r"/\*.*?\*/", "", open(header_path).read(), flags=re.S)
+    return set(re.findall(r"\b(l2s_[a-z_0-9A-Z]+)\s*\(", text))
+
+
 def test_header_symbols_exported(built_lib):
+    """include/l2s.h is the PRODUCT boundary: libl2s_hip.so exports exactly what it declares - what INTEGRATION.md's stub and the package's callers
+    bind - and include/l2s_diag.h the diagnostic surface: libl2s_diag.so exports the product ABI plus exactly those symbols."""
     from lip2speech_amd import native
-    header = open(os.path.join(ROOT, "include", "l2s.h")).read()
-    declared = set(re.findall(r"\b(l2s_[a-z_0-9A-Z]+)\s*\(", header))
+    declared = _declared(os.path.join(ROOT, "include", "l2s.h"))
     assert declared == set(native.ABI_SYMBOLS), declared ^ set(native.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(built_lib, sym), f"{sym} not exported"
     assert built_lib.l2s_abi_version() == 2
+    diag_declared = _declared(os.path.join(ROOT, "include", "l2s_diag.h"))
+    assert diag_declared == set(native.DIAG_SYMBOLS), diag_declared ^ set(native.DIAG_SYMBOLS)
+    for sym in diag_declared:
+        assert not hasattr(built_lib, sym), f"{sym} is a diagnostic entry point: it must not be in the product library"
+    exported = set(re.findall(r" T (l2s_[a-z_0-9A-Z]+)\n", subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout))
+    assert exported == declared, exported ^ declared
+    dlib = ctypes.CDLL(native.DIAG_LIB_PATH)
+    for sym in declared | diag_declared:
+        assert hasattr(dlib, sym), f"libl2s_diag.so lacks {sym}"
+    # the A/B switches of the block forms are diagnostic too: the product library does not know them
+    h = ctypes.c_void_p()
+    assert built_lib.l2s_model_create(ctypes.byref(h)) == 0
+    assert built_lib.l2s_model_set_option(h, b"persist_decode", 0) == 0
+    for name in sorted(native.DIAG_OPTIONS):
+        assert built_lib.l2s_model_set_option(h, name.encode(), 0) != 0, name
+    built_lib.l2s_model_destroy(h)
+    dlib.l2s_model_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    dlib.l2s_model_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    dlib.l2s_model_destroy.argtypes = [ctypes.c_void_p]
+    assert dlib.l2s_model_create(ctypes.byref(h)) == 0
+    for name in sorted(native.DIAG_OPTIONS):
+        assert dlib.l2s_model_set_option(h, name.encode(), 1) == 0, name
+    dlib.l2s_model_destroy(h)
 
 
 def test_sizes_and_errors(built_lib):

@@ -429,21 +429,18 @@ def test_postnet_weight_planes_by_dma_same_bits(synth_sd, nm, B, S):
     an odd number of K steps and K = 2560), and after a device-side weight refresh (the planes are re-derived with the other derived weights)."""
     torch.manual_seed(3)
     mel = torch.randn(B, S, 80, device="cuda")
-    off = pc.fresh_native_model(synth_sd, gemm_x3_dma=0)
+    off = pc.fresh_native_model(synth_sd, gemm_x3_dma=0)   # a diagnostic switch: this model runs in libl2s_diag.so (same sources as the product library)
     a, _ = nm.postnet(mel)
     b, _ = off.postnet(mel)
     assert torch.isfinite(a).all() and torch.equal(a, b)
-    nm.set_option("gemm_x3_dma", 0)                       # the switch is read at launch time
-    try:
-        c, _ = nm.postnet(mel)
-    finally:
-        nm.set_option("gemm_x3_dma", 1)
+    off.set_option("gemm_x3_dma", 1)                      # the switch is read at launch time
+    c, _ = off.postnet(mel)
     assert torch.equal(a, c)
     if B == 32:
         # bound weights changed in place, then the device-side refresh: both forms must follow the new weights (stale planes would keep the old output)
         outs = []
         for v_ in (1, 0):
-            m_ = native.NativeModel()
+            m_ = native.NativeModel(native.diag())
             m_.set_option("refresh_map", 1); m_.set_option("gemm_x3_dma", v_)
             m_.load({k: v.cuda() for k, v in synth_sd.items()}, list(synth_sd.keys()))
             params = {k: v.cuda().clone() for k, v in synth_sd.items() if v.is_floating_point()}
@@ -474,6 +471,8 @@ def test_options_are_per_model(synth_sd, nm):
         native.set_option("fold_step_weights", 1)
     with pytest.raises(RuntimeError):
         a.set_option("no_such_option", 1)
+    with pytest.raises(RuntimeError):
+        a.set_option("skinny_rc", 11)          # a block-form A/B switch: the diagnostic build's (include/l2s_diag.h), unknown to the product library
 
 
 def test_full_size_matches_reference_golden(nm):
@@ -698,6 +697,7 @@ def test_caller_loops_voice_route(synth_sd):
     one = test_collate_fn_pad([items[0] + (("face.npz", "audio.npz"),)])
     two = test_collate_fn_pad([items[1] + (("face.npz", "audio.npz"),)])
     mel, lengths, attn = callers.demo_clip(net, one, speaker_encoder=spk)
+    assert net.native_model().calls["l2s_inference"] == 1      # one clip: the direct call (the library's latency form where the device allows it)
     assert mel.shape[0] == 1 and mel.shape[1] == 80 and mel.shape[2] == int(lengths[0]) and attn.shape[2] == 29
     # the loader-driven form runs on the GROUPED path (three clips = one l2s_inference_multi chain) and returns the clips in order
     nm = net.native_model()
@@ -791,7 +791,7 @@ def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
     # cannot sum u = prenet + o in the loader, so LSTM layer 0 runs on [content | prenet | o | h0] (hoist_vproj = 1: another, equally valid, order of
     # additions): every form is compared on THAT layout - bit for bit among themselves - and the default layout against the single-batch calls above
     # first the split-bf16 LSTM blocks (default, "lstm_x3" = 2: eight waves) in every block shape, and their four-wave form: same bits as the default
-    xown = pc.fresh_native_model(synth_sd)
+    xown = pc.fresh_native_model(synth_sd, diag=True)
     for x3 in (2, 1):
         xown.set_option("lstm_x3", x3)
         for shape in (0, 11, 21, 22, 42):
@@ -800,7 +800,7 @@ def test_grouped_inference_is_bit_identical_per_batch(synth_sd, G, B):
             for a, w in zip(alt, want):
                 assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[2], w[2]), (x3, shape)
     # the f32 block forms among themselves ("lstm_x3" = 0)
-    own = pc.fresh_native_model(synth_sd)
+    own = pc.fresh_native_model(synth_sd, diag=True)
     own.set_option("lstm_x3", 0)
     own.set_option("hoist_vproj", 1)
     want = [tuple(t.clone() for t in own.inference(*b, S=S, want_attn=True)) for b in batches]

@@ -21,6 +21,7 @@ RUNS = {
     "hash_inference.py": ([], {}),
     "hash_train_step.py": ([], {}),
     "kernel_resources.py": ([os.path.join(ROOT, "lip2speech_amd", "csrc", "decoder_kernels.hip")], {}),
+    "overlap_stamps.py": (["1"], {"PAIRS": "10", "S": "10", "CHAINS": "2"}),
     "pdecode_timeline.py": ([], {"B": "2", "S": "20"}),
     "pmc_dense.py": ([], {"ROWS": "32"}),
     "prof_decode.py": ([], {"ROWS": "32", "REPS": "1"}),
@@ -41,7 +42,7 @@ SYNTAX_ONLY = ["pmc_decode_json.py", "pmc_read.py", "rocprof_concurrency.py", "r
 
 def test_tools_inventory_is_what_the_readme_lists():
     have = sorted(f for f in os.listdir(TOOLS) if f.endswith((".py", ".sh")))
-    want = sorted(list(RUNS) + SYNTAX_ONLY + ["ab_bench.sh", "attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r5.sh", "profile_r5_chains.sh"])
+    want = sorted(list(RUNS) + SYNTAX_ONLY + ["ab_bench.sh", "attn_l2_sweep.sh", "gpurun_retry.sh", "pmc_dense_kernels.sh", "pmc_step_kernels.sh", "profile_r5.sh", "profile_r5_chains.sh", "profile_r6.sh"])
     assert have == want, (set(have) ^ set(want))
     readme = open(os.path.join(TOOLS, "README.md")).read()
     for f in have + ["membw/membw.hip", "persist/persist_probe.hip"]:

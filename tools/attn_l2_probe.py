@@ -4,6 +4,7 @@
 (3.7-4.1 MB per XCD) is the L2's size, at 128 / 64 rows it is a half / a quarter of it.
 -> profiles/rNN_attn_l2_probe.txt"""
 import os, sys, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()

@@ -4,6 +4,7 @@ attention block stamps the 100 MHz wall clock at entry / requests issued / q vis
 ROWS env (default 256): clips per launch; the launch runs alone, 40 times back to back, the last one's stamps are read.
 -> profiles/rNN_attn_timeline.txt"""
 import os, sys, torch, numpy as np
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()

@@ -8,6 +8,7 @@ Reported: wall time from a common start to the last chain's end / (launches or s
 that divided by n = what the chip spends per launch / step.  One model, one host thread and one HIP stream per chain.
 Usage: python tools/coresident_probe.py [G]   -> profiles/r05_coresident_probe.txt"""
 import os, sys, threading, time
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -4,6 +4,7 @@ per-group block shapes) from its stamped build (`l2s_op_flat_timeline`): thread 
 a few steps runs; the last first-phase launch leaves its stamps.
 -> profiles/rNN_flat_timeline.txt"""
 import os, sys, torch, numpy as np
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()

@@ -3,6 +3,7 @@
 that stage leaves its stamps.
 -> profiles/rNN_fused_unit_timeline_256clips.txt (B=256)"""
 import os, sys, torch, numpy as np
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = {k: v for k, v in synth.synth_state_dict().items() if k.startswith("encoder.")}

@@ -3,6 +3,7 @@ stamps the shader clock per K tile - consumers (waves 0-3): tile start / first 2
 tile start / older register set landed / split + LDS writes done / past the barrier.  Usage: python tools/gemm_x3_timeline.py [M N K] [block]
 -> profiles/rNN_gemm_x3_timeline.txt (`dma`: rNN_gemm_x3_timeline_dma.txt)"""
 import os, sys
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from lip2speech_amd import native

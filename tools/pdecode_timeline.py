@@ -3,6 +3,7 @@
 (STEP env, default 150) of an l2s_decode_steps call on B clips (B env, default 1; T=29, S=300).
 -> profiles/r04_pdecode_timeline.txt"""
 import os, sys, torch, numpy as np
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 B = int(os.environ.get("B", 1)); step = int(os.environ.get("STEP", 150)); S = int(os.environ.get("S", 300)); T = 29

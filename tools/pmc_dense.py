@@ -2,6 +2,7 @@
 rocprofv3 --pmc / --kernel-trace passes (tools/pmc_dense_kernels.sh).
 -> profiles/rNN_pmc_dense_kernels.txt (through tools/pmc_dense_kernels.sh)"""
 import os, sys, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 ROWS = int(os.environ.get("ROWS", 256))

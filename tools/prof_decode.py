@@ -3,6 +3,7 @@
 rocprofv3 counter passes.
 -> profiles/rNN_kernel_stats_decode256.md, rNN_pmc_decode.json (through tools/profile_r5.sh)"""
 import os, sys, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lip2speech_amd import native, synth

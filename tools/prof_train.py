@@ -1,6 +1,7 @@
 """Per-kernel-name GPU time of one train()-mode training step (B=8, T=29, S=77).
 -> profiles/rNN_train_kernels.txt"""
 import os, sys, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 from lip2speech_amd.training import model_forward_backward, draw_dropout

@@ -2,6 +2,7 @@
 """Phase timeline of the decoder LSTM-cell kernel: the stamped build of skinny_kernel inside a chain of dependent launches.
 -> profiles/rNN_lstm_timeline_x3.txt (X3=2), rNN_lstm_timeline_4wave.txt (X3=1)"""
 import os, sys, torch, numpy as np
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()

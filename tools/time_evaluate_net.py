@@ -3,6 +3,7 @@ targets): wall seconds waiting for the model (grouped HIP path, chains in flight
 + Griffin-Lim, 256 iterations each, torch ops on the device) and in ESTOI on the host (numpy) - VERDICT r2 item 9: time f4 before building it.
 Writes the stage table to stdout (commit under profiles/)."""
 import os
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 import sys
 import time
 

@@ -2,6 +2,7 @@
 f32 MFMA path (0), time per batch and difference.
 -> profiles/rNN_frontend_forms.txt"""
 import os, sys, time, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 sd = synth.synth_state_dict()

@@ -3,6 +3,7 @@
 NT chains in flight, with the HIP-event per-kernel breakdown of one pass (tools: G env = comma list, NT env = chains in flight).
 -> profiles/rNN_group8_breakdown.txt (G=8 NT=2)"""
 import os, sys, time, threading
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -4,6 +4,7 @@ weight-stationary loop (option "persist_decode", pdecode.hip), whole call and de
 deviation between the two paths.  ROWS env: comma list of B (default 1,2); REPS env: calls per median (default 7).
 -> profiles/r04_latency_path.txt"""
 import os, sys, time, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth
 rows = [int(x) for x in os.environ.get("ROWS", "1,2").split(",")]

@@ -2,6 +2,7 @@
 A/B over a run-time option.  Usage: python tools/time_step_phases.py [G] [option=value ...]   (each option is toggled against the default)
 -> profiles/rNN_step_phases.txt"""
 import os, sys
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lip2speech_amd import native, synth

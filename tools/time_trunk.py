@@ -3,6 +3,7 @@
 against the reference golden, and the encoder's per-kernel-name times at B clips (B env, default 256; HIP-event brackets of l2s_prof).
 -> profiles/rNN_trunk_x3.txt"""
 import os, sys, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from lip2speech_amd import native, synth

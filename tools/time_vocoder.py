@@ -1,6 +1,7 @@
 """Per-kernel time of the device vocoder + metric (vocoder.hip) at evaluate.py's sizes: N clips of L = 77 mel frames, 256 + 256 iterations,
 HIP events around each entry point; next to the torch-op restatement of the same algorithms.  -> profiles/r04_vocoder_kernels.txt"""
 import os
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 import sys
 import time
 

@@ -2,6 +2,7 @@
 native entry point of lip2speech_amd.training.model_forward_backward, averaged over N steps.
 -> profiles/rNN_train_stages.txt"""
 import os, sys, collections, torch
+os.environ.setdefault("L2S_LIB", "diag")      # tools run on the diagnostic build (libl2s_diag.so: product ABI + include/l2s_diag.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lip2speech_amd import native, synth, training
 B, T, S = int(os.environ.get("B", 8)), 29, 77
