@@ -23,8 +23,9 @@ use four chains).
 
 The JSON line also carries
   roofline     for the kernel with the largest share of GPU time (HIP events per launch in a separate profiled pass, l2s_profile_*),
-               against its algorithmic FLOPs / bytes: `frac` from what the chip spends per launch with the chains of the timed
-               region in flight, `frac_one_chain` from the duration of a launch that has the chip to itself;
+               `frac` = the FLOPs one launch executes / the duration of ONE launch alone on its stream (one event pair around a chain of
+               launches, in the block form the timed region launches) / the ceiling of the pipe it runs on; `frac_overlapped` beside it =
+               what the chip spends per launch with the timed region's chains in flight; `traffic` from the committed PMC passes;
   cpu_baseline the CPU oracle (oracle/l2s_oracle.py, "port" of the reference math, verified against the imported
                reference) timed on this host's cores on the same workload (rank 0, N=1 only).
 """
@@ -535,14 +536,23 @@ def main():
         roof = {"kernel": name, "rows_per_launch": rows, "launches_per_group_pass": launches // 2, "share_of_gpu_time": total_ms / gpu_ms,
                 "avg_us_event_per_launch": avg_s * 1e6}
         if name == "step_lstm_cell":
-            # per-launch event brackets inflate a us-scale kernel by ~1.8 us; time the same launches as one chain between ONE event pair
-            avg_s = nm.lstm_cell_chain_us(rows, 300) * 1e-6
-            roof["timing"] = "one HIP-event pair around a chain of 600 launches (300 x {layer 0, layer 1}) on the launch stream"
+            # per-launch event brackets inflate a us-scale kernel by ~1.8 us; time the same launches as one chain between ONE event pair on the
+            # launch stream (l2s_op_lstm_cell_chain of the diagnostic build libl2s_diag.so: the product's kernel sources, same launch code).
+            # The block form is the one the timed region launches: with NI >= 2 chains in flight the half-CU form (skinny_rc4h), else the eight-wave one.
+            native.set_thread_chains(NI)
+            try:
+                avg_s = nm.lstm_cell_chain_us(rows, 300) * 1e-6
+            finally:
+                native.set_thread_chains(1)
+            roof["timing"] = ("one HIP-event pair around a chain of 616 launches (308 x {layer 0, layer 1}; 16 warm-up) ALONE on the launch stream, in the block form "
+                              "the timed region launches (half-CU blocks when chains overlap): the duration rocprofv3 reports for the kernel")
+            roof["block_form"] = "skinny_rc4h_kernel<4,2,{6,2},3> (four waves, half a compute unit)" if NI >= 2 else "skinny_rc8x_kernel<4,2,{6,2},4> (eight waves)"
         roof["avg_us"] = avg_s * 1e6
-        one_chain_s = avg_s
+        overlapped_s = None
         if name == "step_lstm_cell" and NI > 1:
-            # The timed region keeps NI launch chains in flight and the step kernels' blocks take half a compute unit, so LSTM launches of different
-            # chains run side by side on the CUs: what the chip spends per launch is the wall time of NI such chains at once / (NI x launches).
+            # Secondary figure: the timed region keeps NI launch chains in flight and the step kernels' blocks take half a compute unit, so LSTM launches
+            # of different chains run side by side on the CUs: what the chip spends per launch is the wall time of NI such chains at once / (NI x launches)
+            # (the in-kernel block-stamp log confirms the overlap without the host's clock: profiles/r06_overlap_stamps.txt)
             import threading
             def chains_at_once(n_pairs=300):
                 bar = threading.Barrier(NI + 1)
@@ -561,51 +571,49 @@ def main():
                 for t_ in th: t_.join()
                 return (time.perf_counter() - t0_) / (NI * (2 * n_pairs + 16))      # the chain op runs 8 warm-up pairs first
             chains_at_once(50)
-            avg_s = min(chains_at_once() for _ in range(3))
-            roof["avg_us_one_chain"] = one_chain_s * 1e6
-            roof["avg_us"] = avg_s * 1e6
-            roof["chains_at_once"] = NI
-            roof["timing"] = (f"wall time of {NI} chains of 616 launches (layer 0 / layer 1 alternating) at once on the pool's {NI} streams / ({NI} x 616): what the "
-                              "chip spends per launch with the chains the timed region keeps in flight; avg_us_one_chain = one HIP-event pair around one "
-                              "such chain alone on its stream (what rocprofv3 reports as the kernel's duration)")
+            overlapped_s = min(chains_at_once() for _ in range(3))
         model = kernel_model(name, rows)
         if model:
             flops, nbytes = model
+            ex = executed_flops(name, rows)
+            if ex:                       # the roofline is priced on what the launch EXECUTES (the algorithmic count credits work hoisted out of the loop)
+                roof["algorithmic_flops_survey"] = flops
+                flops = ex
             ai = flops / nbytes
             if ai < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
                 ach = nbytes / avg_s / 1e9
                 roof.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
             else:
                 roof.update(mfma_roof(name, flops, avg_s))
-            roof["algorithmic_flops"] = flops
+            roof["executed_flops"] = flops
             roof["algorithmic_bytes"] = nbytes
             roof["arithmetic_intensity"] = ai
-            if one_chain_s != avg_s and roof["bound"] == "mfma":
-                roof["frac_one_chain"] = roof["frac"] * avg_s / one_chain_s
-            ex = executed_flops(name, rows)
-            if ex and roof["bound"] == "mfma":
-                roof["executed_flops"] = ex
-                roof["note"] = ("frac = ALGORITHMIC FLOPs (SURVEY.md section 8(d): two K=1024 LSTM layers + the 512x256 attention_proj, which the value "
-                                "projection hoisted into the prologue no longer executes per step) / measured duration / the ceiling of the pipe the "
-                                "kernel runs on (bf16 matrix cores, six products per fp32 product: 416.7 TFLOP/s fp32-equivalent); frac_fp32_equiv is the "
-                                "same rate against the fp32 matrix peak of 157.3 TFLOP/s (the data's dtype; rounds 1-3 quoted that one); frac_one_chain: "
-                                "against the duration of a launch that has the chip to itself (rounds 1-4 quoted that one: 0.238 in round 4) - since round 5 "
-                                "the blocks of the step kernels take half a compute unit and launches of different chains overlap, so a launch's own "
-                                "duration no longer is what the chip spends on it")
-        # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) are collected
-        # OFFLINE (tools/prof_decode.py, one counter group per pass) and committed under profiles/: not measured in this run
+            if overlapped_s and roof["bound"] == "mfma":
+                roof["chains_at_once"] = NI
+                roof["avg_us_overlapped"] = overlapped_s * 1e6
+                roof["frac_overlapped"] = roof["frac"] * avg_s / overlapped_s
+            if roof["bound"] == "mfma":
+                roof["note"] = ("frac = EXECUTED FLOPs of one launch (256 rows x 2048 gate rows x K = 1024, x2) / the duration of ONE launch alone on its stream / the "
+                                "ceiling of the pipe the kernel runs on (bf16 matrix cores, six products per fp32 product: 416.7 TFLOP/s fp32-equivalent) - the "
+                                "definition of rounds 1-4 (0.238 in round 4), frozen; frac_fp32_equiv: the same rate against the fp32 matrix peak of 157.3 TFLOP/s; "
+                                "frac_overlapped / avg_us_overlapped: wall time of the chains the timed region keeps in flight / all their launches - what the chip "
+                                "spends per launch when launches of different chains share the CUs (a utilisation figure, not a kernel duration)")
+        # bytes per launch at the L2's memory side from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected OFFLINE on the
+        # block forms of the timed region with its chains in flight (tools/profile_r6.sh, one counter group per pass) and committed under profiles/
         roof["traffic"] = None
         try:
-            pmc_file = next(f for f in ("r05_pmc_decode.json", "r04_pmc_decode.json", "r03_pmc_decode.json", "r02_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r06_pmc_decode_half3.json", "r05_pmc_decode.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k = pmc["kernels"].get(name)
             if k and pmc.get("rows_per_launch") == rows:
                 roof["traffic"] = k["traffic_bytes_per_launch"]
-                roof["traffic_source"] = f"offline: profiles/{pmc_file} (rocprofv3 --pmc, same kernel and rows per launch), not measured in this run"
+                roof["traffic_kernel_symbols"] = k.get("kernel_symbols")
+                roof["traffic_source"] = f"offline: profiles/{pmc_file} (rocprofv3 --pmc on the symbols listed, {rows} rows per launch), not measured in this run"
+                roof["traffic_over_algorithmic_bytes"] = k["traffic_bytes_per_launch"] / roof["algorithmic_bytes"] if roof.get("algorithmic_bytes") else None
                 roof["l2_hit_rate_offline"] = k.get("l2_hit_rate")
-                if k.get("avg_us_rocprofv3"):
-                    roof["avg_us_rocprofv3_offline"] = k["avg_us_rocprofv3"]
-                    roof["frac_at_rocprofv3_duration"] = roof["frac"] * roof["avg_us"] / k["avg_us_rocprofv3"]      # one chain under the profiler: compare with frac_one_chain
+                for key in ("avg_us_rocprofv3_one_chain", "avg_us_rocprofv3"):
+                    if k.get(key):
+                        roof[key + "_offline"] = k[key]
         except (OSError, KeyError, ValueError, StopIteration):
             pass
         # the other kernels with a closed-form cost model, same pass (per-launch HIP-event brackets: us-scale kernels carry ~1.8 us of it)
@@ -637,7 +645,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LRW single-word, batch=32 per step, 29x96x96 RGB mouth crops, S=300 decode steps, speaker embedding "
                                    "supplied (encoding=voice), random-init weights; every step is one full pass over one B=32 batch",
-                       "batch_per_step": B, "frames": T, "decode_steps": S, "options": list(args.opt), "parallelism": f"dp{world} (clip sharding, no collective)",
+                       "batch_per_step": B, "frames": T, "decode_steps": S, "options": list(args.opt), "library": os.path.basename(native.LIB_PATH), "parallelism": f"dp{world} (clip sharding, no collective)",
                        "batches_per_launch_chain": G, "launch_chains_in_flight_per_gpu": NI, "distinct_batches_per_gpu": n_distinct,
                        "collective_backend": backend, "ranks": world},
             "warmup_extra_steps_until_steady": extra,

@@ -1173,11 +1173,15 @@ int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s) {
 // out[m][n] = relu((A[m][:] . W[n][:]) * scale[n] + shift[n]) for all 16-row tiles of the block: A from the three bf16 planes at `pl` (rows of PITCH
 // bytes, planes PLANE bytes apart), the result as fp32 rows of LDA floats at the SAME address (accumulators held across the barrier).  Work items as
 // su_gemm.  A column tile's weight chunks are requested BD at a time (all of them up to K = 128; three in flight beyond).
-template <class GM, int NCH, int PITCH, int PLANE, int LDA>
+// OPQ: the thread index through an opaque copy - inside a loop over units (shuffle_s1xc_kernel) the operand addresses are loop-invariant, and hoisted out
+// of the loop they would stay in registers across every phase of every unit (spills at the 128-register budget of two blocks per CU)
+template <class GM, int NCH, int PITCH, int PLANE, int LDA, bool OPQ = false>
 __device__ __forceinline__ void su_gemm_x3(unsigned char* __restrict__ pl, const uint4* __restrict__ Wp,
                                            const float* __restrict__ scale, const float* __restrict__ shift, int mrows = 1 << 30) {
     constexpr int G = GM::G, IT = GM::IT, NT = GM::NT, BD = NCH <= 4 ? NCH : 3;      // (two chunks in flight at K = 128: 3 % slower)
-    const int lane = threadIdx.x & 63;
+    int tx = threadIdx.x;
+    if constexpr (OPQ) asm volatile("" : "+v"(tx));
+    const int lane = tx & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lg = lane >> 4;
     float* const buf = reinterpret_cast<float*>(pl);
@@ -1446,6 +1450,283 @@ static int launch_s1x_inst(const ShuffleS1P& p, hipStream_t s) {
     else
 #endif
     hipLaunchKernelGGL((shuffle_s1x_kernel<H, HALF, F, false>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p, (unsigned long long*)nullptr);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ a whole stage's stride-1 units in ONE launch
+// The stride-1 units of a stage (3 at 12x12, 7 at 6x6, 3 at 3x3; shufflenetv2.py:135-148) all work on the same map, and a block of the fused unit
+// already holds its frames' whole map on chip - the passthrough half in registers, the branch half in LDS.  One launch per unit still wrote that map
+// to HBM and read it back, unit after unit (each unit: the map in + the map out, 0.7-0.9 of the launch at ~5 TB/s).  Here a block walks ALL the units
+// of its stage: between two units the output channel order out[2k] = x1[k], out[2k+1] = branch[k] (channel_shuffle) is re-cut into the next unit's
+// halves ON CHIP - a lane holds out[4q .. 4q+3] of its pixel (its passthrough pair and the branch pair it reads back from LDS); the channels below
+// HALF are the next passthrough half: lane q' takes its pair from lane q' >> 1 of the same wave instruction (ds_bpermute, no LDS round trip); the
+// channels from HALF on are the next branch input: split and stored as operand planes where the fp32 branch map was.  Same regions, same registers
+// as one unit; per pixel the arithmetic of the single-unit kernel, operation for operation: same bits.  Only the units' weights stream.
+struct S1UnitW {
+    const void* w1p; const float* s1; const float* b1;      // pw1 operand planes, BN scale / shift
+    const float* wd; const float* sd; const float* bd;      // depthwise [9][half], BN scale / shift
+    const void* w2p; const float* s2; const float* b2;      // pw2
+};
+struct ShuffleS1ChainP {
+    const float* x; float* out;                              // (NF, h, h, 2*half) channel-last: input of the first unit, output of the last
+    int NF, n;
+    S1UnitW u[S1_CHAIN_MAX];
+};
+
+template <int H, int HALF, int F>
+__global__ __launch_bounds__(512, 4) void shuffle_s1xc_kernel(const ShuffleS1ChainP p) {
+    using Q = S1XGeo<H, HALF, F>;
+    constexpr int HH = Q::HH, C = Q::C, LDA = Q::LDA, PPW = Q::PPW, QIT = Q::QIT, PPI = Q::PPI, PITCH = Q::PITCH, PLANE = Q::PLANE;
+    static_assert(HALF % 2 == 0 && (Q::KPAIR - Q::NPAIR) <= 32, "a lane's four output channels are two whole pairs; the K padding is at most 32 pairs");
+    extern __shared__ __attribute__((aligned(16))) float su_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = blockIdx.x * F;
+    const int Mv = min(F, p.NF - f0) * HH;                // valid pixel rows of this block
+    float* buf = su_smem;
+    unsigned char* const pl = reinterpret_cast<unsigned char*>(su_smem);
+    const float* xb = p.x + (int64_t)f0 * HH * C;
+    float* ob = p.out + (int64_t)f0 * HH * C;
+    const int nu = p.n;
+
+    // phase 0 (once): the block's whole input, as in shuffle_s1x_kernel
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, Mv * C * 4, 0x00020000);
+    const int sub = PPI == 2 ? lane >> 5 : 0;
+    typedef unsigned su_u2 __attribute__((ext_vector_type(2)));
+    float2 xr[PPW][QIT];
+    {
+        su_u2 br[PPW][QIT];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int soff = (wave + 8 * i) * PPI * C * 4;
+#pragma unroll
+            for (int j = 0; j < QIT; ++j) {
+                const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+                const int voff = q < Q::NPAIR ? (sub * C + 2 * q) * 4 : 0x7ffffff0;      // past the end: reads 0
+                const su_u2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+                br[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, q < Q::NPAIR ? voff + HALF * 4 : 0x7ffffff0, soff, 0);
+                xr[i][j] = make_float2(__uint_as_float(a.x), __uint_as_float(a.y));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int m = (wave + 8 * i) * PPI + sub;
+#pragma unroll
+            for (int j = 0; j < QIT; ++j) {
+                const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+                unsigned hi, mid, lo;
+                su_split2(__uint_as_float(br[i][j].x), __uint_as_float(br[i][j].y), hi, mid, lo);
+                if (m < Q::ROWS) {
+                    unsigned* d = reinterpret_cast<unsigned*>(pl + m * PITCH + q * 4);
+                    d[0] = hi; d[PLANE / 4] = mid; d[2 * (PLANE / 4)] = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int u = 0; u < nu; ++u) {
+        const S1UnitW& U = p.u[u];
+        const void* const w1p = U.w1p; const float* const s1 = U.s1; const float* const b1 = U.b1;
+        const float* const wd = U.wd; const float* const sdp = U.sd; const float* const bdp = U.bd;
+        const void* const w2p = U.w2p; const float* const s2 = U.s2; const float* const b2 = U.b2;
+        // phase 1: pw1 + BN + ReLU: planes -> fp32 map
+        su_gemm_x3<typename Q::GM, Q::NCH, PITCH, PLANE, LDA, true>(pl, reinterpret_cast<const uint4*>(w1p), s1, b1);
+        // phase 2: depthwise 3x3 (pad 1) + BN over the fp32 map (the sliding window of shuffle_s1x_kernel); its outputs go back as planes
+        {
+            constexpr bool PAIRS = HALF > 64;
+            constexpr int NROW = F * H, RPW = (NROW + 7) / 8;
+            typedef float su_f2 __attribute__((ext_vector_type(2)));
+            using DV = std::conditional_t<PAIRS, su_f2, float>;
+            constexpr int DW = PAIRS ? 2 : 1;                         // channels per lane
+            constexpr int CHD = Q::KP32 / (64 * DW);                  // channel passes (over the padded width: the pad lanes write zeros)
+            DV dv[CHD][RPW][H];
+            const DV zero = DV{};
+            int lane_d = lane;
+            asm volatile("" : "+v"(lane_d));                  // (addresses of this phase must not be hoisted out of the unit loop: registers)
+#pragma unroll
+            for (int jc = 0; jc < CHD; ++jc) {
+                const int c = min(DW * lane_d + 64 * DW * jc, HALF - DW);
+                DV wk[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const DV*>(wd + t * HALF + c);
+                const DV sd = *reinterpret_cast<const DV*>(sdp + c), bd = *reinterpret_cast<const DV*>(bdp + c);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int R = wave + 8 * r;                       // wave-uniform
+                    if (R * H < Mv) {
+                        const int y = R % H;
+                        const bool up = y > 0, dn = y < H - 1;
+                        const float* rm = buf + (R * H) * LDA + c;
+                        const float* ru = rm - (up ? H * LDA : 0);
+                        const float* rd = rm + (dn ? H * LDA : 0);
+                        DV wu[3], wdn[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { wu[k] = up ? wk[k] : zero; wdn[k] = dn ? wk[6 + k] : zero; }
+                        DV a0 = zero, a1 = zero, a2 = zero;
+                        DV b0 = *reinterpret_cast<const DV*>(ru), b1v = *reinterpret_cast<const DV*>(rm), b2v = *reinterpret_cast<const DV*>(rd);
+                        DV c0 = zero, c1 = zero, c2 = zero;
+                        if constexpr (H > 1) { c0 = *reinterpret_cast<const DV*>(ru + LDA); c1 = *reinterpret_cast<const DV*>(rm + LDA); c2 = *reinterpret_cast<const DV*>(rd + LDA); }
+#pragma unroll
+                        for (int x = 0; x < H; ++x) {
+                            DV acc = zero;
+                            if (x > 0) acc = __builtin_elementwise_fma(a0, wu[0], acc);
+                            acc = __builtin_elementwise_fma(b0, wu[1], acc);
+                            if (x < H - 1) acc = __builtin_elementwise_fma(c0, wu[2], acc);
+                            if (x > 0) acc = __builtin_elementwise_fma(a1, wk[3], acc);
+                            acc = __builtin_elementwise_fma(b1v, wk[4], acc);
+                            if (x < H - 1) acc = __builtin_elementwise_fma(c1, wk[5], acc);
+                            if (x > 0) acc = __builtin_elementwise_fma(a2, wdn[0], acc);
+                            acc = __builtin_elementwise_fma(b2v, wdn[1], acc);
+                            if (x < H - 1) acc = __builtin_elementwise_fma(c2, wdn[2], acc);
+                            dv[jc][r][x] = acc * sd + bd;
+                            a0 = b0; a1 = b1v; a2 = b2v; b0 = c0; b1v = c1; b2v = c2;
+                            if (x + 2 < H) {
+                                c0 = *reinterpret_cast<const DV*>(ru + (x + 2) * LDA); c1 = *reinterpret_cast<const DV*>(rm + (x + 2) * LDA);
+                                c2 = *reinterpret_cast<const DV*>(rd + (x + 2) * LDA);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jc = 0; jc < CHD; ++jc) {
+                const int c = DW * lane_d + 64 * DW * jc;         // < KP32: every lane writes (zeros in the K padding)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int R = wave + 8 * r;
+                    if (R * H < Mv) {
+#pragma unroll
+                        for (int x = 0; x < H; ++x) {
+                            unsigned char* d = pl + (R * H + x) * PITCH + c * 2;
+                            if constexpr (PAIRS) {
+                                unsigned hi, mid, lo;
+                                su_split2(c < HALF ? dv[jc][r][x][0] : 0.f, c < HALF ? dv[jc][r][x][1] : 0.f, hi, mid, lo);
+                                *reinterpret_cast<unsigned*>(d) = hi; *reinterpret_cast<unsigned*>(d + PLANE) = mid; *reinterpret_cast<unsigned*>(d + 2 * PLANE) = lo;
+                            } else {
+                                const float v = c < HALF ? dv[jc][r][x] : 0.f;
+                                const float r1 = v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+                                const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                                *reinterpret_cast<unsigned short*>(d) = (unsigned short)(__float_as_uint(v) >> 16);
+                                *reinterpret_cast<unsigned short*>(d + PLANE) = (unsigned short)(__float_as_uint(r1) >> 16);
+                                *reinterpret_cast<unsigned short*>(d + 2 * PLANE) = (unsigned short)(__float_as_uint(r2) >> 16);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // phase 3: pw2 + BN + ReLU: planes -> fp32 map
+        su_gemm_x3<typename Q::GM, Q::NCH, PITCH, PLANE, LDA, true>(pl, reinterpret_cast<const uint4*>(w2p), s2, b2);
+        // phase 4: channel_shuffle: out[2k] = x1[k] (register), out[2k+1] = branch[k] (LDS): a lane's pair q gives out[4q .. 4q+3] of its pixel
+        if (u + 1 == nu) {                                    // last unit: the map leaves the chip, 16 bytes per lane
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int m = (wave + 8 * i) * PPI + sub;
+#pragma unroll
+                for (int j = 0; j < QIT; ++j) {
+                    const int q = PPI == 2 ? (lane & 31) : lane + 64 * j;
+                    if (m < Mv && q < Q::NPAIR) {
+                        const float2 bv = *reinterpret_cast<const float2*>(buf + m * LDA + 2 * q);
+                        *reinterpret_cast<float4*>(ob + (int64_t)m * C + 4 * q) = make_float4(xr[i][j].x, bv.x, xr[i][j].y, bv.y);
+                    }
+                }
+            }
+        } else {                                              // re-cut into the next unit's halves on chip
+            // (index arithmetic from an opaque copy of the lane id: hoisted out of the unit loop it would hold ~40 address registers across every phase)
+            int lane_v = lane;
+            asm volatile("" : "+v"(lane_v));
+            const int sub_v = PPI == 2 ? lane_v >> 5 : 0;
+            float2 bv[PPW][QIT];                              // this lane's branch pair: with its passthrough pair, out[4q .. 4q+3] = (x1.x, br.x, x1.y, br.y)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int m = (wave + 8 * i) * PPI + sub_v;
+#pragma unroll
+                for (int j = 0; j < QIT; ++j) {
+                    const int q = PPI == 2 ? (lane_v & 31) : lane_v + 64 * j;
+                    bv[i][j] = make_float2(0.f, 0.f);
+                    if (m < Q::ROWS && q < Q::NPAIR) bv[i][j] = *reinterpret_cast<const float2*>(buf + m * LDA + 2 * q);
+                }
+            }
+            __syncthreads();                                  // every lane has read its branch pair: the fp32 map may be overwritten by planes
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int m = (wave + 8 * i) * PPI + sub_v;
+#pragma unroll
+                for (int j = 0; j < QIT; ++j) {
+                    const int q = PPI == 2 ? (lane_v & 31) : lane_v + 64 * j;
+                    // channels >= HALF: the next branch input, k = c - HALF (even: a lane's two pairs never straddle HALF)
+                    if (m < Q::ROWS && q < Q::NPAIR) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int c = 4 * q + 2 * e;
+                            if (c >= HALF) {
+                                unsigned hi, mid, lo;
+                                su_split2(e ? xr[i][j].y : xr[i][j].x, e ? bv[i][j].y : bv[i][j].x, hi, mid, lo);
+                                unsigned* d = reinterpret_cast<unsigned*>(pl + m * PITCH + (c - HALF) * 2);
+                                d[0] = hi; d[PLANE / 4] = mid; d[2 * (PLANE / 4)] = lo;
+                            }
+                        }
+                    }
+                    // the K padding of the planes (pairs NPAIR .. KPAIR-1) was overwritten by the fp32 map: zeros again, by the first lanes of the row
+                    if (j == 0 && m < Q::ROWS && q < Q::KPAIR - Q::NPAIR) {
+                        unsigned* d = reinterpret_cast<unsigned*>(pl + m * PITCH + (Q::NPAIR + q) * 4);
+                        d[0] = 0u; d[PLANE / 4] = 0u; d[2 * (PLANE / 4)] = 0u;
+                    }
+                }
+                // channels < HALF: the next passthrough half: pair q of a lane = out[2q], out[2q+1] = one (x1, branch) column of lane q >> 1, register j = 0
+                float2 nx[QIT];
+#pragma unroll
+                for (int j = 0; j < QIT; ++j) {
+                    const int q = PPI == 2 ? (lane_v & 31) : lane_v + 64 * j;
+                    const int srcq = q >> 1;
+                    const int src = PPI == 2 ? ((lane_v & 32) | srcq) : srcq;       // < 64: the passthrough half comes from the first HALF / 4 lanes
+                    const float ex = __shfl(xr[i][0].x, src), ey = __shfl(bv[i][0].x, src), ez = __shfl(xr[i][0].y, src), ew = __shfl(bv[i][0].y, src);
+                    nx[j] = (q & 1) ? make_float2(ez, ew) : make_float2(ex, ey);
+                }
+#pragma unroll
+                for (int j = 0; j < QIT; ++j) xr[i][j] = nx[j];
+            }
+            __syncthreads();                                  // the next unit's operand planes are in place
+        }
+    }
+}
+
+template <int H, int HALF, int F>
+static int launch_s1xc_inst(const ShuffleS1ChainP& p, hipStream_t s) {
+    using Q = S1XGeo<H, HALF, F>;
+    static_assert(Q::SMEM <= 80 * 1024, "two blocks per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        L2S_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_s1xc_kernel<H, HALF, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q::SMEM));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((shuffle_s1xc_kernel<H, HALF, F>), dim3((p.NF + F - 1) / F), dim3(512), Q::SMEM, s, p);
+    return 0;
+}
+
+// n consecutive stride-1 units of one stage (units[0].x -> units[n-1].out) as ONE launch; every unit must carry operand planes (trunk_x3)
+int launch_shuffle_s1_chain(const ShuffleS1P* units, int n, hipStream_t s) {
+    L2S_REQUIRE(n >= 1 && n <= S1_CHAIN_MAX, "shuffle_s1 chain: 1..7 units");
+    ShuffleS1ChainP c{};
+    c.x = units[0].x; c.out = units[n - 1].out; c.NF = units[0].NF; c.n = n;
+    const int h = units[0].h, half = units[0].half;
+    for (int i = 0; i < n; ++i) {
+        const ShuffleS1P& p = units[i];
+        L2S_REQUIRE(p.w1p && p.w2p && p.h == h && p.half == half && p.NF == c.NF && p.Kpad == su_pad16(p.half), "shuffle_s1 chain: units of one stage with operand planes");
+        c.u[i] = S1UnitW{p.w1p, p.s1, p.b1, p.wd, p.sd, p.bd, p.w2p, p.s2, p.b2};
+    }
+    ProfScope ps(h >= 11 ? "shuffle_stage_s1_chain_h12" : h == 6 ? "shuffle_stage_s1_chain_h6" : "shuffle_stage_s1_chain_h3", s);
+    int rc = 1;
+    if (h == 12 && half == 58) rc = launch_s1xc_inst<12, 58, 1>(c, s);
+    else if (h == 11 && half == 58) rc = launch_s1xc_inst<11, 58, 1>(c, s);
+    else if (h == 6 && half == 116) rc = launch_s1xc_inst<6, 116, 2>(c, s);
+    else if (h == 3 && half == 232) rc = c.NF >= 2048 ? launch_s1xc_inst<3, 232, 5>(c, s) : launch_s1xc_inst<3, 232, 2>(c, s);
+    else set_error("shuffle_s1 chain: unsupported unit geometry");
+    if (rc) return 1;
+    L2S_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

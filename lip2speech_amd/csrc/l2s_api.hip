@@ -43,7 +43,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
         {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"flat_half", &Options::flat_half},
-        {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma}, {"flat_xcd", &Options::flat_xcd}, {"attn_skip0", &Options::attn_skip0}};
+        {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma}, {"trunk_chain", &Options::trunk_chain}, {"flat_xcd", &Options::flat_xcd}, {"attn_skip0", &Options::attn_skip0}};
     for (auto& t : diag)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
 #endif
@@ -1033,15 +1033,29 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
             if (launch_gemm1(pw_gemm(t2, half, 0, U.pw2, y, cout, 1, 2, out_px, half, half, ACT_RELU), s, "shuffle_pw_gemm")) return 1;
             h = ho;
         } else if (m->opt.fuse_trunk) {
-            ShuffleS1P sp{};
-            sp.x = x; sp.out = y;
-            sp.w1f = U.pw1_frag; sp.s1 = U.pw1.scale; sp.b1 = U.pw1.shift;
-            sp.wd = U.dw.w9; sp.sd = U.dw.scale; sp.bd = U.dw.shift;
-            sp.w2f = U.pw2_frag; sp.s2 = U.pw2.scale; sp.b2 = U.pw2.shift;
-            sp.NF = NF; sp.h = h; sp.half = half; sp.Kpad = U.kpad;
-            sp.F = h >= 11 ? 1 : 2;                            // informational: fixed by the kernel instance
-            if (m->opt.trunk_x3) { sp.w1p = U.pw1_p3; sp.w2p = U.pw2_p3; }      // pointwise convs on the bf16 matrix cores (exact split)
-            if (launch_shuffle_s1(sp, s)) return 1;
+            auto s1_params = [&](const UnitW& V, const float* in, float* outp) {
+                ShuffleS1P sp{};
+                sp.x = in; sp.out = outp;
+                sp.w1f = V.pw1_frag; sp.s1 = V.pw1.scale; sp.b1 = V.pw1.shift;
+                sp.wd = V.dw.w9; sp.sd = V.dw.scale; sp.bd = V.dw.shift;
+                sp.w2f = V.pw2_frag; sp.s2 = V.pw2.scale; sp.b2 = V.pw2.shift;
+                sp.NF = NF; sp.h = h; sp.half = V.half; sp.Kpad = V.kpad;
+                sp.F = h >= 11 ? 1 : 2;                        // informational: fixed by the kernel instance
+                if (m->opt.trunk_x3) { sp.w1p = V.pw1_p3; sp.w2p = V.pw2_p3; }      // pointwise convs on the bf16 matrix cores (exact split)
+                return sp;
+            };
+            // the run of stride-1 units that starts here (the rest of the stage) as ONE launch: the map stays on chip between the units
+            int run = 1;
+            while (u + run < N_UNITS && !w.unit[u + run].stride2 && w.unit[u + run].half == half) ++run;
+            if (m->opt.trunk_chain && (h >= 6 || m->opt.trunk_chain >= 2) && m->opt.trunk_x3 && U.pw1_p3 && U.pw2_p3 && run >= 2 && run <= S1_CHAIN_MAX) {
+                ShuffleS1P chain[S1_CHAIN_MAX];
+                for (int i = 0; i < run; ++i) chain[i] = s1_params(w.unit[u + i], x, y);
+                if (launch_shuffle_s1_chain(chain, run, s)) return 1;
+                u += run - 1;
+            } else {
+                const ShuffleS1P sp = s1_params(U, x, y);
+                if (launch_shuffle_s1(sp, s)) return 1;
+            }
         } else {
             const int64_t px = (int64_t)NF * h * h;
             if (launch_copy_cols(x, cout, 0, y, cout, 0, 2, px, half, s)) return 1;
@@ -1344,7 +1358,7 @@ static int decode_launches(l2s_model* m, float* state, int B, int T, int S, cons
             pr.seg[0] = {d.p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE;
             if (fold) { pr.epi = SK_FRAG; pr.out = d.p2f; pr.ldo = 256; }
             else { pr.epi = SK_PLAIN; pr.out = d.p2; pr.ldo = 256; }
-            if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds)) return 1;
+            if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds, m->opt.attn_skip0)) return 1;
         }
         if (!fold) {   // phase C: u = prenet + attention_proj(a @ v)
             SkinnyBatch sb{};
@@ -2012,7 +2026,7 @@ int l2s_op_step_attn_chain(l2s_model* m, float* state, int B, int T, int n_launc
         at.B = B; at.T = T; at.m = sl.m;
         SkinnyP pr = sk_base(w.pre2, B);
         pr.seg[0] = {p1, 16}; pr.nseg = 1; pr.act = ACT_PSINE; pr.epi = SK_FRAG; pr.out = p2f; pr.ldo = 256;
-        if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds)) return 1;
+        if (launch_step_attn(at, pr, w.pre2.tiles, s, m->opt.attn_lds, m->opt.attn_skip0)) return 1;
     }
     return 0;
 }

@@ -83,8 +83,13 @@ struct Options {
     int persist = 4;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: up to 4 clips
                                 //   of <= 32 frames, two per launch) as persistent weight-stationary launches instead of four launches per step; 0 = never.  A
                                 //   latency form: one call owns the chip, such launches are chained one after the other; grouped calls (l2s_*_multi) never take it
-    int flat_xcd = 0;           // "flat_xcd" (diagnostic A/B): the flat first phase's block -> tile map XCD-affine (an XCD = one row half x one column quarter of a group)
-    int attn_skip0 = 0;         // "attn_skip0" (diagnostic A/B): the attention blocks fetch a frame's projected values only when its soft-max weight is not exactly zero
+    int trunk_chain = 1;        // "trunk_chain" (diagnostic A/B): the consecutive stride-1 units of a ShuffleNet stage as ONE launch (the map stays on chip between the
+                                //   units; stages 2 and 3 - at 3x3 the per-unit launches are 5 % faster): 3 + 7 launches become 2, the trunk 3.82 -> 3.52 ms per 256 clips,
+                                //   same bits; 0 = one launch per unit, 2 = the 3x3 stage as well
+    int flat_xcd = 1;           // "flat_xcd" (diagnostic A/B): the flat first phase's block -> tile map XCD-affine (an XCD = one row half x one column quarter of a group:
+                                //   weights through two L2s, activations through four, instead of one and eight): 22.3 -> 18.4 MB through the fabric per launch; same bits
+    int attn_skip0 = 1;         // "attn_skip0" (diagnostic A/B): when chains overlap, the attention blocks fetch a frame's projected values only if its soft-max weight is
+                                //   not exactly zero (28.4 -> 23.5 MB per launch; same bits); 2 = also for a chain alone (one more round trip in the block: slower there), 0 = never
     int infer_bf16 = 0;         // "infer_bf16": the bf16 leg of inference / evaluate: front-end conv, GEMMs and Conv1d stacks of encoder, prologue, post-net and
                                 //   voice tower with bf16 operands (fp32 accumulation); the recurrent loops, the fused ShuffleNet units and all statistics stay fp32
 };
@@ -282,6 +287,8 @@ struct ShuffleS1P {
 int64_t su_planes_bytes(int N, int K);
 int launch_su_planes(const float* W, int N, int K, void* out, hipStream_t s);      // [N][K] fp32 -> [ceil(N/16)][pad32(K)/32][3 planes][64 lanes] 16 bytes
 int launch_shuffle_s1(const ShuffleS1P& p, hipStream_t s);
+constexpr int S1_CHAIN_MAX = 7;
+int launch_shuffle_s1_chain(const ShuffleS1P* units, int n, hipStream_t s);      // n consecutive stride-1 units of one stage in ONE launch (the map stays on chip between them); same bits
 void shuffle_set_timeline(unsigned long long* ts, int h);     // non-null: launch the stamped measurement build (tools/fused_unit_timeline.py)
 // fused stride-2 ShuffleNet unit (encoder_kernels.hip): banch1 (dw s2 -> pw) and banch2 (pw -> dw s2 -> pw) of one strip of Ro
 // output rows per block; the full-resolution pw1 map (124 MB at B=32 in stage 2) never leaves the CU
@@ -386,7 +393,7 @@ struct AttnP {
     int B, T, m;
 };
 // attention role + second prenet layer in one grid (skinny.hip)
-int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values = 1);
+int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values = 1, int skip0 = 0);
 // adaptive average pooling of up to 5 channel-last maps into a concatenated (B, m, nmaps*C) buffer
 struct PoolCatP { const float* x[5]; int L[5]; int ld[5]; int nmaps; int B, m, C; float* out; };
 int launch_pool_cat(const PoolCatP& p, hipStream_t s);

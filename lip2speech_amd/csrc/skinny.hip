@@ -289,7 +289,20 @@ struct SkinnyFlat {
     int gid[SKINNY_MAX_GROUP];           // which group (index into SkinnyBatch::p) that is
     int ncol[SKINNY_MAX_GROUP];          // by rank k: column blocks (ceil(tiles / CT))
     int wide[SKINNY_MAX_GROUP];          // by rank k: 1 = a K <= 1024 group (shape S8), 0 = a K <= 512 group (shape S4)
+    int nrow[SKINNY_MAX_GROUP];          // by rank k: row blocks (ceil(mts / RT))
+    int xcd[SKINNY_MAX_GROUP];           // by rank k: 1 = XCD-affine block -> tile map (below), 0 = row-major
 };
+// XCD-affine map ("flat_xcd"): workgroup b of a launch runs on XCD b mod 8, and every XCD has its own L2, which the kernel boundary invalidates - so
+// what a launch pulls through the fabric is (weights) x (XCDs that see each weight tile) + (activations) x (XCDs that see each row).  Row-major order
+// gives every XCD all rows and an eighth of the columns: weights once, activations EIGHT times (the first phase at 256 rows: 3.8 + 8 x 2.0 MB).  Here
+// XCD x owns row half x & 1 and column quarter x >> 1 of the group: weights twice, activations four times (7.6 + 8.0 MB).  Needs the group's first
+// block on a multiple of 8, an even number of row blocks and a multiple of four column blocks.
+__device__ __forceinline__ void flat_xcd_map(int b, int local, int nc, int nr, int& tp, int& mg) {
+    const int x = b & 7, j = local >> 3;
+    const int ncq = nc >> 2, nrh = nr >> 1;
+    mg = (x & 1) * nrh + j / ncq;
+    tp = (x >> 1) * ncq + j % ncq;
+}
 // One instance per pair of shapes (S8 for the K <= 1024 groups, S4 for the K <= 512 groups; RT * 10 + CT): an instance that carries every
 // shape is 60 KB of code and pays ~2.5 us of instruction fetch per launch.
 template <int S8, int S4, int STATIC = 0, bool TIMED = false>
@@ -303,7 +316,8 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
     for (int i = 1; i < SKINNY_MAX_GROUP; ++i) k += (i < batch.count && b >= fl.first[i]) ? 1 : 0;
     const int g = fl.gid[k];
     const int local = b - fl.first[k], nc = fl.ncol[k];
-    const int tp = local % nc, mg = local / nc;
+    int tp = local % nc, mg = local / nc;
+    if (fl.xcd[k]) flat_xcd_map(b, local, nc, fl.nrow[k], tp, mg);
     const SkinnyP& p = batch.p[g];
     L2S_BLOCK_STAMP_BEGIN();
     if constexpr (STATIC == 2) {  // every wide group is [h | h] (K = 1024), every narrow one [h] (K = 512): straight-line four-wave blocks (256 threads)
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(STATIC == 2 ? 256 : 512, STATIC == 2 ? 1 : 2) void 
 // measurements of tools/time_step_phases.py as bytes / 36.5 GB/s (what one block streams through its CU's vector-memory path) plus its MFMA
 // work at 350 GFLOP/s per CU (not overlapped: a 4x2 block of a K = 512 group has twice the matrix work of a 2x1 block of a K = 1024 group with
 // the same bytes, and lasts longer).  Returns 0 when nothing fits (then the uniform grid runs), else S8 * 100 + S4.
-static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl, bool half = false) {
+static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl, bool half = false, bool xcd = false) {
     static const int S8[2] = {21, 22}, S4[3] = {21, 22, 42};
     const int n = bl.count;
     auto shape_of = [&](int g, int s8, int s4) { return bl.p[g].K > 512 ? s8 : s4; };
@@ -353,6 +367,8 @@ static int plan_flat(const SkinnyBatch& bl, int mts, int cap, SkinnyFlat& fl, bo
         fl.first[k] = pos; fl.gid[k] = g;
         fl.ncol[k] = (bl.ntiles[g] + sh % 10 - 1) / (sh % 10);
         fl.wide[k] = bl.p[g].K > 512 ? 1 : 0;
+        fl.nrow[k] = (mts + sh / 10 - 1) / (sh / 10);
+        fl.xcd[k] = (xcd && pos % 8 == 0 && fl.nrow[k] % 2 == 0 && fl.ncol[k] % 4 == 0) ? 1 : 0;
         pos += nblocks(g, sh);
     }
     for (int k = n; k <= SKINNY_MAX_GROUP; ++k) fl.first[k] = pos;
@@ -460,7 +476,7 @@ int launch_skinny(const SkinnyBatch& b, hipStream_t s, const char* name, const O
     if (!g_skinny_ts && bl.count > 1 && mts >= 8 && o.skinny_flat && !o.rc_shape && !o.rc_shape_multi && maxk <= 1024 && rc_kind == 1) {      // a forced block shape wins; LSTM groups (the BiLSTM's two directions) keep the uniform grid of four-wave blocks
         SkinnyFlat fl{};
         const bool half = o.flat_half != 0 && (o.flat_half >= 2 || chains_hint() >= 2);
-        const int plan = plan_flat(bl, mts, half ? 512 : 256, fl, half);
+        const int plan = plan_flat(bl, mts, half ? 512 : 256, fl, half, o.flat_xcd != 0);
         // 0 = general blocks, 1 = straight-line eight-wave blocks (default: 12.4 us at 256 rows against 12.9 general), 2 = straight-line four-wave
         // blocks ("skinny_rc_jb" = 44: 14.9 us - these blocks move 262 KB for 3.4 us of matrix work; eight waves keep more loads in flight)
         int stat = half ? 2 : o.rc_jb == 0 || o.rc_jb == 28 ? 1 : o.rc_jb == 44 ? 2 : 0;
@@ -523,16 +539,16 @@ struct StepB {
 };
 
 constexpr int ATT_PRE2_MAXC = 2;      // prenet layer 2: K = 256 = 16 * 8 waves * 2 chunks
-template <bool VL>
+template <bool VL, bool SKIP0 = false>
 __global__ __launch_bounds__(512) void step_attn_kernel(const StepB sb) {
-    constexpr int SMF = ATT_SM_FLOATS + (VL ? ATT_VLDS_FLOATS : 0);
+    constexpr int SMF = ATT_SM_FLOATS + (VL && !SKIP0 ? ATT_VLDS_FLOATS : 0);
     __shared__ __attribute__((aligned(16))) float sm[SMF > SK_RED_FLOATS ? SMF : SK_RED_FLOATS];
     const int nb = sb.at.B, ptiles = sb.pre2_tiles;
     L2S_PIN_S("s"(nb), "s"(ptiles));
     const int bid = blockIdx.x;
     L2S_BLOCK_STAMP_BEGIN();
     if (bid < nb) {
-        attention_block<false, false, VL>(sb.at, bid, sm);
+        attention_block<false, false, VL, SKIP0>(sb.at, bid, sm);
     } else if (bid < 2 * nb) {
         content_block(sb.at, bid - nb, sm);
     } else {
@@ -562,7 +578,7 @@ static unsigned long long* g_attn_ts = nullptr;
 void attn_set_timeline(unsigned long long* ts) { g_attn_ts = ts; }
 
 #endif
-int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values) {
+int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipStream_t s, int lds_values, int skip0) {
     L2S_REQUIRE(at.T <= ATT_MAXT && at.m <= 16, "attention sizes");
     L2S_REQUIRE(pre2.K <= 16 * SK_WAVES * ATT_PRE2_MAXC, "prenet layer 2 is a 256-wide layer");
     StepB sb;
@@ -579,7 +595,8 @@ int launch_step_attn(const AttnP& at, const SkinnyP& pre2, int pre2_tiles, hipSt
     if (g_attn_ts && vl) hipLaunchKernelGGL(step_attn_timed_kernel, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb, g_attn_ts);
     else
 #endif
-    if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    if (vl && skip0 && (skip0 >= 2 || chains_hint() >= 2)) hipLaunchKernelGGL((step_attn_kernel<true, true>), dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
+    else if (vl) hipLaunchKernelGGL(step_attn_kernel<true>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     else hipLaunchKernelGGL(step_attn_kernel<false>, dim3(2 * at.B + pre2_tiles * sb.mts), dim3(512), 0, s, sb);
     L2S_CHECK_HIP(hipGetLastError());
     return 0;

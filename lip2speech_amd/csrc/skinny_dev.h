@@ -896,8 +896,14 @@ __device__ __forceinline__ float block_sum8(float x, float* scratch) {
 // block's threads fetch V' as 16-byte rows - four requests per thread instead of 29 one-column dword requests for half of them - and pass it through
 // LDS; a@V' then reads its column from there, t ascending as before (same bits).  The stamped build showed the 38 requests of a thread taking 2.1 us
 // to ISSUE (~60 clk each), 40 % of the block's lifetime.
-template <bool TRAIN = false, bool TIMED = false, bool VLDS = false>
+// SKIP0 (with VLDS): tau MULTIPLIES the logits (decoder.py:414), so they spread over thousands and the soft-max of all but one to three frames
+// underflows to EXACTLY 0.0f.  A frame of weight 0 contributes fmaf(0, v, acc) = acc (V' is finite; acc is never -0): skipping it is the same bits.
+// The block then fetches the projected values of the non-zero frames only, AFTER the soft-max (one more round trip in the block's life, a quarter
+// fewer bytes through the fabric per launch: 7.6 of 29.7 MB at 256 rows) - for launches that run beside other chains' kernels, where the launch is
+// bound by the fabric, not by its own latency chain.
+template <bool TRAIN = false, bool TIMED = false, bool VLDS = false, bool SKIP0 = false>
 __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm, const AttnTrain* tr = nullptr, unsigned long long* ats = nullptr) {
+    static_assert(!SKIP0 || VLDS, "the zero-weight skip rides on the buffer-load form of the inference step");
     L2S_ATT_STAMP(0);
     float* qs = sm;                  // 512
     float* sc = sm + 512;            // ATT_MAXT
@@ -939,11 +945,13 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
             }
         }
     }
-    constexpr bool vlds = VLDS;                               // the launch picks the instance: VLDS only with projected values and T <= 32
+    constexpr bool vlds = VLDS && !SKIP0;                     // the launch picks the instance: VLDS only with projected values and T <= 32
     float* const vs = sm + ATT_SM_FLOATS;
-    float vv[vlds ? 1 : 32];
+    float vv[VLDS ? 1 : 32];
     float4 vq[vlds ? 4 : 1];
-    if constexpr (vlds) {
+    if constexpr (SKIP0) {
+        // nothing up front: the values of the frames that count are requested after the soft-max
+    } else if constexpr (vlds) {
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pv + (int64_t)b * T * 256), 0, T * 1024, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) vq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, tid * 16, 8192 * i, 0));
@@ -1031,7 +1039,28 @@ __device__ __forceinline__ void attention_block(const AttnP& p, int b, float* sm
     L2S_ATT_STAMP(5);               // attention weights visible
     // ---- av = a @ v : one column per thread, t ascending
     float acc = 0.f;
-    if constexpr (vlds) {
+    if constexpr (SKIP0) {
+        const unsigned long long nz = __ballot(awr != 0.f);          // the same in every wave (each ran the same soft-max)
+        if (wave < 4) {                                               // 256 value columns: waves 0-3, one column per thread
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pv + (int64_t)b * T * 256), 0, T * 1024, 0x00020000);
+            unsigned long long m = nz;
+            while (m) {                                               // four frames per round: their loads are in flight together; t ascending as in the full form
+                int tt[4]; float ww[4], vl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool on = m != 0ull;
+                    const int t = on ? (int)__builtin_ctzll(m) : 0;
+                    tt[i] = __builtin_amdgcn_readfirstlane(t);
+                    ww[i] = on ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, awr), tt[i])) : 0.f;
+                    m = on ? (m & (m - 1ull)) : 0ull;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, tid * 4, tt[i] * 1024, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(ww[i], vl[i], acc);     // an unused slot adds fmaf(0, v, acc) = acc
+            }
+        }
+    } else if constexpr (vlds) {
         const float* vc = vs + (tid & 255);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                                         // sixteen unconditional reads in flight at a time (a guarded read per frame serialises them)

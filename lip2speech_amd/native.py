@@ -48,7 +48,7 @@ DIAG_SYMBOLS = (
 
 # run-time options only the diagnostic build accepts (block-form A/B switches of the same arithmetic, include/l2s_diag.h)
 DIAG_OPTIONS = frozenset(("overlap_postnet", "fuse_trunk", "fuse_s2", "skinny_static", "skinny_sized", "skinny_split", "skinny_split8", "skinny_rc", "skinny_rc_jb",
-                          "skinny_rc_multi", "skinny_flat", "hoist_vproj", "attn_lds", "flat_half", "half_min_mts", "gemm_x3_dma", "flat_xcd", "attn_skip0"))
+                          "skinny_rc_multi", "skinny_flat", "hoist_vproj", "attn_lds", "flat_half", "half_min_mts", "gemm_x3_dma", "flat_xcd", "attn_skip0", "trunk_chain"))
 
 ST_K, ST_V, ST_CKEY, ST_CVAL, ST_ECELL, ST_H, ST_C, ST_ENC, ST_STOPC = range(9)
 
@@ -227,7 +227,7 @@ class NativeModel:
     def __init__(self, library: Optional[ctypes.CDLL] = None):
         self._L = library or lib()        # every call of this model goes to ONE library: the product, or the diagnostic build (tests of the A/B options, tools)
         self._h = _vp()
-        self._check(self._L.l2s_model_create(ctypes.byref(self._h)), self._L)
+        self._check(self._L.l2s_model_create(ctypes.byref(self._h)))
         self._tls = threading.local()      # the workspace is per host thread: several threads may run batches on ONE model (one weight blob)
         self.calls = collections.Counter()  # whole-path entry points used, by C-ABI name (tests assert which route a caller took)
 

@@ -179,6 +179,23 @@ def test_encoder_trunk_f32_units(nm, synth_sd, hw, B, T):
     assert 0 < d < 2e-6
 
 
+@pytest.mark.parametrize("hw,B,T", [(96, 2, 29), (88, 1, 3), (96, 1, 5), (96, 71, 29)])
+def test_encoder_stage_chain_same_bits(nm, synth_sd, hw, B, T):
+    """Round 6: the stride-1 units of a ShuffleNet stage as ONE launch (shuffle_s1xc_kernel: the map stays on chip between the units, the channel
+    shuffle is re-cut into the next unit's halves with wave shuffles; diagnostic switch "trunk_chain" = 0 gives one launch per unit).  Per pixel the
+    arithmetic is the single-unit kernel's: the features must be the same BITS - also with a half-filled last block (odd frame counts, 88x88
+    crops) and with the five-frames-per-block instance of the 3x3 stage (>= 2048 frames in the launch)."""
+    per_unit = pc.fresh_native_model(synth_sd, trunk_chain=0)
+    v = synth.synth_video(2, T, hw, hw, tag=f"chain{hw}_{T}").repeat((B + 1) // 2, 1, 1, 1, 1)[:B].clone()
+    if B > 2:
+        v += 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(B))
+    a = nm.encoder_fwd(v.cuda())
+    b = per_unit.encoder_fwd(v.cuda())
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    if B <= 2:
+        assert pc.maxdiff(a, orc.encoder_forward(synth_sd, v)) < 2e-5
+
+
 def test_prologue_matches_oracle(nm_both):
     nm = nm_both
     g, _, emb = pc.lrw2_inputs()

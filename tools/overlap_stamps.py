@@ -92,6 +92,9 @@ def analyse(title, n):
     if n > 1 and len(chains) < n:
         print(f"   (only {len(chains)} distinct operand keys for {n} chains: launches of different chains share a key - per-chain grouping by the 3 us gap rule only)")
     lo = max(allsp[allsp[:, 2] == c][:, 0].min() for c in chains); hi = min(allsp[allsp[:, 2] == c][:, 1].max() for c in chains)
+    if hi <= lo:
+        print(f"   the chains did not overlap in time (latest first launch {lo} > earliest last launch {hi}): whole record instead")
+        lo, hi = allsp[:, 0].min(), allsp[:, 1].max()
     win = allsp[(allsp[:, 0] >= lo) & (allsp[:, 1] <= hi)]
     u_all, s_all = union(win[:, :2])
     print(f"   window with all chains active: {(hi - lo) / 100:.1f} us, {len(win)} launches of the step kernels; at least one on the chip {100.0 * u_all / (hi - lo):.1f} % of it; "
@@ -121,12 +124,14 @@ torch.cuda.synchronize()
 for n in CH:
     hint = 2 if n > 1 or os.environ.get("FORMS", "half") == "half" else 1
     if "lstm" in MODE:
+        together(n, hint, lambda i: nm.lstm_cell_chain_us(ROWS, 20))      # warm-up: the threads' workspaces are allocated, the block forms loaded
         log[0] = 0
         native.check(D.l2s_op_stamp_log(log.data_ptr(), CAP), D)
         together(n, hint, lambda i: nm.lstm_cell_chain_us(ROWS, N))
         native.check(D.l2s_op_stamp_log(None, 0), D)
         analyse(f"LSTM launches alone, {ROWS} rows, {2 * N + 16} launches per chain (l2s_op_lstm_cell_chain), chains hint {hint}", n)
     if "decode" in MODE:
+        together(n, hint, lambda i: nm.decode_steps(states[i], ROWS, T, 10, want_attn=False))
         log[0] = 0
         native.check(D.l2s_op_stamp_log(log.data_ptr(), CAP), D)
         together(n, hint, lambda i: nm.decode_steps(states[i], ROWS, T, S, want_attn=False))

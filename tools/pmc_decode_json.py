@@ -2,9 +2,14 @@
 """Turn the rocprofv3 passes of tools/prof_decode.py (kernel trace + three --pmc passes: TCC_HIT_sum TCC_MISS_sum / FETCH_SIZE / WRITE_SIZE)
 into profiles/rNN_pmc_decode.json: per decode-step kernel role, HBM-side bytes per launch (FETCH_SIZE x 2 - the gfx950 correction of
 MI355X_MICROARCH.md - + WRITE_SIZE, both KiB), L2 hit rate and the kernel-trace average duration.
-usage: pmc_decode_json.py <trace.db> <hitmiss.db> <fetch.db> <write.db> <rows> > out.json"""
-import json, sqlite3, sys
+usage: pmc_decode_json.py <trace.db> <hitmiss.db> <fetch.db> <write.db> <rows> [<one_chain_trace.db>] > out.json
+FORMS=half (environment): only the half-CU block forms bench.py's timed region launches (skinny_rc4h, skinny_flat<.., 2, ..>, step_attn<true>) are
+counted - the probes' warm-up launches of the eight-wave forms are left out; the optional sixth argument is a kernel trace of ONE chain in the same
+forms: its mean durations are recorded as avg_us_rocprofv3_one_chain (a launch that has the chip to itself)."""
+import json, os, sqlite3, sys
 trace, hm, fe, wr, rows = sys.argv[1:6]
+trace1 = sys.argv[6] if len(sys.argv) > 6 else None
+HALF = os.environ.get("FORMS") == "half"
 ROLE = [("step_lstm_cell", lambda n, g: "skinny" in n and g[2] == 1 and g[0] * g[1] >= 128 * 512 // 1),      # refined below by grid
         ]
 def table(db):
@@ -12,6 +17,8 @@ def table(db):
     t = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')") if r[0].startswith("counters_collection")][0]
     return list(c.execute(f"select kernel_name, grid_size_x, grid_size_y, grid_size_z, counter_name, avg(value), count(*) from {t} group by 1,2,3,4,5"))
 def role_of(name, gz, n_launch):
+    if HALF and ("skinny_rc8x" in name or "skinny_rc4_" in name or "skinny_rc4x" in name or ("skinny_flat" in name and ", 2, false>" not in name)
+                 or "step_attn_kernel<false" in name): return None
     if "step_attn_kernel" in name: return "step_attention_prenet2"
     if "skinny_flat" in name or ("skinny" in name and gz == 4): return "step_prenet1_q_cq_fc"
     if "skinny" in name and gz == 1 and n_launch >= 250: return "step_lstm_cell"
@@ -32,7 +39,13 @@ for name, gx, gy, gz, n, avg in c.execute("select name, grid_x, grid_y, grid_z, 
     r = role_of(name, gz // 1 if gz else 1, n) if "skinny" in name or "step_attn" in name else None
     if r:
         a = dur.setdefault(r, [0.0, 0]); a[0] += avg * n; a[1] += n
-res = {"note": "rocprofv3 passes over tools/prof_decode.py (3 x 300 decode steps, ROWS clips per launch = 8 batches of 32 per chain) on MI355X: one kernel-trace pass and one "
+dur1 = {}
+if trace1:
+    for name, gx, gy, gz, n, avg in sqlite3.connect(trace1).execute("select name, grid_x, grid_y, grid_z, count(*), avg(duration) from kernels group by 1,2,3,4"):
+        r = role_of(name, gz // 1 if gz else 1, n) if "skinny" in name or "step_attn" in name else None
+        if r:
+            a = dur1.setdefault(r, [0.0, 0]); a[0] += avg * n; a[1] += n
+res = {"note": "rocprofv3 passes over the decode loop (300 steps per chain, ROWS clips per launch = 8 batches of 32 per chain; with FORMS=half: three chains at once through tools/coresident_probe.py, the block forms of bench.py's timed region; avg_us_rocprofv3 is then the duration of a launch that SHARES the chip with the other chains' launches, avg_us_rocprofv3_one_chain that of a launch alone) on MI355X: one kernel-trace pass and one "
                "--pmc pass per counter set (TCC_HIT_sum+TCC_MISS_sum / FETCH_SIZE / WRITE_SIZE). FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md gfx950 "
                "FETCH_SIZE counts wide coalesced reads at half their bytes, so read bytes = 2*FETCH_SIZE*1024. The counters sit at the L2's memory side: they include "
                "Infinity-Cache hits (the step weights never leave the Infinity Cache), so this is fabric traffic, not DRAM traffic.",
@@ -45,5 +58,6 @@ for r, d in out.items():
         k["traffic_bytes_per_launch"] = k["read_bytes"] + k["write_bytes"]
     if "TCC_HIT_sum" in w: k["l2_hit_rate"] = w["TCC_HIT_sum"] / (w["TCC_HIT_sum"] + w["TCC_MISS_sum"])
     if r in dur: k["avg_us_rocprofv3"] = dur[r][0] / dur[r][1] / 1e3
+    if r in dur1: k["avg_us_rocprofv3_one_chain"] = dur1[r][0] / dur1[r][1] / 1e3
     res["kernels"][r] = k
 print(json.dumps(res, indent=1))
