@@ -327,8 +327,9 @@ int l2s_train_encoder_bwd(l2s_model* m, const float* video, int B, int T, int H,
  *                            statistics, master weights and optimizer stay fp32
  *   "gemm_x3"           (1)  inference GEMMs / Conv1d stacks on the bf16 matrix cores through the EXACT three-way split (x = hi + mid + lo, six bf16
  *                            MFMAs per K step of 16 instead of eight f32 MFMAs of K = 2) where the shapes are eligible; 0 = the f32 MFMA kernel
- *   "frontend_x3"       (2)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the same split-bf16 path: 2 = two consecutive
- *                            output frames per block, 1 = one frame per block, 0 = the f32 MFMA kernel
+ *   "frontend_x3"       (3)  the inference front-end conv (Conv3d 5x7x7 + BN + PReLU + MaxPool) on the same split-bf16 path: 3 = two consecutive
+ *                            output frames per block with the next slab's staging interleaved between the MFMAs, 2 = the same with a staging phase of its
+ *                            own (same bits), 1 = one frame per block, 0 = the f32 MFMA kernel
  *   "trunk_x3"          (1)  the fused ShuffleNet units' pointwise convs on the split-bf16 path; 0 = f32 MFMA
  *   "lstm_x3"           (3)  the decode step's two LSTM launches on the split-bf16 path (1 / 2 / 3: four-wave / eight-wave / half-CU block forms of the
  *                            same arithmetic, same bits - 3 picks by l2s_set_thread_chains); 0 = f32 MFMAs (other bits, rounding-level) */

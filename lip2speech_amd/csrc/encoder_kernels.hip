@@ -658,6 +658,245 @@ __global__ __launch_bounds__(256, 2) void frontend3d_x3p_kernel(const FrontendW 
     }
 }
 
+// PIPE (option "frontend_x3" = 3): the same block with the NEXT slab's staging (split into planes + LDS stores) interleaved between the MFMA groups of the
+// current slab instead of in a phase of its own between two barriers: the input planes are double-buffered (2 x 21.5 KB: 79.9 KB of LDS, still two blocks
+// per CU), the next slab's frame rows are requested at the HEAD of the MFMA phase (before its weight pieces) and split at its TAIL, when they have landed,
+// into the other plane buffer - the split's VALU runs in the shadow of the MFMAs and a slab needs ONE barrier.  Same operand bits, same MFMA order: same
+// bits out.
+template <int HW>
+__global__ __launch_bounds__(256, 2) void frontend3d_x3q_kernel(const FrontendW w, const FrameSrc vsrc, int T, float* __restrict__ out) {
+    constexpr int H = HW, W = HW, Hc = H / 2, Wc = W / 2, Hp = Hc / 2, Wp = Wc / 2;
+    constexpr int P = FE_CR * Wc;                    // conv pixels per strip
+    constexpr int PT = (P + 15) / 16;                // 16-pixel MFMA row tiles
+    constexpr int TPW = (PT + 3) / 4;                // tiles per wave
+    // input row pitch 112 bf16 = 56 dwords: the A operand is read with ds_read2_b32 (32 banks, lanes 0-31 and 32-63 as groups), a group holds the 16
+    // pixels of TWO k-groups - placed two input rows apart (112 dwords = 16 mod 32) they cover the 32 banks exactly; one row apart (24 mod 32) eight banks
+    // were hit twice and every operand read cost double (SQ_LDS_BANK_CONFLICT: 24 % of the kernel's CU cycles)
+    constexpr int XLD = 112, PLANE = FE_XROWS * XLD * 2;
+    static_assert(XLD >= W + 8 && (XLD / 2) % 32 == 24, "row pitch");
+    constexpr int XS = 3 * PLANE;                    // bytes: input planes
+    constexpr int WROW = 48, LROW = 32;              // weight row in the packed planes (16 bf16 + pad) and in LDS (no pad: a third fewer DMA pieces)
+    constexpr int WSP = 24 * LROW;                   // bytes per (step, plane) of one output frame: 24 channel rows
+    constexpr int WSO = 12 * WSP;                    // bytes per output frame: 4 steps x 3 planes
+    constexpr int WS = 2 * WSO;                      // 18 432
+    constexpr int CS = P * (FE_CO / 2) * 4;          // conv tile of half the channels of one output frame (aliases the operand area)
+    constexpr int SMEM = (2 * XS + 2 * WS) > CS ? (2 * XS + 2 * WS) : CS;     // two input-plane buffers + two weight buffers: 79.9 KB, two blocks per CU
+    constexpr int NLD = ((FE_XROWS - 1) * (W / 4) + 255) / 256;      // input float4 per thread per slab
+    constexpr int NWU = WS / 16, NWC = NWU / 64;                    // weight uint4 per slab; 1-KB pieces of the weight operand
+    static_assert(NWU % 64 == 0, "the weight operand is a whole number of wave-wide 16-byte pieces");
+    constexpr int SRC_SP = 32 * WROW / 16;           // uint4 per (step, plane) in the packed source (32 channel rows)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const Xs0 = smem;
+    unsigned char* const Ws0 = smem + 2 * XS;
+
+    const int NPAIR = (T + 1) / 2;
+    const int bg = blockIdx.y / NPAIR, t0 = 2 * (blockIdx.y - bg * NPAIR);
+    const bool has1 = t0 + 1 < T;                    // block-uniform
+    const int grp = bg / vsrc.per, b = bg - grp * vsrc.per;
+    const float* __restrict__ video = vsrc.p[grp];
+    const int p0 = blockIdx.x * FE_PR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, kg = lane >> 4;
+    const int kr = ((kg & 1) << 1) | (kg >> 1);       // kernel row (of the four of a K step) this lane's k-group carries: k-groups 0,1,2,3 = rows 0,2,1,3
+
+    for (int i = tid; i < 2 * XS / 16; i += 256) reinterpret_cast<uint4*>(Xs0)[i] = make_uint4(0u, 0u, 0u, 0u);      // both plane buffers: pads and outside rows stay zero
+
+    int base[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        int p = (wave + 4 * j) * 16 + li;
+        p = p < P ? p : P - 1;
+        const int lr = p / Wc, c = p - lr * Wc;
+        base[j] = ((2 * lr + kr) * XLD + 2 * c) * 2;
+    }
+    // weight operand of column tile nt: column q = 16 nt + li -> (frame o, channel ch); this lane's kernel row inside a K step is kr
+    int wof[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int q = nt * 16 + li, o = q >= FE_CO ? 1 : 0, ch = q - FE_CO * o;
+        wof[nt] = o * WSO + (kr >> 1) * (3 * WSP) + ch * LROW + (kr & 1) * 16;
+    }
+    f32x4 acc[TPW][3];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[j][nt] = {0.f, 0.f, 0.f, 0.f};
+
+    const int gy0 = 4 * p0 - 5;
+    // slab sl = ci * 6 + d: input frame tau = t0 - 2 + d; frame t0 takes it through tap d (d <= 4), frame t0 + 1 through tap d - 1 (d >= 1)
+    auto valid = [&](int sl) { const int d = sl % 6, tau = t0 - 2 + d; return tau >= 0 && tau < T && (d <= 4 || has1); };
+    auto next_valid = [&](int sl) { while (sl < 18 && !valid(sl)) ++sl; return sl; };
+
+    float4 rin[NLD];
+    auto fetch_piece = [&](int sl, int q) {
+        const int ci = sl / 6, d = sl - ci * 6;
+        const float* src = video + ((int64_t)(b * 3 + ci) * T + (t0 - 2 + d)) * (H * W);
+        const int i = tid + 256 * q;
+        const int row = i / (W / 4), x4 = i - row * (W / 4);
+        const int gy = gy0 + row;
+        rin[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < (FE_XROWS - 1) * (W / 4) && gy >= 0 && gy < H) rin[q] = *reinterpret_cast<const float4*>(src + gy * W + 4 * x4);
+    };
+    auto fetch = [&](int sl) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) fetch_piece(sl, q);
+    };
+    // the weight operand of slab sl, straight into LDS buffer `buf` (global_load_lds: a wave's 64 lanes fill one contiguous 1-KB piece; no staging
+    // registers, no ds_write pass) - issued at the head of the PREVIOUS slab's MFMA phase, landed by the barrier that ends it.
+    auto dma_piece = [&](int sl, int buf, int kp) {                          // piece c = wave + 4 kp of the NWC 1-KB pieces
+        const int c = wave + 4 * kp;
+        if (c < NWC) {                                                       // wave-uniform
+            const int ci = sl / 6, d = sl - ci * 6;
+            const uint4* w3 = reinterpret_cast<const uint4*>(w.w3);
+            unsigned char* const Wd = Ws0 + buf * WS;
+            const int i = c * 64 + lane;
+            const int o = i >= NWU / 2 ? 1 : 0, r = i - o * (NWU / 2);
+            const int sp = r / (WSP / 16), u = r - sp * (WSP / 16);
+            const int kt = d - o;                                             // the tap through which frame t0 + o sees this input frame
+            const bool on = kt >= 0 && kt <= 4 && (o == 0 || has1);
+            // a frame the slab does not feed takes its rows from a zero chunk of the packed planes (output-channel row 24 of 32 is padding: zeros) -
+            // as ordinary zero stores those lanes cost an s_waitcnt vmcnt(0) each (a store to LDS behind a pending LDS-DMA), i.e. a full drain of
+            // the requests in flight in the middle of the MFMA phase of every edge slab
+            const uint4* src = on ? w3 + (int64_t)(ci * 5 + kt) * (12 * SRC_SP) + sp * SRC_SP + (u >> 1) * (WROW / 16) + (u & 1) : w3 + (24 * WROW) / 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Wd + c * 1024), 16, 0, 0);
+        }
+    };
+    constexpr int NDP = (NWC + 3) / 4;                                       // pieces per wave
+    auto dma_weights = [&](int sl, int buf) {
+#pragma unroll
+        for (int kp = 0; kp < NDP; ++kp) dma_piece(sl, buf, kp);
+    };
+    auto stage_piece = [&](unsigned char* Xd, int q) {
+        const int i = tid + 256 * q;
+        if (i < (FE_XROWS - 1) * (W / 4)) {
+            const int row = i / (W / 4), x4 = i - row * (W / 4);
+            unsigned char* dd = Xd + (row * XLD + 4 + 4 * x4) * 2;
+            uint2 hi, mid, lo;
+            fx_split4(rin[q], hi, mid, lo);
+            *reinterpret_cast<uint2*>(dd) = hi; *reinterpret_cast<uint2*>(dd + PLANE) = mid; *reinterpret_cast<uint2*>(dd + 2 * PLANE) = lo;
+        }
+    };
+
+    int sl = next_valid(0), nslab = 0;
+    if (sl < 18) {
+        fetch(sl); dma_weights(sl, 0);
+        __syncthreads();                             // the zero fill is complete
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) stage_piece(Xs0, q);
+    }
+    static_assert(NLD + NDP + NLD <= 2 * TPW, "one request / one staging piece per pixel tile");
+    while (sl < 18) {
+        __syncthreads();                             // this slab's planes (staged under the previous slab's MFMAs) and weights (LDS-DMA) are in place; the previous slab is consumed
+        const int d = sl % 6;
+        const bool on0 = d <= 4, on1 = d >= 1 && has1;       // block-uniform: which column tiles carry weights (tile 1 always does)
+        const int nxt = next_valid(sl + 1);
+        const bool more = nxt < 18;
+        const unsigned char* const Xs = Xs0 + (nslab & 1) * XS;
+        unsigned char* const Xn = Xs0 + ((nslab + 1) & 1) * XS;
+        const unsigned char* const Ws = Ws0 + (nslab & 1) * WS;
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            fx_bf16x8 bh[3], bm[3], bl[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const unsigned char* wp = Ws + wof[nt] + S * (2 * 3 * WSP);
+                bh[nt] = *reinterpret_cast<const fx_bf16x8*>(wp);
+                bm[nt] = *reinterpret_cast<const fx_bf16x8*>(wp + WSP);
+                bl[nt] = *reinterpret_cast<const fx_bf16x8*>(wp + 2 * WSP);
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (more) {
+                    const int pos = S * TPW + j;                              // compile-time
+                    if (pos < NLD) fetch_piece(nxt, pos);                     // frame rows first: they are split at the tail of this phase
+                    else if (pos < NLD + NDP) dma_piece(nxt, (nslab + 1) & 1, pos - NLD);
+                    else if (pos >= 2 * TPW - NLD) stage_piece(Xn, pos - (2 * TPW - NLD));
+                }
+                {
+                    const unsigned* ap = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2));
+                    const unsigned* am_ = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2) + PLANE);
+                    const unsigned* al_ = reinterpret_cast<const unsigned*>(Xs + base[j] + S * (4 * XLD * 2) + 2 * PLANE);
+                    const fx_bf16x8 ah = __builtin_bit_cast(fx_bf16x8, make_uint4(ap[0], ap[1], ap[2], ap[3]));
+                    const fx_bf16x8 am = __builtin_bit_cast(fx_bf16x8, make_uint4(am_[0], am_[1], am_[2], am_[3]));
+                    const fx_bf16x8 al = __builtin_bit_cast(fx_bf16x8, make_uint4(al_[0], al_[1], al_[2], al_[3]));
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        if ((nt == 0 && !on0) || (nt == 2 && !on1)) continue;       // block-uniform
+                        f32x4 a = acc[j][nt];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[nt], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], a, 0, 0, 0);
+                        acc[j][nt] = a;
+                    }
+                }
+            }
+        }
+        sl = nxt; ++nslab;
+    }
+    __syncthreads();
+
+    // BN + PReLU -> conv tile Cs[pixel][12] -> 3x3 / stride 2 / pad 1 max pool -> channel-last output, twelve channels of one output frame at a time
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CH = FE_CO / 2;
+    float sc[3], sh[3], slp[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int q = nt * 16 + li, ch = q >= FE_CO ? q - FE_CO : q;
+        sc[nt] = w.scale[ch]; sh[nt] = w.shift[ch]; slp[nt] = w.slope[ch];
+    }
+    for (int pass = 0; pass < (has1 ? 4 : 2); ++pass) {
+        const int o = pass >> 1, half = pass & 1;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int q = nt * 16 + li, qo = q >= FE_CO ? 1 : 0, ch = q - FE_CO * qo;
+            if (qo == o && ch >= half * CH && ch < (half + 1) * CH) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    if (wave + 4 * j < PT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int p = (wave + 4 * j) * 16 + 4 * kg + r;
+                            if (p < P) {
+                                float v = acc[j][nt][r] * sc[nt] + sh[nt];
+                                v = v >= 0.f ? v : slp[nt] * v;
+                                Cs[p * CH + (ch - half * CH)] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int f = bg * T + t0 + o;
+        for (int i = tid; i < FE_PR * Wp * CH; i += 256) {
+            const int ch = i % CH;
+            const int pw = (i / CH) % Wp;
+            const int prl = i / (CH * Wp);
+            const int pr = p0 + prl;
+            if (pr >= Hp) continue;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr) {
+                const int crow = 2 * pr - 1 + dr;
+                if (crow < 0 || crow >= Hc) continue;
+                const int lrow = 2 * prl + dr;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int cc = 2 * pw + dc;
+                    if (cc < 0 || cc >= Wc) continue;
+                    m = fmaxf(m, Cs[(lrow * Wc + cc) * CH + ch]);
+                }
+            }
+            out[(((int64_t)f * Hp + pr) * Wp + pw) * FE_CO + half * CH + ch] = m;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int H, int W, float* out, hipStream_t s, float* zout) {
     L2S_REQUIRE(H == W && (H == 96 || H == 88), "frontend supports 96x96 and 88x88 mouth crops");
     L2S_REQUIRE(video.per >= 1 && (B + video.per - 1) / video.per <= MAX_GROUP, "too many frame tensors in one launch");
@@ -671,7 +910,11 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
         else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out);
     } else if (!zout && w.w3 && w.pair) {      // inference on the split-bf16 matrix path, two output frames per block (option "frontend_x3" = 2)
         dim3 gp((Hp + FE_PR - 1) / FE_PR, B * ((T + 1) / 2));
-        if (H == 96) hipLaunchKernelGGL((frontend3d_x3p_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
+        if (w.pipe) {                          // the next slab's staging interleaved with the MFMAs (option "frontend_x3" = 3): more than 64 KB of static LDS is not
+                                               // allowed, so the buffer is declared static at its full size and the kernel keeps two blocks per CU by its 79.9 KB
+            if (H == 96) hipLaunchKernelGGL((frontend3d_x3q_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
+            else hipLaunchKernelGGL((frontend3d_x3q_kernel<88>), gp, dim3(256), 0, s, w, video, T, out);
+        } else if (H == 96) hipLaunchKernelGGL((frontend3d_x3p_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
         else hipLaunchKernelGGL((frontend3d_x3p_kernel<88>), gp, dim3(256), 0, s, w, video, T, out);
     } else if (!zout && w.w3) {                // inference on the split-bf16 matrix path (option "frontend_x3")
         if (H == 96) hipLaunchKernelGGL((frontend3d_x3_kernel<96, 3>), grid, dim3(256), 0, s, w, video, T, out);

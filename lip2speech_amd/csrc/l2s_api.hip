@@ -999,7 +999,7 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
     L2S_REQUIRE(!bp.overflow, "encoder workspace too small");
     FrontendW fe = w.fe;
     if (!m->opt.frontend_x3 || !m->planes_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale
-    fe.pair = m->opt.frontend_x3 == 2;
+    fe.pair = m->opt.frontend_x3 >= 2; fe.pipe = m->opt.frontend_x3 == 3;
     if (!m->opt.infer_bf16 || !m->planes_valid) fe.w1 = nullptr;
     if (launch_frontend(fe, video, B, T, H, W, a, s)) return 1;
     float* x = a; float* y = b;
@@ -1919,7 +1919,7 @@ int l2s_op_frontend(l2s_model* m, const float* video, int B, int T, int H, int W
     L2S_ENC_READY(m);
     FrontendW fe = m->w.fe;
     if (!m->opt.frontend_x3 || !m->planes_valid) fe.w3 = nullptr;
-    fe.pair = m->opt.frontend_x3 == 2;
+    fe.pair = m->opt.frontend_x3 >= 2; fe.pipe = m->opt.frontend_x3 == 3;
     if (!m->opt.infer_bf16 || !m->planes_valid) fe.w1 = nullptr;
     return launch_frontend(fe, frame_src(video, B), B, T, H, W, out, (hipStream_t)stream);
 }

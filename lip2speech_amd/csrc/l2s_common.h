@@ -77,8 +77,10 @@ struct Options {
                                 //   block per CU (the step's first phase), instead of one block shape for every group
     int rc_shape_multi = 0;     // "skinny_rc_multi": the same choice for launches that carry several GEMM groups (the step's first phase); 0 = as "skinny_rc"
     int gemm_x3 = 1;            // "gemm_x3": inference GEMMs / Conv1d stacks on the split-bf16 kernel (gemm_x3.hip) where eligible; 5 = its 128x128x32 tile only
-    int frontend_x3 = 2;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel); 2 (default below): its
-                                //   two-output-frames-per-block form (frontend3d_x3p_kernel)
+    int frontend_x3 = 3;        // "frontend_x3": the inference front-end conv on the split-bf16 matrix path (frontend3d_x3_kernel); 2: its two-output-frames-per-block
+                                //   form (frontend3d_x3p_kernel); 3 (default): the same with the next slab's staging interleaved between the MFMA groups of the
+                                //   current one (frontend3d_x3q_kernel: double-buffered input planes, one barrier per slab; same bits: 0.593 -> 0.562 ms at 32 clips,
+                                //   1.907 -> 1.832 at 128, 3.61 -> 3.59 at 256 - at 256 clips the kernel sits at the chip's clock under MFMA load)
     int train_bf16 = 0;         // "train_bf16": the training step's GEMMs / Conv1d stacks (forward and backward) with bf16 operands on the bf16 matrix cores
     int persist = 4;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: up to 4 clips
                                 //   of <= 32 frames, two per launch) as persistent weight-stationary launches instead of four launches per step; 0 = never.  A
@@ -249,7 +251,8 @@ struct FrontendW {          // device pointers into the weight blob
     const float* w3;        // split-bf16 operand planes of w for frontend3d_x3_kernel: [15 slabs][4 steps][3 planes][32 co][16 taps, 48-byte rows];
                             //   channel rows 24-31 are zeros (frontend3d_x3p_kernel takes the zero rows of an absent frame from row 24)
                             //   (null: f32 MFMA kernel)
-    int pair = 0;           // with w3: two output frames per block (frontend3d_x3p_kernel) - set by the callers from option "frontend_x3" == 2
+    int pair = 0;           // with w3: two output frames per block (frontend3d_x3p_kernel) - set by the callers from option "frontend_x3" >= 2
+    int pipe = 0;           // with pair: the next slab's staging interleaved with the current slab's MFMAs (frontend3d_x3q_kernel) - option "frontend_x3" == 3
     const float* w1;        // the same as ONE plane rounded to nearest even: [15 slabs][4 steps][32 co][16 taps, 48-byte rows] (set by the callers
                             //   of launch_frontend only for a model with "infer_bf16"; takes precedence over w3)
 };

@@ -150,6 +150,17 @@ def test_frontend_kernel_other_forms(synth_sd, nm, x3):
     assert 0 < d < 5e-5                                      # another kernel really ran: rounding-level differences, not zero
 
 
+@pytest.mark.parametrize("hw,T", [(96, 5), (88, 7), (96, 1)])
+def test_frontend_interleaved_staging_same_bits(synth_sd, nm, hw, T):
+    """option frontend_x3 = 3 (default: the next slab's split + LDS stores interleaved between the MFMA groups, double-buffered input planes) against 2 (a staging
+    phase of its own between two barriers): the same operand bits through the same MFMAs - the same output bits, odd T and 88x88 crops included."""
+    two = pc.fresh_native_model(synth_sd, frontend_x3=2)
+    v = synth.synth_video(2, T, hw, hw, tag=f"fe_pipe{hw}_{T}")
+    a, b = nm.op_frontend(v.cuda()), two.op_frontend(v.cuda())
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert pc.maxdiff(a, orc.frontend3d(v, synth_sd).permute(0, 2, 3, 1)) < 2e-5
+
+
 def test_encoder_matches_reference_golden(nm):
     g, video, _ = pc.lrw2_inputs()
     feat = nm.encoder_fwd(video.cuda())
@@ -377,7 +388,7 @@ def test_bf16_leg_avspeech_shaped_full_size(synth_sd):
     ({"use_graph": 1, "fold_step_weights": 0}, False),
     ({"hoist_vproj": 1}, False), ({"hoist_vproj": 0}, False),      # attention_proj on the values (K = 1280 layer 0) / on a @ v through W_ih W_ap (K = 1536)
     ({"skinny_flat": 0}, True),            # uniform first-phase grid
-    ({"frontend_x3": 1}, False), ({"frontend_x3": 0}, False),      # front-end conv: one output frame per block / the f32 MFMA kernel
+    ({"frontend_x3": 2}, True), ({"frontend_x3": 1}, False), ({"frontend_x3": 0}, False),      # front-end conv: staging as a phase of its own (same bits) / one output frame per block / the f32 MFMA kernel
     ({"lstm_x3": 0}, False), ({"lstm_x3": 1}, True),               # LSTM launches on the f32 matrix pipe / the four-wave split-bf16 form
     ({"attn_lds": 0}, True), ({"attn_lds": 2}, True),              # attention blocks: one-column value loads / values through LDS (the default picks by rows)
     ({"skinny_rc_jb": 28}, False),         # the straight-line blocks on eight waves (they do not sum u in the loader: layer 0 on K = 1280, other bits)

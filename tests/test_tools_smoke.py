@@ -28,6 +28,7 @@ RUNS = {
     "prof_train.py": ([], {}),
     "s2_unit_timeline.py": ([], {"B": "32"}),
     "skinny_timeline.py": ([], {"ROWS": "32"}),
+    "steps20_timeline.py": ([], {"K": "3", "REP": "1"}),
     "time_evaluate_net.py": ([], {"N": "2", "ITERS": "4"}),
     "time_frontend.py": ([], {}),
     "time_group.py": ([], {"G": "1", "NT": "1"}),

@@ -18,7 +18,7 @@ def table(db):
     return list(c.execute(f"select kernel_name, grid_size_x, grid_size_y, grid_size_z, counter_name, avg(value), count(*) from {t} group by 1,2,3,4,5"))
 def role_of(name, gz, n_launch):
     if HALF and ("skinny_rc8x" in name or "skinny_rc4_" in name or "skinny_rc4x" in name or ("skinny_flat" in name and ", 2, false>" not in name)
-                 or "step_attn_kernel<false" in name): return None
+                 or "step_attn_kernel<false" in name or "step_attn_kernel<true, false>" in name): return None      # (<true, false>: the probe's warm-up launch outside the chains)
     if "step_attn_kernel" in name: return "step_attention_prenet2"
     if "skinny_flat" in name or ("skinny" in name and gz == 4): return "step_prenet1_q_cq_fc"
     if "skinny" in name and gz == 1 and n_launch >= 250: return "step_lstm_cell"
