@@ -128,10 +128,15 @@ def cpu_baseline(seconds_budget=12.0):
         for c in cands:
             torch.set_num_threads(c)
             orc.inference(sd, video, emb, gum, S=4)
-            t0 = time.time()
-            orc.inference(sd, video, emb, gum, S=20)
-            probe[c] = time.time() - t0
-        cores = min(probe, key=probe.get)
+            best = None
+            for _ in range(2):                                 # best of two S=30 passes: one pass alone flipped the choice between 8 and 16 threads run to run
+                t0 = time.time()
+                orc.inference(sd, video, emb, gum, S=30)
+                dt = time.time() - t0
+                best = dt if best is None else min(best, dt)
+            probe[c] = best
+        fastest = min(probe.values())
+        cores = max(c for c, v in probe.items() if v <= 1.05 * fastest)      # the LARGER thread count on a near-tie (within 5 %)
         torch.set_num_threads(cores)
         t0 = time.time()
         orc.inference(sd, video, emb, gum, S=S)             # warm-up pass (also page-in)
@@ -145,7 +150,7 @@ def cpu_baseline(seconds_budget=12.0):
     med = times[len(times) // 2]
     return {"value": B * S / med, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} full passes of the B={B},T={T},S={S} batch after 1 warm-up ({warm:.1f}s); median {med:.2f}s; "
-                      f"thread-count probe (S=20 pass, seconds): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
+                      f"thread-count probe (best of two S=30 passes, seconds; the larger count within 5 % of the fastest): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
 
 
 def cpu_baseline_train(Bt, St, seconds_budget=25.0):
@@ -399,6 +404,8 @@ def main():
     # replicated weights, per-rank shard of clips (no exchange step on the inference path)
     from lip2speech_amd.parallel import InflightPool
     for kv in args.opt:
+        if kv.split("=")[0] in native.DIAG_OPTIONS and native.lib() is not native.diag():
+            raise SystemExit(f"bench.py --opt {kv}: a block-form A/B switch of the diagnostic build (include/l2s_diag.h) - run with L2S_LIB=diag (tools/ab_bench.sh does)")
         native.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     sd = synth.synth_state_dict()
     tensors = {k: v.cuda() for k, v in sd.items()}

@@ -33,6 +33,7 @@ extern "C" {
  *   "flat_half"         (1)  the step's first launch on four-wave half-CU blocks when chains overlap; 2 = always, 0 = never
  *   "half_min_mts"      (12) with "lstm_x3" = 3 and chains overlapping: an all-LSTM launch takes the half-CU 4x2 form from this many 16-row tiles on
  *   "trunk_chain"       (1)  the stride-1 units of ShuffleNet stages 2 and 3 as ONE launch per stage (the map stays on chip between the units); 2 = stage 4 too, 0 = one launch per unit
+ *   "frontend_solo"     (0)  when chains overlap, the front-end conv one block per CU (an LDS pad) so that other chains' step kernels run beside it: measured -8 %, off
  *   "flat_xcd"          (1)  the step's first launch with an XCD-affine block -> tile map (an XCD = one row half x one column quarter of a group); 0 = row-major
  *   "attn_skip0"        (1)  when chains overlap, attention blocks fetch only the projected-value rows whose soft-max weight is not exactly zero; 2 = always, 0 = never
  *   "skinny_flat"       (1)  multi-group batch-row launches at >= 128 rows as one flat grid of per-group block shapes; 0 = one shape for all groups

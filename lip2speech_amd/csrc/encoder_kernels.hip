@@ -910,10 +910,12 @@ int launch_frontend(const FrontendW& w, const FrameSrc& video, int B, int T, int
         else hipLaunchKernelGGL((frontend3d_x3_kernel<88, 1>), grid, dim3(256), 0, s, w, video, T, out);
     } else if (!zout && w.w3 && w.pair) {      // inference on the split-bf16 matrix path, two output frames per block (option "frontend_x3" = 2)
         dim3 gp((Hp + FE_PR - 1) / FE_PR, B * ((T + 1) / 2));
-        if (w.pipe) {                          // the next slab's staging interleaved with the MFMAs (option "frontend_x3" = 3): more than 64 KB of static LDS is not
-                                               // allowed, so the buffer is declared static at its full size and the kernel keeps two blocks per CU by its 79.9 KB
-            if (H == 96) hipLaunchKernelGGL((frontend3d_x3q_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
-            else hipLaunchKernelGGL((frontend3d_x3q_kernel<88>), gp, dim3(256), 0, s, w, video, T, out);
+        if (w.pipe) {                          // the next slab's staging interleaved with the MFMAs (option "frontend_x3" = 3): 79.9 KB of LDS, two blocks per CU
+            // w.solo (diagnostic "frontend_solo"): a pad of dynamic LDS on top, so that only ONE block fits a CU and the other half of every CU (78 KB of
+            // LDS, 256 registers per lane on one wave per SIMD) stays free for the step kernels of other launch chains
+            const unsigned pad = w.solo ? 4096u : 0u;
+            if (H == 96) hipLaunchKernelGGL((frontend3d_x3q_kernel<96>), gp, dim3(256), pad, s, w, video, T, out);
+            else hipLaunchKernelGGL((frontend3d_x3q_kernel<88>), gp, dim3(256), pad, s, w, video, T, out);
         } else if (H == 96) hipLaunchKernelGGL((frontend3d_x3p_kernel<96>), gp, dim3(256), 0, s, w, video, T, out);
         else hipLaunchKernelGGL((frontend3d_x3p_kernel<88>), gp, dim3(256), 0, s, w, video, T, out);
     } else if (!zout && w.w3) {                // inference on the split-bf16 matrix path (option "frontend_x3")

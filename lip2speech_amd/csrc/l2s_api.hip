@@ -43,7 +43,7 @@ int set_option_field(Options& o, const char* name, int value) {
         {"skinny_static", &Options::skinny_static}, {"skinny_sized", &Options::skinny_sized}, {"skinny_split", &Options::skinny_split},
         {"skinny_split8", &Options::skinny_split8}, {"skinny_rc", &Options::rc_shape}, {"skinny_rc_jb", &Options::rc_jb}, {"skinny_rc_multi", &Options::rc_shape_multi},
         {"skinny_flat", &Options::skinny_flat}, {"hoist_vproj", &Options::hoist_vproj}, {"attn_lds", &Options::attn_lds}, {"flat_half", &Options::flat_half},
-        {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma}, {"trunk_chain", &Options::trunk_chain}, {"flat_xcd", &Options::flat_xcd}, {"attn_skip0", &Options::attn_skip0}};
+        {"half_min_mts", &Options::half_min_mts}, {"gemm_x3_dma", &Options::gemm_x3_dma}, {"trunk_chain", &Options::trunk_chain}, {"frontend_solo", &Options::frontend_solo}, {"flat_xcd", &Options::flat_xcd}, {"attn_skip0", &Options::attn_skip0}};
     for (auto& t : diag)
         if (!std::strcmp(name, t.name)) { o.*(t.field) = value; return 0; }
 #endif
@@ -1000,6 +1000,7 @@ static int encoder_run(l2s_model* m, const FrameSrc& video, int B, int T, int H,
     FrontendW fe = w.fe;
     if (!m->opt.frontend_x3 || !m->planes_valid) fe.w3 = nullptr;        // after a device-side refresh the split planes are stale
     fe.pair = m->opt.frontend_x3 >= 2; fe.pipe = m->opt.frontend_x3 == 3;
+    fe.solo = m->opt.frontend_solo && (m->opt.frontend_solo >= 2 || chains_hint() >= 2);
     if (!m->opt.infer_bf16 || !m->planes_valid) fe.w1 = nullptr;
     if (launch_frontend(fe, video, B, T, H, W, a, s)) return 1;
     float* x = a; float* y = b;

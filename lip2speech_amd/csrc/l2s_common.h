@@ -85,6 +85,8 @@ struct Options {
     int persist = 4;            // "persist_decode": the free-running decode loop of a single-batch call with at most this many clips (pdecode.hip: up to 4 clips
                                 //   of <= 32 frames, two per launch) as persistent weight-stationary launches instead of four launches per step; 0 = never.  A
                                 //   latency form: one call owns the chip, such launches are chained one after the other; grouped calls (l2s_*_multi) never take it
+    int frontend_solo = 0;      // "frontend_solo" (diagnostic A/B): when chains overlap, the front-end conv takes ONE block per CU (an LDS pad) so that step kernels of other
+                                //   chains (half-CU blocks) run beside it instead of waiting for its 530-us blocks to retire
     int trunk_chain = 1;        // "trunk_chain" (diagnostic A/B): the consecutive stride-1 units of a ShuffleNet stage as ONE launch (the map stays on chip between the
                                 //   units; stages 2 and 3 - at 3x3 the per-unit launches are 5 % faster): 3 + 7 launches become 2, the trunk 3.82 -> 3.52 ms per 256 clips,
                                 //   same bits; 0 = one launch per unit, 2 = the 3x3 stage as well
@@ -252,6 +254,7 @@ struct FrontendW {          // device pointers into the weight blob
                             //   channel rows 24-31 are zeros (frontend3d_x3p_kernel takes the zero rows of an absent frame from row 24)
                             //   (null: f32 MFMA kernel)
     int pair = 0;           // with w3: two output frames per block (frontend3d_x3p_kernel) - set by the callers from option "frontend_x3" >= 2
+    int solo = 0;           // with pipe: one block per CU (diagnostic option "frontend_solo" with chains overlapping)
     int pipe = 0;           // with pair: the next slab's staging interleaved with the current slab's MFMAs (frontend3d_x3q_kernel) - option "frontend_x3" == 3
     const float* w1;        // the same as ONE plane rounded to nearest even: [15 slabs][4 steps][32 co][16 taps, 48-byte rows] (set by the callers
                             //   of launch_frontend only for a model with "infer_bf16"; takes precedence over w3)

@@ -48,7 +48,7 @@ DIAG_SYMBOLS = (
 
 # run-time options only the diagnostic build accepts (block-form A/B switches of the same arithmetic, include/l2s_diag.h)
 DIAG_OPTIONS = frozenset(("overlap_postnet", "fuse_trunk", "fuse_s2", "skinny_static", "skinny_sized", "skinny_split", "skinny_split8", "skinny_rc", "skinny_rc_jb",
-                          "skinny_rc_multi", "skinny_flat", "hoist_vproj", "attn_lds", "flat_half", "half_min_mts", "gemm_x3_dma", "flat_xcd", "attn_skip0", "trunk_chain"))
+                          "skinny_rc_multi", "skinny_flat", "hoist_vproj", "attn_lds", "flat_half", "half_min_mts", "gemm_x3_dma", "flat_xcd", "attn_skip0", "trunk_chain", "frontend_solo"))
 
 ST_K, ST_V, ST_CKEY, ST_CVAL, ST_ECELL, ST_H, ST_C, ST_ENC, ST_STOPC = range(9)
 
