@@ -129,28 +129,33 @@ def cpu_baseline(seconds_budget=12.0):
             torch.set_num_threads(c)
             orc.inference(sd, video, emb, gum, S=4)
             best = None
-            for _ in range(2):                                 # best of two S=30 passes: one pass alone flipped the choice between 8 and 16 threads run to run
+            for _ in range(2):                                 # best of two S=60 passes per candidate
                 t0 = time.time()
-                orc.inference(sd, video, emb, gum, S=30)
+                orc.inference(sd, video, emb, gum, S=60)
                 dt = time.time() - t0
                 best = dt if best is None else min(best, dt)
             probe[c] = best
-        fastest = min(probe.values())
-        cores = max(c for c, v in probe.items() if v <= 1.05 * fastest)      # the LARGER thread count on a near-tie (within 5 %)
-        torch.set_num_threads(cores)
-        t0 = time.time()
-        orc.inference(sd, video, emb, gum, S=S)             # warm-up pass (also page-in)
-        warm = time.time() - t0
-        times = []
-        while sum(times) < seconds_budget and len(times) < 5:
+        # the short probe only RANKS the candidates (the 300-step loop weighs the per-step ops more than a 60-step pass does: a probe alone picked 8, 16
+        # or 32 threads from run to run): the two best are both measured on the real workload and the faster one is reported
+        finals = {}
+        warm = 0.0
+        for c in sorted(probe, key=probe.get)[:2]:
+            torch.set_num_threads(c)
             t0 = time.time()
-            orc.inference(sd, video, emb, gum, S=S)
-            times.append(time.time() - t0)
-    times.sort()
+            orc.inference(sd, video, emb, gum, S=S)         # warm-up pass (also page-in)
+            warm += time.time() - t0
+            ts = []
+            while sum(ts) < seconds_budget / 2 and len(ts) < 3:
+                t0 = time.time()
+                orc.inference(sd, video, emb, gum, S=S)
+                ts.append(time.time() - t0)
+            finals[c] = sorted(ts)
+        cores = min(finals, key=lambda c: finals[c][len(finals[c]) // 2])
+        times = finals[cores]
     med = times[len(times) // 2]
     return {"value": B * S / med, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full passes of the B={B},T={T},S={S} batch after 1 warm-up ({warm:.1f}s); median {med:.2f}s; "
-                      f"thread-count probe (best of two S=30 passes, seconds; the larger count within 5 % of the fastest): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
+            "sample": f"{len(times)} full passes of the B={B},T={T},S={S} batch after a warm-up pass; median {med:.2f}s; the two thread counts the probe ranks "
+                      f"best are both measured this way (medians {({k: round(v[len(v) // 2], 2) for k, v in finals.items()})}), the faster is reported; probe (best of two S=60 passes, seconds): {({k: round(v, 2) for k, v in probe.items()})} of {hw} hardware threads"}
 
 
 def cpu_baseline_train(Bt, St, seconds_budget=25.0):
